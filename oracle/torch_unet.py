@@ -1,0 +1,90 @@
+"""PyTorch-CPU restatement of the same U-Net graph (independent cross-check + CPU baseline).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Two uses:
+  * tests/test_oracle_cpu.py: autograd of this graph must agree with the
+    hand-written NumPy forward/backward of oracle/unet.py (two independent
+    implementations of the Keras semantics of utils/model_tools.py:174-415);
+  * bench.py `cpu_baseline` (kind "port"): TensorFlow is absent on the bench
+    host, so the reference's TF-CPU path is stood in for by this oneDNN-backed
+    graph, fp32, all host cores.
+Semantic deltas handled here: Keras BN eps 1e-3, biased
+batch variance, HWIO kernels -> OIHW, Conv2DTranspose (kh,kw,Cout,Cin) ->
+torch (Cin,Cout,kh,kw), concat order skip-first, Keras Adam epsilon placement.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-3
+
+
+def params_to_torch(params, dtype=torch.float32, requires_grad=True):
+    out = {}
+    for k, v in params.items():
+        t = torch.tensor(np.asarray(v), dtype=dtype)
+        if requires_grad and not (k.endswith('moving_mean') or k.endswith('moving_var')):
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def _conv(x, k, b, dilation=1):
+    kh = k.shape[0]
+    pad = dilation * (kh - 1) // 2
+    return F.conv2d(x, k.permute(3, 2, 0, 1), b, padding=pad, dilation=dilation)
+
+
+def _bn(x, p, name, training):
+    g, b = p[f'{name}.gamma'], p[f'{name}.beta']
+    if training:
+        mean = x.mean(dim=(0, 2, 3), keepdim=True)
+        var = x.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    else:
+        mean = p[f'{name}.moving_mean'].view(1, -1, 1, 1)
+        var = p[f'{name}.moving_var'].view(1, -1, 1, 1)
+    return (x - mean) / torch.sqrt(var + BN_EPS) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+
+
+def unet_forward(p, x_nhwc, filters, factors, training=False):
+    """Returns (probs NHWC, classes NHW int32).  p: dict of torch tensors (oracle names)."""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    L = len(filters)
+    skips = []
+    h = x
+    for i in range(L):
+        a = F.relu(_bn(_conv(h, p[f'enc{i}.conv.kernel'], p[f'enc{i}.conv.bias']), p, f'enc{i}.bn', training))
+        skips.append(a)
+        h = F.max_pool2d(a, factors[i], factors[i])
+    h = F.relu(_bn(_conv(h, p['center.conv.kernel'], p['center.conv.bias']), p, 'center.bn', training))
+    for j in range(L - 1, -1, -1):
+        kt = p[f'dec{j}.up.kernel']                      # (s,s,Cout,Cin)
+        up = F.conv_transpose2d(h, kt.permute(3, 2, 0, 1), p[f'dec{j}.up.bias'], stride=factors[j])
+        cat = torch.cat([skips[j], up], dim=1)
+        a0 = F.relu(_bn(cat, p, f'dec{j}.bn0', training))
+        a1 = F.relu(_bn(_conv(a0, p[f'dec{j}.conv1.kernel'], p[f'dec{j}.conv1.bias']), p, f'dec{j}.bn1', training))
+        h = F.relu(_bn(_conv(a1, p[f'dec{j}.conv2.kernel'], p[f'dec{j}.conv2.bias']), p, f'dec{j}.bn2', training))
+    logits = _conv(h, p['probs.kernel'], p['probs.bias'])
+    probs = torch.softmax(logits, dim=1).permute(0, 2, 3, 1)
+    return probs, torch.argmax(probs, dim=-1).to(torch.int32)
+
+
+def weighted_cce_mean(target, output, weights):
+    """mean of utils/model_tools.py:25-40."""
+    w = torch.as_tensor(weights, dtype=output.dtype).view(1, -1)
+    o = output / output.sum(-1, keepdim=True)
+    o = torch.clamp(o, 1e-7, 1 - 1e-7)
+    return (-(w * target * torch.log(o)).sum(-1)).mean()
+
+
+def weighted_bce_mean(y_true, y_pred, pos_weight):
+    yp = torch.clamp(y_pred, 0.00001, 0.99999)
+    return (y_true * -torch.log(yp) * pos_weight + (1 - y_true) * -torch.log(1 - yp)).mean()
+
+
+def keras_adam_(p, grads, m, v, t, lr=9e-4, b1=0.9, b2=0.999, eps=1e-7):
+    alpha = lr * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
+    with torch.no_grad():
+        for k, g in grads.items():
+            m[k].mul_(b1).add_(g, alpha=1 - b1)
+            v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+            p[k].sub_(alpha * m[k] / (v[k].sqrt() + eps))

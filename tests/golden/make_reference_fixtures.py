@@ -1,0 +1,93 @@
+"""Generate golden vectors by RUNNING the reference's own Python in the build container.
+
+Run here only (needs /root/reference, which does not exist on the GPU box):
+    python tests/golden/make_reference_fixtures.py
+Writes tests/golden/tiling_reference.npz and tests/golden/array_tools_reference.npz
+(inputs + expected outputs only -- no reference source travels).
+
+* utils/prediction_tools.py cannot be imported (tensorflow/rasterio missing), so
+  the bodies of generate_chip_indices / extract_chips / predict_chips (:87-156)
+  are AST-extracted and executed against NumPy with a fake model
+  predict(x) = 2 * x[..., :1].
+* utils/array_tools.py imports cleanly (NumPy only) and is called directly.
+"""
+import ast
+import io
+import contextlib
+import os
+import sys
+import numpy as np
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def extract_functions(path, names):
+    src = open(path).read()
+    tree = ast.parse(src)
+    ns = {'np': np}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            code = compile(ast.Module(body=[node], type_ignores=[]), path, 'exec')
+            exec(code, ns)
+    return ns
+
+
+class FakeModel:
+    def predict(self, x, verbose=0):
+        return 2.0 * x[..., :1]
+
+
+def main():
+    pt = extract_functions(f'{REF}/utils/prediction_tools.py',
+                           {'generate_chip_indices', 'extract_chips', 'predict_chips'})
+    rt = extract_functions(f'{REF}/utils/raster_tools.py', {'generate_chip_indices'})
+    out = {}
+    shapes = [(1024, 1024, 4), (384, 384, 4), (640, 640, 4), (1000, 1300, 4), (900, 700, 3), (2048, 1500, 2)]
+    cfgs = [(128, 256), (64, 128), (0, 256), (32, 96)]
+    cases = []
+    for s in shapes:
+        for buff, kernel in cfgs:
+            idx = pt['generate_chip_indices'](np.zeros(s, np.float32), buff, kernel)
+            key = f'idx_{s[0]}_{s[1]}_{s[2]}_{buff}_{kernel}'
+            out[key] = np.asarray(idx, np.int64).reshape(-1, 2)
+            cases.append(key)
+    out['cases'] = np.asarray(cases)
+    for (h, w, b, k) in [(1024, 1024, 128, 256), (1000, 1300, 128, 256), (700, 900, 64, 128)]:
+        out[f'rt_idx_{h}_{w}_{b}_{k}'] = np.asarray(rt['generate_chip_indices'](h, w, b, k), np.int64).reshape(-1, 2)
+
+    rng = np.random.default_rng(7)
+    arr = rng.integers(0, 255, (160, 224, 3)).astype(np.float32)
+    out['pc_arr'] = arr
+    idx = pt['generate_chip_indices'](arr, 16, 32)
+    out['pc_idx'] = np.asarray(idx, np.int64)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tmpl = pt['predict_chips'](arr, idx, np.zeros(arr.shape[:2]), FakeModel(), 32, 16)
+    out['pc_template'] = tmpl
+    sq = rng.integers(0, 255, (128, 128, 2)).astype(np.float32)
+    chips = pt['extract_chips'](sq, 16, 32)
+    out['ec_arr'] = sq
+    out['ec_chips'] = np.stack(chips)
+    np.savez_compressed(f'{OUT}/tiling_reference.npz', **out)
+
+    sys.path.insert(0, f'{REF}/utils')
+    import array_tools as at
+    a = {}
+    x = rng.random((2, 8, 8, 3)).astype(np.float32)
+    a['morph_in'] = x
+    for v in (False, True):
+        for h in (False, True):
+            for r in (0, 1, 2, 3):
+                a[f'morph_{int(v)}{int(h)}{r}'] = at.aug_array_morph(x, v, h, r)
+    a['merge_out'] = at.merge_classes(np.array([1, 2, 3, 2]), [(2, 9), (3, 7)], np.array([1, 2, 3, 2]))
+    img = (rng.random((16, 16, 4)) * 3000).astype(np.float32)
+    a['rescale_in'] = img
+    a['rescale_moments'] = at.rescale_array(img, moments=[(0, 3000)] * 4)
+    a['rescale_axes01'] = at.rescale_array(img, axes=(0, 1))
+    a['normalize_axes01'] = at.normalize_array(img, axes=(0, 1))
+    np.savez_compressed(f'{OUT}/array_tools_reference.npz', **a)
+    print('wrote fixtures:', len(out), len(a))
+
+
+if __name__ == '__main__':
+    main()
