@@ -1,0 +1,211 @@
+/*
+ * satcv.h -- C ABI of the MI355X-native U-Net / ASPP tile pipeline (libsatcv.so).
+ *
+ * The reference (mjevans26/Satellite_ComputerVision) has no FFI for this path:
+ * every tensor op of utils/model_tools.py is delegated to tf.keras layers.  Each
+ * entry point below therefore replaces one Keras layer call site (cited) and is
+ * what the reference-side binding would call instead of TensorFlow (see
+ * INTEGRATION.md for the ctypes stub).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types.
+ *   - every function returns int: 0 = SATCV_OK, <0 = error; satcv_last_error()
+ *     returns a thread-local message.
+ *   - all tensor pointers are DEVICE pointers owned by the caller; the library
+ *     never allocates or frees tensor memory and never synchronises the stream.
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous.
+ *   - activations are NHWC (channels contiguous), storage type `dtype`
+ *     (SATCV_F32 or SATCV_BF16), channel counts padded to a multiple of 16.
+ *     Accumulation, BN statistics, losses, gradients of weights and the
+ *     optimizer are always fp32.
+ */
+#ifndef SATCV_H
+#define SATCV_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SATCV_OK = 0, SATCV_ERR_INVALID = -1, SATCV_ERR_HIP = -2, SATCV_ERR_UNSUPPORTED = -3 };
+enum { SATCV_F32 = 0, SATCV_BF16 = 1 };
+/* rows of replicated per-channel accumulators (sum rows in order to consume) */
+#define SATCV_STAT_ROWS 32
+
+const char* satcv_version(void);
+const char* satcv_last_error(void);
+/* out[0]=CU count, out[1]=LDS bytes/CU, out[2]=wave size, out[3]=gfx arch number (950) */
+int satcv_device_info(int32_t* out4);
+
+/* ---------------------------------------------------------------- data movement
+ * f32 NHWC (n,h,w,c) -> dtype NHWC (n,h,w,cpad), zero-filling channels [c,cpad).
+ * Replaces the implicit float32 feed of Model.predict/fit (utils/prediction_tools.py:152). */
+int satcv_ingest_nhwc(const float* src, void* dst, int64_t npix, int32_t c, int32_t cpad,
+                      int32_t dtype, void* stream);
+/* planar CHW (c,h,w) per tile, any of u8/u16/f32 (src_kind 0/1/2), scaled by `scale`
+ * -> dtype NHWC (n,h,w,cpad).  Mirrors the CHW->HWC + rescale of utils/processing.py:544-613. */
+int satcv_ingest_chw(const void* src, int32_t src_kind, float scale, void* dst, int32_t n,
+                     int32_t c, int32_t h, int32_t w, int32_t cpad, int32_t dtype, void* stream);
+
+/* Keras HWIO fp32 master kernel (kh,kw,cin,cout) -> packed operand images.
+ *   fwd   : [kh*kw][cin_pad/8][cout_pad][8]   (B operand of the forward implicit GEMM)
+ *   dgrad : [kh*kw][cout_pad8/8][cin_pad32][8] spatially flipped, in/out swapped
+ * transposed=1: source is a Conv2DTranspose kernel (kh,kw,cout,cin) (utils/model_tools.py:306);
+ *   fwd   : [1][cin_pad/8][kh*kw*cout][8]  (N index = (i*kw+j)*cout + o)
+ *   dgrad : [1][kh*kw*cout/8][cin_pad32][8] (K index = (i*kw+j)*cout + o)
+ * Either destination may be NULL. */
+int satcv_pack_weights(const float* src, void* dst_fwd, void* dst_dgrad, int32_t kh, int32_t kw,
+                       int32_t cin, int32_t cout, int32_t cin_pad, int32_t transposed,
+                       int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------ implicit-GEMM conv
+ * One descriptor drives Conv2D forward, its data gradient, Conv2DTranspose(k==s)
+ * forward (depth-to-space store) and its data gradient (space-to-depth load).
+ * Replaces layers.Conv2D (utils/model_tools.py:178,312,315,405,544-549) and
+ * layers.Conv2DTranspose (:306), plus the input-side BatchNormalization+ReLU of the
+ * PREVIOUS layer (:179-180, :308-309) which is applied while staging the tile. */
+typedef struct satcv_conv_desc {
+  const void* x0;          /* source 0, NHWC (n, hin, win, c0)                       */
+  const void* x1;          /* optional source 1 (concat along channels), or NULL      */
+  int32_t c0, c1;          /* channels of each source (multiples of 16); K = c0+c1     */
+  const float* in_scale;   /* optional per-input-channel affine (+ReLU) applied on load */
+  const float* in_shift;
+  int32_t in_relu;
+  const void* w;           /* packed weights (satcv_pack_weights)                     */
+  const float* bias;       /* [cstat] or NULL                                         */
+  void* y;                 /* output NHWC, channel stride ldy                         */
+  int32_t ldy;
+  float* stats;            /* optional [SATCV_STAT_ROWS][2][stats_ld] sum / sum-of-squares
+                              of the stored outputs (atomically accumulated)          */
+  int32_t stats_ld;
+  int32_t n, h, w_;        /* GEMM pixel grid (= output grid, or input grid for mode_out=1) */
+  int32_t cout;            /* GEMM N extent (valid columns)                           */
+  int32_t cout_pad;        /* N stride of the packed weights                          */
+  int32_t kh, kw, dil;     /* taps and dilation ('same' zero padding)                 */
+  int32_t mode_in;         /* 0: plain; 1: space-to-depth gather by factor f          */
+  int32_t mode_out;        /* 0: plain; 1: depth-to-space scatter by factor f         */
+  int32_t f;
+  int32_t cstat;           /* modulus mapping N index -> bias/stats channel            */
+  int32_t out_relu;        /* clamp outputs at 0 before storing                        */
+  int32_t dtype;
+} satcv_conv_desc;
+int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream);
+
+/* Weight gradient of the same convolutions: dW[tap][ci][co] = sum_p X[p+tap][ci]*dY[p][co],
+ * written as Keras HWIO fp32.  X is staged with the same optional affine+ReLU as the
+ * forward.  Needs a caller-provided fp32 workspace (satcv_conv2d_wgrad_workspace). */
+typedef struct satcv_wgrad_desc {
+  const void* x0; const void* x1; int32_t c0, c1;
+  const float* in_scale; const float* in_shift; int32_t in_relu;
+  const void* dy; int32_t lddy;      /* (n, h*f, w*f, lddy) when mode_dy=1 else (n,h,w,lddy) */
+  float* dw;                         /* (kh,kw,cin,cout) fp32, or (f,f,cout,cin) when transposed */
+  int32_t cin, cout;                 /* real (unpadded) extents written to dw */
+  int32_t n, h, w_;
+  int32_t kh, kw, dil;
+  int32_t mode_dy;                   /* 1: dy is gathered space-to-depth by f (Conv2DTranspose) */
+  int32_t f;
+  int32_t transposed;                /* dw layout (f,f,cout,cin) */
+  float* workspace; int64_t workspace_bytes;
+  int32_t dtype;
+} satcv_wgrad_desc;
+int64_t satcv_conv2d_wgrad_workspace(const satcv_wgrad_desc* d);
+int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream);
+
+/* --------------------------------------------------------------- batch norm
+ * layers.BatchNormalization (utils/model_tools.py:179,308,313,316): eps, momentum as given.
+ * Training: consume the [ROWS][2][ld] sum/sumsq rows (and zero them), produce per-channel
+ * scale=gamma*rstd, shift=beta-mean*scale, mean, rstd, and update the moving statistics
+ * `updates` times (2 reproduces the double cba1 call of conv_block.call, :238-239). */
+int satcv_bn_finalize_train(float* stats, int32_t stats_ld, int32_t c, float count,
+                            const float* gamma, const float* beta, float eps, float momentum,
+                            int32_t updates, int32_t bessel, float* moving_mean, float* moving_var,
+                            float* scale, float* shift, float* mean, float* rstd, void* stream);
+/* Inference: scale/shift from the moving statistics. */
+int satcv_bn_affine_infer(const float* gamma, const float* beta, const float* moving_mean,
+                          const float* moving_var, float eps, int32_t c, float* scale, float* shift,
+                          void* stream);
+
+/* act = relu(scale*yraw+shift) (written if act != NULL), pooled = maxpool_f(act) ('valid'),
+ * optional sum/sumsq rows of `act` (feeds the decoder's concat BatchNormalization).
+ * Replaces Activation('relu') + MaxPooling2D (utils/model_tools.py:180,281). */
+int satcv_bn_relu_pool(const void* yraw, const float* scale, const float* shift, void* act,
+                       void* pooled, float* stats, int32_t stats_ld, int32_t n, int32_t h,
+                       int32_t w_, int32_t c, int32_t f, int32_t dtype, void* stream);
+
+/* Backward of  a = relu(scale*y+shift)  (training-mode BN):
+ *   g  = (da [+ unpool(dpool)]) * (a > 0)
+ *   reduce : sums[row][0][ch] += g ; sums[row][1][ch] += g * xhat
+ *   finalize: dbeta=sum g, dgamma=sum g*xhat -> grads, coef (c1=dbeta/M, c2=dgamma/M), zero sums
+ *   apply  : dy = scale*(g - c1 - xhat*c2)  (+ optional dbias[ch] += sum dy)            */
+typedef struct satcv_bnbwd_desc {
+  const void* da; int32_t ldda;        /* grad w.r.t. activation, may be NULL if only dpool */
+  const void* dpool; int32_t lddp;     /* optional grad of maxpool_f(a), (n,h/f,w/f,lddp)   */
+  int32_t f;
+  const void* yraw; int32_t ldy;
+  const float* scale; const float* shift; const float* mean; const float* rstd;
+  float* sums; int32_t sums_ld;        /* [ROWS][2][sums_ld]                                */
+  const float* coef;                   /* [2][c] from finalize (apply only)                 */
+  void* dy; int32_t lddy_out;          /* apply output                                      */
+  float* dbias;                        /* optional [c], atomically accumulated (apply)      */
+  int32_t n, h, w_, c;
+  int32_t dtype;
+} satcv_bnbwd_desc;
+int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream);
+int satcv_bn_bwd_finalize(float* sums, int32_t sums_ld, int32_t c, float count, float* dgamma,
+                          float* dbeta, float* coef, void* stream);
+int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------- head
+ * Conv2D(ncls,(1,1),activation) + argmax/threshold (utils/model_tools.py:405-406, :660-661).
+ * activation 0: softmax, classes = argmax (ties -> lowest index);
+ *            1: sigmoid, classes = probs > thresh.
+ * x is the raw output of the last decoder conv; its BN+ReLU is applied on load. */
+typedef struct satcv_head_desc {
+  const void* x; int32_t ldx; int32_t cin;
+  const float* in_scale; const float* in_shift;
+  const float* w;            /* fp32 (cin, ncls) = Keras (1,1,cin,ncls) */
+  const float* b;            /* [ncls] */
+  int32_t ncls; int32_t activation; float thresh;
+  float* probs;              /* (npix, ncls) fp32 */
+  int32_t* classes;          /* (npix) int32 */
+  const float* dlogits;      /* bwd: (npix, ncls) fp32 */
+  void* dx; int32_t lddx;    /* bwd: grad w.r.t. the activated input, storage dtype */
+  float* dw; float* db;      /* bwd: fp32, atomically accumulated */
+  int64_t npix;
+  int32_t dtype;
+} satcv_head_desc;
+int satcv_head_fwd(const satcv_head_desc* d, void* stream);
+int satcv_head_bwd(const satcv_head_desc* d, void* stream);
+
+/* ------------------------------------------------------------------ losses
+ * Each writes loss_out[0] += mean loss contribution (caller zeroes) and
+ * dlogits = dL/dlogits (through the head activation).
+ * kind 0: weighted_categorical_crossentropy (utils/model_tools.py:25-40), weights[ncls]
+ * kind 1: weighted_bce on probabilities (:96-112), weights[0] = pos_weight                 */
+int satcv_loss_fwd_bwd(int32_t kind, const float* probs, const float* y_true,
+                       const float* weights, int32_t ncls, int32_t activation, int64_t npix,
+                       float grad_scale, float* loss_out, float* dlogits, void* stream);
+
+/* confusion[t*ncls + p] += 1 over pixels (MeanIoU / accuracy; notebooks nb:275) */
+int satcv_confusion(const int32_t* classes, const float* y_true, int32_t ncls, int64_t npix,
+                    int64_t* confusion, void* stream);
+
+/* --------------------------------------------------------------- optimizer
+ * Keras Adam (epsilon outside the bias correction).  `state` is a device
+ * float[4]: {lr, step_count, grad_scale, unused}; the kernel increments
+ * step_count itself so that the launch is graph-replayable. */
+int satcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
+                    float beta2, float eps, float* state, const float* lr_mul, void* stream);
+
+/* ------------------------------------------------------- stream utilities */
+int satcv_graph_begin(void* stream);
+int satcv_graph_end(void* stream, void** graph_exec_out);
+int satcv_graph_launch(void* graph_exec, void* stream);
+int satcv_graph_destroy(void* graph_exec);
+/* event pairs recorded around every igemm launch while enabled; total ms + count returned */
+int satcv_prof_enable(int32_t kind_mask);
+int satcv_prof_collect(int32_t kind, double* total_ms, int64_t* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

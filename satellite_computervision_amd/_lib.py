@@ -1,0 +1,119 @@
+"""ctypes binding of libsatcv.so (the C-ABI HIP library, include/satcv.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol
+declared in include/satcv.h is absent, import fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsatcv.so')
+
+F32, BF16 = 0, 1
+STAT_ROWS = 32
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('x0', c_vp), ('x1', c_vp), ('c0', c_i32), ('c1', c_i32),
+                ('in_scale', c_vp), ('in_shift', c_vp), ('in_relu', c_i32),
+                ('w', c_vp), ('bias', c_vp), ('y', c_vp), ('ldy', c_i32),
+                ('stats', c_vp), ('stats_ld', c_i32),
+                ('n', c_i32), ('h', c_i32), ('w_', c_i32),
+                ('cout', c_i32), ('cout_pad', c_i32),
+                ('kh', c_i32), ('kw', c_i32), ('dil', c_i32),
+                ('mode_in', c_i32), ('mode_out', c_i32), ('f', c_i32),
+                ('cstat', c_i32), ('out_relu', c_i32), ('dtype', c_i32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('x0', c_vp), ('x1', c_vp), ('c0', c_i32), ('c1', c_i32),
+                ('in_scale', c_vp), ('in_shift', c_vp), ('in_relu', c_i32),
+                ('dy', c_vp), ('lddy', c_i32), ('dw', c_vp),
+                ('cin', c_i32), ('cout', c_i32),
+                ('n', c_i32), ('h', c_i32), ('w_', c_i32),
+                ('kh', c_i32), ('kw', c_i32), ('dil', c_i32),
+                ('mode_dy', c_i32), ('f', c_i32), ('transposed', c_i32),
+                ('workspace', c_vp), ('workspace_bytes', c_i64), ('dtype', c_i32)]
+
+
+class BnBwdDesc(C.Structure):
+    _fields_ = [('da', c_vp), ('ldda', c_i32), ('dpool', c_vp), ('lddp', c_i32), ('f', c_i32),
+                ('yraw', c_vp), ('ldy', c_i32),
+                ('scale', c_vp), ('shift', c_vp), ('mean', c_vp), ('rstd', c_vp),
+                ('sums', c_vp), ('sums_ld', c_i32), ('coef', c_vp),
+                ('dy', c_vp), ('lddy_out', c_i32), ('dbias', c_vp),
+                ('n', c_i32), ('h', c_i32), ('w_', c_i32), ('c', c_i32), ('dtype', c_i32)]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [('x', c_vp), ('ldx', c_i32), ('cin', c_i32),
+                ('in_scale', c_vp), ('in_shift', c_vp), ('w', c_vp), ('b', c_vp),
+                ('ncls', c_i32), ('activation', c_i32), ('thresh', c_f32),
+                ('probs', c_vp), ('classes', c_vp), ('dlogits', c_vp),
+                ('dx', c_vp), ('lddx', c_i32), ('dw', c_vp), ('db', c_vp),
+                ('npix', c_i64), ('dtype', c_i32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/satcv.h
+_SIGS = {
+    'satcv_version': (C.c_char_p, []),
+    'satcv_last_error': (C.c_char_p, []),
+    'satcv_device_info': (C.c_int, [C.POINTER(c_i32)]),
+    'satcv_ingest_nhwc': (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    'satcv_ingest_chw': (C.c_int, [c_vp, c_i32, c_f32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'satcv_pack_weights': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'satcv_conv2d_igemm': (C.c_int, [C.POINTER(ConvDesc), c_vp]),
+    'satcv_conv2d_wgrad_workspace': (c_i64, [C.POINTER(WgradDesc)]),
+    'satcv_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), c_vp]),
+    'satcv_bn_finalize_train': (C.c_int, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32,
+                                          c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'satcv_bn_affine_infer': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp]),
+    'satcv_bn_relu_pool': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'satcv_bn_bwd_reduce': (C.c_int, [C.POINTER(BnBwdDesc), c_vp]),
+    'satcv_bn_bwd_finalize': (C.c_int, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    'satcv_bn_bwd_apply': (C.c_int, [C.POINTER(BnBwdDesc), c_vp]),
+    'satcv_head_fwd': (C.c_int, [C.POINTER(HeadDesc), c_vp]),
+    'satcv_head_bwd': (C.c_int, [C.POINTER(HeadDesc), c_vp]),
+    'satcv_loss_fwd_bwd': (C.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_f32, c_vp, c_vp, c_vp]),
+    'satcv_confusion': (C.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
+    'satcv_adam_step': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp]),
+    'satcv_graph_begin': (C.c_int, [c_vp]),
+    'satcv_graph_end': (C.c_int, [c_vp, C.POINTER(c_vp)]),
+    'satcv_graph_launch': (C.c_int, [c_vp, c_vp]),
+    'satcv_graph_destroy': (C.c_int, [c_vp]),
+    'satcv_prof_enable': (C.c_int, [c_i32]),
+    'satcv_prof_collect': (C.c_int, [c_i32, C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+class SatcvError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} not found: the HIP extension is required (no CPU fallback). '
+            'Build it with `python -m satellite_computervision_amd.build` or __graft_entry__.build().')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)           # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise SatcvError(f'satcv error {rc}: {lib.satcv_last_error().decode()}')
+
+
+def call(name, *args):
+    check(getattr(lib, name)(*args))

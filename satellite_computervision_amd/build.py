@@ -1,0 +1,62 @@
+"""Builds libsatcv.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m satellite_computervision_amd.build
+
+One translation unit per .hip file, compiled in parallel, linked into
+satellite_computervision_amd/libsatcv.so.  hipcc cross-compiles without a GPU.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(HERE, 'libsatcv.so')
+OBJDIR = os.path.join(HERE, 'csrc', '_obj')
+SOURCES = ['api.hip', 'conv_igemm.hip', 'conv_wgrad.hip', 'elementwise.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
+         '-Wno-unused-variable', '-Wno-pass-failed']
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        h.update(open(p, 'rb').read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.hpp'))]
+    deps.append(os.path.join(os.path.dirname(HERE), 'include', 'satcv.h'))
+    stamp = os.path.join(OBJDIR, 'stamp')
+    dig = _digest(deps)
+    if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return OUT
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, src.replace('.hip', '.o'))
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {src}:\n{r.stderr[-6000:]}')
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr[-2000:])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stderr[-4000:]}')
+    open(stamp, 'w').write(dig)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,107 @@
+// C-ABI plumbing: error string, device info, hipGraph capture helpers, per-kernel-class
+// HIP-event profiling used by bench.py for the roofline numbers.
+#include "common.hpp"
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+void satcv_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* satcv_version(void) { return "satcv 0.1 (gfx950)"; }
+extern "C" const char* satcv_last_error(void) { return g_err; }
+
+extern "C" int satcv_device_info(int32_t* out4) {
+  SATCV_CHECK(out4, "device_info: null");
+  int dev = 0;
+  SATCV_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  SATCV_HIP(hipGetDeviceProperties(&p, dev));
+  out4[0] = p.multiProcessorCount;
+  out4[1] = (int32_t)p.maxSharedMemoryPerMultiProcessor;
+  out4[2] = p.warpSize;
+  int arch = 0;
+  sscanf(p.gcnArchName, "gfx%d", &arch);
+  out4[3] = arch;
+  return SATCV_OK;
+}
+
+// ---------------------------------------------------------------- graph capture
+extern "C" int satcv_graph_begin(void* stream) {
+  SATCV_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return SATCV_OK;
+}
+extern "C" int satcv_graph_end(void* stream, void** graph_exec_out) {
+  SATCV_CHECK(graph_exec_out, "graph_end: null out");
+  hipGraph_t g = nullptr;
+  SATCV_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) { satcv_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  *graph_exec_out = (void*)ge;
+  return SATCV_OK;
+}
+extern "C" int satcv_graph_launch(void* graph_exec, void* stream) {
+  SATCV_CHECK(graph_exec, "graph_launch: null");
+  SATCV_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return SATCV_OK;
+}
+extern "C" int satcv_graph_destroy(void* graph_exec) {
+  if (graph_exec) SATCV_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return SATCV_OK;
+}
+
+// -------------------------------------------------------------------- profiling
+// kind 0: 3x3 (and dilated) implicit-GEMM conv fwd/dgrad; 1: 1x1 / transposed-conv GEMMs;
+// 2: weight-gradient kernel.
+#define PROF_KINDS 3
+struct ProfRec { hipEvent_t a, b; double flops; };
+static std::mutex g_prof_mu;
+static int g_prof_mask = 0;
+static std::vector<ProfRec> g_prof[PROF_KINDS];
+static hipEvent_t g_prof_pending[PROF_KINDS];
+static double g_prof_pending_flops[PROF_KINDS];
+
+void satcv_prof_begin(int kind, double flops, hipStream_t st) {
+  if (!(g_prof_mask & (1 << kind))) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, st);
+  g_prof_pending[kind] = e;
+  g_prof_pending_flops[kind] = flops;
+}
+void satcv_prof_end(int kind, hipStream_t st) {
+  if (!(g_prof_mask & (1 << kind))) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, st);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof[kind].push_back({g_prof_pending[kind], e, g_prof_pending_flops[kind]});
+}
+extern "C" int satcv_prof_enable(int32_t kind_mask) {
+  g_prof_mask = kind_mask;
+  return SATCV_OK;
+}
+// Synchronises on the recorded events (call after the timed region) and clears them.
+extern "C" int satcv_prof_collect(int32_t kind, double* total_ms, int64_t* launches, double* flops) {
+  SATCV_CHECK(kind >= 0 && kind < PROF_KINDS && total_ms && launches && flops, "prof_collect: bad args");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double ms = 0, fl = 0;
+  for (auto& r : g_prof[kind]) {
+    (void)hipEventSynchronize(r.b);
+    float t = 0;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms += t;
+    fl += r.flops;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  *total_ms = ms; *launches = (int64_t)g_prof[kind].size(); *flops = fl;
+  g_prof[kind].clear();
+  return SATCV_OK;
+}

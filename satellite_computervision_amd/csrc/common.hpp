@@ -1,0 +1,89 @@
+// Shared device/host helpers for the satcv HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "../../include/satcv.h"
+
+typedef __bf16 bf16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using short4v = __attribute__((ext_vector_type(4))) short;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// thread-local last error (C ABI: int status + satcv_last_error()).
+void satcv_set_error(const char* fmt, ...);
+#define SATCV_CHECK(cond, ...)                        \
+  do {                                                \
+    if (!(cond)) {                                    \
+      satcv_set_error(__VA_ARGS__);                   \
+      return SATCV_ERR_INVALID;                       \
+    }                                                 \
+  } while (0)
+#define SATCV_HIP(call)                                                        \
+  do {                                                                         \
+    hipError_t e__ = (call);                                                   \
+    if (e__ != hipSuccess) {                                                   \
+      satcv_set_error("%s failed: %s", #call, hipGetErrorString(e__));         \
+      return SATCV_ERR_HIP;                                                    \
+    }                                                                          \
+  } while (0)
+
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- 8-element vectors of the storage type (16 B for bf16, 32 B for f32) ----
+template <typename T>
+struct Vec8;
+template <>
+struct Vec8<bf16> {
+  bf16x8 v;
+};
+template <>
+struct Vec8<float> {
+  float v[8];
+};
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&out)[8]) {
+  if constexpr (std::is_same<T, bf16>::value) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+  } else {
+    float4 a = reinterpret_cast<const float4*>(p)[0];
+    float4 b = reinterpret_cast<const float4*>(p)[1];
+    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
+    out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&in)[8]) {
+  if constexpr (std::is_same<T, bf16>::value) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)in[i];
+    *reinterpret_cast<bf16x8*>(p) = v;
+  } else {
+    reinterpret_cast<float4*>(p)[0] = make_float4(in[0], in[1], in[2], in[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(in[4], in[5], in[6], in[7]);
+  }
+}
+
+// value as it will read back from storage (bf16 rounding, identity for f32)
+template <typename T>
+__device__ __forceinline__ float round_to(float x) {
+  if constexpr (std::is_same<T, bf16>::value) return (float)(bf16)x;
+  else return x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// number of replica rows used for per-channel atomics (spreads contention; the
+// consumer sums the rows in fixed order).
+#define SATCV_STAT_REPL 32

@@ -1,0 +1,331 @@
+// Weight gradient of the implicit-GEMM convolutions on MFMA (gfx950).
+//
+//   dW[tap][ci][co] = sum_pixels  X[pixel + tap][ci] * dY[pixel][co]
+//
+// GEMM view: M = ci, N = co, K = pixels.  Both operands are stored pixel-major (NHWC), i.e.
+// K is the SLOW dimension of both, so the MFMA fragments (8 consecutive k per lane) are
+// gathered with the transposing LDS read ds_read_b64_tr_b16 (bf16) from row-major
+// [pixel][channel] LDS images; fp32 storage uses v_mfma_f32_32x32x2_f32 with one dword per
+// lane.  As in the forward kernel the 9 taps are address offsets of one halo image of X.
+// Each workgroup owns a (ci-block, co-block) of dW for ALL taps, walks a strided subset of
+// the pixel tiles (split-K) and writes an fp32 partial slab; a second kernel sums the slabs
+// in fixed order (deterministic) into the Keras-layout gradient.
+#include "common.hpp"
+
+struct WgradArgs {
+  const void* x0; const void* x1; int c0, c1;
+  const float* in_scale; const float* in_shift; int in_relu;
+  const void* dy; int lddy;
+  float* ws;
+  int n, h, w_;
+  int kh, kw, dil;
+  int mode_dy, f, cout_t;      // cout_t: channels per sub-position of a transposed conv
+  int kpad, npad;              // padded M (ci) and N (co) extents of the slab
+  int cin_lim, n_lim;          // valid channels in X / valid N indices
+  int tiles_x, tiles_y, ngroups, rpi, imgs, seg, rl, cl, halh, halw;
+  int n_ci_blk, n_co_blk, nsplit, total_ptiles;
+};
+
+template <int TW, int NCI, int NCO, int NTAPS, typename T>
+struct WgradGeom {
+  static constexpr int CI_T = 32 * NCI, CO_T = 32 * NCO;
+  // pixel pitch (elements): 64-byte rows are conflict-free for the transposing read; wider
+  // rows are padded by 64 bytes so that 4 consecutive pixels land on distinct bank groups.
+  static constexpr int PADE = 64 / (int)sizeof(T);
+  static constexpr int XP = CI_T + (CI_T == 32 && sizeof(T) == 2 ? 0 : PADE);
+  static constexpr int DP = CO_T + (CO_T == 32 && sizeof(T) == 2 ? 0 : PADE);
+};
+
+__device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
+  short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(p));
+  return __builtin_bit_cast(bf16x4, v);
+}
+
+template <typename T, int TW, int NCI, int NCO, int NTAPS>
+__global__ __launch_bounds__(NCI* NCO * 64) void wgrad_kernel(const WgradArgs a) {
+  using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
+  constexpr int NTHREADS = NCI * NCO * 64;
+  constexpr int BMPIX = 128;
+  constexpr int CI_T = G::CI_T, CO_T = G::CO_T, XP = G::XP, DP = G::DP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* ldsX = reinterpret_cast<T*>(smem_raw);
+  T* ldsD = ldsX + a.rl * a.cl * XP;
+  int* tab = reinterpret_cast<int*>(ldsD + BMPIX * DP);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wci = wave % NCI, wco = wave / NCI;
+  const int r = lane & 31, hh = lane >> 5;
+  const int ci_blk = blockIdx.x % a.n_ci_blk, co_blk = blockIdx.x / a.n_ci_blk;
+  const int sp = blockIdx.y;
+  const int ci0 = ci_blk * CI_T, co0 = co_blk * CO_T;
+
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  for (int q = tid; q < BMPIX; q += NTHREADS) {
+    const int t = q / TW, cx = q % TW;
+    const int k = t / a.rpi;
+    const int l0 = (k < a.imgs) ? k * a.seg + (t - k * a.rpi) : 0;
+    tab[q] = (l0 * a.cl + cx) * XP;
+  }
+
+  const T* dyp = reinterpret_cast<const T*>(a.dy);
+  const int x_items = a.rl * a.cl * (CI_T / 8);
+  constexpr int d_items = BMPIX * (CO_T / 8);
+  constexpr int TH = BMPIX / TW;
+
+  for (int pt = sp; pt < a.total_ptiles; pt += a.nsplit) {
+    int m = pt;
+    const int tx = m % a.tiles_x; m /= a.tiles_x;
+    const int ty = m % a.tiles_y;
+    const int grp = m / a.tiles_y;
+    const int n0 = grp * a.imgs, y0 = ty * TH, x0 = tx * TW;
+    __syncthreads();       // previous tile's fragment reads are done
+    // ---- stage X halo tile (all CI_T channels of this block), with the optional affine+ReLU
+    for (int it = tid; it < x_items; it += NTHREADS) {
+      const int g = it % (CI_T / 8);
+      const int pix = it / (CI_T / 8);
+      const int c = pix % a.cl;
+      const int L = pix / a.cl;
+      const int k = L / a.seg;
+      const int yy = L - k * a.seg - a.halh;
+      const int n = n0 + k, y = y0 + yy, x = x0 + c - a.halw;
+      const int cg = ci0 + g * 8;
+      float v[8];
+      const bool valid = (n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_) && (cg < a.cin_lim);
+      if (valid) {
+        const T* src; int cs, coff;
+        if (cg < a.c0) { src = reinterpret_cast<const T*>(a.x0); cs = a.c0; coff = cg; }
+        else { src = reinterpret_cast<const T*>(a.x1); cs = a.c1; coff = cg - a.c0; }
+        load8<T>(src + ((size_t)(n * a.h + y) * a.w_ + x) * cs + coff, v);
+        if (a.in_scale) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float t = v[e] * a.in_scale[cg + e] + a.in_shift[cg + e];
+            v[e] = a.in_relu ? fmaxf(t, 0.f) : t;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+      store8<T>(ldsX + (L * a.cl + c) * XP + g * 8, v);
+    }
+    // ---- stage dY tile
+    for (int it = tid; it < d_items; it += NTHREADS) {
+      const int g = it % (CO_T / 8);
+      const int q = it / (CO_T / 8);
+      const int t = q / TW, cx = q % TW;
+      const int k = t / a.rpi;
+      const int nimg = n0 + k, y = y0 + (t - k * a.rpi), x = x0 + cx;
+      const int cv = co0 + g * 8;
+      float v[8];
+      const bool valid = (k < a.imgs) && (nimg < a.n) && (y < a.h) && (x < a.w_) && (cv < a.n_lim);
+      if (valid) {
+        size_t off;
+        if (a.mode_dy == 1) {
+          const int ij = cv / a.cout_t, o = cv - ij * a.cout_t;
+          off = ((size_t)(nimg * a.h * a.f + y * a.f + ij / a.f) * (a.w_ * a.f) + x * a.f + ij % a.f) * a.lddy + o;
+        } else {
+          off = ((size_t)(nimg * a.h + y) * a.w_ + x) * a.lddy + cv;
+        }
+        load8<T>(dyp + off, v);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+      store8<T>(ldsD + q * DP + g * 8, v);
+    }
+    __syncthreads();
+    // ---- MFMA: 8 k-steps of 16 pixels
+    for (int ks = 0; ks < BMPIX / 16; ++ks) {
+      if constexpr (std::is_same<T, bf16>::value) {
+        const int gi = lane >> 4, i16 = lane & 15;
+        const int chb = 16 * (gi & 1) + 4 * (i16 & 3);
+        const int qa = ks * 16 + 8 * (gi >> 1) + (i16 >> 2);
+        const int qb = qa + 4;
+        bf16x4 blo = tr_read(ldsD + qa * DP + wco * 32 + chb);
+        bf16x4 bhi = tr_read(ldsD + qb * DP + wco * 32 + chb);
+        bf16x8 bfr = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const int xoa = tab[qa] + wci * 32 + chb;
+        const int xob = tab[qb] + wci * 32 + chb;
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+          const int ky = tap / 3, kx = tap % 3;
+          const int toff = (NTAPS == 1) ? 0 : ((ky * a.dil) * a.cl + kx * a.dil) * XP;
+          bf16x4 alo = tr_read(ldsX + xoa + toff);
+          bf16x4 ahi = tr_read(ldsX + xob + toff);
+          bf16x8 afr = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[tap], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = ks * 16 + 2 * j + hh;
+          const float b = ldsD[q * DP + wco * 32 + r];
+          const int xo = tab[q] + wci * 32 + r;
+#pragma unroll
+          for (int tap = 0; tap < NTAPS; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int toff = (NTAPS == 1) ? 0 : ((ky * a.dil) * a.cl + kx * a.dil) * XP;
+            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(ldsX[xo + toff], b, acc[tap], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- partial slab: ws[sp][tap][ci][co]
+#pragma unroll
+  for (int tap = 0; tap < NTAPS; ++tap) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ci = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      const int co = co0 + wco * 32 + r;
+      a.ws[((size_t)(sp * NTAPS + tap) * a.kpad + ci) * a.npad + co] = acc[tap][i];
+    }
+  }
+}
+
+// dw (Keras layout) = sum over slabs in fixed order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int taps, int kpad, int npad,
+                                    int cin, int nvalid, int transposed) {
+  const long long total = (long long)taps * cin * nvalid;
+  const size_t slab = (size_t)taps * kpad * npad;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(it % nvalid);
+    const int ci = (int)((it / nvalid) % cin);
+    const int tap = (int)(it / ((long long)nvalid * cin));
+    const float* p = ws + ((size_t)tap * kpad + ci) * npad + co;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += p[sp * slab];
+    if (transposed) dw[(size_t)co * cin + ci] = s;          // (f,f,cout,cin): index (ij*cout+o)*cin + ci
+    else dw[((size_t)tap * cin + ci) * nvalid + co] = s;    // (kh,kw,cin,cout)
+  }
+}
+
+// ------------------------------------------------------------------ host side
+struct WgradPlan { int tw, nci, nco, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk; size_t ws_bytes; };
+
+static int pick_tw_w(int w) {
+  int best = 8, bestpad = cdiv(w, 8) * 8;
+  const int cands[2] = {16, 32};
+  for (int i = 0; i < 2; ++i) { int p = cdiv(w, cands[i]) * cands[i]; if (p <= bestpad) { best = cands[i]; bestpad = p; } }
+  return best;
+}
+
+static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
+  const int cinx = d->c0 + d->c1;
+  const int nspace = d->mode_dy ? d->f * d->f * d->cout : d->cout;
+  p.ntaps = d->kh * d->kw;
+  if (!(p.ntaps == 1 || (d->kh == 3 && d->kw == 3))) { satcv_set_error("wgrad: only 1x1 and 3x3 taps"); return SATCV_ERR_UNSUPPORTED; }
+  p.tw = pick_tw_w(d->w_);
+  if (p.ntaps == 1) { p.nci = 1; p.nco = 4; }
+  else if (nspace % 128 == 0) { p.nci = 1; p.nco = 4; }
+  else if (nspace % 64 == 0) { p.nci = (cinx % 64 == 0 && (!d->x1 || d->c0 % 64 == 0)) ? 2 : 1; p.nco = 2; }
+  else { p.nci = (cinx % 64 == 0 && (!d->x1 || d->c0 % 64 == 0)) ? 2 : 1; p.nco = 1; }
+  const int ci_t = 32 * p.nci, co_t = 32 * p.nco;
+  p.n_ci_blk = cdiv(cinx, ci_t); p.n_co_blk = cdiv(nspace, co_t);
+  p.kpad = p.n_ci_blk * ci_t; p.npad = p.n_co_blk * co_t;
+  const int th = 128 / p.tw;
+  const int tiles_x = cdiv(d->w_, p.tw);
+  long long ptiles;
+  if (d->h >= th) ptiles = (long long)d->n * cdiv(d->h, th) * tiles_x;
+  else ptiles = (long long)cdiv(d->n, th / d->h) * tiles_x;
+  long long ns = cdiv(1536, p.n_ci_blk * p.n_co_blk);
+  if (ns > ptiles) ns = ptiles;
+  if (ns > 1024) ns = 1024;
+  if (ns < 1) ns = 1;
+  p.nsplit = (int)ns;
+  p.ws_bytes = (size_t)p.nsplit * p.ntaps * p.kpad * p.npad * sizeof(float);
+  return SATCV_OK;
+}
+
+extern "C" int64_t satcv_conv2d_wgrad_workspace(const satcv_wgrad_desc* d) {
+  WgradPlan p;
+  if (!d || wgrad_plan(d, p) != SATCV_OK) return -1;
+  return (int64_t)p.ws_bytes;
+}
+
+template <typename T, int TW, int NCI, int NCO, int NTAPS>
+static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st) {
+  using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
+  constexpr int TH = 128 / TW;
+  WgradArgs a;
+  a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_relu = d->in_relu;
+  a.dy = d->dy; a.lddy = d->lddy; a.ws = d->workspace;
+  a.n = d->n; a.h = d->h; a.w_ = d->w_; a.kh = d->kh; a.kw = d->kw; a.dil = d->dil;
+  a.mode_dy = d->mode_dy; a.f = d->f; a.cout_t = d->cout;
+  a.kpad = p.kpad; a.npad = p.npad;
+  a.cin_lim = d->c0 + d->c1; a.n_lim = d->mode_dy ? d->f * d->f * d->cout : d->cout;
+  a.halh = d->dil * (d->kh - 1) / 2; a.halw = d->dil * (d->kw - 1) / 2;
+  a.tiles_x = cdiv(d->w_, TW);
+  if (d->h >= TH) { a.rpi = TH; a.imgs = 1; a.tiles_y = cdiv(d->h, TH); a.ngroups = d->n; }
+  else { a.rpi = d->h; a.imgs = TH / d->h; a.tiles_y = 1; a.ngroups = cdiv(d->n, a.imgs); }
+  a.seg = a.rpi + 2 * a.halh; a.rl = a.imgs * a.seg; a.cl = TW + 2 * a.halw;
+  a.n_ci_blk = p.n_ci_blk; a.n_co_blk = p.n_co_blk; a.nsplit = p.nsplit;
+  a.total_ptiles = a.ngroups * a.tiles_y * a.tiles_x;
+  const size_t lds = ((size_t)a.rl * a.cl * G::XP + 128 * G::DP) * sizeof(T) + 128 * sizeof(int);
+  if (lds > 160 * 1024) { satcv_set_error("wgrad: LDS %zu too large", lds); return SATCV_ERR_UNSUPPORTED; }
+  auto kern = wgrad_kernel<T, TW, NCI, NCO, NTAPS>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  }
+  hipLaunchKernelGGL(kern, dim3(p.n_ci_blk * p.n_co_blk, p.nsplit), dim3(NCI * NCO * 64), lds, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { satcv_set_error("wgrad launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  return SATCV_OK;
+}
+
+template <typename T, int TW>
+static int wgrad_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st) {
+  if (p.ntaps == 1) return wgrad_launch<T, TW, 1, 4, 1>(d, p, st);
+  if (p.nci == 1 && p.nco == 4) return wgrad_launch<T, TW, 1, 4, 9>(d, p, st);
+  if (p.nci == 2 && p.nco == 2) return wgrad_launch<T, TW, 2, 2, 9>(d, p, st);
+  if (p.nci == 1 && p.nco == 2) return wgrad_launch<T, TW, 1, 2, 9>(d, p, st);
+  if (p.nci == 2 && p.nco == 1) return wgrad_launch<T, TW, 2, 1, 9>(d, p, st);
+  return wgrad_launch<T, TW, 1, 1, 9>(d, p, st);
+}
+template <typename T>
+static int wgrad_t(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st) {
+  switch (p.tw) {
+    case 32: return wgrad_cfg<T, 32>(d, p, st);
+    case 16: return wgrad_cfg<T, 16>(d, p, st);
+    default: return wgrad_cfg<T, 8>(d, p, st);
+  }
+}
+
+void satcv_prof_begin(int kind, double flops, hipStream_t st);
+void satcv_prof_end(int kind, hipStream_t st);
+
+extern "C" int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream) {
+  SATCV_CHECK(d && d->x0 && d->dy && d->dw && d->workspace, "wgrad: null pointer");
+  SATCV_CHECK(d->c0 > 0 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && (d->c1 == 0) == (d->x1 == nullptr), "wgrad: bad source channels");
+  SATCV_CHECK(d->cin > 0 && d->cin <= d->c0 + d->c1 && d->cout > 0, "wgrad: bad cin/cout");
+  SATCV_CHECK(d->n > 0 && d->h > 0 && d->w_ > 0 && d->dil >= 1, "wgrad: bad dims");
+  SATCV_CHECK(!d->mode_dy || (d->f >= 2 && d->kh == 1 && d->kw == 1 && d->cout % 8 == 0), "wgrad: transposed conv needs 1x1 taps, f>=2");
+  SATCV_CHECK(!d->x1 || d->c0 % 32 == 0, "wgrad: dual source needs c0 %% 32 == 0");
+  WgradPlan p;
+  int rc = wgrad_plan(d, p); if (rc) return rc;
+  SATCV_CHECK((size_t)d->workspace_bytes >= p.ws_bytes, "wgrad: workspace %lld < %zu", (long long)d->workspace_bytes, p.ws_bytes);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nvalid = d->mode_dy ? d->f * d->f * d->cout : d->cout;
+  const double flops = 2.0 * d->n * d->h * d->w_ * (double)nvalid * (double)(d->c0 + d->c1) * d->kh * d->kw;
+  satcv_prof_begin(2, flops, st);
+  if (d->dtype == SATCV_BF16) rc = wgrad_t<bf16>(d, p, st);
+  else if (d->dtype == SATCV_F32) rc = wgrad_t<float>(d, p, st);
+  else { satcv_set_error("wgrad: bad dtype"); rc = SATCV_ERR_INVALID; }
+  satcv_prof_end(2, st);
+  if (rc) return rc;
+  const long long total = (long long)p.ntaps * d->cin * nvalid;
+  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, d->workspace, d->dw, p.nsplit, p.ntaps, p.kpad, p.npad, d->cin, nvalid,
+                     d->transposed);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { satcv_set_error("wgrad reduce launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  return SATCV_OK;
+}

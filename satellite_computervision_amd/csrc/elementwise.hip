@@ -1,0 +1,644 @@
+// HBM-bound kernels of the U-Net path: ingest, weight packing, BatchNorm statistics /
+// apply / backward, ReLU + max-pool, softmax/sigmoid head, losses, confusion matrix, Adam.
+// All are vectorised over 8 channels (16 B bf16 / 32 B f32 per lane) of NHWC tensors.
+#include "common.hpp"
+
+#define EW_BLOCK 256
+static inline int ew_grid(long long items, int cap = 256 * 8) {
+  long long b = (items + EW_BLOCK - 1) / EW_BLOCK;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+#define LAUNCH_OK(name)                                                          \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      satcv_set_error(name " launch: %s", hipGetErrorString(e__));               \
+      return SATCV_ERR_HIP;                                                      \
+    }                                                                            \
+  } while (0)
+#define DISPATCH_T(dtype, ...)                                                   \
+  do {                                                                           \
+    if ((dtype) == SATCV_BF16) { using T = bf16; __VA_ARGS__; }                  \
+    else if ((dtype) == SATCV_F32) { using T = float; __VA_ARGS__; }             \
+    else { satcv_set_error("bad dtype %d", (int)(dtype)); return SATCV_ERR_INVALID; } \
+  } while (0)
+
+// ------------------------------------------------------------------------ ingest
+template <typename T>
+__global__ void ingest_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, long long npix, int c, int cpad) {
+  const int G = cpad / 8;
+  const long long total = npix * G;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+    const long long p = it / G; const int g = (int)(it % G);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int ch = g * 8 + e; v[e] = ch < c ? src[p * c + ch] : 0.f; }
+    store8<T>(dst + p * cpad + g * 8, v);
+  }
+}
+extern "C" int satcv_ingest_nhwc(const float* src, void* dst, int64_t npix, int32_t c, int32_t cpad, int32_t dtype, void* stream) {
+  SATCV_CHECK(src && dst && npix > 0 && c > 0 && cpad >= c && cpad % 8 == 0, "ingest_nhwc: bad args");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(ingest_nhwc_kernel<T>, dim3(ew_grid(npix * (cpad / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, src, (T*)dst, (long long)npix, c, cpad));
+  LAUNCH_OK("ingest_nhwc");
+  return SATCV_OK;
+}
+
+template <typename T, typename S>
+__global__ void ingest_chw_kernel(const S* __restrict__ src, float scale, T* __restrict__ dst, int n, int c, int hw, int cpad) {
+  const int G = cpad / 8;
+  const long long total = (long long)n * hw * G;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(it / ((long long)n * hw));           // group slowest: planes read coalesced
+    const long long p = it % ((long long)n * hw);
+    const long long img = p / hw; const int pix = (int)(p % hw);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = g * 8 + e;
+      v[e] = ch < c ? (float)src[(img * c + ch) * hw + pix] * scale : 0.f;
+    }
+    store8<T>(dst + p * cpad + g * 8, v);
+  }
+}
+extern "C" int satcv_ingest_chw(const void* src, int32_t src_kind, float scale, void* dst, int32_t n, int32_t c, int32_t h, int32_t w, int32_t cpad, int32_t dtype, void* stream) {
+  SATCV_CHECK(src && dst && n > 0 && c > 0 && cpad >= c && cpad % 8 == 0, "ingest_chw: bad args");
+  const int hw = h * w; const int grid = ew_grid((long long)n * hw * (cpad / 8));
+  DISPATCH_T(dtype, {
+    if (src_kind == 0) hipLaunchKernelGGL((ingest_chw_kernel<T, uint8_t>), dim3(grid), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const uint8_t*)src, scale, (T*)dst, n, c, hw, cpad);
+    else if (src_kind == 1) hipLaunchKernelGGL((ingest_chw_kernel<T, uint16_t>), dim3(grid), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const uint16_t*)src, scale, (T*)dst, n, c, hw, cpad);
+    else if (src_kind == 2) hipLaunchKernelGGL((ingest_chw_kernel<T, float>), dim3(grid), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const float*)src, scale, (T*)dst, n, c, hw, cpad);
+    else { satcv_set_error("ingest_chw: src_kind %d", src_kind); return SATCV_ERR_INVALID; }
+  });
+  LAUNCH_OK("ingest_chw");
+  return SATCV_OK;
+}
+
+// ------------------------------------------------------------------ weight packing
+// mode 0: conv fwd    dst[tap][k8][npad][8], k = ci, n = co          src HWIO (tap,ci,co)
+// mode 1: conv dgrad  dst[tap'][k8][npad][8], k = co, n = ci, tap' flipped
+// mode 2: convT fwd   dst[0][k8][npad][8], k = ci, n = (ij)*cout+o   src (ij,o,ci)
+// mode 3: convT dgrad dst[0][k8][npad][8], k = (ij)*cout+o, n = ci
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int mode, int taps, int cin, int cout, int kpad, int npad) {
+  const int ptaps = (mode >= 2) ? 1 : taps;
+  const long long total = (long long)ptaps * (kpad / 8) * npad;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+    const int nn = (int)(it % npad);
+    const int k8 = (int)((it / npad) % (kpad / 8));
+    const int tap = (int)(it / ((long long)npad * (kpad / 8)));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k8 * 8 + e;
+      float x = 0.f;
+      if (mode == 0) { if (k < cin && nn < cout) x = src[((size_t)tap * cin + k) * cout + nn]; }
+      else if (mode == 1) { if (k < cout && nn < cin) x = src[((size_t)(taps - 1 - tap) * cin + nn) * cout + k]; }
+      else if (mode == 2) { if (k < cin && nn < taps * cout) x = src[(size_t)nn * cin + k]; }
+      else { if (k < taps * cout && nn < cin) x = src[(size_t)k * cin + nn]; }
+      v[e] = x;
+    }
+    store8<T>(dst + it * 8, v);
+  }
+}
+static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
+extern "C" int satcv_pack_weights(const float* src, void* dst_fwd, void* dst_dgrad, int32_t kh, int32_t kw, int32_t cin, int32_t cout, int32_t cin_pad, int32_t transposed, int32_t dtype, void* stream) {
+  SATCV_CHECK(src && cin > 0 && cout > 0 && cin_pad >= cin && cin_pad % 16 == 0, "pack_weights: bad args");
+  const int taps = kh * kw;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype, {
+    if (!transposed) {
+      if (dst_fwd) { const int kp = cin_pad, np = rup(cout, 32);
+        hipLaunchKernelGGL(pack_kernel<T>, dim3(ew_grid((long long)taps * (kp / 8) * np)), dim3(EW_BLOCK), 0, st, src, (T*)dst_fwd, 0, taps, cin, cout, kp, np); }
+      if (dst_dgrad) { const int kp = rup(cout, 16), np = rup(cin, 32);
+        hipLaunchKernelGGL(pack_kernel<T>, dim3(ew_grid((long long)taps * (kp / 8) * np)), dim3(EW_BLOCK), 0, st, src, (T*)dst_dgrad, 1, taps, cin, cout, kp, np); }
+    } else {
+      if (dst_fwd) { const int kp = cin_pad, np = rup(taps * cout, 32);
+        hipLaunchKernelGGL(pack_kernel<T>, dim3(ew_grid((long long)(kp / 8) * np)), dim3(EW_BLOCK), 0, st, src, (T*)dst_fwd, 2, taps, cin, cout, kp, np); }
+      if (dst_dgrad) { const int kp = rup(taps * cout, 16), np = rup(cin, 32);
+        hipLaunchKernelGGL(pack_kernel<T>, dim3(ew_grid((long long)(kp / 8) * np)), dim3(EW_BLOCK), 0, st, src, (T*)dst_dgrad, 3, taps, cin, cout, kp, np); }
+    }
+  });
+  LAUNCH_OK("pack_weights");
+  return SATCV_OK;
+}
+
+// -------------------------------------------------------------------- BN finalize
+__global__ void bn_finalize_train_kernel(float* stats, int ld, int c, float count, const float* gamma, const float* beta,
+                                         float eps, float momentum, int updates, int bessel, float* mm, float* mv,
+                                         float* scale, float* shift, float* mean_o, float* rstd_o) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = 0; r < SATCV_STAT_ROWS; ++r) {
+    float* row = stats + (size_t)r * 2 * ld;
+    s1 += row[ch]; s2 += row[ld + ch];
+    row[ch] = 0.f; row[ld + ch] = 0.f;
+  }
+  const float mean = s1 / count;
+  float var = s2 / count - mean * mean;
+  var = fmaxf(var, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  const float sc = gamma[ch] * rstd;
+  scale[ch] = sc; shift[ch] = beta[ch] - mean * sc;
+  mean_o[ch] = mean; rstd_o[ch] = rstd;
+  if (mm) {
+    const float vv = bessel ? var * (count / fmaxf(count - 1.f, 1.f)) : var;
+    float a = mm[ch], b = mv[ch];
+    for (int u = 0; u < updates; ++u) { a = a * momentum + mean * (1.f - momentum); b = b * momentum + vv * (1.f - momentum); }
+    mm[ch] = a; mv[ch] = b;
+  }
+}
+extern "C" int satcv_bn_finalize_train(float* stats, int32_t stats_ld, int32_t c, float count, const float* gamma, const float* beta,
+                                       float eps, float momentum, int32_t updates, int32_t bessel, float* moving_mean, float* moving_var,
+                                       float* scale, float* shift, float* mean, float* rstd, void* stream) {
+  SATCV_CHECK(stats && gamma && beta && scale && shift && mean && rstd && c > 0 && stats_ld >= c && count > 0, "bn_finalize_train: bad args");
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(cdiv(c, 128)), dim3(128), 0, (hipStream_t)stream, stats, stats_ld, c, count, gamma, beta,
+                     eps, momentum, updates, bessel, moving_mean, moving_var, scale, shift, mean, rstd);
+  LAUNCH_OK("bn_finalize_train");
+  return SATCV_OK;
+}
+__global__ void bn_affine_infer_kernel(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, int c, float* scale, float* shift) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const float sc = gamma[ch] / sqrtf(mv[ch] + eps);
+  scale[ch] = sc; shift[ch] = beta[ch] - mm[ch] * sc;
+}
+extern "C" int satcv_bn_affine_infer(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps, int32_t c, float* scale, float* shift, void* stream) {
+  SATCV_CHECK(gamma && beta && moving_mean && moving_var && scale && shift && c > 0, "bn_affine_infer: bad args");
+  hipLaunchKernelGGL(bn_affine_infer_kernel, dim3(cdiv(c, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, moving_mean, moving_var, eps, c, scale, shift);
+  LAUNCH_OK("bn_affine_infer");
+  return SATCV_OK;
+}
+
+// Block-level per-channel accumulation into LDS then one global atomic per channel per block.
+// Threads iterate items = (window, group) with a stride that is a multiple of G so that a
+// thread's channel group never changes.
+__device__ __forceinline__ void block_channel_reduce(float* lds, const float (&a)[8], const float (&b)[8], int g, bool active,
+                                                     int c, float* out, int out_ld) {
+  for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(&lds[g * 8 + e], a[e]); atomicAdd(&lds[c + g * 8 + e], b[e]); }
+  }
+  __syncthreads();
+  float* row = out + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * out_ld;
+  for (int i = threadIdx.x; i < c; i += blockDim.x) { atomicAdd(row + i, lds[i]); atomicAdd(row + out_ld + i, lds[c + i]); }
+}
+
+// ------------------------------------------------------------- BN + ReLU + maxpool
+template <typename T>
+__global__ void bn_relu_pool_kernel(const T* __restrict__ yraw, const float* __restrict__ scale, const float* __restrict__ shift,
+                                    T* __restrict__ act, T* __restrict__ pooled, float* stats, int stats_ld,
+                                    int n, int h, int w, int c, int f) {
+  extern __shared__ float lds[];
+  const int G = c / 8;
+  const int hp = h / f, wp = w / f;               // 'valid' pooling
+  const int hw_ = cdiv(h, f), ww = cdiv(w, f);    // windows incl. partial ones (act must cover every pixel)
+  const long long total = (long long)n * hw_ * ww * G;
+  const long long nthreads = (long long)gridDim.x * blockDim.x;
+  const long long stride = nthreads / G * G;
+  const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int g = (int)(gid % G);
+  float sc[8], sh[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = scale[g * 8 + e]; sh[e] = shift[g * 8 + e]; s1[e] = 0.f; s2[e] = 0.f; }
+  const bool active = gid < stride;
+  if (active) {
+    for (long long it = gid; it < total; it += stride) {
+      long long wdw = it / G;
+      const int px = (int)(wdw % ww); wdw /= ww;
+      const int py = (int)(wdw % hw_);
+      const int img = (int)(wdw / hw_);
+      float mx[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
+      for (int i = 0; i < f; ++i) {
+        const int y = py * f + i; if (y >= h) break;
+        for (int j = 0; j < f; ++j) {
+          const int x = px * f + j; if (x >= w) break;
+          const size_t off = ((size_t)(img * h + y) * w + x) * c + g * 8;
+          float v[8];
+          load8<T>(yraw + off, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float a = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+            a = round_to<T>(a);
+            v[e] = a; mx[e] = fmaxf(mx[e], a); s1[e] += a; s2[e] += a * a;
+          }
+          if (act) store8<T>(act + off, v);
+        }
+      }
+      if (pooled && py < hp && px < wp) store8<T>(pooled + ((size_t)(img * hp + py) * wp + px) * c + g * 8, mx);
+    }
+  }
+  if (stats) block_channel_reduce(lds, s1, s2, g, active, c, stats, stats_ld);
+}
+extern "C" int satcv_bn_relu_pool(const void* yraw, const float* scale, const float* shift, void* act, void* pooled, float* stats,
+                                  int32_t stats_ld, int32_t n, int32_t h, int32_t w_, int32_t c, int32_t f, int32_t dtype, void* stream) {
+  SATCV_CHECK(yraw && scale && shift && n > 0 && h > 0 && w_ > 0 && c > 0 && c % 8 == 0 && c <= 2048 && f >= 1, "bn_relu_pool: bad args");
+  const long long items = (long long)n * cdiv(h, f) * cdiv(w_, f) * (c / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_pool_kernel<T>, dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? 2 * c * sizeof(float) : 0, (hipStream_t)stream,
+                                       (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f));
+  LAUNCH_OK("bn_relu_pool");
+  return SATCV_OK;
+}
+
+// -------------------------------------------------------------------- BN backward
+// APPLY=false: accumulate sum g, sum g*xhat.  APPLY=true: write dy, optional dbias.
+template <typename T, bool APPLY>
+__global__ void bn_bwd_kernel(const satcv_bnbwd_desc d) {
+  extern __shared__ float lds[];
+  const int c = d.c, f = d.dpool ? d.f : 1;
+  const int G = c / 8;
+  const int h = d.h, w = d.w_;
+  const int hp = h / f, wp = w / f, hw_ = cdiv(h, f), ww = cdiv(w, f);
+  const long long total = (long long)d.n * hw_ * ww * G;
+  const long long nthreads = (long long)gridDim.x * blockDim.x;
+  const long long stride = nthreads / G * G;
+  const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int g = (int)(gid % G);
+  const T* da = (const T*)d.da; const T* dp = (const T*)d.dpool; const T* yr = (const T*)d.yraw; T* dy = (T*)d.dy;
+  float sc[8], sh[8], mu[8], rs[8], c1[8], c2[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = g * 8 + e;
+    sc[e] = d.scale[ch]; sh[e] = d.shift[ch]; mu[e] = d.mean[ch]; rs[e] = d.rstd[ch];
+    c1[e] = APPLY ? d.coef[ch] : 0.f; c2[e] = APPLY ? d.coef[c + ch] : 0.f;
+    s1[e] = 0.f; s2[e] = 0.f;
+  }
+  const bool active = gid < stride;
+  if (active) {
+    for (long long it = gid; it < total; it += stride) {
+      long long wdw = it / G;
+      const int px = (int)(wdw % ww); wdw /= ww;
+      const int py = (int)(wdw % hw_);
+      const int img = (int)(wdw / hw_);
+      // first arg-max of the activated window (only when routing a pooled gradient)
+      int am[8]; float gp[8];
+      const bool full = dp && py < hp && px < wp;
+      if (full) {
+        float mx[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; am[e] = 0; }
+        for (int i = 0; i < f; ++i) for (int j = 0; j < f; ++j) {
+          float v[8];
+          load8<T>(yr + ((size_t)(img * h + py * f + i) * w + px * f + j) * d.ldy + g * 8, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float a = round_to<T>(fmaxf(v[e] * sc[e] + sh[e], 0.f));
+            if (a > mx[e]) { mx[e] = a; am[e] = i * f + j; }
+          }
+        }
+        load8<T>(dp + ((size_t)(img * hp + py) * wp + px) * d.lddp + g * 8, gp);
+      }
+      for (int i = 0; i < f; ++i) {
+        const int y = py * f + i; if (y >= h) break;
+        for (int j = 0; j < f; ++j) {
+          const int x = px * f + j; if (x >= w) break;
+          const size_t pix = (size_t)(img * h + y) * w + x;
+          float v[8], gr[8];
+          load8<T>(yr + pix * d.ldy + g * 8, v);
+          if (da) load8<T>(da + pix * d.ldda + g * 8, gr);
+          else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gr[e] = 0.f;
+          }
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float gg = gr[e];
+            if (full && am[e] == i * f + j) gg += gp[e];
+            const float a = v[e] * sc[e] + sh[e];
+            gg = a > 0.f ? gg : 0.f;
+            const float xh = (v[e] - mu[e]) * rs[e];
+            if (APPLY) { const float t = sc[e] * (gg - c1[e] - xh * c2[e]); o[e] = round_to<T>(t); s1[e] += o[e]; }
+            else { s1[e] += gg; s2[e] += gg * xh; }
+          }
+          if (APPLY) store8<T>(dy + pix * d.lddy_out + g * 8, o);
+        }
+      }
+    }
+  }
+  if (!APPLY) block_channel_reduce(lds, s1, s2, g, active, c, d.sums, d.sums_ld);
+  else if (d.dbias) {
+    for (int i = threadIdx.x; i < c; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(&lds[g * 8 + e], s1[e]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(d.dbias + i, lds[i]);
+  }
+}
+static int bnbwd_check(const satcv_bnbwd_desc* d, bool apply) {
+  SATCV_CHECK(d && d->yraw && d->scale && d->shift && d->mean && d->rstd, "bn_bwd: null pointer");
+  SATCV_CHECK(d->da || d->dpool, "bn_bwd: no incoming gradient");
+  SATCV_CHECK(d->c > 0 && d->c % 8 == 0 && d->c <= 2048 && d->n > 0 && d->h > 0 && d->w_ > 0, "bn_bwd: bad dims");
+  SATCV_CHECK(!d->dpool || d->f >= 1, "bn_bwd: pool factor");
+  if (apply) SATCV_CHECK(d->coef && d->dy, "bn_bwd_apply: coef/dy missing");
+  else SATCV_CHECK(d->sums && d->sums_ld >= d->c, "bn_bwd_reduce: sums missing");
+  return SATCV_OK;
+}
+extern "C" int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream) {
+  int rc = bnbwd_check(d, false); if (rc) return rc;
+  const int f = d->dpool ? d->f : 1;
+  const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
+  DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), 2 * d->c * sizeof(float), (hipStream_t)stream, *d));
+  LAUNCH_OK("bn_bwd_reduce");
+  return SATCV_OK;
+}
+extern "C" int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream) {
+  int rc = bnbwd_check(d, true); if (rc) return rc;
+  const int f = d->dpool ? d->f : 1;
+  const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
+  DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), d->c * sizeof(float), (hipStream_t)stream, *d));
+  LAUNCH_OK("bn_bwd_apply");
+  return SATCV_OK;
+}
+__global__ void bn_bwd_finalize_kernel(float* sums, int ld, int c, float count, float* dgamma, float* dbeta, float* coef) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = 0; r < SATCV_STAT_ROWS; ++r) {
+    float* row = sums + (size_t)r * 2 * ld;
+    s1 += row[ch]; s2 += row[ld + ch];
+    row[ch] = 0.f; row[ld + ch] = 0.f;
+  }
+  if (dbeta) dbeta[ch] = s1;
+  if (dgamma) dgamma[ch] = s2;
+  coef[ch] = s1 / count; coef[c + ch] = s2 / count;
+}
+extern "C" int satcv_bn_bwd_finalize(float* sums, int32_t sums_ld, int32_t c, float count, float* dgamma, float* dbeta, float* coef, void* stream) {
+  SATCV_CHECK(sums && coef && c > 0 && sums_ld >= c && count > 0, "bn_bwd_finalize: bad args");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 128)), dim3(128), 0, (hipStream_t)stream, sums, sums_ld, c, count, dgamma, dbeta, coef);
+  LAUNCH_OK("bn_bwd_finalize");
+  return SATCV_OK;
+}
+
+// --------------------------------------------------------------------------- head
+#define HEAD_NCMAX 8
+template <typename T>
+__global__ void head_fwd_kernel(const satcv_head_desc d) {
+  extern __shared__ float lds[];                     // w[cin][ncls], b[ncls], scale[cin], shift[cin]
+  const int cin = d.cin, nc = d.ncls;
+  float* lw = lds; float* lb = lw + cin * nc; float* lsc = lb + nc; float* lsh = lsc + cin;
+  for (int i = threadIdx.x; i < cin * nc; i += blockDim.x) lw[i] = d.w[i];
+  for (int i = threadIdx.x; i < nc; i += blockDim.x) lb[i] = d.b[i];
+  for (int i = threadIdx.x; i < cin; i += blockDim.x) { lsc[i] = d.in_scale ? d.in_scale[i] : 1.f; lsh[i] = d.in_shift ? d.in_shift[i] : 0.f; }
+  __syncthreads();
+  const T* x = (const T*)d.x;
+  const bool tr = d.in_scale != nullptr;
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < d.npix; p += (long long)gridDim.x * blockDim.x) {
+    float z[HEAD_NCMAX];
+#pragma unroll
+    for (int k = 0; k < HEAD_NCMAX; ++k) z[k] = k < nc ? lb[k] : -INFINITY;
+    for (int g = 0; g < cin / 8; ++g) {
+      float v[8];
+      load8<T>(x + p * d.ldx + g * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = g * 8 + e;
+        const float a = tr ? fmaxf(v[e] * lsc[ch] + lsh[ch], 0.f) : v[e];
+#pragma unroll
+        for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) z[k] += a * lw[ch * nc + k];
+      }
+    }
+    if (d.activation == 0) {
+      float mx = z[0]; int am = 0;
+#pragma unroll
+      for (int k = 1; k < HEAD_NCMAX; ++k) if (k < nc && z[k] > mx) { mx = z[k]; }
+      float s = 0.f, ex[HEAD_NCMAX];
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) { ex[k] = k < nc ? expf(z[k] - mx) : 0.f; s += ex[k]; }
+      const float inv = 1.f / s;
+      float best = -1.f;
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) {
+        const float pr = ex[k] * inv;
+        d.probs[p * nc + k] = pr;
+        if (pr > best) { best = pr; am = k; }          // ties -> lowest index (tf.argmax)
+      }
+      if (d.classes) d.classes[p] = am;
+    } else {
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) {
+        const float pr = 1.f / (1.f + expf(-z[k]));
+        d.probs[p * nc + k] = pr;
+        if (d.classes) d.classes[p * nc + k] = pr > d.thresh ? 1 : 0;
+      }
+    }
+  }
+}
+extern "C" int satcv_head_fwd(const satcv_head_desc* d, void* stream) {
+  SATCV_CHECK(d && d->x && d->w && d->b && d->probs, "head_fwd: null pointer");
+  SATCV_CHECK(d->cin > 0 && d->cin % 8 == 0 && d->ncls >= 1 && d->ncls <= HEAD_NCMAX && d->npix > 0, "head_fwd: bad dims (cin=%d ncls=%d)", d->cin, d->ncls);
+  const size_t lds = (size_t)(d->cin * d->ncls + d->ncls + 2 * d->cin) * sizeof(float);
+  DISPATCH_T(d->dtype, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(ew_grid(d->npix)), dim3(EW_BLOCK), lds, (hipStream_t)stream, *d));
+  LAUNCH_OK("head_fwd");
+  return SATCV_OK;
+}
+
+// dx[p][c] = sum_k dl[p][k] w[c][k];  dw[c][k] += sum_p a[p][c] dl[p][k];  db[k] += sum_p dl[p][k]
+template <typename T>
+__global__ void head_bwd_kernel(const satcv_head_desc d) {
+  extern __shared__ float lds[];                     // w[cin][ncls], scale, shift, accw[cin][ncls], accb[ncls]
+  const int cin = d.cin, nc = d.ncls;
+  float* lw = lds; float* lsc = lw + cin * nc; float* lsh = lsc + cin; float* aw = lsh + cin; float* ab = aw + cin * nc;
+  for (int i = threadIdx.x; i < cin * nc; i += blockDim.x) { lw[i] = d.w[i]; aw[i] = 0.f; }
+  for (int i = threadIdx.x; i < nc; i += blockDim.x) ab[i] = 0.f;
+  for (int i = threadIdx.x; i < cin; i += blockDim.x) { lsc[i] = d.in_scale ? d.in_scale[i] : 1.f; lsh[i] = d.in_shift ? d.in_shift[i] : 0.f; }
+  __syncthreads();
+  const T* x = (const T*)d.x; T* dx = (T*)d.dx;
+  const bool tr = d.in_scale != nullptr;
+  const int lane = threadIdx.x & 63;
+  for (int g = 0; g < cin / 8; ++g) {
+    float acc[8][HEAD_NCMAX];
+    float accb[HEAD_NCMAX];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) acc[e][k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < HEAD_NCMAX; ++k) accb[k] = 0.f;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < d.npix; p += (long long)gridDim.x * blockDim.x) {
+      float dl[HEAD_NCMAX];
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) dl[k] = k < nc ? d.dlogits[p * nc + k] : 0.f;
+      float v[8], o[8];
+      load8<T>(x + p * d.ldx + g * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = g * 8 + e;
+        const float a = tr ? fmaxf(v[e] * lsc[ch] + lsh[ch], 0.f) : v[e];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) { s += dl[k] * lw[ch * nc + k]; acc[e][k] += a * dl[k]; }
+        o[e] = s;
+      }
+      if (dx) store8<T>(dx + p * d.lddx + g * 8, o);
+      if (g == 0) {
+#pragma unroll
+        for (int k = 0; k < HEAD_NCMAX; ++k) accb[k] += dl[k];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) {
+        const float s = wave_sum(acc[e][k]);
+        if (lane == 0) atomicAdd(&aw[(g * 8 + e) * nc + k], s);
+      }
+    if (g == 0) {
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) { const float s = wave_sum(accb[k]); if (lane == 0) atomicAdd(&ab[k], s); }
+    }
+  }
+  __syncthreads();
+  if (d.dw) for (int i = threadIdx.x; i < cin * nc; i += blockDim.x) atomicAdd(d.dw + i, aw[i]);
+  if (d.db) for (int i = threadIdx.x; i < nc; i += blockDim.x) atomicAdd(d.db + i, ab[i]);
+}
+extern "C" int satcv_head_bwd(const satcv_head_desc* d, void* stream) {
+  SATCV_CHECK(d && d->x && d->w && d->dlogits, "head_bwd: null pointer");
+  SATCV_CHECK(d->cin > 0 && d->cin % 8 == 0 && d->ncls >= 1 && d->ncls <= HEAD_NCMAX && d->npix > 0, "head_bwd: bad dims");
+  const size_t lds = (size_t)(2 * d->cin * d->ncls + d->ncls + 2 * d->cin) * sizeof(float);
+  DISPATCH_T(d->dtype, hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(ew_grid(d->npix, 1024)), dim3(EW_BLOCK), lds, (hipStream_t)stream, *d));
+  LAUNCH_OK("head_bwd");
+  return SATCV_OK;
+}
+
+// ------------------------------------------------------------------------- losses
+__global__ void loss_kernel(int kind, const float* __restrict__ probs, const float* __restrict__ yt, const float* __restrict__ wts,
+                            int nc, int activation, long long npix, float grad_scale, float* loss_out, float* dlogits) {
+  __shared__ float red[EW_BLOCK / 64];
+  float lsum = 0.f;
+  const float inv_n = 1.f / (float)npix;
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+    float pr[HEAD_NCMAX], t[HEAD_NCMAX], gp[HEAD_NCMAX];
+#pragma unroll
+    for (int k = 0; k < HEAD_NCMAX; ++k) { pr[k] = k < nc ? probs[p * nc + k] : 0.f; t[k] = k < nc ? yt[p * nc + k] : 0.f; gp[k] = 0.f; }
+    if (kind == 0) {            // weighted categorical cross-entropy, mean over pixels
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) s += pr[k];
+      const float lo = 1e-7f, hi = 1.f - 1e-7f;
+      float G[HEAD_NCMAX], dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) {
+        G[k] = 0.f;
+        if (k < nc) {
+          const float o = pr[k] / s;
+          const float oc = fminf(fmaxf(o, lo), hi);
+          lsum += -wts[k] * t[k] * logf(oc) * inv_n;
+          const bool inside = (o >= lo) && (o <= hi);
+          G[k] = inside ? -wts[k] * t[k] / oc * inv_n : 0.f;
+          dot += G[k] * o;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) gp[k] = (G[k] - dot) / s;
+    } else {                    // weighted BCE on probabilities, mean over pixels*classes
+      const float pw = wts[0], lo = 0.00001f, hi = 0.99999f;
+      const float inv_e = inv_n / (float)nc;
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) {
+        const float yp = fminf(fmaxf(pr[k], lo), hi);
+        lsum += (t[k] * -logf(yp) * pw + (1.f - t[k]) * -logf(1.f - yp)) * inv_e;
+        const bool inside = (pr[k] >= lo) && (pr[k] <= hi);
+        gp[k] = inside ? (-t[k] * pw / yp + (1.f - t[k]) / (1.f - yp)) * inv_e : 0.f;
+      }
+    }
+    if (activation == 0) {      // softmax Jacobian
+      float dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) dot += gp[k] * pr[k];
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) dlogits[p * nc + k] = grad_scale * pr[k] * (gp[k] - dot);
+    } else {
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) dlogits[p * nc + k] = grad_scale * gp[k] * pr[k] * (1.f - pr[k]);
+    }
+  }
+  lsum = wave_sum(lsum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < EW_BLOCK / 64; ++i) s += red[i]; atomicAdd(loss_out, s); }
+}
+extern "C" int satcv_loss_fwd_bwd(int32_t kind, const float* probs, const float* y_true, const float* weights, int32_t ncls, int32_t activation,
+                                  int64_t npix, float grad_scale, float* loss_out, float* dlogits, void* stream) {
+  SATCV_CHECK(probs && y_true && weights && loss_out && dlogits, "loss: null pointer");
+  SATCV_CHECK((kind == 0 || kind == 1) && ncls >= 1 && ncls <= HEAD_NCMAX && npix > 0, "loss: bad args (kind=%d ncls=%d)", kind, ncls);
+  hipLaunchKernelGGL(loss_kernel, dim3(ew_grid(npix, 1024)), dim3(EW_BLOCK), 0, (hipStream_t)stream, kind, probs, y_true, weights, ncls, activation,
+                     (long long)npix, grad_scale, loss_out, dlogits);
+  LAUNCH_OK("loss");
+  return SATCV_OK;
+}
+
+// --------------------------------------------------------------------- confusion
+__global__ void confusion_kernel(const int32_t* __restrict__ classes, const float* __restrict__ yt, int nc, long long npix, unsigned long long* conf) {
+  __shared__ unsigned int cnt[HEAD_NCMAX * HEAD_NCMAX];
+  for (int i = threadIdx.x; i < nc * nc; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+    int t = 0; float best = yt[p * nc];
+    for (int k = 1; k < nc; ++k) { const float v = yt[p * nc + k]; if (v > best) { best = v; t = k; } }
+    int pc = classes[p]; pc = pc < 0 ? 0 : (pc >= nc ? nc - 1 : pc);
+    atomicAdd(&cnt[t * nc + pc], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nc * nc; i += blockDim.x) if (cnt[i]) atomicAdd(conf + i, (unsigned long long)cnt[i]);
+}
+extern "C" int satcv_confusion(const int32_t* classes, const float* y_true, int32_t ncls, int64_t npix, int64_t* confusion, void* stream) {
+  SATCV_CHECK(classes && y_true && confusion && ncls >= 1 && ncls <= HEAD_NCMAX && npix > 0, "confusion: bad args");
+  hipLaunchKernelGGL(confusion_kernel, dim3(ew_grid(npix, 512)), dim3(EW_BLOCK), 0, (hipStream_t)stream, classes, y_true, ncls, (long long)npix, (unsigned long long*)confusion);
+  LAUNCH_OK("confusion");
+  return SATCV_OK;
+}
+
+// -------------------------------------------------------------------------- Adam
+// state = {lr, step_count, grad_scale, _}.  Block 0 / thread 0 bumps the step counter AFTER
+// every block has read it?  No cross-block ordering exists, so the counter is advanced by a
+// separate single-thread kernel launched after the update kernel on the same stream.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                            float b1, float b2, float eps, const float* __restrict__ state, const float* __restrict__ lr_mul) {
+  const float lr = state[0], t = state[1] + 1.f, gs = state[2];
+  const float alpha = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  const long long n4 = n / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float4 lm = lr_mul ? reinterpret_cast<const float4*>(lr_mul)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
+    float* P = &pp.x; const float* Gp = &gg.x; float* M = &mm.x; float* V = &vv.x; const float* L = &lm.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = Gp[e] * gs;
+      const float mn = b1 * M[e] + (1.f - b1) * gr;
+      const float vn = b2 * V[e] + (1.f - b2) * gr * gr;
+      if (L[e] != 0.f) { M[e] = mn; V[e] = vn; P[e] -= L[e] * alpha * mn / (sqrtf(vn) + eps); }
+    }
+    reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  // tail
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = n4 * 4 + threadIdx.x;
+    const float l = lr_mul ? lr_mul[i] : 1.f;
+    const float gr = g[i] * gs;
+    const float mn = b1 * m[i] + (1.f - b1) * gr, vn = b2 * v[i] + (1.f - b2) * gr * gr;
+    if (l != 0.f) { m[i] = mn; v[i] = vn; p[i] -= l * alpha * mn / (sqrtf(vn) + eps); }
+  }
+}
+__global__ void adam_bump_kernel(float* state) { state[1] += 1.f; }
+extern "C" int satcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps, float* state,
+                               const float* lr_mul, void* stream) {
+  SATCV_CHECK(p && g && m && v && state && n > 0, "adam: bad args");
+  SATCV_CHECK(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0), "adam: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1, 4096)), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps, state, lr_mul);
+  hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+  LAUNCH_OK("adam");
+  return SATCV_OK;
+}

@@ -1,0 +1,316 @@
+"""Operator-level Python wrappers over the C ABI (torch tensors are only the device-memory
+container: every wrapper passes raw `data_ptr()`s and the current HIP stream to libsatcv).
+
+Each wrapper names the Keras layer call site of /root/reference/utils/model_tools.py that
+the underlying kernel replaces.  There is no CPU path: tensors must live on a ROCm device.
+"""
+import ctypes as C
+import torch
+
+from . import _lib
+from ._lib import lib, check, ConvDesc, WgradDesc, BnBwdDesc, HeadDesc, F32, BF16, STAT_ROWS
+
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def rup(a, b):
+    return (a + b - 1) // b * b
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, 'satcv ops need device tensors (no CPU fallback)'
+    return C.c_void_p(t.data_ptr())
+
+
+def new_stats(c, device):
+    return torch.zeros(STAT_ROWS, 2, c, dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------ data movement
+def ingest_nhwc(x_f32, cpad, dtype):
+    """f32 NHWC -> storage dtype NHWC with channels zero-padded to cpad."""
+    n, h, w, c = x_f32.shape
+    x_f32 = x_f32.contiguous()
+    out = torch.empty(n, h, w, cpad, dtype=TORCH_DTYPE[dtype], device=x_f32.device)
+    check(lib.satcv_ingest_nhwc(ptr(x_f32), ptr(out), n * h * w, c, cpad, dtype, stream_ptr()))
+    return out
+
+
+def ingest_chw(planes, scale, cpad, dtype):
+    """planar (n,c,h,w) uint8/uint16(int16 view)/float32 -> storage NHWC, value*scale."""
+    n, c, h, w = planes.shape
+    kind = {torch.uint8: 0, torch.int16: 1, torch.uint16: 1, torch.float32: 2}[planes.dtype]
+    out = torch.empty(n, h, w, cpad, dtype=TORCH_DTYPE[dtype], device=planes.device)
+    check(lib.satcv_ingest_chw(ptr(planes.contiguous()), kind, float(scale), ptr(out), n, c, h, w, cpad, dtype, stream_ptr()))
+    return out
+
+
+def packed_sizes(kh, kw, cin, cout, cin_pad, transposed):
+    """(elements of fwd pack, elements of dgrad pack, N pad of fwd, N pad of dgrad)."""
+    taps = kh * kw
+    if not transposed:
+        nf, nd = rup(cout, 32), rup(cin, 32)
+        return taps * cin_pad * nf, taps * rup(cout, 16) * nd, nf, nd
+    nf, nd = rup(taps * cout, 32), rup(cin, 32)
+    return cin_pad * nf, rup(taps * cout, 16) * nd, nf, nd
+
+
+def pack_weights(kernel_f32, cin_pad, dtype, transposed=False, want_dgrad=True, out_fwd=None, out_dgrad=None):
+    """Keras kernel (kh,kw,cin,cout) [or Conv2DTranspose (kh,kw,cout,cin)] -> MFMA operand images."""
+    if transposed:
+        kh, kw, cout, cin = kernel_f32.shape
+    else:
+        kh, kw, cin, cout = kernel_f32.shape
+    ef, ed, _, _ = packed_sizes(kh, kw, cin, cout, cin_pad, transposed)
+    td = TORCH_DTYPE[dtype]
+    fwd = out_fwd if out_fwd is not None else torch.empty(ef, dtype=td, device=kernel_f32.device)
+    dg = out_dgrad if out_dgrad is not None else (torch.empty(ed, dtype=td, device=kernel_f32.device) if want_dgrad else None)
+    check(lib.satcv_pack_weights(ptr(kernel_f32.contiguous()), ptr(fwd), ptr(dg), kh, kw, cin, cout, cin_pad,
+                                 1 if transposed else 0, dtype, stream_ptr()))
+    return fwd, dg
+
+
+# --------------------------------------------------------------------------- conv
+def make_conv_desc(*, x0, c0, w, y, ldy, n, h, w_, cout, cout_pad, dtype, x1=None, c1=0, in_scale=None, in_shift=None,
+                   in_relu=0, bias=None, stats=None, stats_ld=0, kh=3, kw=3, dil=1, mode_in=0, mode_out=0, f=1,
+                   cstat=None, out_relu=0):
+    d = ConvDesc()
+    d.x0, d.x1, d.c0, d.c1 = x0, x1, c0, c1
+    d.in_scale, d.in_shift, d.in_relu = in_scale, in_shift, int(in_relu)
+    d.w, d.bias, d.y, d.ldy = w, bias, y, ldy
+    d.stats, d.stats_ld = stats, stats_ld
+    d.n, d.h, d.w_ = n, h, w_
+    d.cout, d.cout_pad = cout, cout_pad
+    d.kh, d.kw, d.dil = kh, kw, dil
+    d.mode_in, d.mode_out, d.f = mode_in, mode_out, f
+    d.cstat = cstat if cstat is not None else cout
+    d.out_relu, d.dtype = int(out_relu), dtype
+    return d
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def conv2d(x, w_packed, cout, *, kh=3, kw=3, dil=1, bias=None, x1=None, in_scale=None, in_shift=None, in_relu=False,
+           stats=None, out=None, out_relu=False):
+    """layers.Conv2D(cout,(kh,kw),padding='same',dilation_rate=dil) (utils/model_tools.py:178) on
+    NHWC storage tensors; optional fused input BatchNorm-affine+ReLU and output sum/sumsq."""
+    n, h, w_, c0 = x.shape
+    dtype = DTYPE_CODE[x.dtype]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    cpad = rup(cout, 32)
+    y = out if out is not None else torch.empty(n, h, w_, rup(cout, 16), dtype=x.dtype, device=x.device)
+    d = make_conv_desc(x0=_p(x), c0=c0, x1=_p(x1), c1=c1, w=_p(w_packed), y=_p(y), ldy=y.shape[-1], n=n, h=h, w_=w_,
+                       cout=cout, cout_pad=cpad, dtype=dtype, in_scale=_p(in_scale), in_shift=_p(in_shift),
+                       in_relu=in_relu, bias=_p(bias), stats=_p(stats), stats_ld=stats.shape[-1] if stats is not None else 0,
+                       kh=kh, kw=kw, dil=dil, out_relu=out_relu)
+    check(lib.satcv_conv2d_igemm(C.byref(d), stream_ptr()))
+    return y
+
+
+def conv2d_transpose(x, w_packed, cout, f, *, bias=None, in_scale=None, in_shift=None, in_relu=False, stats=None, out=None):
+    """layers.Conv2DTranspose(cout, f, strides=f, padding='same') (utils/model_tools.py:306)."""
+    n, h, w_, c0 = x.shape
+    dtype = DTYPE_CODE[x.dtype]
+    y = out if out is not None else torch.empty(n, h * f, w_ * f, rup(cout, 16), dtype=x.dtype, device=x.device)
+    d = make_conv_desc(x0=_p(x), c0=c0, w=_p(w_packed), y=_p(y), ldy=y.shape[-1], n=n, h=h, w_=w_, cout=f * f * cout,
+                       cout_pad=rup(f * f * cout, 32), dtype=dtype, in_scale=_p(in_scale), in_shift=_p(in_shift),
+                       in_relu=in_relu, bias=_p(bias), stats=_p(stats), stats_ld=stats.shape[-1] if stats is not None else 0,
+                       kh=1, kw=1, dil=1, mode_out=1, f=f, cstat=cout)
+    check(lib.satcv_conv2d_igemm(C.byref(d), stream_ptr()))
+    return y
+
+
+def conv2d_dgrad(dy, w_dgrad, cin, *, kh=3, kw=3, dil=1, out=None):
+    """Data gradient of Conv2D: 'same' correlation of dy with the flipped, in/out-swapped kernel."""
+    n, h, w_, cy = dy.shape
+    dtype = DTYPE_CODE[dy.dtype]
+    dx = out if out is not None else torch.empty(n, h, w_, rup(cin, 16), dtype=dy.dtype, device=dy.device)
+    d = make_conv_desc(x0=_p(dy), c0=cy, w=_p(w_dgrad), y=_p(dx), ldy=dx.shape[-1], n=n, h=h, w_=w_, cout=cin,
+                       cout_pad=rup(cin, 32), dtype=dtype, kh=kh, kw=kw, dil=dil)
+    check(lib.satcv_conv2d_igemm(C.byref(d), stream_ptr()))
+    return dx
+
+
+def conv2d_transpose_dgrad(dy, w_dgrad, cin, cout, f, *, out=None):
+    """Data gradient of Conv2DTranspose(k==s): space-to-depth gather of dy, 1x1 GEMM."""
+    n, hf, wf, cy = dy.shape
+    h, w_ = hf // f, wf // f
+    dtype = DTYPE_CODE[dy.dtype]
+    assert cy == cout, 'dy channel stride must equal cout'
+    dx = out if out is not None else torch.empty(n, h, w_, rup(cin, 16), dtype=dy.dtype, device=dy.device)
+    d = make_conv_desc(x0=_p(dy), c0=cy, w=_p(w_dgrad), y=_p(dx), ldy=dx.shape[-1], n=n, h=h, w_=w_, cout=cin,
+                       cout_pad=rup(cin, 32), dtype=dtype, kh=1, kw=1, dil=1, mode_in=1, f=f)
+    check(lib.satcv_conv2d_igemm(C.byref(d), stream_ptr()))
+    return dx
+
+
+def make_wgrad_desc(*, x0, c0, dy, lddy, dw, cin, cout, n, h, w_, dtype, x1=None, c1=0, in_scale=None, in_shift=None,
+                    in_relu=0, kh=3, kw=3, dil=1, mode_dy=0, f=1, transposed=0, workspace=None, workspace_bytes=0):
+    d = WgradDesc()
+    d.x0, d.x1, d.c0, d.c1 = x0, x1, c0, c1
+    d.in_scale, d.in_shift, d.in_relu = in_scale, in_shift, int(in_relu)
+    d.dy, d.lddy, d.dw, d.cin, d.cout = dy, lddy, dw, cin, cout
+    d.n, d.h, d.w_, d.kh, d.kw, d.dil = n, h, w_, kh, kw, dil
+    d.mode_dy, d.f, d.transposed = mode_dy, f, transposed
+    d.workspace, d.workspace_bytes, d.dtype = workspace, workspace_bytes, dtype
+    return d
+
+
+def conv2d_wgrad(x, dy, cin, cout, *, kh=3, kw=3, dil=1, x1=None, in_scale=None, in_shift=None, in_relu=False,
+                 transposed_f=0, dw=None):
+    """Kernel gradient, Keras layout: (kh,kw,cin,cout), or (f,f,cout,cin) for Conv2DTranspose."""
+    n, h, w_, c0 = x.shape
+    dtype = DTYPE_CODE[x.dtype]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    f = transposed_f
+    if dw is None:
+        shape = (f, f, cout, cin) if f else (kh, kw, cin, cout)
+        dw = torch.empty(shape, dtype=torch.float32, device=x.device)
+    d = make_wgrad_desc(x0=_p(x), c0=c0, x1=_p(x1), c1=c1, dy=_p(dy), lddy=dy.shape[-1], dw=_p(dw), cin=cin, cout=cout,
+                        n=n, h=h, w_=w_, dtype=dtype, in_scale=_p(in_scale), in_shift=_p(in_shift), in_relu=in_relu,
+                        kh=1 if f else kh, kw=1 if f else kw, dil=dil, mode_dy=1 if f else 0, f=f if f else 1,
+                        transposed=1 if f else 0)
+    nbytes = lib.satcv_conv2d_wgrad_workspace(C.byref(d))
+    if nbytes < 0:
+        raise _lib.SatcvError(lib.satcv_last_error().decode())
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    check(lib.satcv_conv2d_wgrad(C.byref(d), stream_ptr()))
+    return dw
+
+
+# ------------------------------------------------------------------------ batch norm
+def bn_finalize_train(stats, count, gamma, beta, moving_mean, moving_var, eps=1e-3, momentum=0.99, updates=1, bessel=False):
+    c = gamma.numel()
+    dev = gamma.device
+    scale, shift, mean, rstd = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+    check(lib.satcv_bn_finalize_train(ptr(stats), stats.shape[-1], c, float(count), ptr(gamma), ptr(beta), eps, momentum,
+                                      updates, int(bessel), ptr(moving_mean), ptr(moving_var), ptr(scale), ptr(shift),
+                                      ptr(mean), ptr(rstd), stream_ptr()))
+    return scale, shift, mean, rstd
+
+
+def bn_affine_infer(gamma, beta, moving_mean, moving_var, eps=1e-3):
+    c = gamma.numel()
+    scale = torch.empty(c, dtype=torch.float32, device=gamma.device)
+    shift = torch.empty_like(scale)
+    check(lib.satcv_bn_affine_infer(ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), eps, c, ptr(scale), ptr(shift), stream_ptr()))
+    return scale, shift
+
+
+def bn_relu_pool(yraw, scale, shift, f, want_act=True, want_pool=True, stats=None):
+    """Activation('relu')(BatchNormalization()(y)) + MaxPooling2D(f, strides=f) (utils/model_tools.py:179-180, 281)."""
+    n, h, w_, c = yraw.shape
+    act = torch.empty_like(yraw) if want_act else None
+    pooled = torch.empty(n, h // f, w_ // f, c, dtype=yraw.dtype, device=yraw.device) if want_pool else None
+    check(lib.satcv_bn_relu_pool(ptr(yraw), ptr(scale), ptr(shift), ptr(act), ptr(pooled), ptr(stats),
+                                 stats.shape[-1] if stats is not None else 0, n, h, w_, c, f, DTYPE_CODE[yraw.dtype], stream_ptr()))
+    return act, pooled
+
+
+def make_bnbwd_desc(*, yraw, ldy, scale, shift, mean, rstd, n, h, w_, c, dtype, da=None, ldda=0, dpool=None, lddp=0, f=1,
+                    sums=None, sums_ld=0, coef=None, dy=None, lddy_out=0, dbias=None):
+    d = BnBwdDesc()
+    d.da, d.ldda, d.dpool, d.lddp, d.f = da, ldda, dpool, lddp, f
+    d.yraw, d.ldy = yraw, ldy
+    d.scale, d.shift, d.mean, d.rstd = scale, shift, mean, rstd
+    d.sums, d.sums_ld, d.coef = sums, sums_ld, coef
+    d.dy, d.lddy_out, d.dbias = dy, lddy_out, dbias
+    d.n, d.h, d.w_, d.c, d.dtype = n, h, w_, c, dtype
+    return d
+
+
+def bn_relu_bwd(yraw, scale, shift, mean, rstd, da=None, dpool=None, f=1, want_dbias=False):
+    """Backward of relu(BN_train(y)) given grad of the activation (and/or of its max-pool).
+    Returns (dy, dgamma, dbeta, dbias)."""
+    n, h, w_, c = yraw.shape
+    dev, dtype = yraw.device, DTYPE_CODE[yraw.dtype]
+    sums = new_stats(c, dev)
+    coef = torch.empty(2, c, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty_like(dgamma)
+    dy = torch.empty_like(yraw)
+    dbias = torch.zeros(c, dtype=torch.float32, device=dev) if want_dbias else None
+    d = make_bnbwd_desc(yraw=_p(yraw), ldy=c, scale=_p(scale), shift=_p(shift), mean=_p(mean), rstd=_p(rstd), n=n, h=h, w_=w_,
+                        c=c, dtype=dtype, da=_p(da), ldda=da.shape[-1] if da is not None else 0, dpool=_p(dpool),
+                        lddp=dpool.shape[-1] if dpool is not None else 0, f=f, sums=_p(sums), sums_ld=c, coef=_p(coef),
+                        dy=_p(dy), lddy_out=c, dbias=_p(dbias))
+    check(lib.satcv_bn_bwd_reduce(C.byref(d), stream_ptr()))
+    check(lib.satcv_bn_bwd_finalize(ptr(sums), c, c, float(n * h * w_), ptr(dgamma), ptr(dbeta), ptr(coef), stream_ptr()))
+    check(lib.satcv_bn_bwd_apply(C.byref(d), stream_ptr()))
+    return dy, dgamma, dbeta, dbias
+
+
+# ------------------------------------------------------------------------------ head
+def make_head_desc(*, x, ldx, cin, w, b, ncls, activation, npix, dtype, in_scale=None, in_shift=None, thresh=0.5,
+                   probs=None, classes=None, dlogits=None, dx=None, lddx=0, dw=None, db=None):
+    d = HeadDesc()
+    d.x, d.ldx, d.cin = x, ldx, cin
+    d.in_scale, d.in_shift, d.w, d.b = in_scale, in_shift, w, b
+    d.ncls, d.activation, d.thresh = ncls, activation, thresh
+    d.probs, d.classes, d.dlogits = probs, classes, dlogits
+    d.dx, d.lddx, d.dw, d.db = dx, lddx, dw, db
+    d.npix, d.dtype = npix, dtype
+    return d
+
+
+def head_fwd(x, w, b, activation='softmax', in_scale=None, in_shift=None, thresh=0.5):
+    """Conv2D(ncls,(1,1),activation) + argmax / threshold (utils/model_tools.py:405-406, 660-661)."""
+    n, h, w_, c = x.shape
+    cin, ncls = w.shape
+    act = 0 if activation == 'softmax' else 1
+    probs = torch.empty(n, h, w_, ncls, dtype=torch.float32, device=x.device)
+    classes = torch.empty((n, h, w_) if act == 0 else (n, h, w_, ncls), dtype=torch.int32, device=x.device)
+    d = make_head_desc(x=_p(x), ldx=c, cin=cin, w=_p(w), b=_p(b), ncls=ncls, activation=act, npix=n * h * w_,
+                       dtype=DTYPE_CODE[x.dtype], in_scale=_p(in_scale), in_shift=_p(in_shift), thresh=thresh,
+                       probs=_p(probs), classes=_p(classes))
+    check(lib.satcv_head_fwd(C.byref(d), stream_ptr()))
+    return probs, classes
+
+
+def head_bwd(x, w, dlogits, in_scale=None, in_shift=None):
+    n, h, w_, c = x.shape
+    cin, ncls = w.shape
+    dx = torch.empty(n, h, w_, c, dtype=x.dtype, device=x.device)
+    if c > cin:
+        dx.zero_()
+    dw = torch.zeros(cin, ncls, dtype=torch.float32, device=x.device)
+    db = torch.zeros(ncls, dtype=torch.float32, device=x.device)
+    d = make_head_desc(x=_p(x), ldx=c, cin=cin, w=_p(w), b=_p(db), ncls=ncls, activation=0, npix=n * h * w_,
+                       dtype=DTYPE_CODE[x.dtype], in_scale=_p(in_scale), in_shift=_p(in_shift), dlogits=_p(dlogits),
+                       dx=_p(dx), lddx=c, dw=_p(dw), db=_p(db))
+    check(lib.satcv_head_bwd(C.byref(d), stream_ptr()))
+    return dx, dw, db
+
+
+LOSS_KINDS = {'weighted_categorical_crossentropy': 0, 'weighted_bce': 1}
+
+
+def loss_fwd_bwd(kind, probs, y_true, weights, activation='softmax', grad_scale=1.0):
+    """Returns (loss scalar tensor, dL/dlogits)."""
+    ncls = probs.shape[-1]
+    npix = probs.numel() // ncls
+    loss = torch.zeros(1, dtype=torch.float32, device=probs.device)
+    dlogits = torch.empty_like(probs)
+    check(lib.satcv_loss_fwd_bwd(LOSS_KINDS[kind], ptr(probs), ptr(y_true.contiguous()), ptr(weights), ncls,
+                                 0 if activation == 'softmax' else 1, npix, grad_scale, ptr(loss), ptr(dlogits), stream_ptr()))
+    return loss, dlogits
+
+
+def confusion(classes, y_true, ncls):
+    conf = torch.zeros(ncls, ncls, dtype=torch.int64, device=classes.device)
+    check(lib.satcv_confusion(ptr(classes), ptr(y_true.contiguous()), ncls, classes.numel(), ptr(conf), stream_ptr()))
+    return conf
+
+
+def adam_step(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-7, lr_mul=None):
+    check(lib.satcv_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), beta1, beta2, eps, ptr(state), ptr(lr_mul), stream_ptr()))

@@ -1,0 +1,323 @@
+"""Op-level parity: every HIP kernel, through the C ABI, against the NumPy oracle (float64)
+on the same seeded inputs.  fp32 storage: tight tolerance (exact fp32 MFMA products);
+bf16 storage: inputs are pre-rounded to bf16 so only accumulation order and the final
+bf16 rounding differ (tolerance 2^-7 relative to the output scale)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import keras_ops as K
+from oracle import losses as OL
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from satellite_computervision_amd import ops as _ops
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return _ops
+
+
+def dev():
+    return torch.device('cuda')
+
+
+def rnd(rng, shape, td, scale=1.0):
+    """float64 array whose values are exactly representable in the storage dtype."""
+    x = torch.tensor(rng.standard_normal(shape) * scale, dtype=torch.float32)
+    return x.to(td).to(torch.float64).numpy()
+
+
+def to_dev(x64, td, cpad=None):
+    t = torch.tensor(x64, dtype=torch.float32)
+    if cpad is not None and cpad > t.shape[-1]:
+        t = torch.nn.functional.pad(t, (0, cpad - t.shape[-1]))
+    return t.to(td).to(dev()).contiguous()
+
+
+def f32dev(x64):
+    return torch.tensor(x64, dtype=torch.float32, device=dev()).contiguous()
+
+
+def back(t, c=None):
+    a = t.detach().float().cpu().numpy().astype(np.float64)
+    return a if c is None else a[..., :c]
+
+
+def close(got, ref, td, what='', k=1.0):
+    scale = max(np.abs(ref).max(), 1e-6)
+    tol = (2e-5 if td == torch.float32 else 1.2e-2) * k
+    err = np.abs(got - ref).max() / scale
+    assert err < tol, f'{what}: rel-to-max err {err:.3e} >= {tol:.1e} (scale {scale:.3e})'
+
+
+def rup(a, b):
+    return (a + b - 1) // b * b
+
+
+# ------------------------------------------------------------------------- ingest
+@pytest.mark.parametrize('td', DT)
+def test_ingest(ops, td):
+    rng = np.random.default_rng(0)
+    x = rng.random((2, 5, 7, 4)).astype(np.float32)
+    y = ops.ingest_nhwc(torch.tensor(x, device=dev()), 16, ops.DTYPE_CODE[td])
+    ref = torch.tensor(x).to(td).float().numpy()
+    assert np.array_equal(back(y, 4), ref.astype(np.float64))
+    assert not back(y)[..., 4:].any()
+    planes = torch.tensor(rng.integers(0, 10000, (2, 4, 6, 5)).astype(np.int16), device=dev())
+    z = ops.ingest_chw(planes, 1.0 / 10000, 16, ops.DTYPE_CODE[td])
+    refz = (planes.cpu().numpy().astype(np.float32) * np.float32(1.0 / 10000)).transpose(0, 2, 3, 1)
+    np.testing.assert_allclose(back(z, 4), torch.tensor(refz).to(td).float().numpy(), rtol=1e-6, atol=1e-7)
+
+
+# --------------------------------------------------------------------- conv forward
+CONV_CASES = [
+    # n, h, w, cin, cout, k, dil
+    (2, 32, 32, 4, 32, 3, 1),      # first layer: 4 real channels padded to 16, BN=32 config
+    (2, 32, 64, 32, 64, 3, 1),     # BN=64 config, TW=32
+    (1, 16, 16, 64, 128, 3, 1),    # BN=128 config, TW=16
+    (3, 8, 8, 32, 128, 3, 1),      # TW=8, several images per tile (H < TH), odd image count
+    (2, 20, 24, 16, 32, 3, 1),     # ragged: W=24 -> TW=8, H not a multiple of TH
+    (1, 12, 12, 32, 32, 3, 1),     # 384-chip bottleneck size
+    (1, 40, 40, 32, 32, 3, 3),     # dilated (ASPP rate 3)
+    (1, 32, 32, 32, 64, 3, 6),     # dilated (ASPP rate 6)
+    (2, 16, 16, 64, 32, 1, 1),     # 1x1
+    (1, 32, 32, 48, 96, 3, 1),     # channel counts that are not powers of two
+    (1, 256, 256, 16, 32, 3, 1),   # full-resolution tile
+]
+
+
+@pytest.mark.parametrize('td', DT)
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_fwd(ops, td, case):
+    n, h, w, cin, cout, k, dil = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (k, k, cin, cout), td, 0.2)
+    b = rng.standard_normal(cout)
+    ref = K.conv2d_same(x, kern, b, dil)
+    cpad = rup(cin, 16)
+    wf, _ = ops.pack_weights(f32dev(kern), cpad, ops.DTYPE_CODE[td], want_dgrad=False)
+    stats = ops.new_stats(rup(cout, 16), dev())
+    y = ops.conv2d(to_dev(x, td, cpad), wf, cout, kh=k, kw=k, dil=dil, bias=f32dev(b), stats=stats)
+    torch.cuda.synchronize()
+    got = back(y, cout)
+    close(got, ref, td, f'conv {case}')
+    # epilogue statistics are those of the STORED values
+    s = stats.sum(0).double().cpu().numpy()
+    np.testing.assert_allclose(s[0, :cout], got.sum((0, 1, 2)), rtol=2e-4, atol=2e-3 * np.sqrt(n * h * w))
+    np.testing.assert_allclose(s[1, :cout], (got ** 2).sum((0, 1, 2)), rtol=2e-4)
+
+
+@pytest.mark.parametrize('td', DT)
+def test_conv2d_dual_source_affine(ops, td):
+    """decoder conv1: concat([skip, up]) -> BN -> ReLU fused into the loader (model_tools.py:307-312)."""
+    rng = np.random.default_rng(11)
+    n, h, w, c0, c1, cout = 2, 32, 32, 32, 32, 32
+    xa, xb = rnd(rng, (n, h, w, c0), td), rnd(rng, (n, h, w, c1), td)
+    sc, sh = rng.standard_normal(c0 + c1), rng.standard_normal(c0 + c1)
+    kern = rnd(rng, (3, 3, c0 + c1, cout), td, 0.2)
+    sc32, sh32 = sc.astype(np.float32).astype(np.float64), sh.astype(np.float32).astype(np.float64)
+    a = np.maximum(np.concatenate([xa, xb], -1) * sc32 + sh32, 0)
+    if td == torch.bfloat16:
+        a = torch.tensor(a, dtype=torch.float32).to(td).double().numpy()     # the staged tile is rounded to bf16
+    ref = K.conv2d_same(a, kern, None, 1)
+    wf, _ = ops.pack_weights(f32dev(kern), c0 + c1, ops.DTYPE_CODE[td], want_dgrad=False)
+    y = ops.conv2d(to_dev(xa, td), wf, cout, x1=to_dev(xb, td), in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
+    close(back(y, cout), ref, td, 'dual-source conv', k=2.0)
+
+
+# ---------------------------------------------------------------------- conv backward
+BWD_CASES = [
+    (2, 32, 32, 16, 32),     # wgrad cfg (1,1)
+    (2, 32, 32, 64, 32),     # wgrad cfg (2,1)
+    (2, 16, 16, 32, 64),     # (1,2), TW=16
+    (2, 16, 32, 64, 64),     # (2,2)
+    (3, 8, 8, 64, 128),      # (1,4), TW=8 multi-image
+    (1, 20, 24, 32, 32),     # ragged
+    (1, 64, 64, 32, 32),     # many pixel tiles -> split-K
+]
+
+
+@pytest.mark.parametrize('td', DT)
+@pytest.mark.parametrize('case', BWD_CASES)
+def test_conv2d_dgrad_wgrad(ops, td, case):
+    n, h, w, cin, cout = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (3, 3, cin, cout), td, 0.2)
+    dy = rnd(rng, (n, h, w, cout), td)
+    dx_ref, dk_ref, _ = K.conv2d_same_bwd(x, kern, dy, 1)
+    _, wd = ops.pack_weights(f32dev(kern), cin, ops.DTYPE_CODE[td])
+    dx = ops.conv2d_dgrad(to_dev(dy, td), wd, cin)
+    close(back(dx, cin), dx_ref, td, f'dgrad {case}')
+    dk = ops.conv2d_wgrad(to_dev(x, td), to_dev(dy, td), cin, cout)
+    close(back(dk), dk_ref, torch.float32 if td == torch.float32 else td, f'wgrad {case}', k=(5.0 if td == torch.float32 else 0.5))
+
+
+@pytest.mark.parametrize('td', DT)
+def test_wgrad_padded_input_and_affine(ops, td):
+    """first layer (4 real of 16 stored channels) and a fused input BN+ReLU, dilation 3."""
+    rng = np.random.default_rng(5)
+    n, h, w, cin, cout = 2, 32, 32, 4, 32
+    x = rnd(rng, (n, h, w, cin), td); dy = rnd(rng, (n, h, w, cout), td)
+    _, dk_ref, _ = K.conv2d_same_bwd(x, np.zeros((3, 3, cin, cout)), dy, 1)
+    dk = ops.conv2d_wgrad(to_dev(x, td, 16), to_dev(dy, td), cin, cout)
+    close(back(dk), dk_ref, td, 'wgrad cin=4', k=(5.0 if td == torch.float32 else 0.5))
+    cin = 32
+    x = rnd(rng, (n, h, w, cin), td)
+    sc, sh = rng.standard_normal(cin).astype(np.float32), rng.standard_normal(cin).astype(np.float32)
+    a = np.maximum(x * sc.astype(np.float64) + sh.astype(np.float64), 0)
+    if td == torch.bfloat16:
+        a = torch.tensor(a, dtype=torch.float32).to(td).double().numpy()
+    _, dk_ref, _ = K.conv2d_same_bwd(a, np.zeros((3, 3, cin, cout)), dy, 3)
+    dk = ops.conv2d_wgrad(to_dev(x, td), to_dev(dy, td), cin, cout, dil=3, in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
+    close(back(dk), dk_ref, td, 'wgrad affine dil3', k=(5.0 if td == torch.float32 else 0.5))
+
+
+# ------------------------------------------------------------------ transposed conv
+@pytest.mark.parametrize('td', DT)
+@pytest.mark.parametrize('case', [(2, 8, 8, 64, 32, 2), (1, 16, 16, 128, 64, 2), (2, 4, 4, 256, 128, 2), (1, 6, 6, 32, 32, 3)])
+def test_conv2d_transpose(ops, td, case):
+    n, h, w, cin, cout, f = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rnd(rng, (n, h, w, cin), td)
+    kt = rnd(rng, (f, f, cout, cin), td, 0.2)
+    b = rng.standard_normal(cout)
+    dy = rnd(rng, (n, h * f, w * f, cout), td)
+    ref = K.conv2d_transpose_ks(x, kt, b)
+    dx_ref, dk_ref, _ = K.conv2d_transpose_ks_bwd(x, kt, dy)
+    wf, wd = ops.pack_weights(f32dev(kt), cin, ops.DTYPE_CODE[td], transposed=True)
+    stats = ops.new_stats(cout, dev())
+    y = ops.conv2d_transpose(to_dev(x, td), wf, cout, f, bias=f32dev(b), stats=stats)
+    got = back(y, cout)
+    close(got, ref, td, f'convT fwd {case}')
+    s = stats.sum(0).double().cpu().numpy()
+    np.testing.assert_allclose(s[0], got.sum((0, 1, 2)), rtol=2e-4, atol=2e-3 * np.sqrt(got.size / cout))
+    dx = ops.conv2d_transpose_dgrad(to_dev(dy, td), wd, cin, cout, f)
+    close(back(dx, cin), dx_ref, td, f'convT dgrad {case}')
+    dk = ops.conv2d_wgrad(to_dev(x, td), to_dev(dy, td), cin, cout, transposed_f=f)
+    close(back(dk), dk_ref, td, f'convT wgrad {case}', k=(5.0 if td == torch.float32 else 0.5))
+
+
+# ------------------------------------------------------------------------ batch norm
+@pytest.mark.parametrize('td', DT)
+@pytest.mark.parametrize('f', [2, 3])
+def test_bn_relu_pool_and_backward(ops, td, f):
+    rng = np.random.default_rng(21 + f)
+    n, h, w, c = 2, 12, 18, 32
+    y = rnd(rng, (n, h, w, c), td) * 1.5 + 0.3
+    if td == torch.bfloat16:
+        y = torch.tensor(y, dtype=torch.float32).to(td).double().numpy()
+    g, b = rng.standard_normal(c).astype(np.float32).astype(np.float64), rng.standard_normal(c).astype(np.float32).astype(np.float64)
+    # training statistics from the (conv-epilogue style) sum / sumsq rows
+    stats = ops.new_stats(c, dev())
+    stats[3, 0] = f32dev(y.sum((0, 1, 2))); stats[7, 1] = f32dev((y ** 2).sum((0, 1, 2)))
+    mm, mv = torch.zeros(c, device=dev()), torch.ones(c, device=dev())
+    scale, shift, mean, rstd = ops.bn_finalize_train(stats, n * h * w, f32dev(g), f32dev(b), mm, mv, updates=2)
+    z, m_ref, v_ref = K.batchnorm_train(y, g, b)
+    np.testing.assert_allclose(back(mean), m_ref, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(back(rstd), 1 / np.sqrt(v_ref + 1e-3), rtol=1e-4)
+    np.testing.assert_allclose(back(mm), m_ref * (1 - 0.99 ** 2), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(back(mv), 0.99 ** 2 + v_ref * (1 - 0.99 ** 2), rtol=1e-4)
+    assert not stats.any()                                   # consumed and zeroed
+    act_ref = K.relu(z)
+    st2 = ops.new_stats(c, dev())
+    act, pooled = ops.bn_relu_pool(to_dev(y, td), scale, shift, f, stats=st2)
+    close(back(act), act_ref, td, 'act')
+    close(back(pooled), K.maxpool(act_ref, f), td, 'pooled')
+    np.testing.assert_allclose(st2.sum(0)[0].double().cpu().numpy(), back(act).sum((0, 1, 2)), rtol=1e-4, atol=1e-2)
+    # backward with gradient arriving both densely (skip) and through the pool
+    da = rnd(rng, (n, h, w, c), td)
+    dp = rnd(rng, (n, h // f, w // f, c), td)
+    dz = K.relu_bwd(act_ref, da + K.maxpool_bwd(act_ref, f, dp))
+    dy_ref, dg_ref, db_ref = K.batchnorm_train_bwd(y, g, m_ref, v_ref, dz)
+    dy, dgamma, dbeta, dbias = ops.bn_relu_bwd(to_dev(y, td), scale, shift, mean, rstd, da=to_dev(da, td), dpool=to_dev(dp, td), f=f,
+                                               want_dbias=True)
+    close(back(dy), dy_ref, td, 'bn bwd dy', k=4.0)
+    close(back(dgamma), dg_ref, td, 'dgamma', k=4.0)
+    close(back(dbeta), db_ref, td, 'dbeta', k=4.0)
+    np.testing.assert_allclose(back(dbias), back(dy).sum((0, 1, 2)), rtol=1e-3, atol=2e-2)
+    # dense-only path
+    dz = K.relu_bwd(act_ref, da)
+    dy_ref, _, _ = K.batchnorm_train_bwd(y, g, m_ref, v_ref, dz)
+    dy, _, _, _ = ops.bn_relu_bwd(to_dev(y, td), scale, shift, mean, rstd, da=to_dev(da, td))
+    close(back(dy), dy_ref, td, 'bn bwd dense', k=4.0)
+    # inference affine
+    s2, h2 = ops.bn_affine_infer(f32dev(g), f32dev(b), f32dev(m_ref), f32dev(v_ref))
+    np.testing.assert_allclose(back(s2), g / np.sqrt(v_ref + 1e-3), rtol=1e-5)
+    np.testing.assert_allclose(back(h2), b - m_ref * g / np.sqrt(v_ref + 1e-3), rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------- head and losses
+@pytest.mark.parametrize('td', DT)
+@pytest.mark.parametrize('ncls,activation', [(2, 'softmax'), (5, 'softmax'), (1, 'sigmoid')])
+def test_head_and_losses(ops, td, ncls, activation):
+    rng = np.random.default_rng(31 + ncls)
+    n, h, w, c = 2, 16, 24, 32
+    yraw = rnd(rng, (n, h, w, c), td)
+    sc, sh = rng.standard_normal(c).astype(np.float32), rng.standard_normal(c).astype(np.float32)
+    wh = rng.standard_normal((c, ncls)).astype(np.float32) * 0.3
+    bh = rng.standard_normal(ncls).astype(np.float32)
+    a = np.maximum(yraw * sc.astype(np.float64) + sh.astype(np.float64), 0)
+    logits = a @ wh.astype(np.float64) + bh
+    p_ref = K.softmax(logits) if activation == 'softmax' else K.sigmoid(logits)
+    probs, classes = ops.head_fwd(to_dev(yraw, td), f32dev(wh), f32dev(bh), activation, f32dev(sc), f32dev(sh))
+    np.testing.assert_allclose(back(probs), p_ref, rtol=2e-4, atol=2e-6)
+    if activation == 'softmax':
+        margin = np.sort(p_ref, -1)[..., -1] - np.sort(p_ref, -1)[..., -2]
+        ok = margin > 1e-4
+        assert np.array_equal(classes.cpu().numpy()[ok], K.argmax_classes(p_ref)[ok])
+        assert classes.dtype == torch.int32
+        lab = rng.integers(0, ncls, (n, h, w)); t = np.eye(ncls)[lab]
+        wts = (1.0 + np.arange(ncls) * 3.0)
+        pg = back(probs)
+        l_ref, g_ref, _ = OL.weighted_categorical_crossentropy(t, pg, wts)
+        dl_ref = K.softmax_bwd(pg, g_ref)
+        loss, dl = ops.loss_fwd_bwd('weighted_categorical_crossentropy', probs, f32dev(t), f32dev(wts))
+        np.testing.assert_allclose(loss.item(), l_ref, rtol=1e-4)
+        np.testing.assert_allclose(back(dl), dl_ref, rtol=2e-3, atol=1e-9)
+        l_ref, g_ref = OL.weighted_bce(t, pg, 5.0)
+        loss, dl2 = ops.loss_fwd_bwd('weighted_bce', probs, f32dev(t), f32dev(np.array([5.0])))
+        np.testing.assert_allclose(loss.item(), l_ref, rtol=1e-4)
+        np.testing.assert_allclose(back(dl2), K.softmax_bwd(pg, g_ref), rtol=2e-3, atol=1e-9)
+        conf = ops.confusion(classes, f32dev(t), ncls).cpu().numpy()
+        cref = np.zeros((ncls, ncls), np.int64)
+        np.add.at(cref, (lab.ravel(), classes.cpu().numpy().ravel()), 1)
+        assert np.array_equal(conf, cref)
+    else:
+        assert np.array_equal(classes.cpu().numpy(), (back(probs) > 0.5).astype(np.int32))
+        t = (rng.random((n, h, w, 1)) < 0.3).astype(np.float64)
+        pg = back(probs)
+        l_ref, g_ref = OL.weighted_bce(t, pg, 5.0)
+        loss, dl = ops.loss_fwd_bwd('weighted_bce', probs, f32dev(t), f32dev(np.array([5.0])), activation='sigmoid')
+        np.testing.assert_allclose(loss.item(), l_ref, rtol=1e-4)
+        np.testing.assert_allclose(back(dl), g_ref * pg * (1 - pg), rtol=2e-3, atol=1e-9)
+    # head backward
+    dlg = rng.standard_normal((n, h, w, ncls)).astype(np.float32)
+    dx, dw, db = ops.head_bwd(to_dev(yraw, td), f32dev(wh), f32dev(dlg), f32dev(sc), f32dev(sh))
+    dl64 = dlg.astype(np.float64)
+    close(back(dx), dl64 @ wh.astype(np.float64).T, td, 'head dx')
+    np.testing.assert_allclose(back(dw), a.reshape(-1, c).T @ dl64.reshape(-1, ncls), rtol=2e-3, atol=2e-2)
+    np.testing.assert_allclose(back(db), dl64.reshape(-1, ncls).sum(0), rtol=1e-3, atol=1e-3)
+
+
+def test_adam_keras_formulation(ops):
+    rng = np.random.default_rng(41)
+    nel = 1003
+    p, g = rng.standard_normal(nel), rng.standard_normal(nel)
+    pd, m, v = f32dev(p), torch.zeros(nel, device=dev()), torch.zeros(nel, device=dev())
+    state = torch.tensor([9e-4, 0.0, 1.0, 0.0], device=dev())
+    pr, mr, vr = p.copy(), np.zeros(nel), np.zeros(nel)
+    for t in range(1, 4):
+        gd = f32dev(g * t)
+        ops.adam_step(pd, gd, m, v, state)
+        gr = g.astype(np.float32).astype(np.float64) * t
+        mr = 0.9 * mr + 0.1 * gr; vr = 0.999 * vr + 0.001 * gr * gr
+        alpha = 9e-4 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        pr = pr - alpha * mr / (np.sqrt(vr) + 1e-7)
+    np.testing.assert_allclose(back(pd), pr, rtol=1e-5, atol=1e-6)
+    assert state[1].item() == 3.0
