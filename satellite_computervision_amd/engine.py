@@ -1,0 +1,543 @@
+"""Graph + executor behind the Keras-style surface of model_tools.py.
+
+A model is a list of block-level nodes (conv+BN+ReLU, max-pool, transposed conv,
+concat+BN+ReLU, 1x1 head) built by the layer classes in model_tools.py.  `Plan`
+lowers that list, for one (batch, H, W), into a static sequence of C-ABI kernel
+launches on preallocated device buffers (torch tensors are only the allocator).
+
+Fusion contract (what the HIP kernels expect):
+  * a conv output is stored RAW (pre-BatchNorm); its BN affine + ReLU is applied by
+    whichever kernel consumes it (conv loader, pool kernel, head);
+  * concat([skip, up]) is never materialised: the consumer conv reads two sources;
+  * train-mode BN statistics come from the producing kernel's epilogue.
+There is no CPU path: everything here requires the HIP library and a ROCm device.
+"""
+import ctypes as C
+import itertools
+from collections import defaultdict
+from fractions import Fraction
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import lib, check, F32, BF16, STAT_ROWS
+
+BN_EPS = 1e-3
+BN_MOMENTUM = 0.99
+
+
+# ------------------------------------------------------------------ symbolic graph
+class KTensor:
+    """Symbolic NHWC tensor (the analogue of a KerasTensor)."""
+    _ids = itertools.count()
+
+    def __init__(self, node, channels, down=Fraction(1), name=None):
+        self.id = next(KTensor._ids)
+        self.node, self.channels, self.down, self.name = node, channels, down, name
+
+    @property
+    def shape(self):
+        return (None, None, None, self.channels)
+
+
+class Node:
+    def __init__(self, op, inputs, layer=None, **attrs):
+        self.op, self.inputs, self.layer, self.attrs = op, list(inputs), layer, attrs
+        self.outputs = []
+
+    def out(self, channels, down, name=None):
+        t = KTensor(self, channels, down, name)
+        self.outputs.append(t)
+        return t
+
+
+class ParamSpec:
+    def __init__(self, name, shape, kind, init):
+        self.name, self.shape, self.kind, self.init = name, tuple(shape), kind, init
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+
+def rup(a, b):
+    return (a + b - 1) // b * b
+
+
+def topo_nodes(outputs):
+    seen, order = set(), []
+
+    def visit(node):
+        if id(node) in seen:
+            return
+        seen.add(id(node))
+        for t in node.inputs:
+            visit(t.node)
+        order.append(node)
+    for t in outputs:
+        visit(t.node)
+    return order
+
+
+# -------------------------------------------------------------------- runtime refs
+class TRef:
+    """Runtime tensor: 1-2 device sources + an optional pending BN affine (+ReLU)."""
+
+    def __init__(self, srcs, n, h, w, affine=None, relu=False):
+        self.srcs, self.n, self.h, self.w = srcs, n, h, w      # srcs: [(torch tensor, channels)]
+        self.affine, self.relu = affine, relu                   # affine: dict(scale, shift, mean, rstd)
+
+    @property
+    def c(self):
+        return sum(c for _, c in self.srcs)
+
+
+def _fp(t, off=0):
+    """device address of float32 tensor element `off` (or None)."""
+    return None if t is None else t.data_ptr() + 4 * off
+
+
+class Runtime:
+    """Device state of one model: flat fp32 parameters / gradients / Adam slots, packed MFMA
+    weight images, BN moving statistics."""
+
+    def __init__(self, model, dtype):
+        if not torch.cuda.is_available():
+            raise RuntimeError('satellite_computervision_amd needs a ROCm GPU (no CPU fallback)')
+        self.model, self.dtype = model, dtype
+        self.tdtype = ops.TORCH_DTYPE[dtype]
+        self.esize = 2 if dtype == BF16 else 4
+        self.dev = torch.device('cuda', torch.cuda.current_device())
+        # flat layout: trainables (Adam sees one buffer), then non-trainable BN moving statistics
+        self.offsets = {}
+        off = 0
+        for p in model.param_specs:
+            if p.kind in ('moving_mean', 'moving_var'):
+                continue
+            self.offsets[p.name] = off
+            off += rup(p.size, 4)
+        self.n_train = off
+        soff = 0
+        self.soffsets = {}
+        for p in model.param_specs:
+            if p.kind in ('moving_mean', 'moving_var'):
+                self.soffsets[p.name] = soff
+                soff += rup(p.size, 4)
+        self.pflat = torch.zeros(max(off, 4), dtype=torch.float32, device=self.dev)
+        self.gflat = torch.zeros_like(self.pflat)
+        self.sflat = torch.zeros(max(soff, 4), dtype=torch.float32, device=self.dev)
+        self.adam_m = self.adam_v = None
+        self.adam_state = torch.tensor([1e-3, 0.0, 1.0, 0.0], dtype=torch.float32, device=self.dev)
+        self.lr_mul = None
+        host = np.zeros(self.pflat.numel(), np.float32)
+        hs = np.zeros(self.sflat.numel(), np.float32)
+        for p in model.param_specs:
+            v = np.asarray(p.init(), np.float32).reshape(-1)
+            if p.name in self.offsets:
+                host[self.offsets[p.name]:self.offsets[p.name] + p.size] = v
+            else:
+                hs[self.soffsets[p.name]:self.soffsets[p.name] + p.size] = v
+        self.pflat.copy_(torch.from_numpy(host))
+        self.sflat.copy_(torch.from_numpy(hs))
+        self.specs = {p.name: p for p in model.param_specs}
+        # packed weights per conv-like layer
+        self.packed = {}
+        for node in model.nodes:
+            if node.op in ('cba', 'convT'):
+                lay = node.layer
+                if lay.name in self.packed:
+                    continue
+                ks = self.specs[lay.kernel_name].shape
+                tr = node.op == 'convT'
+                cin, cout = (ks[3], ks[2]) if tr else (ks[2], ks[3])
+                cin_pad = rup(cin, 16)
+                ef, ed, _, _ = ops.packed_sizes(ks[0], ks[1], cin, cout, cin_pad, tr)
+                self.packed[lay.name] = dict(
+                    fwd=torch.zeros(ef, dtype=self.tdtype, device=self.dev),
+                    dgrad=torch.zeros(ed, dtype=self.tdtype, device=self.dev),
+                    k=(ks[0], ks[1]), cin=cin, cout=cout, cin_pad=cin_pad, transposed=tr)
+        self.repack()
+        self.plans = {}
+
+    # ---- parameter access
+    def pptr(self, name):
+        return _fp(self.pflat, self.offsets[name])
+
+    def gptr(self, name):
+        return _fp(self.gflat, self.offsets[name])
+
+    def sptr(self, name):
+        return _fp(self.sflat, self.soffsets[name])
+
+    def get_param(self, name):
+        p = self.specs[name]
+        if name in self.offsets:
+            return self.pflat[self.offsets[name]:self.offsets[name] + p.size].view(p.shape)
+        return self.sflat[self.soffsets[name]:self.soffsets[name] + p.size].view(p.shape)
+
+    def get_grad(self, name):
+        p = self.specs[name]
+        return self.gflat[self.offsets[name]:self.offsets[name] + p.size].view(p.shape)
+
+    def set_param(self, name, value):
+        self.get_param(name).copy_(torch.as_tensor(np.asarray(value, np.float32)).to(self.dev).view(self.specs[name].shape))
+
+    def repack(self):
+        """fp32 Keras-layout kernels -> MFMA operand images (after every weight update)."""
+        st = ops.stream_ptr()
+        for lname, pk in self.packed.items():
+            check(lib.satcv_pack_weights(self.pptr(lname + '/kernel'), pk['fwd'].data_ptr(), pk['dgrad'].data_ptr(),
+                                         pk['k'][0], pk['k'][1], pk['cin'], pk['cout'], pk['cin_pad'],
+                                         1 if pk['transposed'] else 0, self.dtype, st))
+
+    def ensure_adam(self):
+        if self.adam_m is None:
+            self.adam_m = torch.zeros_like(self.pflat)
+            self.adam_v = torch.zeros_like(self.pflat)
+
+    def plan(self, n, h, w, training):
+        key = (n, h, w, bool(training))
+        if key not in self.plans:
+            self.plans[key] = Plan(self, n, h, w, training)
+        return self.plans[key]
+
+
+class Plan:
+    """Static launch sequence for one input shape."""
+
+    def __init__(self, rt, n, h, w, training):
+        self.rt, self.n, self.h, self.w, self.training = rt, n, h, w, training
+        self.fwd, self.bwd = [], []
+        self.keep = []                        # ctypes descriptors / tensors kept alive
+        self.outputs = {}
+        self._build()
+
+    # -- helpers
+    def _z(self, *shape, dtype=None):
+        t = torch.zeros(*shape, dtype=dtype or self.rt.tdtype, device=self.rt.dev)
+        self.keep.append(t)
+        return t
+
+    def _dims(self, t):
+        hh, ww = self.h * t.down, self.w * t.down
+        if hh.denominator != 1 or ww.denominator != 1:
+            raise ValueError(f'input {self.h}x{self.w} is not divisible by the model downsampling ({1 / t.down})')
+        return int(hh), int(ww)
+
+    def _conv_step(self, **kw):
+        d = ops.make_conv_desc(**kw)
+        self.keep.append(d)
+        return lambda st, d=d: check(lib.satcv_conv2d_igemm(C.byref(d), st))
+
+    def _src_args(self, r):
+        (x0, c0) = r.srcs[0]
+        x1, c1 = (r.srcs[1] if len(r.srcs) > 1 else (None, 0))
+        a = r.affine
+        return dict(x0=x0.data_ptr(), c0=c0, x1=x1.data_ptr() if x1 is not None else None, c1=c1,
+                    in_scale=_fp(a['scale']) if a else None, in_shift=_fp(a['shift']) if a else None,
+                    in_relu=1 if (a and r.relu) else 0)
+
+    def _bn_forward(self, bnname, stats, ld, off, c, count, updates):
+        """emit finalize (train) / affine (infer); returns affine dict of [c] tensors."""
+        rt = self.rt
+        a = dict(scale=self._z(c, dtype=torch.float32), shift=self._z(c, dtype=torch.float32),
+                 mean=self._z(c, dtype=torch.float32), rstd=self._z(c, dtype=torch.float32))
+        g, b = rt.pptr(bnname + '/gamma'), rt.pptr(bnname + '/beta')
+        mm, mv = rt.sptr(bnname + '/moving_mean'), rt.sptr(bnname + '/moving_var')
+        if self.training:
+            bessel = 1 if rt.model.bn_bessel else 0
+            self.fwd.append(lambda st: check(lib.satcv_bn_finalize_train(
+                _fp(stats, off), ld, c, float(count), g, b, BN_EPS, BN_MOMENTUM, updates, bessel, mm, mv,
+                _fp(a['scale']), _fp(a['shift']), _fp(a['mean']), _fp(a['rstd']), st)))
+        else:
+            self.fwd.append(lambda st: check(lib.satcv_bn_affine_infer(g, b, mm, mv, BN_EPS, c, _fp(a['scale']), _fp(a['shift']), st)))
+        return a
+
+    def _materialize(self, t, r, f=1, pooled=None, sink=None):
+        """relu(bn(raw)) -> dense activated tensor (and optional pooled / stats)."""
+        (y, c) = r.srcs[0]
+        hh, ww = r.h, r.w
+        act = self._z(self.n, hh, ww, c)
+        st_ptr, ld = (None, 0)
+        if sink is not None and self.training:
+            st_ptr, ld = _fp(sink[0], sink[1]), sink[2]
+        a = r.affine
+        dt = self.rt.dtype
+        self.fwd.append(lambda st: check(lib.satcv_bn_relu_pool(
+            y.data_ptr(), _fp(a['scale']), _fp(a['shift']), act.data_ptr(), pooled.data_ptr() if pooled is not None else None,
+            st_ptr, ld, self.n, hh, ww, c, f, dt, st)))
+        return TRef([(act, c)], self.n, hh, ww)
+
+    # -- lowering
+    def _build(self):
+        rt, m, n = self.rt, self.rt.model, self.n
+        T, dt, es = rt.tdtype, rt.dtype, rt.esize
+        training = self.training
+        consumers = defaultdict(list)
+        for node in m.nodes:
+            for t in node.inputs:
+                consumers[t.id].append(node)
+        vals, acts, ctx = {}, {}, {}
+        sinks, cat_stats = {}, {}
+        for node in m.nodes:
+            if node.op == 'concat_bn_relu':
+                a, b = node.inputs
+                ctot = a.channels + b.channels
+                st = self._z(STAT_ROWS, 2, ctot, dtype=torch.float32)
+                cat_stats[id(node)] = st
+                sinks[a.id] = (st, 0, ctot)
+                sinks[b.id] = (st, a.channels, ctot)
+
+        for node in m.nodes:
+            op = node.op
+            if op == 'input':
+                t = node.outputs[0]
+                cp = rup(t.channels, 16)
+                x = self._z(n, self.h, self.w, cp)
+                xin = self._z(n, self.h, self.w, t.channels, dtype=torch.float32)
+                self.x_f32 = xin
+                npix = n * self.h * self.w
+                cc = t.channels
+                self.fwd.append(lambda st, xin=xin, x=x, npix=npix, cc=cc, cp=cp: check(lib.satcv_ingest_nhwc(xin.data_ptr(), x.data_ptr(), npix, cc, cp, dt, st)))
+                vals[t.id] = TRef([(x, cp)], n, self.h, self.w)
+            elif op == 'cba':
+                tin, tout = node.inputs[0], node.outputs[0]
+                r = vals[tin.id]
+                lay = node.layer
+                pk = rt.packed[lay.name]
+                cout = tout.channels
+                if cout % 16:
+                    raise NotImplementedError(f'{lay.name}: filters must be a multiple of 16 (got {cout})')
+                if r.c != pk['cin_pad']:
+                    raise ValueError(f'{lay.name}: input has {r.c} stored channels, kernel expects {pk["cin_pad"]}')
+                y = self._z(n, r.h, r.w, cout)
+                stats = self._z(STAT_ROWS, 2, cout, dtype=torch.float32) if training else None
+                k, dil = node.attrs['k'], node.attrs['dil']
+                self.fwd.append(self._conv_step(w=pk['fwd'].data_ptr(), bias=rt.pptr(lay.name + '/bias'), y=y.data_ptr(), ldy=cout,
+                                                stats=_fp(stats), stats_ld=cout, n=n, h=r.h, w_=r.w, cout=cout, cout_pad=rup(cout, 32),
+                                                kh=k, kw=k, dil=dil, dtype=dt, **self._src_args(r)))
+                aff = self._bn_forward(lay.bn_name, stats, cout, 0, cout, n * r.h * r.w, node.attrs.get('bn_updates', 1))
+                vals[tout.id] = TRef([(y, cout)], n, r.h, r.w, affine=aff, relu=True)
+                ctx[id(node)] = dict(r=r, y=y, aff=aff, cout=cout, k=k, dil=dil)
+            elif op == 'pool':
+                tin, tout = node.inputs[0], node.outputs[0]
+                r = vals[tin.id]
+                f = node.attrs['f']
+                if not (r.affine and len(r.srcs) == 1):
+                    raise NotImplementedError('max-pool expects the output of a conv_batch_act block')
+                c = r.c
+                pooled = self._z(n, r.h // f, r.w // f, c)
+                others = [cn for cn in consumers[tin.id] if cn is not node]
+                if others:
+                    acts[tin.id] = self._materialize(tin, r, f, pooled, sinks.get(tin.id))
+                else:
+                    (y, _) = r.srcs[0]
+                    a = r.affine
+                    hh, ww = r.h, r.w
+                    self.fwd.append(lambda st, y=y, a=a, pooled=pooled, hh=hh, ww=ww, c=c, f=f: check(lib.satcv_bn_relu_pool(
+                        y.data_ptr(), _fp(a['scale']), _fp(a['shift']), None, pooled.data_ptr(), None, 0, n, hh, ww, c, f, dt, st)))
+                vals[tout.id] = TRef([(pooled, c)], n, r.h // f, r.w // f)
+                ctx[id(node)] = dict(f=f)
+            elif op == 'convT':
+                tin, tout = node.inputs[0], node.outputs[0]
+                r = vals[tin.id]
+                if len(r.srcs) != 1:
+                    raise NotImplementedError('transposed conv on a concatenated input')
+                lay = node.layer
+                pk = rt.packed[lay.name]
+                cout, f = tout.channels, node.attrs['f']
+                if cout % 32:
+                    raise NotImplementedError(f'{lay.name}: transposed-conv filters must be a multiple of 32')
+                u = self._z(n, r.h * f, r.w * f, cout)
+                sink = sinks.get(tout.id) if training else None
+                self.fwd.append(self._conv_step(w=pk['fwd'].data_ptr(), bias=rt.pptr(lay.name + '/bias'), y=u.data_ptr(), ldy=cout,
+                                                stats=_fp(sink[0], sink[1]) if sink else None, stats_ld=sink[2] if sink else 0,
+                                                n=n, h=r.h, w_=r.w, cout=f * f * cout, cout_pad=rup(f * f * cout, 32), kh=1, kw=1, dil=1,
+                                                mode_out=1, f=f, cstat=cout, dtype=dt, **self._src_args(r)))
+                vals[tout.id] = TRef([(u, cout)], n, r.h * f, r.w * f)
+                ctx[id(node)] = dict(r=r, u=u, cout=cout, f=f)
+            elif op == 'concat_bn_relu':
+                ta, tb = node.inputs
+                tout = node.outputs[0]
+                if ta.id not in acts:
+                    ra0 = vals[ta.id]
+                    acts[ta.id] = self._materialize(ta, ra0, 1, None, sinks.get(ta.id)) if ra0.affine else ra0
+                ra, rb = acts[ta.id], vals[tb.id]
+                if rb.affine or len(rb.srcs) != 1 or len(ra.srcs) != 1:
+                    raise NotImplementedError('concat+BN expects (activated skip, transposed-conv output)')
+                ca, cb = ra.c, rb.c
+                st = cat_stats[id(node)]
+                aff = self._bn_forward(node.layer.name, st, ca + cb, 0, ca + cb, n * ra.h * ra.w, 1)
+                vals[tout.id] = TRef([ra.srcs[0], rb.srcs[0]], n, ra.h, ra.w, affine=aff, relu=True)
+                ctx[id(node)] = dict(ra=ra, rb=rb, aff=aff, ca=ca, cb=cb)
+            elif op == 'dropout':
+                if training:
+                    raise NotImplementedError('dropout is not implemented in the training path yet')
+                vals[node.outputs[0].id] = vals[node.inputs[0].id]
+            elif op == 'head':
+                tin, tout = node.inputs[0], node.outputs[0]
+                r = vals[tin.id]
+                if len(r.srcs) != 1:
+                    raise NotImplementedError('head on concatenated input')
+                lay = node.layer
+                ncls = tout.channels
+                act = 0 if node.attrs['activation'] == 'softmax' else 1
+                (y, c) = r.srcs[0]
+                npix = n * r.h * r.w
+                probs = self._z(n, r.h, r.w, ncls, dtype=torch.float32)
+                classes = self._z(*((n, r.h, r.w) if act == 0 else (n, r.h, r.w, ncls)), dtype=torch.int32)
+                hd = ops.make_head_desc(x=y.data_ptr(), ldx=c, cin=c, w=rt.pptr(lay.name + '/kernel'), b=rt.pptr(lay.name + '/bias'),
+                                        ncls=ncls, activation=act, npix=npix, dtype=dt,
+                                        in_scale=_fp(r.affine['scale']) if r.affine else None,
+                                        in_shift=_fp(r.affine['shift']) if r.affine else None,
+                                        thresh=node.attrs.get('thresh', 0.5), probs=probs.data_ptr(), classes=classes.data_ptr())
+                self.keep.append(hd)
+                self.fwd.append(lambda st, hd=hd: check(lib.satcv_head_fwd(C.byref(hd), st)))
+                self.outputs[tout.id] = probs
+                ctx[id(node)] = dict(r=r, probs=probs, classes=classes, act=act, ncls=ncls)
+                self.head = ctx[id(node)]
+                self.head_node = node
+            elif op == 'classes':
+                hctx = ctx[id(node.inputs[0].node)]
+                if 'thresh' in node.attrs:
+                    node.inputs[0].node.attrs['thresh'] = node.attrs['thresh']
+                self.outputs[node.outputs[0].id] = hctx['classes']
+            else:
+                raise NotImplementedError(f'op {op}')
+        self.vals = vals
+        if training:
+            self._build_backward(consumers, vals, acts, ctx, cat_stats)
+
+    def _build_backward(self, consumers, vals, acts, ctx, cat_stats):
+        rt, m, n = self.rt, self.rt.model, self.n
+        dt, es = rt.dtype, rt.esize
+        gact, gpool, gpool_f, graw = {}, {}, {}, {}
+        ws_need = 0
+        wdescs = []
+        # loss -> dlogits is written by Model.train step into this buffer
+        h = self.head
+        self.dlogits = self._z(n * h['r'].h * h['r'].w, h['ncls'], dtype=torch.float32)
+        self.loss_buf = self._z(1, dtype=torch.float32)
+
+        def bn_bwd_steps(da, ldda, dp, lddp, f, yraw, ldy, aff, aoff, sums, sums_off, sums_ld, c, hh, ww, dy, lddy, dbias,
+                         dgamma, dbeta):
+            coef = self._z(2, c, dtype=torch.float32)
+            d = ops.make_bnbwd_desc(yraw=yraw, ldy=ldy, scale=_fp(aff['scale'], aoff), shift=_fp(aff['shift'], aoff),
+                                    mean=_fp(aff['mean'], aoff), rstd=_fp(aff['rstd'], aoff), n=n, h=hh, w_=ww, c=c, dtype=dt,
+                                    da=da, ldda=ldda, dpool=dp, lddp=lddp, f=f, sums=_fp(sums, sums_off), sums_ld=sums_ld,
+                                    coef=_fp(coef), dy=dy, lddy_out=lddy, dbias=dbias)
+            self.keep.append(d)
+            cnt = float(n * hh * ww)
+            red = lambda st: check(lib.satcv_bn_bwd_reduce(C.byref(d), st))
+            fin = lambda st: check(lib.satcv_bn_bwd_finalize(_fp(sums, sums_off), sums_ld, c, cnt, dgamma, dbeta, _fp(coef), st))
+            app = lambda st: check(lib.satcv_bn_bwd_apply(C.byref(d), st))
+            return red, fin, app
+
+        def wgrad_step(r, dy, lddy, lay, cin_real, cout, hh, ww, k, dil, f=0):
+            nonlocal ws_need
+            sa = self._src_args(r)
+            d = ops.make_wgrad_desc(dy=dy, lddy=lddy, dw=rt.gptr(lay.name + '/kernel'), cin=cin_real, cout=cout, n=n, h=hh, w_=ww,
+                                    dtype=dt, kh=k, kw=k, dil=dil, mode_dy=1 if f else 0, f=f if f else 1, transposed=1 if f else 0, **sa)
+            nb = lib.satcv_conv2d_wgrad_workspace(C.byref(d))
+            if nb < 0:
+                raise RuntimeError(lib.satcv_last_error().decode())
+            ws_need = max(ws_need, nb)
+            wdescs.append(d)
+            self.keep.append(d)
+            return lambda st: check(lib.satcv_conv2d_wgrad(C.byref(d), st))
+
+        for node in reversed(m.nodes):
+            op = node.op
+            cx = ctx.get(id(node))
+            if op == 'head':
+                r = cx['r']
+                (y, c) = r.srcs[0]
+                dx = self._z(n, r.h, r.w, c)
+                lay = node.layer
+                hd = ops.make_head_desc(x=y.data_ptr(), ldx=c, cin=c, w=rt.pptr(lay.name + '/kernel'), b=rt.pptr(lay.name + '/bias'),
+                                        ncls=cx['ncls'], activation=cx['act'], npix=n * r.h * r.w, dtype=dt,
+                                        in_scale=_fp(r.affine['scale']) if r.affine else None,
+                                        in_shift=_fp(r.affine['shift']) if r.affine else None,
+                                        dlogits=self.dlogits.data_ptr(), dx=dx.data_ptr(), lddx=c,
+                                        dw=rt.gptr(lay.name + '/kernel'), db=rt.gptr(lay.name + '/bias'))
+                self.keep.append(hd)
+                self.bwd.append(lambda st, hd=hd: check(lib.satcv_head_bwd(C.byref(hd), st)))
+                gact[node.inputs[0].id] = dx
+            elif op == 'cba':
+                tin, tout = node.inputs[0], node.outputs[0]
+                da, dp = gact.get(tout.id), gpool.get(tout.id)
+                if da is None and dp is None:
+                    continue
+                lay, r, y, aff, cout = node.layer, cx['r'], cx['y'], cx['aff'], cx['cout']
+                hh, ww = r.h, r.w
+                sums = self._z(STAT_ROWS, 2, cout, dtype=torch.float32)
+                dy = self._z(n, hh, ww, cout)
+                red, fin, app = bn_bwd_steps(da.data_ptr() if da is not None else None, cout, dp.data_ptr() if dp is not None else None,
+                                             cout, gpool_f.get(tout.id, 1), y.data_ptr(), cout, aff, 0, sums, 0, cout, cout, hh, ww,
+                                             dy.data_ptr(), cout, rt.gptr(lay.name + '/bias'),
+                                             rt.gptr(lay.bn_name + '/gamma'), rt.gptr(lay.bn_name + '/beta'))
+                self.bwd += [red, fin, app]
+                pk = rt.packed[lay.name]
+                self.bwd.append(wgrad_step(r, dy.data_ptr(), cout, lay, pk['cin'], cout, hh, ww, cx['k'], cx['dil']))
+                if tin.node.op != 'input':
+                    cinp = r.c
+                    gin = self._z(n, hh, ww, cinp)
+                    self.bwd.append(self._conv_step(x0=dy.data_ptr(), c0=cout, w=pk['dgrad'].data_ptr(), y=gin.data_ptr(), ldy=cinp,
+                                                    n=n, h=hh, w_=ww, cout=cinp, cout_pad=rup(cinp, 32), kh=cx['k'], kw=cx['k'],
+                                                    dil=cx['dil'], dtype=dt))
+                    gact[tin.id] = gin
+            elif op == 'pool':
+                tin, tout = node.inputs[0], node.outputs[0]
+                if tout.id in gact:
+                    gpool[tin.id] = gact[tout.id]
+                    gpool_f[tin.id] = cx['f']
+            elif op == 'concat_bn_relu':
+                ta, tb = node.inputs
+                tout = node.outputs[0]
+                g = gact.get(tout.id)
+                if g is None:
+                    continue
+                ra, rb, aff, ca, cb = cx['ra'], cx['rb'], cx['aff'], cx['ca'], cx['cb']
+                ctot = ca + cb
+                hh, ww = ra.h, ra.w
+                sums = self._z(STAT_ROWS, 2, ctot, dtype=torch.float32)
+                dskip = self._z(n, hh, ww, ca)
+                du = self._z(n, hh, ww, cb)
+                bn = node.layer.name
+                upl = tb.node.layer
+                ra_, fa_, aa_ = bn_bwd_steps(g.data_ptr(), ctot, None, 0, 1, ra.srcs[0][0].data_ptr(), ca, aff, 0, sums, 0, ctot, ca, hh, ww,
+                                             dskip.data_ptr(), ca, None, rt.gptr(bn + '/gamma'), rt.gptr(bn + '/beta'))
+                rb_, fb_, ab_ = bn_bwd_steps(g.data_ptr() + ca * es, ctot, None, 0, 1, rb.srcs[0][0].data_ptr(), cb, aff, ca, sums, ca, ctot, cb,
+                                             hh, ww, du.data_ptr(), cb, rt.gptr(upl.name + '/bias') if tb.node.op == 'convT' else None,
+                                             rt.gptr(bn + '/gamma') + 4 * ca, rt.gptr(bn + '/beta') + 4 * ca)
+                self.bwd += [ra_, rb_, fa_, fb_, aa_, ab_]
+                # the skip is the activated output of an encoder conv_batch_act block
+                gact[ta.id] = dskip
+                graw[tb.id] = du
+            elif op == 'convT':
+                tin, tout = node.inputs[0], node.outputs[0]
+                du = graw.get(tout.id)
+                if du is None:
+                    continue
+                lay, r, cout, f = node.layer, cx['r'], cx['cout'], cx['f']
+                pk = rt.packed[lay.name]
+                self.bwd.append(wgrad_step(r, du.data_ptr(), cout, lay, pk['cin'], cout, r.h, r.w, 1, 1, f=f))
+                cinp = r.c
+                gin = self._z(n, r.h, r.w, cinp)
+                self.bwd.append(self._conv_step(x0=du.data_ptr(), c0=cout, w=pk['dgrad'].data_ptr(), y=gin.data_ptr(), ldy=cinp, n=n, h=r.h,
+                                                w_=r.w, cout=cinp, cout_pad=rup(cinp, 32), kh=1, kw=1, dil=1, mode_in=1, f=f, dtype=dt))
+                gact[tin.id] = gin
+        if ws_need:
+            ws = self._z(max(ws_need // 4, 1), dtype=torch.float32)
+            for d in wdescs:
+                d.workspace, d.workspace_bytes = ws.data_ptr(), ws_need
+
+    # -- execution
+    def run_forward(self, st):
+        for s in self.fwd:
+            s(st)
+
+    def run_backward(self, st):
+        for s in self.bwd:
+            s(st)

@@ -1,0 +1,872 @@
+"""MI355X-native drop-in for the U-Net / ASPP path of the reference's utils/model_tools.py.
+
+Same names, argument meaning and return conventions as
+/root/reference/utils/model_tools.py (cited per symbol); underneath, every tensor op is a
+hand-written HIP kernel reached through the C ABI (include/satcv.h).  There is no
+TensorFlow and no CPU fallback: building a graph is pure Python, running it needs the
+HIP library and a ROCm device.
+
+Surface mirrored here
+  losses         weighted_categorical_crossentropy :25, gen_dice :42, weighted_bce :96,
+                 iou_loss :131, mse_4d :142
+  blocks         conv_batch_act :174, conv_block :211 (AS CODED: one conv per level, BN moving
+                 statistics updated twice), encoder_block :262, decoder_block :288
+  builders       build_unet_layers :321, get_unet_model :394, DilatedSpatialPyramidPooling :533
+  Model          compile / fit / evaluate / predict / save / load_weights / layers[i].trainable /
+                 optimizer.learning_rate / metrics_names (call sites: utils/model_tools.py:1128-1176,
+                 utils/prediction_tools.py:152,333; notebooks/UNET_G4G_2019_solar.ipynb:1206-1277)
+"""
+import json
+import os
+import time
+from collections import defaultdict
+from fractions import Fraction
+
+import numpy as np
+import torch
+
+from . import engine as E
+from . import ops
+from ._lib import lib, check, F32, BF16
+
+# ------------------------------------------------------------------------- globals
+_DEFAULT_DTYPE = 'bfloat16'
+_RNG = np.random.default_rng(0)
+_UIDS = defaultdict(int)
+
+
+def set_compute_dtype(name):
+    """'bfloat16' (bf16 storage, MFMA bf16, fp32 accumulate) or 'float32' (exact fp32 MFMA)."""
+    global _DEFAULT_DTYPE
+    assert name in ('bfloat16', 'float32')
+    _DEFAULT_DTYPE = name
+
+
+def set_seed(seed):
+    global _RNG
+    _RNG = np.random.default_rng(seed)
+
+
+def reset_uids():
+    _UIDS.clear()
+
+
+def _unique(base):
+    """Keras-style automatic layer names: conv2d, conv2d_1, ..."""
+    i = _UIDS[base]
+    _UIDS[base] += 1
+    return base if i == 0 else f'{base}_{i}'
+
+
+def _glorot(shape, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return lambda: _RNG.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+class _Constant:
+    """tf.keras.initializers.Constant"""
+
+    def __init__(self, value):
+        self.value = value
+
+
+# --------------------------------------------------------------------------- layers
+class _LayerBase:
+    def __init__(self, name):
+        self.name = name
+        self.trainable = True
+        self.specs = []
+
+    def _add(self, suffix, shape, kind, init):
+        p = E.ParamSpec(f'{self.name}/{suffix}', shape, kind, init)
+        self.specs.append(p)
+        return p
+
+    @property
+    def weights(self):
+        return [p.name for p in self.specs]
+
+
+class _ConvParams(_LayerBase):
+    """kernel + bias of a Conv2D / Conv2DTranspose (Keras defaults: glorot_uniform, zeros)."""
+
+    def __init__(self, name, filters, kernel_size, transposed=False, bias_initializer='zeros'):
+        super().__init__(name)
+        self.filters, self.kernel_size, self.transposed = filters, kernel_size, transposed
+        self.bias_initializer = bias_initializer
+        self.bn_name = None
+        self.built = False
+
+    @property
+    def kernel_name(self):
+        return self.name + '/kernel'
+
+    def build(self, cin):
+        if self.built:
+            return
+        kh, kw = self.kernel_size
+        f = self.filters
+        shape = (kh, kw, f, cin) if self.transposed else (kh, kw, cin, f)
+        rec = kh * kw
+        self._add('kernel', shape, 'kernel', _glorot(shape, shape[2] * rec, shape[3] * rec))
+        bi = self.bias_initializer
+        if isinstance(bi, _Constant):
+            init = lambda: np.full((f,), bi.value, np.float32)
+        elif bi is None:
+            # Keras add_weight default when the initializer argument is None
+            init = _glorot((f,), f, f)
+        else:
+            init = lambda: np.zeros((f,), np.float32)
+        self._add('bias', (f,), 'bias', init)
+        self.built = True
+
+
+class _BNParams(_LayerBase):
+    """layers.BatchNormalization() defaults: axis -1, momentum 0.99, epsilon 1e-3."""
+
+    def __init__(self, name=None):
+        super().__init__(name or _unique('batch_normalization'))
+        self.built = False
+
+    def build(self, c):
+        if self.built:
+            return
+        self._add('gamma', (c,), 'gamma', lambda: np.ones((c,), np.float32))
+        self._add('beta', (c,), 'beta', lambda: np.zeros((c,), np.float32))
+        self._add('moving_mean', (c,), 'moving_mean', lambda: np.zeros((c,), np.float32))
+        self._add('moving_var', (c,), 'moving_var', lambda: np.ones((c,), np.float32))
+        self.built = True
+
+
+def Input(shape, name=None):
+    """layers.Input(shape=[None, None, nchannels]) (utils/model_tools.py:397)."""
+    node = E.Node('input', [])
+    return node.out(int(shape[-1]), Fraction(1), name or _unique('input'))
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class conv_batch_act:
+    """Single convolution -> batch norm -> activation layer stack (utils/model_tools.py:174-186).
+
+    Lowered to ONE node: implicit-GEMM conv kernel with BN statistics in its epilogue; the BN
+    affine + ReLU is applied by the consumer's loader."""
+
+    def __init__(self, num_filters, kernel_size=(3, 3), dilation_rate=1, name='conv_batch_act', **kwargs):
+        self.name = name
+        ks = _pair(kernel_size)
+        assert ks[0] == ks[1] and ks[0] in (1, 3), 'kernel_size must be (1,1) or (3,3)'
+        self.conv_layer = _ConvParams(_unique('conv2d'), num_filters, ks)
+        self.bn_layer = _BNParams()
+        self.conv_layer.bn_name = self.bn_layer.name
+        self.dilation_rate = dilation_rate if isinstance(dilation_rate, int) else dilation_rate[0]
+        self.num_filters = num_filters
+        self.bn_updates = 1
+
+    @property
+    def trainable(self):
+        return self.conv_layer.trainable
+
+    @trainable.setter
+    def trainable(self, v):
+        self.conv_layer.trainable = self.bn_layer.trainable = v
+
+    def _sublayers(self):
+        return [self.conv_layer, self.bn_layer]
+
+    def __call__(self, inputs, bn_updates=None):
+        self.conv_layer.build(inputs.channels)
+        self.bn_layer.build(self.num_filters)
+        node = E.Node('cba', [inputs], layer=self.conv_layer, k=self.conv_layer.kernel_size[0], dil=self.dilation_rate,
+                      bn_updates=bn_updates or self.bn_updates, owner=self)
+        return node.out(self.num_filters, inputs.down)
+
+    call = __call__
+
+
+class conv_block:
+    """U-Net convolution block (utils/model_tools.py:211-240).
+
+    AS CODED the reference's call() runs `self.cba1(inputs)` twice and never uses cba2
+    (:238-240): the block is ONE conv->BN->ReLU whose BN moving statistics are updated twice
+    per training step.  cba2 is constructed (it consumes layer
+    names, as in Keras) but never built.  `double_conv=True` gives the evidently intended
+    conv->BN->ReLU x2 of the notebooks (notebooks/UNET_G4G_2019_solar.ipynb:1162-1169)."""
+
+    def __init__(self, num_filters, kernel_size=(3, 3), dilation_rate=1, name='conv_block', double_conv=False, **kwargs):
+        self.name = name
+        self.cba1 = conv_batch_act(num_filters, kernel_size, dilation_rate)
+        self.cba2 = conv_batch_act(num_filters, kernel_size, dilation_rate)
+        self.double_conv = double_conv
+
+    def _sublayers(self):
+        return self.cba1._sublayers() + (self.cba2._sublayers() if self.double_conv else [])
+
+    def __call__(self, inputs):
+        if self.double_conv:
+            return self.cba2(self.cba1(inputs))
+        return self.cba1(inputs, bn_updates=2)
+
+    call = __call__
+
+
+class encoder_block:
+    """U-Net downsampling encoder block conv -> max pool (utils/model_tools.py:262-286).
+    Returns (pooled, encoded)."""
+
+    def __init__(self, num_filters, kernel_size=(3, 3), dilation_rate=1, pool_size=(2, 2), name='encoder_block', **kwargs):
+        self.name = name
+        self.encoder = conv_block(num_filters, kernel_size, dilation_rate, **kwargs)
+        ps = _pair(pool_size)
+        assert ps[0] == ps[1]
+        self.pool = ps[0]
+        _unique('max_pooling2d')
+
+    def _sublayers(self):
+        return self.encoder._sublayers()
+
+    def __call__(self, input):
+        encoded = self.encoder(input)
+        node = E.Node('pool', [encoded], f=self.pool)
+        pooled = node.out(encoded.channels, encoded.down / self.pool)
+        return pooled, encoded
+
+    call = __call__
+
+
+def _dropout(x, rate, spatial):
+    node = E.Node('dropout', [x], rate=rate, spatial=spatial)
+    return node.out(x.channels, x.down)
+
+
+def decoder_block(input_tensor, concat_tensor, num_filters, up_size=(2, 2), dropout=None):
+    """U-Net upsampling decoder block (utils/model_tools.py:288-318):
+    Conv2DTranspose(k=s=up_size) -> concatenate([skip, up]) -> BN -> ReLU -> [SpatialDropout2D]
+    -> (Conv3x3 -> BN -> ReLU) x 2.  The concat is never materialised."""
+    us = _pair(up_size)
+    assert us[0] == us[1]
+    f = us[0]
+    up = _ConvParams(_unique('conv2d_transpose'), num_filters, (f, f), transposed=True)
+    up.build(input_tensor.channels)
+    n_up = E.Node('convT', [input_tensor], layer=up, f=f)
+    t_up = n_up.out(num_filters, input_tensor.down * f)
+    _unique('concatenate')
+    bn0 = _BNParams()
+    bn0.build(concat_tensor.channels + num_filters)
+    n_cat = E.Node('concat_bn_relu', [concat_tensor, t_up], layer=bn0)
+    decoder = n_cat.out(concat_tensor.channels + num_filters, t_up.down)
+    if dropout is not None:
+        decoder = _dropout(decoder, dropout, True)
+    for _ in range(2):
+        cba = conv_batch_act(num_filters, (3, 3), 1, name='decoder_conv')
+        cba.name = cba.conv_layer.name
+        decoder = cba(decoder)
+    return decoder
+
+
+# ------------------------------------------------------------------ model construction
+def build_unet_layers(input_tensor, filters=[32, 64, 128, 256, 512], factors=[2, 2, 2, 2, 2], dropout=None, double_conv=False):
+    """Create U-Net layers (utils/model_tools.py:321-379)."""
+    assert len(filters) == len(factors), 'number of filters and factors must be equal'
+    levels = len(filters)
+    net = {}
+    encoder_pool = input_tensor
+    for i, filt in enumerate(filters):
+        factor = factors[i]
+        encoder = encoder_block(filt, pool_size=(factor, factor), name=f'encoder_{i}', double_conv=double_conv)
+        encoder_pool, encoded = encoder(encoder_pool)
+        if i == 0 and dropout is not None:
+            encoder_pool = _dropout(encoder_pool, dropout, True)          # :350-351
+        net[f'encoder{i}'] = encoded
+        net[f'encoder_pool{i}'] = encoder_pool
+    conv = conv_block(filters[-1] * 2, double_conv=double_conv)
+    center = conv(net[f'encoder_pool{levels - 1}'])
+    decoder = _dropout(center, dropout, False) if dropout is not None else center   # :362-365
+    for j in range(levels - 1, -1, -1):
+        decoder = decoder_block(decoder, net[f'encoder{j}'], filters[j], up_size=(factors[j], factors[j]),
+                                dropout=dropout if j == 0 else None)      # :373-377
+    return decoder
+
+
+class _Head:
+    """layers.Conv2D(nclasses,(1,1),activation=...) fused with the argmax / threshold Lambda."""
+
+    def __init__(self, nclasses, activation, bias_initializer, name):
+        self.name = name
+        self.params = _ConvParams(name, nclasses, (1, 1), bias_initializer=bias_initializer)
+        self.activation = activation
+
+    def __call__(self, x):
+        self.params.build(x.channels)
+        node = E.Node('head', [x], layer=self.params, activation=self.activation)
+        return node.out(self.params.filters, x.down, self.name)
+
+
+def _classes(probs, name, thresh=None):
+    if thresh is not None:
+        probs.node.attrs['thresh'] = float(thresh)
+    node = E.Node('classes', [probs])
+    return node.out(1, probs.down, name)
+
+
+def get_unet_model(nclasses, nchannels, filters=[32, 64, 128, 256, 512], factors=[2, 2, 2, 2, 2], bias=None, dropout=None,
+                   head_name: str = '', double_conv=False):
+    """utils/model_tools.py:394-415: U-Net -> Conv2D(nclasses,1x1,softmax) 'probs' -> argmax int32
+    f'{head_name}classes'.  Returns an UNCOMPILED Model(inputs, [probs, classes])."""
+    bias_init = _Constant(bias) if bias is not None else None
+    inputs = Input(shape=[None, None, nchannels])
+    decoder = build_unet_layers(inputs, filters, factors, dropout=dropout, double_conv=double_conv)
+    logit_input = _dropout(decoder, dropout, True) if dropout is not None else decoder
+    probs = _Head(nclasses, 'softmax', bias_init, 'probs')(logit_input)
+    classes = _classes(probs, f'{head_name}classes')
+    model = Model(inputs=inputs, outputs=[probs, classes])
+    model._builder = dict(fn='get_unet_model', nclasses=nclasses, nchannels=nchannels, filters=list(filters), factors=list(factors),
+                          bias=bias, dropout=dropout, head_name=head_name, double_conv=double_conv)
+    return model
+
+
+# ---------------------------------------------------------------------------- losses
+class LossSpec:
+    def __init__(self, kind, weights):
+        self.kind, self.weights = kind, np.asarray(weights, np.float32).reshape(-1)
+
+
+class _LossArg:
+    """placeholder handed to a user loss function so that it can describe itself"""
+
+    def __init__(self, what):
+        self.what = what
+
+
+def _eager_loss(kind, y_true, y_pred, weights, activation='softmax'):
+    dev = torch.device('cuda')
+    p = torch.as_tensor(np.asarray(y_pred, np.float32)).to(dev).contiguous()
+    t = torch.as_tensor(np.asarray(y_true, np.float32)).to(dev).contiguous()
+    w = torch.as_tensor(np.asarray(weights, np.float32).reshape(-1)).to(dev)
+    loss, _ = ops.loss_fwd_bwd(kind, p, t, w, activation)
+    return float(loss.item())
+
+
+def weighted_categorical_crossentropy(target, output, weights, axis=-1):
+    """utils/model_tools.py:25-40 (reduced to its mean, as Keras does for a loss function)."""
+    if isinstance(output, _LossArg):
+        return LossSpec('weighted_categorical_crossentropy', weights)
+    return _eager_loss('weighted_categorical_crossentropy', target, output, weights)
+
+
+def weighted_bce(y_true, y_pred, pos_weight, logits=False):
+    """utils/model_tools.py:96-112 (probability form; logits=True is not on the fused path)."""
+    if logits:
+        raise NotImplementedError('weighted_bce(logits=True): the model heads output probabilities')
+    if isinstance(y_pred, _LossArg):
+        return LossSpec('weighted_bce', [pos_weight])
+    return _eager_loss('weighted_bce', y_true, y_pred, [pos_weight])
+
+
+def gen_dice(y_true, y_pred, eps=1e-6, global_weights=None):
+    raise NotImplementedError('gen_dice (utils/model_tools.py:42-94) is not built yet')
+
+
+def iou_loss(true, pred):
+    raise NotImplementedError('iou_loss (utils/model_tools.py:131-140) is not built yet')
+
+
+def mse_4d(y_true, y_pred, eps=1e-6):
+    raise NotImplementedError('mse_4d (utils/model_tools.py:142-166) is not built yet')
+
+
+# ------------------------------------------------------------- optimizers / metrics
+class _LR:
+    def __init__(self, opt):
+        self._opt = opt
+
+    def numpy(self):
+        return np.float32(self._opt._lr)
+
+    def assign(self, v):
+        self._opt._set_lr(float(v))
+
+    def __float__(self):
+        return float(self._opt._lr)
+
+
+class Adam:
+    """tf.keras.optimizers.Adam: epsilon 1e-7 outside the bias correction."""
+
+    def __init__(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, **kwargs):
+        self._lr = float(kwargs.get('lr', learning_rate))
+        self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
+        self._rt = None
+
+    def _set_lr(self, v):
+        self._lr = v
+        if self._rt is not None:
+            self._rt.adam_state[0:1].fill_(v)
+
+    @property
+    def learning_rate(self):
+        return _LR(self)
+
+    @learning_rate.setter
+    def learning_rate(self, v):
+        self._set_lr(float(v))
+
+    lr = learning_rate
+
+
+class MeanIoU:
+    """tf.keras.metrics.MeanIoU(num_classes): mean over classes of TP/(TP+FP+FN), on class ids."""
+
+    def __init__(self, num_classes, name='mean_io_u'):
+        self.num_classes, self.name = num_classes, name
+
+
+class History:
+    def __init__(self):
+        self.history = defaultdict(list)
+        self.epoch = []
+
+
+class ModelCheckpoint:
+    """tf.keras.callbacks.ModelCheckpoint (nb:1228-1235); `.best` is mutable as retrain_model needs (:1168)."""
+
+    def __init__(self, filepath, monitor='val_loss', verbose=0, save_best_only=False, save_weights_only=False, mode='auto', **kw):
+        self.filepath, self.monitor, self.verbose = filepath, monitor, verbose
+        self.save_best_only, self.save_weights_only = save_best_only, save_weights_only
+        if mode == 'auto':
+            mode = 'max' if ('acc' in monitor or 'io_u' in monitor or 'iou' in monitor) else 'min'
+        self.mode = mode
+        self.best = -np.inf if mode == 'max' else np.inf
+        self.model = None
+
+    def on_epoch_end(self, epoch, logs):
+        cur = logs.get(self.monitor)
+        path = self.filepath.format(epoch=epoch + 1, **logs)
+        if self.save_best_only:
+            if cur is None:
+                return
+            better = cur > self.best if self.mode == 'max' else cur < self.best
+            if not better:
+                return
+            self.best = cur
+        (self.model.save_weights if self.save_weights_only else self.model.save)(path)
+
+
+class TensorBoard:
+    """tf.keras.callbacks.TensorBoard stand-in: appends epoch scalars as JSON lines under log_dir."""
+
+    def __init__(self, log_dir='logs', **kw):
+        self.log_dir = log_dir
+        self.model = None
+
+    def on_epoch_end(self, epoch, logs):
+        os.makedirs(self.log_dir, exist_ok=True)
+        with open(os.path.join(self.log_dir, 'scalars.jsonl'), 'a') as f:
+            f.write(json.dumps(dict(epoch=epoch, **{k: float(v) for k, v in logs.items()})) + '\n')
+
+
+# ----------------------------------------------------------------------------- Model
+def _as_batches(x, y, batch_size):
+    """ndarray pair / Sequence / iterable of (x, y) -> generator of batches (possibly endless)."""
+    if y is not None or isinstance(x, (np.ndarray, torch.Tensor)):
+        n = x.shape[0]
+        bs = batch_size or 32
+
+        def gen():
+            for i in range(0, n, bs):
+                yield (x[i:i + bs], y[i:i + bs]) if y is not None else x[i:i + bs]
+        return gen(), (n + bs - 1) // bs
+    if hasattr(x, '__getitem__') and hasattr(x, '__len__'):          # keras.utils.Sequence
+
+        def gen():
+            for i in range(len(x)):
+                yield x[i]
+        return gen(), len(x)
+    return iter(x), None
+
+
+class Model:
+    """models.Model(inputs, outputs) with the subset of the Keras API the reference's callers use."""
+
+    def __init__(self, inputs, outputs, name='model', dtype=None):
+        self.inputs = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
+        self.outputs = list(outputs) if isinstance(outputs, (list, tuple)) else [outputs]
+        self._single_output = not isinstance(outputs, (list, tuple))
+        self.name = name
+        self.nodes = E.topo_nodes(self.outputs)
+        if len(self.inputs) != 1:
+            raise NotImplementedError('multi-input models (Siamese) are not built yet')
+        seen, self.layers, self.param_specs = set(), [], []
+        for node in self.nodes:
+            lay = node.layer
+            subs = [lay] if lay is not None else []
+            if node.op == 'cba':
+                subs = [lay, node.attrs['owner'].bn_layer]
+            for l in subs:
+                if id(l) not in seen:
+                    seen.add(id(l))
+                    self.layers.append(l)
+                    self.param_specs += l.specs
+        self.compute_dtype = dtype or _DEFAULT_DTYPE
+        self.bn_bessel = False
+        self._rt = None
+        self.optimizer, self._loss, self._metrics = None, None, []
+        self.metrics_names = []
+        self.stop_training = False
+        self._builder = None
+        self.output_names = [t.name for t in self.outputs]
+
+    # ---- runtime
+    @property
+    def runtime(self):
+        if self._rt is None:
+            self._rt = E.Runtime(self, BF16 if self.compute_dtype == 'bfloat16' else F32)
+            if self.optimizer is not None:
+                self.optimizer._rt = self._rt
+                self._rt.adam_state[0:1].fill_(self.optimizer._lr)
+        return self._rt
+
+    def count_params(self):
+        return sum(p.size for p in self.param_specs)
+
+    def get_layer(self, name):
+        for l in self.layers:
+            if l.name == name:
+                return l
+        raise ValueError(f'No such layer: {name}')
+
+    def get_weights_dict(self):
+        rt = self.runtime
+        torch.cuda.synchronize()
+        return {p.name: rt.get_param(p.name).detach().cpu().numpy().copy() for p in self.param_specs}
+
+    def set_weights_dict(self, d, skip_mismatch=False):
+        rt = self.runtime
+        for k, v in d.items():
+            if k not in rt.specs:
+                if skip_mismatch:
+                    continue
+                raise KeyError(k)
+            if tuple(np.shape(v)) != rt.specs[k].shape:
+                if skip_mismatch:
+                    continue
+                raise ValueError(f'{k}: shape {np.shape(v)} != {rt.specs[k].shape}')
+            rt.set_param(k, v)
+        rt.repack()
+
+    # ---- persistence (own .npz container; Keras HDF5 import is a later row of SURVEY §8f)
+    def save_weights(self, path):
+        np.savez(path if path.endswith('.npz') else path + '.npz', **self.get_weights_dict())
+
+    def load_weights(self, path, by_name=False, skip_mismatch=False):
+        p = path if os.path.exists(path) else path + '.npz'
+        with np.load(p, allow_pickle=False) as z:
+            self.set_weights_dict({k: z[k] for k in z.files if not k.startswith('__')}, skip_mismatch=skip_mismatch or by_name)
+
+    def save(self, path):
+        d = self.get_weights_dict()
+        d['__builder__'] = np.asarray(json.dumps(self._builder or {}))
+        rt = self.runtime
+        if rt.adam_m is not None:
+            d['__adam_m__'], d['__adam_v__'] = rt.adam_m.cpu().numpy(), rt.adam_v.cpu().numpy()
+            d['__adam_state__'] = rt.adam_state.cpu().numpy()
+        np.savez(path if path.endswith('.npz') else path + '.npz', **d)
+
+    # ---- compile
+    def compile(self, optimizer='adam', loss=None, metrics=None, **kw):
+        self.optimizer = Adam() if isinstance(optimizer, str) else optimizer
+        if callable(loss):
+            spec = loss(_LossArg('y_true'), _LossArg('y_pred'))
+        elif isinstance(loss, LossSpec):
+            spec = loss
+        else:
+            raise ValueError('loss must be one of the model_tools loss functions (or a lambda wrapping one)')
+        if not isinstance(spec, LossSpec):
+            raise ValueError('loss function did not resolve to a fused device loss')
+        self._loss = spec
+        self._metrics = list(metrics or [])
+        names = ['loss']
+        for mt in self._metrics:
+            names.append(mt if isinstance(mt, str) else mt.name)
+        self.metrics_names = names
+        if self._rt is not None:
+            self.optimizer._rt = self._rt
+            self._rt.adam_state[0:1].fill_(self.optimizer._lr)
+
+    # ---- inference
+    def _head_plan(self, n, h, w, training):
+        return self.runtime.plan(n, h, w, training)
+
+    def _stage_x(self, plan, xb):
+        if isinstance(xb, torch.Tensor):
+            plan.x_f32.copy_(xb.to(torch.float32), non_blocking=True)
+        else:
+            plan.x_f32.copy_(torch.from_numpy(np.ascontiguousarray(xb, dtype=np.float32)), non_blocking=True)
+
+    def predict_on_device(self, xb):
+        """xb: (n,h,w,c) ndarray or device tensor -> list of device tensors [probs, classes] (no host sync)."""
+        n, h, w, _ = xb.shape
+        plan = self._head_plan(n, h, w, False)
+        self._stage_x(plan, xb)
+        plan.run_forward(ops.stream_ptr())
+        return [plan.outputs[t.id] for t in self.outputs]
+
+    def predict(self, x, batch_size=None, verbose=0, steps=None, **kw):
+        """Model.predict semantics used by the reference (utils/prediction_tools.py:152, 251, 333, 515):
+        inference-mode forward; ndarray or iterable of batches; list of arrays in output order."""
+        batches, nb = _as_batches(x, None, batch_size or 32)
+        outs = [[] for _ in self.outputs]
+        for i, xb in enumerate(batches):
+            if steps is not None and i >= steps:
+                break
+            if isinstance(xb, (tuple, list)):
+                xb = xb[0]
+            res = self.predict_on_device(xb)
+            for o, r in zip(outs, res):
+                o.append(r.cpu().numpy())
+        arrays = [np.concatenate(o, axis=0) for o in outs]
+        return arrays[0] if self._single_output else arrays
+
+    __call__ = predict_on_device
+
+    # ---- training
+    def _apply_trainable(self):
+        rt = self.runtime
+        frozen = [l for l in self.layers if not l.trainable]
+        if not frozen:
+            rt.lr_mul = None
+            return
+        mul = torch.ones_like(rt.pflat)
+        for l in frozen:
+            for p in l.specs:
+                if p.name in rt.offsets:
+                    mul[rt.offsets[p.name]:rt.offsets[p.name] + p.size] = 0
+        rt.lr_mul = mul
+
+    def _loss_launch(self, plan, st, grad_scale=1.0):
+        rt = self.runtime
+        h = plan.head
+        if getattr(self, '_loss_w', None) is None or self._loss_w_spec is not self._loss:
+            self._loss_w = torch.as_tensor(self._loss.weights).to(rt.dev)
+            self._loss_w_spec = self._loss
+        kind = ops.LOSS_KINDS[self._loss.kind]
+        if kind == 0 and self._loss_w.numel() != h['ncls']:
+            raise ValueError('weighted_categorical_crossentropy needs one weight per class')
+        check(lib.satcv_loss_fwd_bwd(kind, h['probs'].data_ptr(), plan.y_true.data_ptr(), self._loss_w.data_ptr(), h['ncls'], h['act'],
+                                     plan.n * h['r'].h * h['r'].w, grad_scale, plan.loss_buf.data_ptr(), plan.dlogits.data_ptr(), st))
+
+    def _stage_y(self, plan, yb):
+        if not hasattr(plan, 'y_true'):
+            h = plan.head
+            plan.y_true = torch.zeros(plan.n, h['r'].h, h['r'].w, h['ncls'], dtype=torch.float32, device=self.runtime.dev)
+        if isinstance(yb, torch.Tensor):
+            plan.y_true.copy_(yb.to(torch.float32), non_blocking=True)
+        else:
+            plan.y_true.copy_(torch.from_numpy(np.ascontiguousarray(yb, dtype=np.float32)), non_blocking=True)
+
+    def train_step_device(self, xb, yb, sync_grads=None):
+        """One optimisation step; returns the device loss scalar (no host sync).
+        sync_grads: optional callable(flat_grad_tensor) run between backward and Adam
+        (data-parallel all-reduce, see parallel.py)."""
+        if self._loss is None:
+            raise RuntimeError('compile() the model before fit/train')
+        rt = self.runtime
+        rt.ensure_adam()
+        n, h, w, _ = xb.shape
+        plan = self._head_plan(n, h, w, True)
+        self._stage_x(plan, xb)
+        self._stage_y(plan, yb)
+        st = ops.stream_ptr()
+        rt.gflat.zero_()
+        plan.loss_buf.zero_()
+        plan.run_forward(st)
+        self._loss_launch(plan, st)
+        plan.run_backward(st)
+        if sync_grads is not None:
+            sync_grads(rt.gflat)
+        opt = self.optimizer
+        check(lib.satcv_adam_step(rt.pflat.data_ptr(), rt.gflat.data_ptr(), rt.adam_m.data_ptr(), rt.adam_v.data_ptr(), rt.pflat.numel(),
+                                  opt.beta_1, opt.beta_2, opt.epsilon, rt.adam_state.data_ptr(),
+                                  rt.lr_mul.data_ptr() if rt.lr_mul is not None else None, st))
+        rt.repack()
+        return plan
+
+    def train_on_batch(self, x, y):
+        plan = self.train_step_device(x, y, getattr(self, '_sync_grads', None))
+        return float(plan.loss_buf.item())
+
+    def _metric_values(self, conf, loss):
+        vals = [loss]
+        conf = conf.astype(np.float64)
+        for mt in self._metrics:
+            if isinstance(mt, str):
+                vals.append(float(np.trace(conf) / max(conf.sum(), 1)))
+            else:
+                tp = np.diag(conf)
+                denom = conf.sum(0) + conf.sum(1) - tp
+                valid = denom > 0
+                vals.append(float((tp[valid] / denom[valid]).mean()) if valid.any() else 0.0)
+        return vals
+
+    def _run_epoch(self, batches, steps, train):
+        rt = self.runtime
+        loss_sum = torch.zeros(1, dtype=torch.float32, device=rt.dev)
+        conf, cnt = None, 0
+        sync = getattr(self, '_sync_grads', None)
+        for i, b in enumerate(batches):
+            if steps is not None and i >= steps:
+                break
+            xb, yb = b[0], b[1]
+            if train:
+                plan = self.train_step_device(xb, yb, sync)
+            else:
+                n, h, w, _ = xb.shape
+                plan = self._head_plan(n, h, w, False)
+                self._stage_x(plan, xb)
+                self._stage_y(plan, yb)
+                st = ops.stream_ptr()
+                if not hasattr(plan, 'loss_buf'):
+                    plan.loss_buf = torch.zeros(1, dtype=torch.float32, device=rt.dev)
+                    plan.dlogits = torch.zeros(plan.n * plan.head['r'].h * plan.head['r'].w, plan.head['ncls'], dtype=torch.float32, device=rt.dev)
+                plan.loss_buf.zero_()
+                plan.run_forward(st)
+                self._loss_launch(plan, st)
+            loss_sum += plan.loss_buf
+            hd = plan.head
+            if self._metrics and hd['act'] == 0:
+                if conf is None:
+                    conf = torch.zeros(hd['ncls'], hd['ncls'], dtype=torch.int64, device=rt.dev)
+                check(lib.satcv_confusion(hd['classes'].data_ptr(), plan.y_true.data_ptr(), hd['ncls'], hd['classes'].numel(),
+                                          conf.data_ptr(), ops.stream_ptr()))
+            cnt += 1
+        loss = float(loss_sum.item()) / max(cnt, 1)
+        c = conf.cpu().numpy() if conf is not None else np.zeros((1, 1))
+        return self._metric_values(c, loss)
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, validation_data=None, steps_per_epoch=None,
+            validation_steps=None, initial_epoch=0, **kw):
+        """Model.fit as the notebooks call it (notebooks/UNET_G4G_2019_solar.ipynb:1267-1275)."""
+        self._apply_trainable()
+        hist = History()
+        callbacks = list(callbacks or [])
+        for cb in callbacks:
+            cb.model = self
+        it = None
+        for epoch in range(initial_epoch, epochs):
+            t0 = time.time()
+            if it is None or steps_per_epoch is None:
+                it, _ = _as_batches(x, y, batch_size)
+            vals = self._run_epoch(it, steps_per_epoch, True)
+            logs = dict(zip(self.metrics_names, vals))
+            if validation_data is not None:
+                if isinstance(validation_data, tuple) and len(validation_data) == 2 and isinstance(validation_data[0], (np.ndarray, torch.Tensor)):
+                    vit, _ = _as_batches(validation_data[0], validation_data[1], batch_size)
+                else:
+                    vit, _ = _as_batches(validation_data, None, batch_size)
+                vvals = self._run_epoch(vit, validation_steps, False)
+                logs.update({'val_' + k: v for k, v in zip(self.metrics_names, vvals)})
+            for k, v in logs.items():
+                hist.history[k].append(v)
+            hist.epoch.append(epoch)
+            if verbose:
+                print(f'Epoch {epoch + 1}/{epochs} - {time.time() - t0:.1f}s - ' + ' - '.join(f'{k}: {v:.4f}' for k, v in logs.items()))
+            for cb in callbacks:
+                if hasattr(cb, 'on_epoch_end'):
+                    cb.on_epoch_end(epoch, logs)
+            if hasattr(x, 'on_epoch_end'):
+                x.on_epoch_end()
+            if self.stop_training:
+                break
+        return hist
+
+    def evaluate(self, x=None, y=None, batch_size=None, verbose=0, steps=None, **kw):
+        """Model.evaluate -> list aligned with metrics_names (utils/model_tools.py:1164-1168)."""
+        it, _ = _as_batches(x, y, batch_size)
+        vals = self._run_epoch(it, steps, False)
+        return vals if len(vals) > 1 else vals[0]
+
+    def summary(self):
+        print(f'Model "{self.name}": {len(self.layers)} weighted layers, {self.count_params():,} parameters, dtype {self.compute_dtype}')
+        for l in self.layers:
+            print(f'  {l.name:40s} ' + ', '.join(f'{p.name.split("/")[-1]}{p.shape}' for p in l.specs))
+
+
+def load_model(path, custom_objects=None, compile=False):
+    """models.load_model for files written by Model.save (own .npz container)."""
+    p = path if os.path.exists(path) else path + '.npz'
+    with np.load(p, allow_pickle=False) as z:
+        cfg = json.loads(str(z['__builder__']))
+        if cfg.get('fn') != 'get_unet_model':
+            raise ValueError('file does not describe a get_unet_model() network')
+        cfg.pop('fn')
+        reset_uids()
+        m = get_unet_model(**cfg)
+        m.set_weights_dict({k: z[k] for k in z.files if not k.startswith('__')})
+        if '__adam_m__' in z.files:
+            rt = m.runtime
+            rt.ensure_adam()
+            rt.adam_m.copy_(torch.from_numpy(z['__adam_m__']))
+            rt.adam_v.copy_(torch.from_numpy(z['__adam_v__']))
+            rt.adam_state.copy_(torch.from_numpy(z['__adam_state__']))
+    return m
+
+
+def retrain_model(model_file, checkpoint, eval_data, metric, weights_file=None, custom_objects=None, lr=None, freeze=None):
+    """utils/model_tools.py:1128-1176: load a saved model, evaluate it, seed checkpoint.best with the
+    current value of `metric`, optionally set the learning rate and freeze all but the last layer."""
+    m = load_model(model_file, custom_objects=custom_objects)
+    if weights_file is not None:
+        m.load_weights(weights_file, by_name=True, skip_mismatch=True)
+    if custom_objects and 'compile' in custom_objects:
+        m.compile(**custom_objects['compile'])
+    if m._loss is not None:
+        evalMetrics = m.evaluate(x=eval_data, verbose=1)
+        evalMetrics = evalMetrics if isinstance(evalMetrics, list) else [evalMetrics]
+        index = m.metrics_names.index(metric)
+        checkpoint.best = evalMetrics[index]
+    if lr and m.optimizer is not None:
+        m.optimizer.learning_rate = lr
+    if freeze:
+        for layer in m.layers[:-1]:
+            layer.trainable = False
+    return m
+
+
+def structural_names(model):
+    """Map structural weight names (enc{i}.conv.kernel, enc{i}.bn.gamma, center.*, dec{j}.up.*,
+    dec{j}.bn0.*, dec{j}.conv1/2.*, dec{j}.bn1/2.*, probs.*) to this model's parameter names, for a
+    network built by get_unet_model / build_unet_layers (as coded, single conv per level).
+    Used for weight interchange with a Keras model of the same topology."""
+    cbas = [n for n in model.nodes if n.op == 'cba']
+    ups = [n for n in model.nodes if n.op == 'convT']
+    cats = [n for n in model.nodes if n.op == 'concat_bn_relu']
+    head = [n for n in model.nodes if n.op == 'head'][0]
+    L = len(ups)
+    out = {}
+
+    def conv(prefix, node):
+        out[f'{prefix}.kernel'] = node.layer.name + '/kernel'
+        out[f'{prefix}.bias'] = node.layer.name + '/bias'
+
+    def bn(prefix, lname):
+        for s in ('gamma', 'beta', 'moving_mean', 'moving_var'):
+            out[f'{prefix}.{s}'] = f'{lname}/{s}'
+
+    assert len(cbas) == 3 * L + 1, 'not an as-coded U-Net'
+    for i in range(L):
+        conv(f'enc{i}.conv', cbas[i])
+        bn(f'enc{i}.bn', cbas[i].attrs['owner'].bn_layer.name)
+    conv('center.conv', cbas[L])
+    bn('center.bn', cbas[L].attrs['owner'].bn_layer.name)
+    for q in range(L):
+        j = L - 1 - q
+        conv(f'dec{j}.up', ups[q])
+        bn(f'dec{j}.bn0', cats[q].layer.name)
+        for r in (1, 2):
+            node = cbas[L + 1 + 2 * q + (r - 1)]
+            conv(f'dec{j}.conv{r}', node)
+            bn(f'dec{j}.bn{r}', node.attrs['owner'].bn_layer.name)
+    conv('probs', head)
+    return out
