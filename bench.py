@@ -52,7 +52,7 @@ def cpu_baseline(seconds_budget=20.0):
     """torch-CPU port of the identical training step (fp32), batch 2, all host cores."""
     from oracle.unet import UNetOracle
     from oracle import torch_unet as TU
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)       # more oneDNN threads than this only slows the 256^2 convs
     torch.set_num_threads(cores)
     o = UNetOracle(NCLS, CH, dtype=np.float32, seed=0)
     p = TU.params_to_torch(o.params, torch.float32)
@@ -60,7 +60,7 @@ def cpu_baseline(seconds_budget=20.0):
     m = {k: torch.zeros_like(p[k]) for k in train}
     v = {k: torch.zeros_like(p[k]) for k in train}
     rng = np.random.default_rng(0)
-    bs = 2
+    bs = 1
     x, y = synth_batch(rng, bs)
     xt, yt = torch.from_numpy(x), torch.from_numpy(y)
     filters, factors = [32, 64, 128, 256, 512], [2, 2, 2, 2, 2]
@@ -75,7 +75,7 @@ def cpu_baseline(seconds_budget=20.0):
     step(1)                                  # warm-up (oneDNN primitive creation)
     t0 = time.perf_counter()
     nsteps = 0
-    while time.perf_counter() - t0 < seconds_budget and nsteps < 50:
+    while (time.perf_counter() - t0 < seconds_budget and nsteps < 50) or nsteps < 1:
         step(nsteps + 2)
         nsteps += 1
     dt = time.perf_counter() - t0

@@ -6,6 +6,10 @@ declared in include/satcv.h is absent, import fails loudly.
 import ctypes as C
 import os
 
+# The library takes device pointers and streams from torch, so both must sit on ONE HIP runtime:
+# import torch first (it loads its bundled libamdhip64) so that libsatcv.so binds to that copy.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsatcv.so')
 
@@ -99,6 +103,9 @@ def _load():
         raise ImportError(
             f'{LIB_PATH} not found: the HIP extension is required (no CPU fallback). '
             'Build it with `python -m satellite_computervision_amd.build` or __graft_entry__.build().')
+    hip = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if os.path.exists(hip):
+        C.CDLL(hip, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)           # AttributeError if a declared symbol is missing
