@@ -15,62 +15,8 @@
 //   B: [taps][KC/8][BN][8]
 // The previous layer's BatchNorm affine + ReLU is applied to A while staging
 // (zero padding is inserted AFTER the transform, as Keras pads the activated tensor).
-#include "common.hpp"
-
-struct IgemmArgs {
-  const void* x0; const void* x1;
-  int c0, c1;
-  const float* in_scale; const float* in_shift; int in_relu;
-  const void* w; const float* bias;
-  void* y; int ldy;
-  float* stats; int stats_ld;
-  int n, h, w_;            // GEMM pixel grid
-  int hs, ws;              // source spatial dims
-  int cout, cout_pad;
-  int kh, kw, dil;
-  int mode_in, mode_out, f;
-  int cstat, out_relu;
-  // derived tiling
-  int tiles_x, tiles_y, ngroups;   // M tiles = ngroups * tiles_y * tiles_x
-  int rpi, imgs, seg, rl, cl, pitch, halh, halw;
-  int n_tiles;                     // N tiles
-  int nchunks;
-};
-
-template <typename T>
-struct FragT;
-template <>
-struct FragT<bf16> { bf16x8 v; };
-template <>
-struct FragT<float> { float4 lo, hi; };
-
-template <typename T>
-__device__ __forceinline__ FragT<T> lds_frag(const T* p) {
-  FragT<T> f;
-  if constexpr (std::is_same<T, bf16>::value) {
-    f.v = *reinterpret_cast<const bf16x8*>(p);
-  } else {
-    f.lo = reinterpret_cast<const float4*>(p)[0];
-    f.hi = reinterpret_cast<const float4*>(p)[1];
-  }
-  return f;
-}
-
-template <typename T>
-__device__ __forceinline__ void mma32(f32x16& acc, const FragT<T>& a, const FragT<T>& b) {
-  if constexpr (std::is_same<T, bf16>::value) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
-  } else {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.x, b.lo.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.y, b.lo.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.z, b.lo.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.w, b.lo.w, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.x, b.hi.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.y, b.hi.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.z, b.hi.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.w, b.hi.w, acc, 0, 0, 0);
-  }
-}
+#include "igemm_common.hpp"
+#include <cstdlib>
 
 // TW: tile width (pixels); WM x WN waves; each wave MT x NT MFMA tiles of 32x32; KS k-steps
 // of 16 channels per chunk.
@@ -277,16 +223,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
 }
 
 // ------------------------------------------------------------------ host side
-static int pick_tw(int w) {
-  int best = 8, bestpad = cdiv(w, 8) * 8;
-  const int cands[2] = {16, 32};
-  for (int i = 0; i < 2; ++i) {
-    int p = cdiv(w, cands[i]) * cands[i];
-    if (p <= bestpad) { best = cands[i]; bestpad = p; }
-  }
-  return best;
-}
-
 template <typename T, int TW, int WM, int WN, int MT, int NT, int KS>
 static int launch_cfg(IgemmArgs& a, hipStream_t st) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, KC = KS * 16;
@@ -342,7 +278,7 @@ static int launch_tw(IgemmArgs& a, hipStream_t st) {
 
 template <typename T>
 static int launch_t(IgemmArgs& a, hipStream_t st) {
-  switch (pick_tw(a.w_)) {
+  switch (igemm_pick_tw(a.w_)) {
     case 32: return launch_tw<T, 32>(a, st);
     case 16: return launch_tw<T, 16>(a, st);
     default: return launch_tw<T, 8>(a, st);
@@ -380,8 +316,11 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * d->n * d->h * d->w_ * (double)d->cout * (double)(a.c0 + a.c1) * d->kh * d->kw;
   satcv_prof_begin(d->kh * d->kw > 1 ? 0 : 1, flops, st);
-  int rc;
-  if (d->dtype == SATCV_BF16) rc = launch_t<bf16>(a, st);
+  int rc = SATCV_ERR_UNSUPPORTED;
+  static const bool force_generic = [] { const char* e = getenv("SATCV_IGEMM"); return e && e[0] == 'g'; }();
+  if (!force_generic) rc = igemm_fast_launch(a, d->dtype, st);
+  if (rc != SATCV_ERR_UNSUPPORTED) { /* launched (or failed hard) */ }
+  else if (d->dtype == SATCV_BF16) rc = launch_t<bf16>(a, st);
   else if (d->dtype == SATCV_F32) rc = launch_t<float>(a, st);
   else { satcv_set_error("igemm: bad dtype %d", d->dtype); rc = SATCV_ERR_INVALID; }
   satcv_prof_end(d->kh * d->kw > 1 ? 0 : 1, st);

@@ -1,0 +1,382 @@
+// Software-pipelined implicit-GEMM convolution (the hot variant of conv_igemm.hip).
+//
+// Same math, LDS images and MFMA fragment addressing as igemm_kernel, plus:
+//   * the halo-tile gather table (LDS offset + source pixel per staged 16-byte item) is computed
+//     ONCE per workgroup and kept in registers -- no integer divisions in the K loop;
+//   * register-prefetch pipeline: the global loads of chunk c+1 are issued before the MFMAs of
+//     chunk c and written to LDS after them (one LDS buffer, T14-style issue-early/write-late);
+//   * the previous layer's BN affine + ReLU is applied in registers between load and LDS write;
+//   * the output tile is staged through LDS and written with 16-byte coalesced stores
+//     (NHWC rows; depth-to-space rows for the transposed conv);
+//   * blockIdx is remapped so that the workgroups sharing an activation tile / neighbouring
+//     halos run on the same XCD (private L2).
+#include "igemm_common.hpp"
+
+template <typename T>
+struct Raw8 {
+  static constexpr int NQ = sizeof(T) / 2;      // 16-byte quads per 8 elements
+  uint4 q[NQ];
+};
+
+template <typename T>
+__device__ __forceinline__ Raw8<T> gload8(const T* p) {
+  Raw8<T> r;
+#pragma unroll
+  for (int i = 0; i < Raw8<T>::NQ; ++i) r.q[i] = reinterpret_cast<const uint4*>(p)[i];
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void lstore8(T* p, const Raw8<T>& r) {
+#pragma unroll
+  for (int i = 0; i < Raw8<T>::NQ; ++i) reinterpret_cast<uint4*>(p)[i] = r.q[i];
+}
+template <typename T>
+__device__ __forceinline__ Raw8<T> zero8() {
+  Raw8<T> r;
+#pragma unroll
+  for (int i = 0; i < Raw8<T>::NQ; ++i) r.q[i] = make_uint4(0, 0, 0, 0);
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ Raw8<T> affine8(const Raw8<T>& r, const float* sc, const float* sh, int relu) {
+  Raw8<T> o;
+  if constexpr (std::is_same<T, bf16>::value) {
+    bf16x8 v = __builtin_bit_cast(bf16x8, r.q[0]);
+    bf16x8 w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (float)v[e] * sc[e] + sh[e];
+      t = relu ? fmaxf(t, 0.f) : t;
+      w[e] = (bf16)t;
+    }
+    o.q[0] = __builtin_bit_cast(uint4, w);
+  } else {
+    const float* f = reinterpret_cast<const float*>(&r.q[0]);
+    float* g = reinterpret_cast<float*>(&o.q[0]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = f[e] * sc[e] + sh[e];
+      g[e] = relu ? fmaxf(t, 0.f) : t;
+    }
+  }
+  return o;
+}
+
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs a) {
+  constexpr int NTHREADS = WM * WN * 64;
+  constexpr int BM = WM * MT * 32;
+  constexpr int BN = WN * NT * 32;
+  constexpr int TH = BM / TW;
+  constexpr int KC = KS * 16;
+  constexpr int SLOTS = KC / 8;
+  constexpr int AI = 4;                                             // staged A items per thread (host-checked)
+  constexpr int BI = (TAPS * SLOTS * BN + NTHREADS - 1) / NTHREADS;  // staged B items per thread
+  constexpr int OPITCH = BN + 16 / (int)sizeof(T);                   // output staging pitch (elements)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* ldsA = reinterpret_cast<T*>(smem_raw);
+  T* ldsB = ldsA + SLOTS * a.rl * a.pitch * 8;
+  T* ldsO = reinterpret_cast<T*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, hh = lane >> 5;
+
+  // ---- XCD-aware tile id: blocks b and b+8 share an XCD, give each XCD a contiguous tile range
+  int bid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, rem = nwg & 7;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+  }
+  const int nt = bid % a.n_tiles;
+  int mt = bid / a.n_tiles;
+  const int tx = mt % a.tiles_x; mt /= a.tiles_x;
+  const int ty = mt % a.tiles_y;
+  const int grp = mt / a.tiles_y;
+  const int n0 = grp * a.imgs;
+  const int y0 = ty * TH;
+  const int x0 = tx * TW;
+  const int nbase = nt * BN;
+  const int cin = a.c0 + a.c1;
+  const int fs = a.mode_in == 1 ? a.f : 1;
+  const int slot_t = tid % SLOTS;                  // NTHREADS % SLOTS == 0: a thread's slot is fixed
+
+  // ---- gather tables (registers)
+  int a_l[AI], a_p[AI];
+  const int a_items = a.rl * a.cl * SLOTS;
+#pragma unroll
+  for (int j = 0; j < AI; ++j) {
+    const int it = tid + j * NTHREADS;
+    a_l[j] = -1; a_p[j] = -1;
+    if (it < a_items) {
+      const int pix = it / SLOTS;
+      const int c = pix % a.cl;
+      const int L = pix / a.cl;
+      const int k = L / a.seg;
+      const int yy = L - k * a.seg - a.halh;
+      const int n = n0 + k, y = y0 + yy, x = x0 + c - a.halw;
+      a_l[j] = ((slot_t * a.rl + L) * a.pitch + c) * 8;
+      if ((n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_)) a_p[j] = (n * a.hs + y * fs) * a.ws + x * fs;
+    }
+  }
+  constexpr int b_items = TAPS * SLOTS * BN;
+  int b_g[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int it = tid + j * NTHREADS;
+    const int co = it % BN, run = it / BN;
+    b_g[j] = ((run / SLOTS) * (cin / 8) + (run % SLOTS)) * a.cout_pad + nbase + co;
+  }
+
+  int a_off[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int q = (wm * MT + m) * 32 + r;
+    const int t = q / TW, cx = q % TW;
+    const int k = t / a.rpi;
+    const int l0 = (k < a.imgs) ? k * a.seg + (t - k * a.rpi) : 0;
+    a_off[m] = (l0 * a.pitch + cx) * 8;
+  }
+  const int slot_stride = a.rl * a.pitch * 8;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  const T* wp = reinterpret_cast<const T*>(a.w);
+  Raw8<T> ra[AI], rb[BI];
+
+  auto load_regs = [&](int chunk) {
+    const int cg0 = chunk * KC;
+    const T* src; int cs, coff, sadd = 0;
+    if (a.mode_in == 1) {
+      const int ij = cg0 / a.c0;
+      sadd = (ij / a.f) * a.ws + (ij % a.f);
+      src = reinterpret_cast<const T*>(a.x0); cs = a.c0; coff = cg0 - ij * a.c0;
+    } else if (cg0 < a.c0) {
+      src = reinterpret_cast<const T*>(a.x0); cs = a.c0; coff = cg0;
+    } else {
+      src = reinterpret_cast<const T*>(a.x1); cs = a.c1; coff = cg0 - a.c0;
+    }
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      if (a_p[j] >= 0) ra[j] = gload8<T>(src + (size_t)(a_p[j] + sadd) * cs + coff + slot_t * 8);
+      else ra[j] = zero8<T>();
+    }
+    const size_t cadd = (size_t)chunk * SLOTS * a.cout_pad;
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+      if (tid + j * NTHREADS < b_items) rb[j] = gload8<T>(wp + ((size_t)b_g[j] + cadd) * 8);
+    }
+  };
+  auto store_lds = [&](int chunk) {
+    const int cg0 = chunk * KC + slot_t * 8;
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      if (a_l[j] >= 0) {
+        Raw8<T> v = ra[j];
+        if (a.in_scale && a_p[j] >= 0) v = affine8<T>(v, a.in_scale + cg0, a.in_shift + cg0, a.in_relu);
+        lstore8<T>(ldsA + a_l[j], v);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+      const int it = tid + j * NTHREADS;
+      if (it < b_items) lstore8<T>(ldsB + (size_t)it * 8, rb[j]);
+    }
+  };
+
+  load_regs(0);
+  store_lds(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    const bool more = chunk + 1 < a.nchunks;
+    if (more) load_regs(chunk + 1);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap % 3;
+      const int tap_off = (ky * a.dil * a.pitch + kx * a.dil) * 8;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int slot = s * 2 + hh;
+        FragT<T> af[MT], bf[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = lds_frag<T>(ldsA + slot * slot_stride + a_off[m] + tap_off);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[n] = lds_frag<T>(ldsB + ((tap * SLOTS + slot) * BN + (wn * NT + n) * 32 + r) * 8);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) mma32<T>(acc[m][n], af[m], bf[n]);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      store_lds(chunk + 1);
+      __syncthreads();
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // 1) bias, optional ReLU, rounding, BN statistics from registers; stage the tile in LDS [BM][OPITCH]
+  unsigned pvmask[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    pvmask[m] = 0;
+    if (a.stats) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int q = (wm * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const int t = q / TW, cx = q % TW;
+        const int k = (a.imgs == 1) ? 0 : t / a.rpi;
+        const bool pv = (k < a.imgs) && (n0 + k < a.n) && (y0 + (t - k * a.rpi) < a.h) && (x0 + cx < a.w_);
+        pvmask[m] |= (pv ? 1u : 0u) << i;
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int cl_ = (wn * NT + n) * 32 + r;          // column inside the tile
+    const int cn = nbase + cl_;
+    const bool cvalid = cn < a.cout;
+    const int cch = cvalid ? cn % a.cstat : 0;
+    const float bv = (a.bias && cvalid) ? a.bias[cch] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const int q = (wm * MT + m) * 32 + row;
+        float v = acc[m][n][i] + bv;
+        if (a.out_relu) v = fmaxf(v, 0.f);
+        const T tv = (T)v;
+        ldsO[q * OPITCH + cl_] = tv;
+        const float fv = ((pvmask[m] >> i) & 1u) ? (float)tv : 0.f;
+        s1 += fv; s2 += fv * fv;
+      }
+    }
+    if (a.stats) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (hh == 0 && cvalid) {
+        float* rowp = a.stats + (size_t)((blockIdx.x + wave) % SATCV_STAT_ROWS) * 2 * a.stats_ld;
+        atomicAdd(rowp + cch, s1);
+        atomicAdd(rowp + a.stats_ld + cch, s2);
+      }
+    }
+  }
+  __syncthreads();
+  // 2) coalesced 16-byte stores of whole channel rows
+  {
+    constexpr int EPV = 16 / (int)sizeof(T);        // elements per 16-byte vector
+    constexpr int VPR = BN / EPV;                   // vectors per tile row
+    T* yp = reinterpret_cast<T*>(a.y);
+    const int ho = a.mode_out ? a.h * a.f : a.h;
+    const int wo = a.mode_out ? a.w_ * a.f : a.w_;
+    const int ncols = min(BN, a.cout - nbase);      // valid columns of this tile
+    int ij = 0, cbase = nbase;
+    if (a.mode_out == 1) { ij = nbase / a.cstat; cbase = nbase - ij * a.cstat; }
+    for (int it = tid; it < BM * VPR; it += NTHREADS) {
+      const int q = it / VPR, v = it % VPR;
+      if (v * EPV >= ncols) continue;
+      const int t = q / TW, cx = q % TW;
+      const int k = (a.imgs == 1) ? 0 : t / a.rpi;
+      const int nimg = n0 + k, y = y0 + (t - k * a.rpi), x = x0 + cx;
+      if (!((k < a.imgs) && (nimg < a.n) && (y < a.h) && (x < a.w_))) continue;
+      size_t off;
+      if (a.mode_out == 1) off = ((size_t)(nimg * ho + y * a.f + ij / a.f) * wo + x * a.f + ij % a.f) * a.ldy + cbase + v * EPV;
+      else off = ((size_t)(nimg * ho + y) * wo + x) * a.ldy + cbase + v * EPV;
+      const T* sp = ldsO + q * OPITCH + v * EPV;
+      if (ncols - v * EPV >= EPV) {
+        *reinterpret_cast<uint4*>(yp + off) = *reinterpret_cast<const uint4*>(sp);
+      } else {
+        for (int e = 0; e < ncols - v * EPV; ++e) yp[off + e] = sp[e];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
+static int fast_cfg(IgemmArgs& a, hipStream_t st) {
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, KC = KS * 16, NTHREADS = WM * WN * 64;
+  a.halh = a.dil * (a.kh - 1) / 2;
+  a.halw = a.dil * (a.kw - 1) / 2;
+  a.tiles_x = cdiv(a.w_, TW);
+  if (a.h >= TH) { a.rpi = TH; a.imgs = 1; a.tiles_y = cdiv(a.h, TH); a.ngroups = a.n; }
+  else { a.rpi = a.h; a.imgs = TH / a.h; a.tiles_y = 1; a.ngroups = cdiv(a.n, a.imgs); }
+  a.seg = a.rpi + 2 * a.halh;
+  a.rl = a.imgs * a.seg;
+  a.cl = TW + 2 * a.halw;
+  if (TW == 32) a.pitch = a.cl;
+  else if (TW == 16) a.pitch = cdiv(a.cl, 16) * 16;
+  else a.pitch = (a.cl <= 8) ? 8 : (cdiv(a.cl - 8, 16) * 16 + 8);
+  a.n_tiles = cdiv(a.cout, BN);
+  const int cin = a.c0 + a.c1;
+  a.nchunks = cin / KC;
+  if (cin % KC != 0 || (a.x1 && a.c0 % KC != 0) || (a.mode_in == 1 && a.c0 % KC != 0)) return SATCV_ERR_UNSUPPORTED;
+  if (a.mode_out == 1 && (a.cstat % BN != 0)) return SATCV_ERR_UNSUPPORTED;
+  if (a.cout_pad < a.n_tiles * BN) return SATCV_ERR_UNSUPPORTED;
+  if (a.rl * a.cl * (KC / 8) > 4 * NTHREADS) return SATCV_ERR_UNSUPPORTED;        // AI items per thread
+  if (a.ldy % (16 / (int)sizeof(T)) != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;
+  if (a.mode_out == 0 && a.cout % (16 / (int)sizeof(T)) != 0 && a.cout < a.ldy) { /* tail handled by scalar stores */ }
+  const size_t lds_stage = ((size_t)(KC / 8) * a.rl * a.pitch * 8 + (size_t)TAPS * (KC / 8) * BN * 8) * sizeof(T);
+  const size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T);
+  const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
+  if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
+  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  }
+  const long long blocks = (long long)a.ngroups * a.tiles_y * a.tiles_x * a.n_tiles;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return SATCV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHREADS), lds, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { satcv_set_error("igemm_fast launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  return SATCV_OK;
+}
+
+template <typename T, int TW, int TAPS>
+static int fast_tw(IgemmArgs& a, hipStream_t st) {
+  const int cin = a.c0 + a.c1;
+  const int nspace = a.mode_out ? a.cstat : a.cout;
+  // 32-channel chunks only for 1x1 taps (the 9-tap weight slab of a 32-channel chunk would not leave
+  // room for 2-3 workgroups per CU)
+  if constexpr (TAPS == 1) {
+    const bool ks2 = (cin % 32 == 0) && (!a.x1 || a.c0 % 32 == 0) && (a.mode_in != 1 || a.c0 % 32 == 0);
+    if (ks2) {
+      if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS>(a, st);
+      if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 2, TAPS>(a, st);
+      return fast_cfg<T, TW, 4, 1, 2, 1, 2, TAPS>(a, st);
+    }
+  }
+  if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 1, TAPS>(a, st);
+  if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 1, TAPS>(a, st);
+  return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS>(a, st);
+}
+
+template <typename T, int TAPS>
+static int fast_t(IgemmArgs& a, hipStream_t st) {
+  switch (igemm_pick_tw(a.w_)) {
+    case 32: return fast_tw<T, 32, TAPS>(a, st);
+    case 16: return fast_tw<T, 16, TAPS>(a, st);
+    default: return fast_tw<T, 8, TAPS>(a, st);
+  }
+}
+
+int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st) {
+  const int taps = a.kh * a.kw;
+  if (!(taps == 1 || (a.kh == 3 && a.kw == 3))) return SATCV_ERR_UNSUPPORTED;
+  if (dtype == SATCV_BF16) return taps == 1 ? fast_t<bf16, 1>(a, st) : fast_t<bf16, 9>(a, st);
+  if (dtype == SATCV_F32) return taps == 1 ? fast_t<float, 1>(a, st) : fast_t<float, 9>(a, st);
+  return SATCV_ERR_UNSUPPORTED;
+}

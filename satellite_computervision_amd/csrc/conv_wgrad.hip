@@ -41,19 +41,22 @@ __device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
   return __builtin_bit_cast(bf16x4, v);
 }
 
-template <typename T, int TW, int NCI, int NCO, int NTAPS>
-__global__ __launch_bounds__(NCI* NCO * 64) void wgrad_kernel(const WgradArgs a) {
+// NCI x NCO waves own distinct (ci, co) 32x32 tiles; NKS waves share a tile and split the
+// k-steps (pixels) of every staged tile, each writing its own partial slab.
+template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS>
+__global__ __launch_bounds__(NCI* NCO* NKS * 64) void wgrad_kernel(const WgradArgs a) {
   using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
-  constexpr int NTHREADS = NCI * NCO * 64;
+  constexpr int NTHREADS = NCI * NCO * NKS * 64;
   constexpr int BMPIX = 128;
   constexpr int CI_T = G::CI_T, CO_T = G::CO_T, XP = G::XP, DP = G::DP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* ldsX = reinterpret_cast<T*>(smem_raw);
   T* ldsD = ldsX + a.rl * a.cl * XP;
   int* tab = reinterpret_cast<int*>(ldsD + BMPIX * DP);
+  int* ptab = tab + BMPIX;                 // halo pixel -> packed (image-in-tile, row, column), tile invariant
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wci = wave % NCI, wco = wave / NCI;
+  const int wci = wave % NCI, wco = (wave / NCI) % NCO, wks = wave / (NCI * NCO);
   const int r = lane & 31, hh = lane >> 5;
   const int ci_blk = blockIdx.x % a.n_ci_blk, co_blk = blockIdx.x / a.n_ci_blk;
   const int sp = blockIdx.y;
@@ -72,6 +75,14 @@ __global__ __launch_bounds__(NCI* NCO * 64) void wgrad_kernel(const WgradArgs a)
     tab[q] = (l0 * a.cl + cx) * XP;
   }
 
+  for (int pix = tid; pix < a.rl * a.cl; pix += NTHREADS) {
+    const int c = pix % a.cl, L = pix / a.cl;
+    const int k = L / a.seg;
+    const int yy = L - k * a.seg - a.halh;
+    ptab[pix] = (k << 20) | ((yy + 64) << 10) | c;
+  }
+  __syncthreads();
+
   const T* dyp = reinterpret_cast<const T*>(a.dy);
   const int x_items = a.rl * a.cl * (CI_T / 8);
   constexpr int d_items = BMPIX * (CO_T / 8);
@@ -88,10 +99,8 @@ __global__ __launch_bounds__(NCI* NCO * 64) void wgrad_kernel(const WgradArgs a)
     for (int it = tid; it < x_items; it += NTHREADS) {
       const int g = it % (CI_T / 8);
       const int pix = it / (CI_T / 8);
-      const int c = pix % a.cl;
-      const int L = pix / a.cl;
-      const int k = L / a.seg;
-      const int yy = L - k * a.seg - a.halh;
+      const int pm = ptab[pix];
+      const int c = pm & 1023, yy = ((pm >> 10) & 1023) - 64, k = pm >> 20;
       const int n = n0 + k, y = y0 + yy, x = x0 + c - a.halw;
       const int cg = ci0 + g * 8;
       float v[8];
@@ -112,14 +121,14 @@ __global__ __launch_bounds__(NCI* NCO * 64) void wgrad_kernel(const WgradArgs a)
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
       }
-      store8<T>(ldsX + (L * a.cl + c) * XP + g * 8, v);
+      store8<T>(ldsX + pix * XP + g * 8, v);
     }
     // ---- stage dY tile
     for (int it = tid; it < d_items; it += NTHREADS) {
       const int g = it % (CO_T / 8);
       const int q = it / (CO_T / 8);
       const int t = q / TW, cx = q % TW;
-      const int k = t / a.rpi;
+      const int k = (a.imgs == 1) ? 0 : t / a.rpi;
       const int nimg = n0 + k, y = y0 + (t - k * a.rpi), x = x0 + cx;
       const int cv = co0 + g * 8;
       float v[8];
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(NCI* NCO * 64) void wgrad_kernel(const WgradArgs a)
     }
     __syncthreads();
     // ---- MFMA: 8 k-steps of 16 pixels
-    for (int ks = 0; ks < BMPIX / 16; ++ks) {
+    for (int ks = wks; ks < BMPIX / 16; ks += NKS) {
       if constexpr (std::is_same<T, bf16>::value) {
         const int gi = lane >> 4, i16 = lane & 15;
         const int chb = 16 * (gi & 1) + 4 * (i16 & 3);
@@ -184,30 +193,47 @@ __global__ __launch_bounds__(NCI* NCO * 64) void wgrad_kernel(const WgradArgs a)
     for (int i = 0; i < 16; ++i) {
       const int ci = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
       const int co = co0 + wco * 32 + r;
-      a.ws[((size_t)(sp * NTAPS + tap) * a.kpad + ci) * a.npad + co] = acc[tap][i];
+      a.ws[((size_t)((sp * NKS + wks) * NTAPS + tap) * a.kpad + ci) * a.npad + co] = acc[tap][i];
     }
   }
 }
 
-// dw (Keras layout) = sum over slabs in fixed order
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int taps, int kpad, int npad,
-                                    int cin, int nvalid, int transposed) {
+// dw (Keras layout) = sum over slabs in a fixed order (deterministic): 64 outputs x 4 split lanes
+// per block, each lane sums every 4th slab, LDS combines the 4 partial sums.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab, int taps, int kpad,
+                                                           int npad, int cin, int nvalid, int transposed) {
+  __shared__ float part[4][64];
   const long long total = (long long)taps * cin * nvalid;
   const size_t slab = (size_t)taps * kpad * npad;
-  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
-    const int co = (int)(it % nvalid);
-    const int ci = (int)((it / nvalid) % cin);
-    const int tap = (int)(it / ((long long)nvalid * cin));
-    const float* p = ws + ((size_t)tap * kpad + ci) * npad + co;
+  const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+    const long long it = base + ol;
     float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += p[sp * slab];
-    if (transposed) dw[(size_t)co * cin + ci] = s;          // (f,f,cout,cin): index (ij*cout+o)*cin + ci
-    else dw[((size_t)tap * cin + ci) * nvalid + co] = s;    // (kh,kw,cin,cout)
+    int co = 0, ci = 0, tap = 0;
+    if (it < total) {
+      co = (int)(it % nvalid);
+      ci = (int)((it / nvalid) % cin);
+      tap = (int)(it / ((long long)nvalid * cin));
+      const float* p = ws + ((size_t)tap * kpad + ci) * npad + co;
+      float s0 = 0.f, s1 = 0.f;
+      int sp = sl;
+      for (; sp + 4 < nslab; sp += 8) { s0 += p[(size_t)sp * slab]; s1 += p[(size_t)(sp + 4) * slab]; }
+      if (sp < nslab) s0 += p[(size_t)sp * slab];
+      s = s0 + s1;
+    }
+    part[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && it < total) {
+      const float r = (part[0][ol] + part[1][ol]) + (part[2][ol] + part[3][ol]);
+      if (transposed) dw[(size_t)co * cin + ci] = r;
+      else dw[((size_t)tap * cin + ci) * nvalid + co] = r;
+    }
+    __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------ host side
-struct WgradPlan { int tw, nci, nco, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk; size_t ws_bytes; };
+struct WgradPlan { int tw, nci, nco, nks, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk; size_t ws_bytes; };
 
 static int pick_tw_w(int w) {
   int best = 8, bestpad = cdiv(w, 8) * 8;
@@ -224,8 +250,9 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   p.tw = pick_tw_w(d->w_);
   if (p.ntaps == 1) { p.nci = 1; p.nco = 4; }
   else if (nspace % 128 == 0) { p.nci = 1; p.nco = 4; }
-  else if (nspace % 64 == 0) { p.nci = (cinx % 64 == 0 && (!d->x1 || d->c0 % 64 == 0)) ? 2 : 1; p.nco = 2; }
-  else { p.nci = (cinx % 64 == 0 && (!d->x1 || d->c0 % 64 == 0)) ? 2 : 1; p.nco = 1; }
+  else if (nspace % 64 == 0) { p.nci = (cinx % 64 == 0) ? 2 : 1; p.nco = 2; }
+  else { p.nci = (cinx % 64 == 0) ? 2 : 1; p.nco = 1; }
+  p.nks = 4 / (p.nci * p.nco);                 // always 4 waves per workgroup
   const int ci_t = 32 * p.nci, co_t = 32 * p.nco;
   p.n_ci_blk = cdiv(cinx, ci_t); p.n_co_blk = cdiv(nspace, co_t);
   p.kpad = p.n_ci_blk * ci_t; p.npad = p.n_co_blk * co_t;
@@ -234,12 +261,12 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   long long ptiles;
   if (d->h >= th) ptiles = (long long)d->n * cdiv(d->h, th) * tiles_x;
   else ptiles = (long long)cdiv(d->n, th / d->h) * tiles_x;
-  long long ns = cdiv(1536, p.n_ci_blk * p.n_co_blk);
+  long long ns = cdiv(1024, p.n_ci_blk * p.n_co_blk);      // ~4 workgroups per CU
   if (ns > ptiles) ns = ptiles;
-  if (ns > 1024) ns = 1024;
+  if (ns > 512) ns = 512;
   if (ns < 1) ns = 1;
   p.nsplit = (int)ns;
-  p.ws_bytes = (size_t)p.nsplit * p.ntaps * p.kpad * p.npad * sizeof(float);
+  p.ws_bytes = (size_t)p.nsplit * p.nks * p.ntaps * p.kpad * p.npad * sizeof(float);
   return SATCV_OK;
 }
 
@@ -249,7 +276,7 @@ extern "C" int64_t satcv_conv2d_wgrad_workspace(const satcv_wgrad_desc* d) {
   return (int64_t)p.ws_bytes;
 }
 
-template <typename T, int TW, int NCI, int NCO, int NTAPS>
+template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS>
 static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st) {
   using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
   constexpr int TH = 128 / TW;
@@ -268,14 +295,14 @@ static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream
   a.seg = a.rpi + 2 * a.halh; a.rl = a.imgs * a.seg; a.cl = TW + 2 * a.halw;
   a.n_ci_blk = p.n_ci_blk; a.n_co_blk = p.n_co_blk; a.nsplit = p.nsplit;
   a.total_ptiles = a.ngroups * a.tiles_y * a.tiles_x;
-  const size_t lds = ((size_t)a.rl * a.cl * G::XP + 128 * G::DP) * sizeof(T) + 128 * sizeof(int);
+  const size_t lds = ((size_t)a.rl * a.cl * G::XP + 128 * G::DP) * sizeof(T) + (128 + (size_t)a.rl * a.cl) * sizeof(int);
   if (lds > 160 * 1024) { satcv_set_error("wgrad: LDS %zu too large", lds); return SATCV_ERR_UNSUPPORTED; }
-  auto kern = wgrad_kernel<T, TW, NCI, NCO, NTAPS>;
+  auto kern = wgrad_kernel<T, TW, NCI, NCO, NKS, NTAPS>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
   }
-  hipLaunchKernelGGL(kern, dim3(p.n_ci_blk * p.n_co_blk, p.nsplit), dim3(NCI * NCO * 64), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(p.n_ci_blk * p.n_co_blk, p.nsplit), dim3(NCI * NCO * NKS * 64), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("wgrad launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
   return SATCV_OK;
@@ -283,12 +310,12 @@ static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream
 
 template <typename T, int TW>
 static int wgrad_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st) {
-  if (p.ntaps == 1) return wgrad_launch<T, TW, 1, 4, 1>(d, p, st);
-  if (p.nci == 1 && p.nco == 4) return wgrad_launch<T, TW, 1, 4, 9>(d, p, st);
-  if (p.nci == 2 && p.nco == 2) return wgrad_launch<T, TW, 2, 2, 9>(d, p, st);
-  if (p.nci == 1 && p.nco == 2) return wgrad_launch<T, TW, 1, 2, 9>(d, p, st);
-  if (p.nci == 2 && p.nco == 1) return wgrad_launch<T, TW, 2, 1, 9>(d, p, st);
-  return wgrad_launch<T, TW, 1, 1, 9>(d, p, st);
+  if (p.ntaps == 1) return wgrad_launch<T, TW, 1, 4, 1, 1>(d, p, st);
+  if (p.nci == 1 && p.nco == 4) return wgrad_launch<T, TW, 1, 4, 1, 9>(d, p, st);
+  if (p.nci == 2 && p.nco == 2) return wgrad_launch<T, TW, 2, 2, 1, 9>(d, p, st);
+  if (p.nci == 1 && p.nco == 2) return wgrad_launch<T, TW, 1, 2, 2, 9>(d, p, st);
+  if (p.nci == 2 && p.nco == 1) return wgrad_launch<T, TW, 2, 1, 2, 9>(d, p, st);
+  return wgrad_launch<T, TW, 1, 1, 4, 9>(d, p, st);
 }
 template <typename T>
 static int wgrad_t(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st) {
@@ -322,9 +349,9 @@ extern "C" int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream) {
   satcv_prof_end(2, st);
   if (rc) return rc;
   const long long total = (long long)p.ntaps * d->cin * nvalid;
-  int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, d->workspace, d->dw, p.nsplit, p.ntaps, p.kpad, p.npad, d->cin, nvalid,
-                     d->transposed);
+  int grid = (int)((total + 63) / 64); if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, d->workspace, d->dw, p.nsplit * p.nks, p.ntaps, p.kpad, p.npad, d->cin,
+                     nvalid, d->transposed);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("wgrad reduce launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
   return SATCV_OK;

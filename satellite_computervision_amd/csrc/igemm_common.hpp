@@ -1,0 +1,73 @@
+// Shared argument block and MFMA fragment helpers of the implicit-GEMM convolution kernels.
+#pragma once
+#include "common.hpp"
+
+struct IgemmArgs {
+  const void* x0; const void* x1;
+  int c0, c1;
+  const float* in_scale; const float* in_shift; int in_relu;
+  const void* w; const float* bias;
+  void* y; int ldy;
+  float* stats; int stats_ld;
+  int n, h, w_;            // GEMM pixel grid
+  int hs, ws;              // source spatial dims
+  int cout, cout_pad;
+  int kh, kw, dil;
+  int mode_in, mode_out, f;
+  int cstat, out_relu;
+  // derived tiling
+  int tiles_x, tiles_y, ngroups;   // M tiles = ngroups * tiles_y * tiles_x
+  int rpi, imgs, seg, rl, cl, pitch, halh, halw;
+  int n_tiles;                     // N tiles
+  int nchunks;
+};
+
+template <typename T>
+struct FragT;
+template <>
+struct FragT<bf16> { bf16x8 v; };
+template <>
+struct FragT<float> { float4 lo, hi; };
+
+template <typename T>
+__device__ __forceinline__ FragT<T> lds_frag(const T* p) {
+  FragT<T> f;
+  if constexpr (std::is_same<T, bf16>::value) {
+    f.v = *reinterpret_cast<const bf16x8*>(p);
+  } else {
+    f.lo = reinterpret_cast<const float4*>(p)[0];
+    f.hi = reinterpret_cast<const float4*>(p)[1];
+  }
+  return f;
+}
+
+template <typename T>
+__device__ __forceinline__ void mma32(f32x16& acc, const FragT<T>& a, const FragT<T>& b) {
+  if constexpr (std::is_same<T, bf16>::value) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.x, b.lo.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.y, b.lo.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.z, b.lo.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.w, b.lo.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.x, b.hi.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.y, b.hi.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.z, b.hi.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi.w, b.hi.w, acc, 0, 0, 0);
+  }
+}
+
+
+static inline int igemm_pick_tw(int w) {
+  int best = 8, bestpad = cdiv(w, 8) * 8;
+  const int cands[2] = {16, 32};
+  for (int i = 0; i < 2; ++i) {
+    int p = cdiv(w, cands[i]) * cands[i];
+    if (p <= bestpad) { best = cands[i]; bestpad = p; }
+  }
+  return best;
+}
+
+// software-pipelined variant (conv_igemm_fast.hip); returns SATCV_ERR_UNSUPPORTED when the
+// shape is outside its static limits so that the caller falls back to the generic kernel.
+int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st);
