@@ -99,9 +99,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:              # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     from satellite_computervision_amd import model_tools as mt
     from satellite_computervision_amd import parallel
@@ -112,7 +114,7 @@ def main():
     mt.set_compute_dtype(args.dtype)
     model = mt.get_unet_model(NCLS, CH)
     model.compile(optimizer=mt.Adam(9e-4), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 20.0]))
-    sync = parallel.make_grad_sync(model) if world > 1 else None
+    sync = parallel.make_grad_sync(model) if dist is not None else None
 
     rng = np.random.default_rng(1000 + rank)           # per-rank data shard
     B = args.batch

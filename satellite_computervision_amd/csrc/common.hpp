@@ -71,6 +71,57 @@ __device__ __forceinline__ void store8(T* p, const float (&in)[8]) {
   }
 }
 
+// ---- raw 8-element (16/32-byte) moves and the in-register BN affine + ReLU ----
+template <typename T>
+struct Raw8 {
+  static constexpr int NQ = sizeof(T) / 2;      // 16-byte quads per 8 elements
+  uint4 q[NQ];
+};
+
+template <typename T>
+__device__ __forceinline__ Raw8<T> gload8(const T* p) {
+  Raw8<T> r;
+#pragma unroll
+  for (int i = 0; i < Raw8<T>::NQ; ++i) r.q[i] = reinterpret_cast<const uint4*>(p)[i];
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void lstore8(T* p, const Raw8<T>& r) {
+#pragma unroll
+  for (int i = 0; i < Raw8<T>::NQ; ++i) reinterpret_cast<uint4*>(p)[i] = r.q[i];
+}
+template <typename T>
+__device__ __forceinline__ Raw8<T> zero8() {
+  Raw8<T> r;
+#pragma unroll
+  for (int i = 0; i < Raw8<T>::NQ; ++i) r.q[i] = make_uint4(0, 0, 0, 0);
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ Raw8<T> affine8(const Raw8<T>& r, const float* sc, const float* sh, int relu) {
+  Raw8<T> o;
+  if constexpr (std::is_same<T, bf16>::value) {
+    bf16x8 v = __builtin_bit_cast(bf16x8, r.q[0]);
+    bf16x8 w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (float)v[e] * sc[e] + sh[e];
+      t = relu ? fmaxf(t, 0.f) : t;
+      w[e] = (bf16)t;
+    }
+    o.q[0] = __builtin_bit_cast(uint4, w);
+  } else {
+    const float* f = reinterpret_cast<const float*>(&r.q[0]);
+    float* g = reinterpret_cast<float*>(&o.q[0]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = f[e] * sc[e] + sh[e];
+      g[e] = relu ? fmaxf(t, 0.f) : t;
+    }
+  }
+  return o;
+}
+
 // value as it will read back from storage (bf16 rounding, identity for f32)
 template <typename T>
 __device__ __forceinline__ float round_to(float x) {

@@ -12,56 +12,6 @@
 //     halos run on the same XCD (private L2).
 #include "igemm_common.hpp"
 
-template <typename T>
-struct Raw8 {
-  static constexpr int NQ = sizeof(T) / 2;      // 16-byte quads per 8 elements
-  uint4 q[NQ];
-};
-
-template <typename T>
-__device__ __forceinline__ Raw8<T> gload8(const T* p) {
-  Raw8<T> r;
-#pragma unroll
-  for (int i = 0; i < Raw8<T>::NQ; ++i) r.q[i] = reinterpret_cast<const uint4*>(p)[i];
-  return r;
-}
-template <typename T>
-__device__ __forceinline__ void lstore8(T* p, const Raw8<T>& r) {
-#pragma unroll
-  for (int i = 0; i < Raw8<T>::NQ; ++i) reinterpret_cast<uint4*>(p)[i] = r.q[i];
-}
-template <typename T>
-__device__ __forceinline__ Raw8<T> zero8() {
-  Raw8<T> r;
-#pragma unroll
-  for (int i = 0; i < Raw8<T>::NQ; ++i) r.q[i] = make_uint4(0, 0, 0, 0);
-  return r;
-}
-template <typename T>
-__device__ __forceinline__ Raw8<T> affine8(const Raw8<T>& r, const float* sc, const float* sh, int relu) {
-  Raw8<T> o;
-  if constexpr (std::is_same<T, bf16>::value) {
-    bf16x8 v = __builtin_bit_cast(bf16x8, r.q[0]);
-    bf16x8 w;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t = (float)v[e] * sc[e] + sh[e];
-      t = relu ? fmaxf(t, 0.f) : t;
-      w[e] = (bf16)t;
-    }
-    o.q[0] = __builtin_bit_cast(uint4, w);
-  } else {
-    const float* f = reinterpret_cast<const float*>(&r.q[0]);
-    float* g = reinterpret_cast<float*>(&o.q[0]);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t = f[e] * sc[e] + sh[e];
-      g[e] = relu ? fmaxf(t, 0.f) : t;
-    }
-  }
-  return o;
-}
-
 template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs a) {
   constexpr int NTHREADS = WM * WN * 64;
@@ -70,13 +20,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs
   constexpr int TH = BM / TW;
   constexpr int KC = KS * 16;
   constexpr int SLOTS = KC / 8;
-  constexpr int AI = 4;                                             // staged A items per thread (host-checked)
+  // staged A items per thread: halo tile of a 3x3 / dilation-1 conv incl. the several-images-per-tile case
+  constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+  constexpr int AI = (XMAXPIX * SLOTS + NTHREADS - 1) / NTHREADS;
   constexpr int BI = (TAPS * SLOTS * BN + NTHREADS - 1) / NTHREADS;  // staged B items per thread
   constexpr int OPITCH = BN + 16 / (int)sizeof(T);                   // output staging pitch (elements)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* ldsA = reinterpret_cast<T*>(smem_raw);
   T* ldsB = ldsA + SLOTS * a.rl * a.pitch * 8;
   T* ldsO = reinterpret_cast<T*>(smem_raw);
+  float* ldsS = reinterpret_cast<float*>(smem_raw + (size_t)BM * OPITCH * sizeof(T));   // [WM][2][BN] partial BN sums
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -113,9 +66,14 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs
     a_l[j] = -1; a_p[j] = -1;
     if (it < a_items) {
       const int pix = it / SLOTS;
-      const int c = pix % a.cl;
-      const int L = pix / a.cl;
-      const int k = L / a.seg;
+      int c, L;
+      if (a.dil == 1) {                      // compile-time halo width: division by a constant
+        constexpr int CL1 = TW + (TAPS == 9 ? 2 : 0);
+        c = pix % CL1; L = pix / CL1;
+      } else {
+        c = pix % a.cl; L = pix / a.cl;
+      }
+      const int k = (a.imgs == 1) ? 0 : L / a.seg;
       const int yy = L - k * a.seg - a.halh;
       const int n = n0 + k, y = y0 + yy, x = x0 + c - a.halw;
       a_l[j] = ((slot_t * a.rl + L) * a.pitch + c) * 8;
@@ -136,7 +94,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs
   for (int m = 0; m < MT; ++m) {
     const int q = (wm * MT + m) * 32 + r;
     const int t = q / TW, cx = q % TW;
-    const int k = t / a.rpi;
+    const int k = (a.imgs == 1) ? 0 : t / a.rpi;
     const int l0 = (k < a.imgs) ? k * a.seg + (t - k * a.rpi) : 0;
     a_off[m] = (l0 * a.pitch + cx) * 8;
   }
@@ -266,14 +224,23 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs
     if (a.stats) {
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
-      if (hh == 0 && cvalid) {
-        float* rowp = a.stats + (size_t)((blockIdx.x + wave) % SATCV_STAT_ROWS) * 2 * a.stats_ld;
-        atomicAdd(rowp + cch, s1);
-        atomicAdd(rowp + a.stats_ld + cch, s2);
-      }
+      if (hh == 0) { ldsS[(wm * 2 + 0) * BN + cl_] = s1; ldsS[(wm * 2 + 1) * BN + cl_] = s2; }
     }
   }
   __syncthreads();
+  if (a.stats && tid < BN) {
+    // one pair of atomics per output channel per workgroup (fixed wave order)
+    const int cn = nbase + tid;
+    if (cn < a.cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { t1 += ldsS[(w * 2 + 0) * BN + tid]; t2 += ldsS[(w * 2 + 1) * BN + tid]; }
+      const int cch = cn % a.cstat;
+      float* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
+      atomicAdd(rowp + cch, t1);
+      atomicAdd(rowp + a.stats_ld + cch, t2);
+    }
+  }
   // 2) coalesced 16-byte stores of whole channel rows
   {
     constexpr int EPV = 16 / (int)sizeof(T);        // elements per 16-byte vector
@@ -325,11 +292,15 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st) {
   if (cin % KC != 0 || (a.x1 && a.c0 % KC != 0) || (a.mode_in == 1 && a.c0 % KC != 0)) return SATCV_ERR_UNSUPPORTED;
   if (a.mode_out == 1 && (a.cstat % BN != 0)) return SATCV_ERR_UNSUPPORTED;
   if (a.cout_pad < a.n_tiles * BN) return SATCV_ERR_UNSUPPORTED;
-  if (a.rl * a.cl * (KC / 8) > 4 * NTHREADS) return SATCV_ERR_UNSUPPORTED;        // AI items per thread
+  {
+    constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+    constexpr int AI = (XMAXPIX * (KC / 8) + NTHREADS - 1) / NTHREADS;
+    if (a.rl * a.cl * (KC / 8) > AI * NTHREADS) return SATCV_ERR_UNSUPPORTED;     // register-staged items per thread
+  }
   if (a.ldy % (16 / (int)sizeof(T)) != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;
   if (a.mode_out == 0 && a.cout % (16 / (int)sizeof(T)) != 0 && a.cout < a.ldy) { /* tail handled by scalar stores */ }
   const size_t lds_stage = ((size_t)(KC / 8) * a.rl * a.pitch * 8 + (size_t)TAPS * (KC / 8) * BN * 8) * sizeof(T);
-  const size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T);
+  const size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)WM * 2 * BN * sizeof(float);
   const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
   auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS>;
@@ -360,6 +331,8 @@ static int fast_tw(IgemmArgs& a, hipStream_t st) {
     }
   }
   if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 1, TAPS>(a, st);
+  // (32-channel chunks for the thin 3x3 layers were measured SLOWER: 144 vs 113 us on enc1, 425 vs 351 us on
+  //  dec0.conv1 -- fewer resident workgroups outweigh the halved barrier count)
   if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 1, TAPS>(a, st);
   return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS>(a, st);
 }

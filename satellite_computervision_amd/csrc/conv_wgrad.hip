@@ -44,7 +44,7 @@ __device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
 // NCI x NCO waves own distinct (ci, co) 32x32 tiles; NKS waves share a tile and split the
 // k-steps (pixels) of every staged tile, each writing its own partial slab.
 template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS>
-__global__ __launch_bounds__(NCI* NCO* NKS * 64) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(NCI* NCO* NKS * 64, 2) void wgrad_kernel(const WgradArgs a) {
   using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
   constexpr int NTHREADS = NCI * NCO * NKS * 64;
   constexpr int BMPIX = 128;
@@ -87,53 +87,53 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64) void wgrad_kernel(const WgradAr
   const int x_items = a.rl * a.cl * (CI_T / 8);
   constexpr int d_items = BMPIX * (CO_T / 8);
   constexpr int TH = BMPIX / TW;
+  // register-staged items per thread: halo tile of a 3x3 / dilation-1 conv incl. the several-images-per-tile case
+  constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+  constexpr int XI = (XMAXPIX * (CI_T / 8) + NTHREADS - 1) / NTHREADS;
+  constexpr int DI = (d_items + NTHREADS - 1) / NTHREADS;
 
-  for (int pt = sp; pt < a.total_ptiles; pt += a.nsplit) {
+  Raw8<T> xr[XI];
+  Raw8<T> dr[DI];
+  bool xv[XI];
+
+  // issue every global load of tile `pt` back to back into registers (memory-level parallelism)
+  auto load_tile = [&](int pt) {
     int m = pt;
     const int tx = m % a.tiles_x; m /= a.tiles_x;
     const int ty = m % a.tiles_y;
     const int grp = m / a.tiles_y;
     const int n0 = grp * a.imgs, y0 = ty * TH, x0 = tx * TW;
-    __syncthreads();       // previous tile's fragment reads are done
-    // ---- stage X halo tile (all CI_T channels of this block), with the optional affine+ReLU
-    for (int it = tid; it < x_items; it += NTHREADS) {
-      const int g = it % (CI_T / 8);
-      const int pix = it / (CI_T / 8);
-      const int pm = ptab[pix];
-      const int c = pm & 1023, yy = ((pm >> 10) & 1023) - 64, k = pm >> 20;
-      const int n = n0 + k, y = y0 + yy, x = x0 + c - a.halw;
-      const int cg = ci0 + g * 8;
-      float v[8];
-      const bool valid = (n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_) && (cg < a.cin_lim);
-      if (valid) {
-        const T* src; int cs, coff;
-        if (cg < a.c0) { src = reinterpret_cast<const T*>(a.x0); cs = a.c0; coff = cg; }
-        else { src = reinterpret_cast<const T*>(a.x1); cs = a.c1; coff = cg - a.c0; }
-        load8<T>(src + ((size_t)(n * a.h + y) * a.w_ + x) * cs + coff, v);
-        if (a.in_scale) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float t = v[e] * a.in_scale[cg + e] + a.in_shift[cg + e];
-            v[e] = a.in_relu ? fmaxf(t, 0.f) : t;
-          }
+    for (int j = 0; j < XI; ++j) {
+      const int it = tid + j * NTHREADS;
+      xr[j] = zero8<T>(); xv[j] = false;
+      if (it < x_items) {
+        const int g = it % (CI_T / 8);
+        const int pix = it / (CI_T / 8);
+        const int pm = ptab[pix];
+        const int c = pm & 1023, yy = ((pm >> 10) & 1023) - 64, k = pm >> 20;
+        const int n = n0 + k, y = y0 + yy, x = x0 + c - a.halw;
+        const int cg = ci0 + g * 8;
+        if ((n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_) && (cg < a.cin_lim)) {
+          const T* src; int cs, coff;
+          if (cg < a.c0) { src = reinterpret_cast<const T*>(a.x0); cs = a.c0; coff = cg; }
+          else { src = reinterpret_cast<const T*>(a.x1); cs = a.c1; coff = cg - a.c0; }
+          xr[j] = gload8<T>(src + ((size_t)(n * a.h + y) * a.w_ + x) * cs + coff);
+          xv[j] = true;
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.f;
       }
-      store8<T>(ldsX + pix * XP + g * 8, v);
     }
-    // ---- stage dY tile
-    for (int it = tid; it < d_items; it += NTHREADS) {
+#pragma unroll
+    for (int j = 0; j < DI; ++j) {
+      const int it = tid + j * NTHREADS;
       const int g = it % (CO_T / 8);
       const int q = it / (CO_T / 8);
       const int t = q / TW, cx = q % TW;
       const int k = (a.imgs == 1) ? 0 : t / a.rpi;
       const int nimg = n0 + k, y = y0 + (t - k * a.rpi), x = x0 + cx;
       const int cv = co0 + g * 8;
-      float v[8];
-      const bool valid = (k < a.imgs) && (nimg < a.n) && (y < a.h) && (x < a.w_) && (cv < a.n_lim);
-      if (valid) {
+      dr[j] = zero8<T>();
+      if ((it < d_items) && (k < a.imgs) && (nimg < a.n) && (y < a.h) && (x < a.w_) && (cv < a.n_lim)) {
         size_t off;
         if (a.mode_dy == 1) {
           const int ij = cv / a.cout_t, o = cv - ij * a.cout_t;
@@ -141,15 +141,76 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64) void wgrad_kernel(const WgradAr
         } else {
           off = ((size_t)(nimg * a.h + y) * a.w_ + x) * a.lddy + cv;
         }
-        load8<T>(dyp + off, v);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        dr[j] = gload8<T>(dyp + off);
       }
-      store8<T>(ldsD + q * DP + g * 8, v);
     }
-    __syncthreads();
-    // ---- MFMA: 8 k-steps of 16 pixels
+  };
+  // BN affine + ReLU of the producing layer (in registers), then LDS
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const int it = tid + j * NTHREADS;
+      if (it < x_items) {
+        const int g = it % (CI_T / 8);
+        const int pix = it / (CI_T / 8);
+        Raw8<T> v = xr[j];
+        if (a.in_scale && xv[j]) v = affine8<T>(v, a.in_scale + ci0 + g * 8, a.in_shift + ci0 + g * 8, a.in_relu);
+        lstore8<T>(ldsX + pix * XP + g * 8, v);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DI; ++j) {
+      const int it = tid + j * NTHREADS;
+      if (it < d_items) lstore8<T>(ldsD + (it / (CO_T / 8)) * DP + (it % (CO_T / 8)) * 8, dr[j]);
+    }
+  };
+  // fallback for halo tiles larger than the register budget (dilated taps): serial staging
+  auto stage_generic = [&](int pt) {
+    int m = pt;
+    const int tx = m % a.tiles_x; m /= a.tiles_x;
+    const int ty = m % a.tiles_y;
+    const int grp = m / a.tiles_y;
+    const int n0 = grp * a.imgs, y0 = ty * TH, x0 = tx * TW;
+    for (int it = tid; it < x_items; it += NTHREADS) {
+      const int g = it % (CI_T / 8);
+      const int pix = it / (CI_T / 8);
+      const int pm = ptab[pix];
+      const int c = pm & 1023, yy = ((pm >> 10) & 1023) - 64, k = pm >> 20;
+      const int n = n0 + k, y = y0 + yy, x = x0 + c - a.halw;
+      const int cg = ci0 + g * 8;
+      Raw8<T> v = zero8<T>();
+      if ((n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_) && (cg < a.cin_lim)) {
+        const T* src; int cs, coff;
+        if (cg < a.c0) { src = reinterpret_cast<const T*>(a.x0); cs = a.c0; coff = cg; }
+        else { src = reinterpret_cast<const T*>(a.x1); cs = a.c1; coff = cg - a.c0; }
+        v = gload8<T>(src + ((size_t)(n * a.h + y) * a.w_ + x) * cs + coff);
+        if (a.in_scale) v = affine8<T>(v, a.in_scale + cg, a.in_shift + cg, a.in_relu);
+      }
+      lstore8<T>(ldsX + pix * XP + g * 8, v);
+    }
+    for (int it = tid; it < d_items; it += NTHREADS) {
+      const int g = it % (CO_T / 8);
+      const int q = it / (CO_T / 8);
+      const int t = q / TW, cx = q % TW;
+      const int k = (a.imgs == 1) ? 0 : t / a.rpi;
+      const int nimg = n0 + k, y = y0 + (t - k * a.rpi), x = x0 + cx;
+      const int cv = co0 + g * 8;
+      Raw8<T> v = zero8<T>();
+      if ((k < a.imgs) && (nimg < a.n) && (y < a.h) && (x < a.w_) && (cv < a.n_lim)) {
+        size_t off;
+        if (a.mode_dy == 1) {
+          const int ij = cv / a.cout_t, o = cv - ij * a.cout_t;
+          off = ((size_t)(nimg * a.h * a.f + y * a.f + ij / a.f) * (a.w_ * a.f) + x * a.f + ij % a.f) * a.lddy + o;
+        } else {
+          off = ((size_t)(nimg * a.h + y) * a.w_ + x) * a.lddy + cv;
+        }
+        v = gload8<T>(dyp + off);
+      }
+      lstore8<T>(ldsD + q * DP + g * 8, v);
+    }
+  };
+  // 8 k-steps of 16 pixels on the staged tile
+  auto mfma_phase = [&]() {
     for (int ks = wks; ks < BMPIX / 16; ks += NKS) {
       if constexpr (std::is_same<T, bf16>::value) {
         const int gi = lane >> 4, i16 = lane & 15;
@@ -185,15 +246,63 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64) void wgrad_kernel(const WgradAr
         }
       }
     }
+  };
+
+  if (x_items <= XI * NTHREADS) {
+    // register-prefetch pipeline: loads of tile t+1 are in flight while tile t is multiplied
+    if (sp < a.total_ptiles) {
+      load_tile(sp);
+      store_tile();
+    }
+    __syncthreads();
+    for (int pt = sp; pt < a.total_ptiles; pt += a.nsplit) {
+      const int nxt = pt + a.nsplit;
+      if (nxt < a.total_ptiles) load_tile(nxt);
+      mfma_phase();
+      __syncthreads();
+      if (nxt < a.total_ptiles) {
+        store_tile();
+        __syncthreads();
+      }
+    }
+  } else {
+    for (int pt = sp; pt < a.total_ptiles; pt += a.nsplit) {
+      __syncthreads();
+      stage_generic(pt);
+      __syncthreads();
+      mfma_phase();
+    }
+  }
+  // ---- combine the k-slice waves of a tile through LDS (fixed order), one tap at a time
+  if constexpr (NKS > 1) {
+    float* red = reinterpret_cast<float*>(smem_raw);          // staging buffers are dead now
+    const int tile_id = wci + NCI * wco;                      // which (ci, co) tile this wave works on
+#pragma unroll
+    for (int tap = 0; tap < NTAPS; ++tap) {
+      __syncthreads();
+      if (wks > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[((tile_id * (NKS - 1) + (wks - 1)) * 16 + i) * 64 + lane] = acc[tap][i];
+      }
+      __syncthreads();
+      if (wks == 0) {
+#pragma unroll
+        for (int k = 0; k < NKS - 1; ++k)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[tap][i] += red[((tile_id * (NKS - 1) + k) * 16 + i) * 64 + lane];
+      }
+    }
   }
   // ---- partial slab: ws[sp][tap][ci][co]
+  if (wks == 0) {
 #pragma unroll
-  for (int tap = 0; tap < NTAPS; ++tap) {
+    for (int tap = 0; tap < NTAPS; ++tap) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int ci = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      const int co = co0 + wco * 32 + r;
-      a.ws[((size_t)((sp * NKS + wks) * NTAPS + tap) * a.kpad + ci) * a.npad + co] = acc[tap][i];
+      for (int i = 0; i < 16; ++i) {
+        const int ci = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const int co = co0 + wco * 32 + r;
+        a.ws[((size_t)(sp * NTAPS + tap) * a.kpad + ci) * a.npad + co] = acc[tap][i];
+      }
     }
   }
 }
@@ -261,12 +370,12 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   long long ptiles;
   if (d->h >= th) ptiles = (long long)d->n * cdiv(d->h, th) * tiles_x;
   else ptiles = (long long)cdiv(d->n, th / d->h) * tiles_x;
-  long long ns = cdiv(1024, p.n_ci_blk * p.n_co_blk);      // ~4 workgroups per CU
+  long long ns = cdiv(768, p.n_ci_blk * p.n_co_blk);       // ~3 workgroups per CU (2 resident + tail balance)
   if (ns > ptiles) ns = ptiles;
-  if (ns > 512) ns = 512;
+  if (ns > 768) ns = 768;
   if (ns < 1) ns = 1;
   p.nsplit = (int)ns;
-  p.ws_bytes = (size_t)p.nsplit * p.nks * p.ntaps * p.kpad * p.npad * sizeof(float);
+  p.ws_bytes = (size_t)p.nsplit * p.ntaps * p.kpad * p.npad * sizeof(float);
   return SATCV_OK;
 }
 
@@ -295,7 +404,8 @@ static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream
   a.seg = a.rpi + 2 * a.halh; a.rl = a.imgs * a.seg; a.cl = TW + 2 * a.halw;
   a.n_ci_blk = p.n_ci_blk; a.n_co_blk = p.n_co_blk; a.nsplit = p.nsplit;
   a.total_ptiles = a.ngroups * a.tiles_y * a.tiles_x;
-  const size_t lds = ((size_t)a.rl * a.cl * G::XP + 128 * G::DP) * sizeof(T) + (128 + (size_t)a.rl * a.cl) * sizeof(int);
+  size_t lds = ((size_t)a.rl * a.cl * G::XP + 128 * G::DP) * sizeof(T) + (128 + (size_t)a.rl * a.cl) * sizeof(int);
+  if (lds < 3 * 4096) lds = 3 * 4096;          // k-slice reduction scratch
   if (lds > 160 * 1024) { satcv_set_error("wgrad: LDS %zu too large", lds); return SATCV_ERR_UNSUPPORTED; }
   auto kern = wgrad_kernel<T, TW, NCI, NCO, NKS, NTAPS>;
   if (lds > 48 * 1024) {
@@ -350,7 +460,7 @@ extern "C" int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream) {
   if (rc) return rc;
   const long long total = (long long)p.ntaps * d->cin * nvalid;
   int grid = (int)((total + 63) / 64); if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, d->workspace, d->dw, p.nsplit * p.nks, p.ntaps, p.kpad, p.npad, d->cin,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, d->workspace, d->dw, p.nsplit, p.ntaps, p.kpad, p.npad, d->cin,
                      nvalid, d->transposed);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("wgrad reduce launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }

@@ -207,11 +207,12 @@ __global__ void bn_relu_pool_kernel(const T* __restrict__ yraw, const float* __r
   for (int e = 0; e < 8; ++e) { sc[e] = scale[g * 8 + e]; sh[e] = shift[g * 8 + e]; s1[e] = 0.f; s2[e] = 0.f; }
   const bool active = gid < stride;
   if (active) {
-    for (long long it = gid; it < total; it += stride) {
-      long long wdw = it / G;
-      const int px = (int)(wdw % ww); wdw /= ww;
-      const int py = (int)(wdw % hw_);
-      const int img = (int)(wdw / hw_);
+    const unsigned nwin = (unsigned)n * hw_ * ww, wstep = (unsigned)(stride / G);
+    for (unsigned wdw0 = (unsigned)(gid / G); wdw0 < nwin; wdw0 += wstep) {
+      unsigned wdw = wdw0;
+      const int px = (int)(wdw % (unsigned)ww); wdw /= (unsigned)ww;
+      const int py = (int)(wdw % (unsigned)hw_);
+      const int img = (int)(wdw / (unsigned)hw_);
       float mx[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
@@ -271,11 +272,12 @@ __global__ void bn_bwd_kernel(const satcv_bnbwd_desc d) {
   }
   const bool active = gid < stride;
   if (active) {
-    for (long long it = gid; it < total; it += stride) {
-      long long wdw = it / G;
-      const int px = (int)(wdw % ww); wdw /= ww;
-      const int py = (int)(wdw % hw_);
-      const int img = (int)(wdw / hw_);
+    const unsigned nwin = (unsigned)d.n * hw_ * ww, wstep = (unsigned)(stride / G);
+    for (unsigned wdw0 = (unsigned)(gid / G); wdw0 < nwin; wdw0 += wstep) {
+      unsigned wdw = wdw0;
+      const int px = (int)(wdw % (unsigned)ww); wdw /= (unsigned)ww;
+      const int py = (int)(wdw % (unsigned)hw_);
+      const int img = (int)(wdw / (unsigned)hw_);
       // first arg-max of the activated window (only when routing a pooled gradient)
       int am[8]; float gp[8];
       const bool full = dp && py < hp && px < wp;
@@ -334,6 +336,55 @@ __global__ void bn_bwd_kernel(const satcv_bnbwd_desc d) {
     for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(d.dbias + i, lds[i]);
   }
 }
+// Dense variant (no pooled gradient): pure linear sweep, 32-bit incremental indexing.
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbwd_desc d) {
+  extern __shared__ float lds[];
+  const int c = d.c, G = c / 8;
+  const unsigned npix = (unsigned)d.n * d.h * d.w_;
+  const unsigned nthreads = gridDim.x * blockDim.x;
+  const unsigned per = nthreads / G;
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = gid < per * G;
+  const int g = gid % G;
+  const T* da = (const T*)d.da + g * 8; const T* yr = (const T*)d.yraw + g * 8; T* dy = (T*)d.dy + g * 8;
+  float sc[8], sh[8], mu[8], rs[8], c1[8], c2[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = g * 8 + e;
+    sc[e] = d.scale[ch]; sh[e] = d.shift[ch]; mu[e] = d.mean[ch]; rs[e] = d.rstd[ch];
+    c1[e] = APPLY ? d.coef[ch] : 0.f; c2[e] = APPLY ? d.coef[c + ch] : 0.f;
+    s1[e] = 0.f; s2[e] = 0.f;
+  }
+  if (active) {
+#pragma unroll 2
+    for (unsigned p = gid / G; p < npix; p += per) {
+      float v[8], gr[8], o[8];
+      load8<T>(yr + (size_t)p * d.ldy, v);
+      load8<T>(da + (size_t)p * d.ldda, gr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = v[e] * sc[e] + sh[e];
+        const float gg = a > 0.f ? gr[e] : 0.f;
+        const float xh = (v[e] - mu[e]) * rs[e];
+        if (APPLY) { const float t = sc[e] * (gg - c1[e] - xh * c2[e]); o[e] = round_to<T>(t); s1[e] += o[e]; }
+        else { s1[e] += gg; s2[e] += gg * xh; }
+      }
+      if (APPLY) store8<T>(dy + (size_t)p * d.lddy_out, o);
+    }
+  }
+  if (!APPLY) block_channel_reduce(lds, s1, s2, g, active, c, d.sums, d.sums_ld);
+  else if (d.dbias) {
+    for (int i = threadIdx.x; i < c; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(&lds[g * 8 + e], s1[e]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(d.dbias + i, lds[i]);
+  }
+}
 static int bnbwd_check(const satcv_bnbwd_desc* d, bool apply) {
   SATCV_CHECK(d && d->yraw && d->scale && d->shift && d->mean && d->rstd, "bn_bwd: null pointer");
   SATCV_CHECK(d->da || d->dpool, "bn_bwd: no incoming gradient");
@@ -347,7 +398,11 @@ extern "C" int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream) {
   int rc = bnbwd_check(d, false); if (rc) return rc;
   const int f = d->dpool ? d->f : 1;
   const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
-  DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), 2 * d->c * sizeof(float), (hipStream_t)stream, *d));
+  if (!d->dpool && d->da && (long long)d->n * d->h * d->w_ < 0x7fffffffLL) {
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), 2 * d->c * sizeof(float), (hipStream_t)stream, *d));
+  } else {
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), 2 * d->c * sizeof(float), (hipStream_t)stream, *d));
+  }
   LAUNCH_OK("bn_bwd_reduce");
   return SATCV_OK;
 }
@@ -355,7 +410,11 @@ extern "C" int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream) {
   int rc = bnbwd_check(d, true); if (rc) return rc;
   const int f = d->dpool ? d->f : 1;
   const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
-  DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), d->c * sizeof(float), (hipStream_t)stream, *d));
+  if (!d->dpool && d->da && (long long)d->n * d->h * d->w_ < 0x7fffffffLL) {
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), d->c * sizeof(float), (hipStream_t)stream, *d));
+  } else {
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), d->c * sizeof(float), (hipStream_t)stream, *d));
+  }
   LAUNCH_OK("bn_bwd_apply");
   return SATCV_OK;
 }
@@ -433,11 +492,134 @@ __global__ void head_fwd_kernel(const satcv_head_desc d) {
     }
   }
 }
+
+// ---- register-resident variants for the common small heads (CIN * NC <= 128): every weight and every
+// dW accumulator lives in registers, one pass over the pixels.
+template <typename T, int NC, int CIN>
+__global__ __launch_bounds__(EW_BLOCK) void head_fwd_fast_kernel(const satcv_head_desc d) {
+  float w[CIN][NC], b[NC], sc[CIN], sh[CIN];
+  const bool tr = d.in_scale != nullptr;
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) {
+    sc[c] = tr ? d.in_scale[c] : 1.f; sh[c] = tr ? d.in_shift[c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) w[c][k] = d.w[c * NC + k];
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) b[k] = d.b[k];
+  const T* x = (const T*)d.x;
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < d.npix; p += (long long)gridDim.x * blockDim.x) {
+    float z[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) z[k] = b[k];
+#pragma unroll
+    for (int g = 0; g < CIN / 8; ++g) {
+      float v[8];
+      load8<T>(x + p * d.ldx + g * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = tr ? fmaxf(v[e] * sc[g * 8 + e] + sh[g * 8 + e], 0.f) : v[e];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) z[k] += a * w[g * 8 + e][k];
+      }
+    }
+    if (d.activation == 0) {
+      float mx = z[0];
+#pragma unroll
+      for (int k = 1; k < NC; ++k) mx = fmaxf(mx, z[k]);
+      float s = 0.f, ex[NC];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) { ex[k] = expf(z[k] - mx); s += ex[k]; }
+      const float inv = 1.f / s;
+      float best = -1.f; int am = 0;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const float pr = ex[k] * inv;
+        d.probs[p * NC + k] = pr;
+        if (pr > best) { best = pr; am = k; }
+      }
+      if (d.classes) d.classes[p] = am;
+    } else {
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const float pr = 1.f / (1.f + expf(-z[k]));
+        d.probs[p * NC + k] = pr;
+        if (d.classes) d.classes[p * NC + k] = pr > d.thresh ? 1 : 0;
+      }
+    }
+  }
+}
+
+template <typename T, int NC, int CIN>
+__global__ __launch_bounds__(EW_BLOCK) void head_bwd_fast_kernel(const satcv_head_desc d) {
+  __shared__ float aw[CIN * NC + NC];
+  float w[CIN][NC], sc[CIN], sh[CIN], acc[CIN][NC], accb[NC];
+  const bool tr = d.in_scale != nullptr;
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) {
+    sc[c] = tr ? d.in_scale[c] : 1.f; sh[c] = tr ? d.in_shift[c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { w[c][k] = d.w[c * NC + k]; acc[c][k] = 0.f; }
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) accb[k] = 0.f;
+  for (int i = threadIdx.x; i < CIN * NC + NC; i += blockDim.x) aw[i] = 0.f;
+  __syncthreads();
+  const T* x = (const T*)d.x; T* dx = (T*)d.dx;
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < d.npix; p += (long long)gridDim.x * blockDim.x) {
+    float dl[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { dl[k] = d.dlogits[p * NC + k]; accb[k] += dl[k]; }
+#pragma unroll
+    for (int g = 0; g < CIN / 8; ++g) {
+      float v[8], o[8];
+      load8<T>(x + p * d.ldx + g * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        const float a = tr ? fmaxf(v[e] * sc[c] + sh[c], 0.f) : v[e];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) { s += dl[k] * w[c][k]; acc[c][k] += a * dl[k]; }
+        o[e] = s;
+      }
+      if (dx) store8<T>(dx + p * d.lddx + g * 8, o);
+    }
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < CIN; ++c)
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const float s = wave_sum(acc[c][k]);
+      if (lane == 0) atomicAdd(&aw[c * NC + k], s);
+    }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) { const float s = wave_sum(accb[k]); if (lane == 0) atomicAdd(&aw[CIN * NC + k], s); }
+  __syncthreads();
+  if (d.dw) for (int i = threadIdx.x; i < CIN * NC; i += blockDim.x) atomicAdd(d.dw + i, aw[i]);
+  if (d.db) for (int i = threadIdx.x; i < NC; i += blockDim.x) atomicAdd(d.db + i, aw[CIN * NC + i]);
+}
+
+template <typename T, bool BWD>
+static bool head_fast_launch(const satcv_head_desc* d, hipStream_t st) {
+  const int grid = ew_grid(d->npix, 1024);
+#define HEAD_CASE(NC_, CIN_)                                                                                      \
+  if (d->ncls == NC_ && d->cin == CIN_) {                                                                         \
+    if (BWD) hipLaunchKernelGGL((head_bwd_fast_kernel<T, NC_, CIN_>), dim3(grid), dim3(EW_BLOCK), 0, st, *d);      \
+    else hipLaunchKernelGGL((head_fwd_fast_kernel<T, NC_, CIN_>), dim3(grid), dim3(EW_BLOCK), 0, st, *d);         \
+    return true;                                                                                                  \
+  }
+  HEAD_CASE(1, 16) HEAD_CASE(2, 16) HEAD_CASE(1, 32) HEAD_CASE(2, 32) HEAD_CASE(3, 32) HEAD_CASE(4, 32) HEAD_CASE(1, 64) HEAD_CASE(2, 64)
+#undef HEAD_CASE
+  return false;
+}
 extern "C" int satcv_head_fwd(const satcv_head_desc* d, void* stream) {
   SATCV_CHECK(d && d->x && d->w && d->b && d->probs, "head_fwd: null pointer");
   SATCV_CHECK(d->cin > 0 && d->cin % 8 == 0 && d->ncls >= 1 && d->ncls <= HEAD_NCMAX && d->npix > 0, "head_fwd: bad dims (cin=%d ncls=%d)", d->cin, d->ncls);
   const size_t lds = (size_t)(d->cin * d->ncls + d->ncls + 2 * d->cin) * sizeof(float);
-  DISPATCH_T(d->dtype, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(ew_grid(d->npix)), dim3(EW_BLOCK), lds, (hipStream_t)stream, *d));
+  DISPATCH_T(d->dtype, { if (!head_fast_launch<T, false>(d, (hipStream_t)stream))
+      hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(ew_grid(d->npix)), dim3(EW_BLOCK), lds, (hipStream_t)stream, *d); });
   LAUNCH_OK("head_fwd");
   return SATCV_OK;
 }
@@ -505,7 +687,8 @@ extern "C" int satcv_head_bwd(const satcv_head_desc* d, void* stream) {
   SATCV_CHECK(d && d->x && d->w && d->dlogits, "head_bwd: null pointer");
   SATCV_CHECK(d->cin > 0 && d->cin % 8 == 0 && d->ncls >= 1 && d->ncls <= HEAD_NCMAX && d->npix > 0, "head_bwd: bad dims");
   const size_t lds = (size_t)(2 * d->cin * d->ncls + d->ncls + 2 * d->cin) * sizeof(float);
-  DISPATCH_T(d->dtype, hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(ew_grid(d->npix, 1024)), dim3(EW_BLOCK), lds, (hipStream_t)stream, *d));
+  DISPATCH_T(d->dtype, { if (!head_fast_launch<T, true>(d, (hipStream_t)stream))
+      hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(ew_grid(d->npix, 1024)), dim3(EW_BLOCK), lds, (hipStream_t)stream, *d); });
   LAUNCH_OK("head_bwd");
   return SATCV_OK;
 }
