@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsatcv.so')
+LIB_PATH = os.environ.get('SATCV_LIB') or os.path.join(_HERE, 'libsatcv.so')     # SATCV_LIB: profiling variants only
 
 F32, BF16 = 0, 1
 STAT_ROWS = 32

@@ -16,6 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libsatcv.so')
 OBJDIR = os.path.join(HERE, 'csrc', '_obj')
 SOURCES = ['api.hip', 'conv_igemm.hip', 'conv_igemm_fast.hip', 'conv_wgrad.hip', 'elementwise.hip']
+EXTRA = []
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-Wno-unused-variable', '-Wno-pass-failed']
 
@@ -25,11 +26,18 @@ def _digest(paths):
     for p in sorted(paths):
         h.update(open(p, 'rb').read())
     h.update(' '.join(FLAGS).encode())
+    h.update(' '.join(EXTRA).encode())
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, extra_flags=(), out=None, objdir=None):
+    global OUT, OBJDIR
+    if out:
+        OUT = out
+    if objdir:
+        OBJDIR = objdir
     os.makedirs(OBJDIR, exist_ok=True)
+    EXTRA[:] = list(extra_flags)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.hpp'))]
     deps.append(os.path.join(os.path.dirname(HERE), 'include', 'satcv.h'))
     stamp = os.path.join(OBJDIR, 'stamp')
@@ -40,7 +48,7 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, src.replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + EXTRA + ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {src}:\n{r.stderr[-6000:]}')
@@ -59,4 +67,9 @@ def build(force=False, verbose=True):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    ab = [a for a in sys.argv[1:] if a.startswith('-D')]
+    if ab:      # profiling variant: python -m ...build -DSATCV_ABLATE=2 -> libsatcv_<tag>.so
+        tag = ''.join(c for c in '_'.join(ab) if c.isalnum() or c == '_')
+        print(build(force=True, extra_flags=ab, out=os.path.join(HERE, f'libsatcv{tag}.so'), objdir=os.path.join(CSRC, '_obj' + tag)))
+    else:
+        print(build(force='--force' in sys.argv))

@@ -308,6 +308,7 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   a.kh = d->kh; a.kw = d->kw; a.dil = d->dil;
   a.mode_in = d->mode_in; a.mode_out = d->mode_out; a.f = d->f;
   a.cstat = d->cstat; a.out_relu = d->out_relu;
+  { static const int dbg = [] { const char* e = getenv("SATCV_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
   if (a.mode_in == 1) {
     // K = f*f*c0 virtual channels gathered from one source
     SATCV_CHECK(!d->x1, "igemm: s2d with dual source");

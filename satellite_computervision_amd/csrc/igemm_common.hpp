@@ -20,6 +20,7 @@ struct IgemmArgs {
   int rpi, imgs, seg, rl, cl, pitch, halh, halw;
   int n_tiles;                     // N tiles
   int nchunks;
+  int dbg;                         // ablation bits (env SATCV_DBG): 1 skip stores, 2 skip MFMA, 4 skip A loads, 8 skip B loads
 };
 
 template <typename T>
