@@ -87,6 +87,7 @@ typedef struct satcv_conv_desc {
   int32_t cstat;           /* modulus mapping N index -> bias/stats channel            */
   int32_t out_relu;        /* clamp outputs at 0 before storing                        */
   int32_t dtype;
+  int32_t accumulate;      /* y += result instead of y = result (fan-out of a tensor into several convs) */
 } satcv_conv_desc;
 int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream);
 
@@ -184,6 +185,16 @@ int satcv_head_bwd(const satcv_head_desc* d, void* stream);
 int satcv_loss_fwd_bwd(int32_t kind, const float* probs, const float* y_true,
                        const float* weights, int32_t ncls, int32_t activation, int64_t npix,
                        float grad_scale, float* loss_out, float* dlogits, void* stream);
+
+/* Ratio-type losses that need global sums before the gradient exists (two passes inside):
+ * kind 2: gen_dice (utils/model_tools.py:42-94; class_weights = global_weights or NULL for the
+ *         per-image 1/count^2 weights with `eps` for empty classes), 3: iou_loss (:131-140),
+ *         4: mse_4d (:142-166, mean over finite elements).
+ * workspace: nimg*3*ncls floats (zeroed here).  Writes loss_out[0] += loss and dL/dlogits. */
+int satcv_loss_global_fwd_bwd(int32_t kind, const float* probs, const float* y_true,
+                              const float* class_weights, int32_t ncls, int32_t activation,
+                              int32_t nimg, int64_t pix_per_img, float eps, float grad_scale,
+                              float* workspace, float* loss_out, float* dlogits, void* stream);
 
 /* confusion[t*ncls + p] += 1 over pixels (MeanIoU / accuracy; notebooks nb:275) */
 int satcv_confusion(const int32_t* classes, const float* y_true, int32_t ncls, int64_t npix,

@@ -88,3 +88,24 @@ def keras_adam_(p, grads, m, v, t, lr=9e-4, b1=0.9, b2=0.999, eps=1e-7):
             m[k].mul_(b1).add_(g, alpha=1 - b1)
             v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
             p[k].sub_(alpha * m[k] / (v[k].sqrt() + eps))
+
+
+def aspp_net_forward(p, x_nhwc, training=False):
+    """Small encoder -> ASPP -> decoder -> softmax head used to check the ASPP block
+    (DilatedSpatialPyramidPooling, utils/model_tools.py:533-574) inside a trainable graph.
+    Parameter names: enc.*, aspp.{cba,cba3_3,cba3_6,cba3_12,cba3}.*, up.*, bn0.*, conv1.*, conv2.*, probs.*"""
+    x = x_nhwc.permute(0, 3, 1, 2)
+
+    def cba(name, t, d=1):
+        return F.relu(_bn(_conv(t, p[f'{name}.kernel'], p[f'{name}.bias'], d), p, f'{name}.bn', training))
+    enc = cba('enc', x)
+    pooled = F.max_pool2d(enc, 2, 2)
+    br = [cba('aspp.cba', pooled), cba('aspp.cba3_3', pooled, 3), cba('aspp.cba3_6', pooled, 6), cba('aspp.cba3_12', pooled, 12)]
+    a = cba('aspp.cba3', torch.cat(br, dim=1))
+    up = F.conv_transpose2d(a, p['up.kernel'].permute(3, 2, 0, 1), p['up.bias'], stride=2)
+    cat = torch.cat([enc, up], dim=1)
+    a0 = F.relu(_bn(cat, p, 'bn0', training))
+    h = cba('conv2', cba('conv1', a0))
+    logits = _conv(h, p['probs.kernel'], p['probs.bias'])
+    probs = torch.softmax(logits, dim=1).permute(0, 2, 3, 1)
+    return probs, torch.argmax(probs, dim=-1).to(torch.int32)

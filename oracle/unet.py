@@ -125,6 +125,7 @@ class UNetOracle:
         dy, g[f'{bnname}.gamma'], g[f'{bnname}.beta'] = K.batchnorm_train_bwd(
             y, p[f'{bnname}.gamma'], mean, var, dz, BN_EPS)
         dx, g[f'{name}.kernel'], g[f'{name}.bias'] = K.conv2d_same_bwd(x, p[f'{name}.kernel'], dy, dilation)
+        self.dbg[f'dy:{name}'], self.dbg[f'dx:{name}'] = dy, dx
         return dx
 
     # ----------------------------------------------------------------- forward
@@ -159,6 +160,7 @@ class UNetOracle:
     def backward(self, dprobs):
         """Gradients of all trainable params given dL/dprobs (after a training forward)."""
         p, c, g = self.params, self.cache, {}
+        self.dbg = {}
         L = len(self.filters)
         h, probs = c['head']
         dlogits = K.softmax_bwd(probs, np.asarray(dprobs, self.dtype))
@@ -173,8 +175,10 @@ class UNetOracle:
                 cat, p[f'dec{j}.bn0.gamma'], mean, var, dz, BN_EPS)
             f = self.filters[j]
             dskip[j] = dcat[..., :f]
+            self.dbg[f'dskip:dec{j}.bn0'], self.dbg[f'du:dec{j}.bn0'] = dcat[..., :f], dcat[..., f:]
             dh, g[f'dec{j}.up.kernel'], g[f'dec{j}.up.bias'] = K.conv2d_transpose_ks_bwd(
                 hin, p[f'dec{j}.up.kernel'], dcat[..., f:])
+            self.dbg[f'dx:dec{j}.up'] = dh
         dh = self._cba_bwd('center.conv', 'center.bn', dh, c, g)
         for i in range(L - 1, -1, -1):
             a = c[f'enc{i}']

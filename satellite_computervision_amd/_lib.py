@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
                 ('cout', c_i32), ('cout_pad', c_i32),
                 ('kh', c_i32), ('kw', c_i32), ('dil', c_i32),
                 ('mode_in', c_i32), ('mode_out', c_i32), ('f', c_i32),
-                ('cstat', c_i32), ('out_relu', c_i32), ('dtype', c_i32)]
+                ('cstat', c_i32), ('out_relu', c_i32), ('dtype', c_i32), ('accumulate', c_i32)]
 
 
 class WgradDesc(C.Structure):
@@ -81,6 +81,7 @@ _SIGS = {
     'satcv_head_fwd': (C.c_int, [C.POINTER(HeadDesc), c_vp]),
     'satcv_head_bwd': (C.c_int, [C.POINTER(HeadDesc), c_vp]),
     'satcv_loss_fwd_bwd': (C.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_f32, c_vp, c_vp, c_vp]),
+    'satcv_loss_global_fwd_bwd': (C.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     'satcv_confusion': (C.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
     'satcv_adam_step': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp]),
     'satcv_graph_begin': (C.c_int, [c_vp]),

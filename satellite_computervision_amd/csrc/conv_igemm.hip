@@ -204,8 +204,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
           } else {
             off = ((size_t)(nimg * ho + y) * wo + x) * a.ldy + cn;
           }
-          yp[off] = tv;
-          const float fv = (float)tv;
+          const T tvv = a.accumulate ? (T)((float)yp[off] + v) : tv;
+          yp[off] = tvv;
+          const float fv = (float)tvv;
           s1 += fv; s2 += fv * fv;
         }
       }
@@ -267,13 +268,16 @@ static int launch_tw(IgemmArgs& a, hipStream_t st) {
   const int nspace = a.mode_out ? a.cstat : a.cout;      // BN must divide cstat in d2s mode
   const bool ks2 = (cin % 32 == 0) && (!a.x1 || a.c0 % 32 == 0) && (a.mode_in != 1 || a.c0 % 32 == 0) &&
                    (a.kh * a.kw == 1);                   // KC=32 only for 1x1 (LDS budget), else 16
-  if (nspace >= 128 && nspace % 128 == 0) {
-    return ks2 ? launch_cfg<T, TW, 2, 2, 2, 2, 2>(a, st) : launch_cfg<T, TW, 2, 2, 2, 2, 1>(a, st);
-  } else if (nspace >= 64 && nspace % 64 == 0) {
-    return ks2 ? launch_cfg<T, TW, 2, 2, 2, 1, 2>(a, st) : launch_cfg<T, TW, 2, 2, 2, 1, 1>(a, st);
-  } else {
-    return ks2 ? launch_cfg<T, TW, 4, 1, 2, 1, 2>(a, st) : launch_cfg<T, TW, 4, 1, 2, 1, 1>(a, st);
-  }
+  // preferred N tile first; if its LDS images do not fit (large dilation halo, fp32 storage) fall back to a
+  // narrower N tile, whose weight slab is smaller
+  int rc = SATCV_ERR_UNSUPPORTED;
+  if (nspace >= 128 && nspace % 128 == 0)
+    rc = ks2 ? launch_cfg<T, TW, 2, 2, 2, 2, 2>(a, st) : launch_cfg<T, TW, 2, 2, 2, 2, 1>(a, st);
+  if (rc == SATCV_ERR_UNSUPPORTED && nspace >= 64 && nspace % 64 == 0)
+    rc = ks2 ? launch_cfg<T, TW, 2, 2, 2, 1, 2>(a, st) : launch_cfg<T, TW, 2, 2, 2, 1, 1>(a, st);
+  if (rc == SATCV_ERR_UNSUPPORTED)
+    rc = ks2 ? launch_cfg<T, TW, 4, 1, 2, 1, 2>(a, st) : launch_cfg<T, TW, 4, 1, 2, 1, 1>(a, st);
+  return rc;
 }
 
 template <typename T>
@@ -296,6 +300,7 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   SATCV_CHECK(d->n > 0 && d->h > 0 && d->w_ > 0 && d->cout > 0, "igemm: bad dims");
   SATCV_CHECK(d->cstat > 0, "igemm: cstat");
   SATCV_CHECK((!d->mode_in && !d->mode_out) || (d->f >= 2 && d->kh == 1 && d->kw == 1), "igemm: s2d/d2s need 1x1 taps and f>=2");
+  SATCV_CHECK(!(d->accumulate && d->stats), "igemm: accumulate with statistics");
   SATCV_CHECK(!(d->mode_in && d->in_scale), "igemm: s2d source cannot carry an input transform");
   IgemmArgs a;
   a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1;
@@ -307,7 +312,7 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   a.cout = d->cout; a.cout_pad = d->cout_pad;
   a.kh = d->kh; a.kw = d->kw; a.dil = d->dil;
   a.mode_in = d->mode_in; a.mode_out = d->mode_out; a.f = d->f;
-  a.cstat = d->cstat; a.out_relu = d->out_relu;
+  a.cstat = d->cstat; a.out_relu = d->out_relu; a.accumulate = d->accumulate;
   { static const int dbg = [] { const char* e = getenv("SATCV_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
   if (a.mode_in == 1) {
     // K = f*f*c0 virtual channels gathered from one source

@@ -272,7 +272,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs
       else off = ((size_t)(nimg * ho + y) * wo + x) * a.ldy + cbase + v * EPV;
       const T* sp = ldsO + q * OPITCH + v * EPV;
       if (ABL(1)) continue;
-      if (ncols - v * EPV >= EPV) {
+      if (a.accumulate) {
+        const int ne = min(EPV, ncols - v * EPV);
+        for (int e = 0; e < ne; ++e) yp[off + e] = (T)((float)yp[off + e] + (float)sp[e]);
+      } else if (ncols - v * EPV >= EPV) {
         *reinterpret_cast<uint4*>(yp + off) = *reinterpret_cast<const uint4*>(sp);
       } else {
         for (int e = 0; e < ncols - v * EPV; ++e) yp[off + e] = sp[e];

@@ -24,6 +24,7 @@ struct WgradArgs {
   int cin_lim, n_lim;          // valid channels in X / valid N indices
   int tiles_x, tiles_y, ngroups, rpi, imgs, seg, rl, cl, halh, halw;
   int n_ci_blk, n_co_blk, nsplit, total_ptiles;
+  int sy, sx;                  // extra source shift (one tap of a dilated conv handled as a shifted 1x1)
 };
 
 template <int TW, int NCI, int NCO, int NTAPS, typename T>
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 2) void wgrad_kernel(const Wgra
         const int pix = it / (CI_T / 8);
         const int pm = ptab[pix];
         const int c = pm & 1023, yy = ((pm >> 10) & 1023) - 64, k = pm >> 20;
-        const int n = n0 + k, y = y0 + yy, x = x0 + c - a.halw;
+        const int n = n0 + k, y = y0 + yy + a.sy, x = x0 + c - a.halw + a.sx;
         const int cg = ci0 + g * 8;
         if ((n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_) && (cg < a.cin_lim)) {
           const T* src; int cs, coff;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 2) void wgrad_kernel(const Wgra
       const int pix = it / (CI_T / 8);
       const int pm = ptab[pix];
       const int c = pm & 1023, yy = ((pm >> 10) & 1023) - 64, k = pm >> 20;
-      const int n = n0 + k, y = y0 + yy, x = x0 + c - a.halw;
+      const int n = n0 + k, y = y0 + yy + a.sy, x = x0 + c - a.halw + a.sx;
       const int cg = ci0 + g * 8;
       Raw8<T> v = zero8<T>();
       if ((n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_) && (cg < a.cin_lim)) {
@@ -382,22 +383,30 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
 extern "C" int64_t satcv_conv2d_wgrad_workspace(const satcv_wgrad_desc* d) {
   WgradPlan p;
   if (!d || wgrad_plan(d, p) != SATCV_OK) return -1;
-  return (int64_t)p.ws_bytes;
+  size_t need = p.ws_bytes;
+  if (p.ntaps == 9) {                       // per-tap fallback of strongly dilated convs
+    satcv_wgrad_desc d1 = *d;
+    d1.kh = d1.kw = 1;
+    WgradPlan p1;
+    if (wgrad_plan(&d1, p1) == SATCV_OK && p1.ws_bytes > need) need = p1.ws_bytes;
+  }
+  return (int64_t)need;
 }
 
 template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS>
-static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st) {
+static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy = 0, int sx = 0) {
   using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
   constexpr int TH = 128 / TW;
   WgradArgs a;
   a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_relu = d->in_relu;
   a.dy = d->dy; a.lddy = d->lddy; a.ws = d->workspace;
-  a.n = d->n; a.h = d->h; a.w_ = d->w_; a.kh = d->kh; a.kw = d->kw; a.dil = d->dil;
+  a.n = d->n; a.h = d->h; a.w_ = d->w_; a.kh = NTAPS == 1 ? 1 : d->kh; a.kw = NTAPS == 1 ? 1 : d->kw; a.dil = d->dil;
+  a.sy = sy; a.sx = sx;
   a.mode_dy = d->mode_dy; a.f = d->f; a.cout_t = d->cout;
   a.kpad = p.kpad; a.npad = p.npad;
   a.cin_lim = d->c0 + d->c1; a.n_lim = d->mode_dy ? d->f * d->f * d->cout : d->cout;
-  a.halh = d->dil * (d->kh - 1) / 2; a.halw = d->dil * (d->kw - 1) / 2;
+  a.halh = a.dil * (a.kh - 1) / 2; a.halw = a.dil * (a.kw - 1) / 2;
   a.tiles_x = cdiv(d->w_, TW);
   if (d->h >= TH) { a.rpi = TH; a.imgs = 1; a.tiles_y = cdiv(d->h, TH); a.ngroups = d->n; }
   else { a.rpi = d->h; a.imgs = TH / d->h; a.tiles_y = 1; a.ngroups = cdiv(d->n, a.imgs); }
@@ -406,7 +415,7 @@ static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream
   a.total_ptiles = a.ngroups * a.tiles_y * a.tiles_x;
   size_t lds = ((size_t)a.rl * a.cl * G::XP + 128 * G::DP) * sizeof(T) + (128 + (size_t)a.rl * a.cl) * sizeof(int);
   if (lds < 3 * 4096) lds = 3 * 4096;          // k-slice reduction scratch
-  if (lds > 160 * 1024) { satcv_set_error("wgrad: LDS %zu too large", lds); return SATCV_ERR_UNSUPPORTED; }
+  if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
   auto kern = wgrad_kernel<T, TW, NCI, NCO, NKS, NTAPS>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -419,8 +428,8 @@ static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream
 }
 
 template <typename T, int TW>
-static int wgrad_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st) {
-  if (p.ntaps == 1) return wgrad_launch<T, TW, 1, 4, 1, 1>(d, p, st);
+static int wgrad_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy = 0, int sx = 0) {
+  if (p.ntaps == 1) return wgrad_launch<T, TW, 1, 4, 1, 1>(d, p, st, sy, sx);
   if (p.nci == 1 && p.nco == 4) return wgrad_launch<T, TW, 1, 4, 1, 9>(d, p, st);
   if (p.nci == 2 && p.nco == 2) return wgrad_launch<T, TW, 2, 2, 1, 9>(d, p, st);
   if (p.nci == 1 && p.nco == 2) return wgrad_launch<T, TW, 1, 2, 2, 9>(d, p, st);
@@ -428,12 +437,27 @@ static int wgrad_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t 
   return wgrad_launch<T, TW, 1, 1, 4, 9>(d, p, st);
 }
 template <typename T>
-static int wgrad_t(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st) {
+static int wgrad_t(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy = 0, int sx = 0) {
   switch (p.tw) {
-    case 32: return wgrad_cfg<T, 32>(d, p, st);
-    case 16: return wgrad_cfg<T, 16>(d, p, st);
-    default: return wgrad_cfg<T, 8>(d, p, st);
+    case 32: return wgrad_cfg<T, 32>(d, p, st, sy, sx);
+    case 16: return wgrad_cfg<T, 16>(d, p, st, sy, sx);
+    default: return wgrad_cfg<T, 8>(d, p, st, sy, sx);
   }
+}
+static int wgrad_any(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy = 0, int sx = 0) {
+  if (d->dtype == SATCV_BF16) return wgrad_t<bf16>(d, p, st, sy, sx);
+  if (d->dtype == SATCV_F32) return wgrad_t<float>(d, p, st, sy, sx);
+  satcv_set_error("wgrad: bad dtype");
+  return SATCV_ERR_INVALID;
+}
+static int wgrad_reduce_launch(const satcv_wgrad_desc* d, const WgradPlan& p, float* dw, int nvalid, hipStream_t st) {
+  const long long total = (long long)p.ntaps * d->cin * nvalid;
+  int grid = (int)((total + 63) / 64); if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, d->workspace, dw, p.nsplit, p.ntaps, p.kpad, p.npad, d->cin, nvalid,
+                     d->transposed);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { satcv_set_error("wgrad reduce launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  return SATCV_OK;
 }
 
 void satcv_prof_begin(int kind, double flops, hipStream_t st);
@@ -453,16 +477,22 @@ extern "C" int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream) {
   const int nvalid = d->mode_dy ? d->f * d->f * d->cout : d->cout;
   const double flops = 2.0 * d->n * d->h * d->w_ * (double)nvalid * (double)(d->c0 + d->c1) * d->kh * d->kw;
   satcv_prof_begin(2, flops, st);
-  if (d->dtype == SATCV_BF16) rc = wgrad_t<bf16>(d, p, st);
-  else if (d->dtype == SATCV_F32) rc = wgrad_t<float>(d, p, st);
-  else { satcv_set_error("wgrad: bad dtype"); rc = SATCV_ERR_INVALID; }
+  rc = wgrad_any(d, p, st);
+  if (rc == SATCV_ERR_UNSUPPORTED && p.ntaps == 9) {
+    // halo tile of a strongly dilated conv does not fit the LDS: treat every tap as a shifted 1x1 product
+    satcv_wgrad_desc d1 = *d;
+    d1.kh = d1.kw = 1;
+    WgradPlan p1;
+    rc = wgrad_plan(&d1, p1);
+    if (rc == SATCV_OK && (size_t)d->workspace_bytes < p1.ws_bytes) { satcv_set_error("wgrad: workspace too small for the per-tap path"); rc = SATCV_ERR_INVALID; }
+    for (int tap = 0; tap < 9 && rc == SATCV_OK; ++tap) {
+      rc = wgrad_any(&d1, p1, st, (tap / 3 - 1) * d->dil, (tap % 3 - 1) * d->dil);
+      if (rc == SATCV_OK) rc = wgrad_reduce_launch(&d1, p1, d->dw + (size_t)tap * d->cin * nvalid, nvalid, st);
+    }
+    satcv_prof_end(2, st);
+    return rc;
+  }
   satcv_prof_end(2, st);
   if (rc) return rc;
-  const long long total = (long long)p.ntaps * d->cin * nvalid;
-  int grid = (int)((total + 63) / 64); if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, d->workspace, d->dw, p.nsplit, p.ntaps, p.kpad, p.npad, d->cin,
-                     nvalid, d->transposed);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { satcv_set_error("wgrad reduce launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
-  return SATCV_OK;
+  return wgrad_reduce_launch(d, p, d->dw, nvalid, st);
 }

@@ -760,6 +760,103 @@ extern "C" int satcv_loss_fwd_bwd(int32_t kind, const float* probs, const float*
   return SATCV_OK;
 }
 
+
+// ---- ratio-type losses: need global (or per-image) sums before the gradient is known
+// ws layout: [nimg][3][ncls] = per image, per class: sum t*p, sum (t+p) [dice] / sum (t+(1-t)p) [iou], sum t (counts);
+// mse_4d uses ws[0] = sum of squared finite errors, ws[1] = count of finite elements.
+__global__ void loss_sums_kernel(int kind, const float* __restrict__ probs, const float* __restrict__ yt, int nc, long long ppi, int nimg, float* ws) {
+  const int img = blockIdx.y;
+  float a[HEAD_NCMAX], b[HEAD_NCMAX], c[HEAD_NCMAX];
+#pragma unroll
+  for (int k = 0; k < HEAD_NCMAX; ++k) { a[k] = 0.f; b[k] = 0.f; c[k] = 0.f; }
+  for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < ppi; q += (long long)gridDim.x * blockDim.x) {
+    const long long p = img * ppi + q;
+#pragma unroll
+    for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) {
+      const float pr = probs[p * nc + k], t = yt[p * nc + k];
+      if (kind == 2) { a[k] += t * pr; b[k] += t + pr; c[k] += t; }
+      else if (kind == 3) { a[k] += t * pr; b[k] += t + (1.f - t) * pr; }
+      else { const float d = (pr - t) * (pr - t); if (isfinite(d)) { a[k] += d; b[k] += 1.f; } }
+    }
+  }
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) {
+    const float sa = wave_sum(a[k]), sb = wave_sum(b[k]), sc = wave_sum(c[k]);
+    if (lane == 0) {
+      float* w = ws + ((size_t)img * 3) * nc;
+      atomicAdd(w + k, sa); atomicAdd(w + nc + k, sb); atomicAdd(w + 2 * nc + k, sc);
+    }
+  }
+}
+__global__ void loss_global_grad_kernel(int kind, const float* __restrict__ probs, const float* __restrict__ yt, const float* __restrict__ gw,
+                                        int nc, int activation, long long ppi, int nimg, float eps, float grad_scale, const float* __restrict__ ws,
+                                        float* loss_out, float* dlogits) {
+  const int img = blockIdx.y;
+  // per-image (dice) or global (iou, mse) constants, recomputed by every thread from the tiny sums array
+  float wk[HEAD_NCMAX], num = 0.f, den = 0.f, I = 0.f, U = 0.f, cnt = 0.f, sq = 0.f;
+  if (kind == 2) {
+#pragma unroll
+    for (int k = 0; k < HEAD_NCMAX; ++k) {
+      wk[k] = 0.f;
+      if (k < nc) {
+        const float* w = ws + ((size_t)img * 3) * nc;
+        if (gw) wk[k] = gw[k];
+        else { const float cn = w[2 * nc + k]; const float t = 1.f / (cn * cn); wk[k] = isfinite(t) ? t : eps; }
+        num += wk[k] * w[k]; den += wk[k] * w[nc + k];
+      }
+    }
+  } else {
+    for (int i = 0; i < nimg; ++i) for (int k = 0; k < nc; ++k) {
+      const float* w = ws + ((size_t)i * 3) * nc;
+      if (kind == 3) { I += w[k]; U += w[nc + k]; } else { sq += w[k]; cnt += w[nc + k]; }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (kind == 2) atomicAdd(loss_out, (1.f - 2.f * num / den) / (float)nimg);
+    else if (img == 0) atomicAdd(loss_out, kind == 3 ? 1.f - I / U : sq / cnt);
+  }
+  for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < ppi; q += (long long)gridDim.x * blockDim.x) {
+    const long long p = img * ppi + q;
+    float pr[HEAD_NCMAX], gp[HEAD_NCMAX];
+#pragma unroll
+    for (int k = 0; k < HEAD_NCMAX; ++k) {
+      pr[k] = 0.f; gp[k] = 0.f;
+      if (k < nc) {
+        pr[k] = probs[p * nc + k];
+        const float t = yt[p * nc + k];
+        if (kind == 2) gp[k] = -2.f * wk[k] * (t * den - num) / (den * den) / (float)nimg;
+        else if (kind == 3) gp[k] = -(t * U - I * (1.f - t)) / (U * U);
+        else { const float d = pr[k] - t; gp[k] = isfinite(d * d) ? 2.f * d / cnt : 0.f; }
+      }
+    }
+    if (activation == 0) {
+      float dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) dot += gp[k] * pr[k];
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) dlogits[p * nc + k] = grad_scale * pr[k] * (gp[k] - dot);
+    } else {
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) dlogits[p * nc + k] = grad_scale * gp[k] * pr[k] * (1.f - pr[k]);
+    }
+  }
+}
+extern "C" int satcv_loss_global_fwd_bwd(int32_t kind, const float* probs, const float* y_true, const float* class_weights, int32_t ncls,
+                                         int32_t activation, int32_t nimg, int64_t pix_per_img, float eps, float grad_scale, float* workspace,
+                                         float* loss_out, float* dlogits, void* stream) {
+  SATCV_CHECK(probs && y_true && workspace && loss_out && dlogits, "loss_global: null pointer");
+  SATCV_CHECK(kind >= 2 && kind <= 4 && ncls >= 1 && ncls <= HEAD_NCMAX && nimg > 0 && nimg <= 65535 && pix_per_img > 0, "loss_global: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  SATCV_HIP(hipMemsetAsync(workspace, 0, (size_t)nimg * 3 * ncls * sizeof(float), st));
+  int gx = (int)((pix_per_img + EW_BLOCK - 1) / EW_BLOCK); if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(loss_sums_kernel, dim3(gx, nimg), dim3(EW_BLOCK), 0, st, kind, probs, y_true, ncls, (long long)pix_per_img, nimg, workspace);
+  hipLaunchKernelGGL(loss_global_grad_kernel, dim3(gx, nimg), dim3(EW_BLOCK), 0, st, kind, probs, y_true, class_weights, ncls, activation,
+                     (long long)pix_per_img, nimg, eps, grad_scale, workspace, loss_out, dlogits);
+  LAUNCH_OK("loss_global");
+  return SATCV_OK;
+}
+
 // --------------------------------------------------------------------- confusion
 __global__ void confusion_kernel(const int32_t* __restrict__ classes, const float* __restrict__ yt, int nc, long long npix, unsigned long long* conf) {
   __shared__ unsigned int cnt[HEAD_NCMAX * HEAD_NCMAX];

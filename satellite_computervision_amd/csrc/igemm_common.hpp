@@ -14,7 +14,7 @@ struct IgemmArgs {
   int cout, cout_pad;
   int kh, kw, dil;
   int mode_in, mode_out, f;
-  int cstat, out_relu;
+  int cstat, out_relu, accumulate;
   // derived tiling
   int tiles_x, tiles_y, ngroups;   // M tiles = ngroups * tiles_y * tiles_x
   int rpi, imgs, seg, rl, cl, pitch, halh, halw;

@@ -238,20 +238,21 @@ class Plan:
                     in_scale=_fp(a['scale']) if a else None, in_shift=_fp(a['shift']) if a else None,
                     in_relu=1 if (a and r.relu) else 0)
 
-    def _bn_forward(self, bnname, stats, ld, off, c, count, updates):
-        """emit finalize (train) / affine (infer); returns affine dict of [c] tensors."""
+    def _bn_forward(self, bnname, stats, ld, off, c, count, updates, aff=None, aoff=0):
+        """emit finalize (train) / affine (infer); returns affine dict of per-channel tensors
+        (freshly allocated [c], or the caller's shared arrays written at channel offset aoff)."""
         rt = self.rt
-        a = dict(scale=self._z(c, dtype=torch.float32), shift=self._z(c, dtype=torch.float32),
-                 mean=self._z(c, dtype=torch.float32), rstd=self._z(c, dtype=torch.float32))
+        a = aff or dict(scale=self._z(c, dtype=torch.float32), shift=self._z(c, dtype=torch.float32),
+                        mean=self._z(c, dtype=torch.float32), rstd=self._z(c, dtype=torch.float32))
         g, b = rt.pptr(bnname + '/gamma'), rt.pptr(bnname + '/beta')
         mm, mv = rt.sptr(bnname + '/moving_mean'), rt.sptr(bnname + '/moving_var')
         if self.training:
             bessel = 1 if rt.model.bn_bessel else 0
             self.fwd.append(lambda st: check(lib.satcv_bn_finalize_train(
                 _fp(stats, off), ld, c, float(count), g, b, BN_EPS, BN_MOMENTUM, updates, bessel, mm, mv,
-                _fp(a['scale']), _fp(a['shift']), _fp(a['mean']), _fp(a['rstd']), st)))
+                _fp(a['scale'], aoff), _fp(a['shift'], aoff), _fp(a['mean'], aoff), _fp(a['rstd'], aoff), st)))
         else:
-            self.fwd.append(lambda st: check(lib.satcv_bn_affine_infer(g, b, mm, mv, BN_EPS, c, _fp(a['scale']), _fp(a['shift']), st)))
+            self.fwd.append(lambda st: check(lib.satcv_bn_affine_infer(g, b, mm, mv, BN_EPS, c, _fp(a['scale'], aoff), _fp(a['shift'], aoff), st)))
         return a
 
     def _materialize(self, t, r, f=1, pooled=None, sink=None):
@@ -289,6 +290,23 @@ class Plan:
                 sinks[a.id] = (st, 0, ctot)
                 sinks[b.id] = (st, a.channels, ctot)
 
+        slots = {}
+        for node in m.nodes:
+            if node.op == 'concat':
+                if not all(t.node.op == 'cba' and len(consumers[t.id]) == 1 for t in node.inputs):
+                    raise NotImplementedError('concatenate is supported for conv_batch_act outputs consumed only by the concat (ASPP)')
+                ctot = sum(t.channels for t in node.inputs)
+                hh, ww = self._dims(node.inputs[0])
+                yshared = self._z(n, hh, ww, ctot)
+                stshared = self._z(STAT_ROWS, 2, ctot, dtype=torch.float32) if training else None
+                aff = dict(scale=self._z(ctot, dtype=torch.float32), shift=self._z(ctot, dtype=torch.float32),
+                           mean=self._z(ctot, dtype=torch.float32), rstd=self._z(ctot, dtype=torch.float32))
+                off = 0
+                for t in node.inputs:
+                    slots[t.id] = dict(y=yshared, off=off, ctot=ctot, stats=stshared, aff=aff)
+                    off += t.channels
+                ctx[id(node)] = dict(y=yshared, ctot=ctot, aff=aff)
+
         for node in m.nodes:
             op = node.op
             if op == 'input':
@@ -311,15 +329,25 @@ class Plan:
                     raise NotImplementedError(f'{lay.name}: filters must be a multiple of 16 (got {cout})')
                 if r.c != pk['cin_pad']:
                     raise ValueError(f'{lay.name}: input has {r.c} stored channels, kernel expects {pk["cin_pad"]}')
-                y = self._z(n, r.h, r.w, cout)
-                stats = self._z(STAT_ROWS, 2, cout, dtype=torch.float32) if training else None
                 k, dil = node.attrs['k'], node.attrs['dil']
-                self.fwd.append(self._conv_step(w=pk['fwd'].data_ptr(), bias=rt.pptr(lay.name + '/bias'), y=y.data_ptr(), ldy=cout,
-                                                stats=_fp(stats), stats_ld=cout, n=n, h=r.h, w_=r.w, cout=cout, cout_pad=rup(cout, 32),
+                sl = slots.get(tout.id)
+                if sl is None:
+                    y = self._z(n, r.h, r.w, cout)
+                    stats = self._z(STAT_ROWS, 2, cout, dtype=torch.float32) if training else None
+                    yoff, ldy, aoff, aff_in = 0, cout, 0, None
+                else:           # branch of a concatenation: write into the channel slice of the shared tensor
+                    y, stats, yoff, ldy, aoff, aff_in = sl['y'], sl['stats'], sl['off'], sl['ctot'], sl['off'], sl['aff']
+                self.fwd.append(self._conv_step(w=pk['fwd'].data_ptr(), bias=rt.pptr(lay.name + '/bias'), y=y.data_ptr() + yoff * es, ldy=ldy,
+                                                stats=_fp(stats, aoff), stats_ld=ldy, n=n, h=r.h, w_=r.w, cout=cout, cout_pad=rup(cout, 32),
                                                 kh=k, kw=k, dil=dil, dtype=dt, **self._src_args(r)))
-                aff = self._bn_forward(lay.bn_name, stats, cout, 0, cout, n * r.h * r.w, node.attrs.get('bn_updates', 1))
-                vals[tout.id] = TRef([(y, cout)], n, r.h, r.w, affine=aff, relu=True)
-                ctx[id(node)] = dict(r=r, y=y, aff=aff, cout=cout, k=k, dil=dil)
+                aff = self._bn_forward(lay.bn_name, stats, ldy, aoff, cout, n * r.h * r.w, node.attrs.get('bn_updates', 1), aff_in, aoff)
+                if sl is None:
+                    vals[tout.id] = TRef([(y, cout)], n, r.h, r.w, affine=aff, relu=True)
+                ctx[id(node)] = dict(r=r, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout, k=k, dil=dil)
+            elif op == 'concat':
+                cx = ctx[id(node)]
+                hh, ww = self._dims(node.inputs[0])
+                vals[node.outputs[0].id] = TRef([(cx['y'], cx['ctot'])], n, hh, ww, affine=cx['aff'], relu=True)
             elif op == 'pool':
                 tin, tout = node.inputs[0], node.outputs[0]
                 r = vals[tin.id]
@@ -413,6 +441,7 @@ class Plan:
         rt, m, n = self.rt, self.rt.model, self.n
         dt, es = rt.dtype, rt.esize
         gact, gpool, gpool_f, graw = {}, {}, {}, {}
+        self.dbg = {}                       # layer name -> intermediate gradient tensors (diagnostics only)
         ws_need = 0
         wdescs = []
         # loss -> dlogits is written by Model.train step into this buffer
@@ -463,33 +492,51 @@ class Plan:
                                         dw=rt.gptr(lay.name + '/kernel'), db=rt.gptr(lay.name + '/bias'))
                 self.keep.append(hd)
                 self.bwd.append(lambda st, hd=hd: check(lib.satcv_head_bwd(C.byref(hd), st)))
-                gact[node.inputs[0].id] = dx
+                gact[node.inputs[0].id] = (dx, 0, c)
             elif op == 'cba':
                 tin, tout = node.inputs[0], node.outputs[0]
                 da, dp = gact.get(tout.id), gpool.get(tout.id)
                 if da is None and dp is None:
                     continue
                 lay, r, y, aff, cout = node.layer, cx['r'], cx['y'], cx['aff'], cx['cout']
+                yoff, ldy, aoff = cx['yoff'], cx['ldy'], cx['aoff']
                 hh, ww = r.h, r.w
                 sums = self._z(STAT_ROWS, 2, cout, dtype=torch.float32)
                 dy = self._z(n, hh, ww, cout)
-                red, fin, app = bn_bwd_steps(da.data_ptr() if da is not None else None, cout, dp.data_ptr() if dp is not None else None,
-                                             cout, gpool_f.get(tout.id, 1), y.data_ptr(), cout, aff, 0, sums, 0, cout, cout, hh, ww,
+                da_ptr = da[0].data_ptr() + da[1] * es if da is not None else None
+                red, fin, app = bn_bwd_steps(da_ptr, da[2] if da is not None else 0, dp[0].data_ptr() if dp is not None else None,
+                                             cout, gpool_f.get(tout.id, 1), y.data_ptr() + yoff * es, ldy, aff, aoff, sums, 0, cout, cout, hh, ww,
                                              dy.data_ptr(), cout, rt.gptr(lay.name + '/bias'),
                                              rt.gptr(lay.bn_name + '/gamma'), rt.gptr(lay.bn_name + '/beta'))
                 self.bwd += [red, fin, app]
+                self.dbg['dy:' + lay.name] = dy
+                self.dbg['_ctx:' + lay.name] = dict(da=da, dp=dp, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout)
                 pk = rt.packed[lay.name]
                 self.bwd.append(wgrad_step(r, dy.data_ptr(), cout, lay, pk['cin'], cout, hh, ww, cx['k'], cx['dil']))
                 if tin.node.op != 'input':
                     cinp = r.c
-                    gin = self._z(n, hh, ww, cinp)
+                    prev = gact.get(tin.id)
+                    if prev is not None and (prev[1] != 0 or prev[2] != cinp):
+                        raise NotImplementedError('gradient fan-in into a channel slice')
+                    gin = prev[0] if prev is not None else self._z(n, hh, ww, cinp)
                     self.bwd.append(self._conv_step(x0=dy.data_ptr(), c0=cout, w=pk['dgrad'].data_ptr(), y=gin.data_ptr(), ldy=cinp,
                                                     n=n, h=hh, w_=ww, cout=cinp, cout_pad=rup(cinp, 32), kh=cx['k'], kw=cx['k'],
-                                                    dil=cx['dil'], dtype=dt))
-                    gact[tin.id] = gin
+                                                    dil=cx['dil'], dtype=dt, accumulate=1 if prev is not None else 0))
+                    gact[tin.id] = (gin, 0, cinp)
+                    self.dbg['dx:' + lay.name] = gin
+            elif op == 'concat':
+                g = gact.get(node.outputs[0].id)
+                if g is None:
+                    continue
+                off = 0
+                for t in node.inputs:          # each branch sees its channel slice of the gradient
+                    gact[t.id] = (g[0], g[1] + off, g[2])
+                    off += t.channels
             elif op == 'pool':
                 tin, tout = node.inputs[0], node.outputs[0]
                 if tout.id in gact:
+                    if gact[tout.id][1] != 0:
+                        raise NotImplementedError('pooled gradient in a channel slice')
                     gpool[tin.id] = gact[tout.id]
                     gpool_f[tin.id] = cx['f']
             elif op == 'concat_bn_relu':
@@ -506,14 +553,19 @@ class Plan:
                 du = self._z(n, hh, ww, cb)
                 bn = node.layer.name
                 upl = tb.node.layer
-                ra_, fa_, aa_ = bn_bwd_steps(g.data_ptr(), ctot, None, 0, 1, ra.srcs[0][0].data_ptr(), ca, aff, 0, sums, 0, ctot, ca, hh, ww,
+                if g[2] != ctot:
+                    raise NotImplementedError('decoder concat gradient in a channel slice')
+                gptr_ = g[0].data_ptr() + g[1] * es
+                ra_, fa_, aa_ = bn_bwd_steps(gptr_, ctot, None, 0, 1, ra.srcs[0][0].data_ptr(), ca, aff, 0, sums, 0, ctot, ca, hh, ww,
                                              dskip.data_ptr(), ca, None, rt.gptr(bn + '/gamma'), rt.gptr(bn + '/beta'))
-                rb_, fb_, ab_ = bn_bwd_steps(g.data_ptr() + ca * es, ctot, None, 0, 1, rb.srcs[0][0].data_ptr(), cb, aff, ca, sums, ca, ctot, cb,
+                rb_, fb_, ab_ = bn_bwd_steps(gptr_ + ca * es, ctot, None, 0, 1, rb.srcs[0][0].data_ptr(), cb, aff, ca, sums, ca, ctot, cb,
                                              hh, ww, du.data_ptr(), cb, rt.gptr(upl.name + '/bias') if tb.node.op == 'convT' else None,
                                              rt.gptr(bn + '/gamma') + 4 * ca, rt.gptr(bn + '/beta') + 4 * ca)
                 self.bwd += [ra_, rb_, fa_, fb_, aa_, ab_]
                 # the skip is the activated output of an encoder conv_batch_act block
-                gact[ta.id] = dskip
+                gact[ta.id] = (dskip, 0, ca)
+                self.dbg['dskip:' + bn] = dskip
+                self.dbg['du:' + bn] = du
                 graw[tb.id] = du
             elif op == 'convT':
                 tin, tout = node.inputs[0], node.outputs[0]
@@ -527,7 +579,8 @@ class Plan:
                 gin = self._z(n, r.h, r.w, cinp)
                 self.bwd.append(self._conv_step(x0=du.data_ptr(), c0=cout, w=pk['dgrad'].data_ptr(), y=gin.data_ptr(), ldy=cinp, n=n, h=r.h,
                                                 w_=r.w, cout=cinp, cout_pad=rup(cinp, 32), kh=1, kw=1, dil=1, mode_in=1, f=f, dtype=dt))
-                gact[tin.id] = gin
+                gact[tin.id] = (gin, 0, cinp)
+                self.dbg['dx:' + lay.name] = gin
         if ws_need:
             ws = self._z(max(ws_need // 4, 1), dtype=torch.float32)
             for d in wdescs:

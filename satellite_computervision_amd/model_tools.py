@@ -266,6 +266,31 @@ def decoder_block(input_tensor, concat_tensor, num_filters, up_size=(2, 2), drop
     return decoder
 
 
+
+class DilatedSpatialPyramidPooling:
+    """ASPP layer (utils/model_tools.py:533-574): cba3_1x1(concat[cba_1x1(x), cba3x3_d3(x), cba3x3_d6(x), cba3x3_d12(x)]).
+    The image-pooling branch is commented out in the reference (:568-570) and cba2 is constructed but unused.
+    The four branch convolutions write straight into channel slices of one tensor (no concatenate pass)."""
+
+    def __init__(self, num_filters, name='ASPP', **kwargs):
+        self.name = name
+        self.cba = conv_batch_act(num_filters, kernel_size=(1, 1), dilation_rate=1)
+        self.cba2 = conv_batch_act(num_filters, kernel_size=(1, 1), dilation_rate=1)
+        self.cba3 = conv_batch_act(num_filters, kernel_size=(1, 1), dilation_rate=1)
+        self.cba3_3 = conv_batch_act(num_filters, kernel_size=(3, 3), dilation_rate=3)
+        self.cba3_6 = conv_batch_act(num_filters, kernel_size=(3, 3), dilation_rate=6)
+        self.cba3_12 = conv_batch_act(num_filters, kernel_size=(3, 3), dilation_rate=12)
+
+    def __call__(self, input):
+        outs = [self.cba(input), self.cba3_3(input), self.cba3_6(input), self.cba3_12(input)]
+        _unique('concatenate')
+        node = E.Node('concat', outs)
+        x = node.out(sum(t.channels for t in outs), input.down)
+        return self.cba3(x)
+
+    call = __call__
+
+
 # ------------------------------------------------------------------ model construction
 def build_unet_layers(input_tensor, filters=[32, 64, 128, 256, 512], factors=[2, 2, 2, 2, 2], dropout=None, double_conv=False):
     """Create U-Net layers (utils/model_tools.py:321-379)."""
@@ -329,8 +354,9 @@ def get_unet_model(nclasses, nchannels, filters=[32, 64, 128, 256, 512], factors
 
 # ---------------------------------------------------------------------------- losses
 class LossSpec:
-    def __init__(self, kind, weights):
-        self.kind, self.weights = kind, np.asarray(weights, np.float32).reshape(-1)
+    def __init__(self, kind, weights=None, eps=1e-6):
+        self.kind, self.eps = kind, float(eps)
+        self.weights = None if weights is None else np.asarray(weights, np.float32).reshape(-1)
 
 
 class _LossArg:
@@ -340,12 +366,12 @@ class _LossArg:
         self.what = what
 
 
-def _eager_loss(kind, y_true, y_pred, weights, activation='softmax'):
+def _eager_loss(kind, y_true, y_pred, weights, activation='softmax', eps=1e-6):
     dev = torch.device('cuda')
     p = torch.as_tensor(np.asarray(y_pred, np.float32)).to(dev).contiguous()
     t = torch.as_tensor(np.asarray(y_true, np.float32)).to(dev).contiguous()
-    w = torch.as_tensor(np.asarray(weights, np.float32).reshape(-1)).to(dev)
-    loss, _ = ops.loss_fwd_bwd(kind, p, t, w, activation)
+    w = None if weights is None else torch.as_tensor(np.asarray(weights, np.float32).reshape(-1)).to(dev)
+    loss, _ = ops.loss_fwd_bwd(kind, p, t, w, activation, eps=eps)
     return float(loss.item())
 
 
@@ -366,15 +392,26 @@ def weighted_bce(y_true, y_pred, pos_weight, logits=False):
 
 
 def gen_dice(y_true, y_pred, eps=1e-6, global_weights=None):
-    raise NotImplementedError('gen_dice (utils/model_tools.py:42-94) is not built yet')
+    """utils/model_tools.py:42-94: generalised Dice over (b, h*w, classes), mean over the batch.
+    With global_weights=None the per-image class weights are 1/count^2 (eps where a class is absent) --
+    the documented intent; the reference's own reduction axis (:80) does not broadcast."""
+    if isinstance(y_pred, _LossArg):
+        return LossSpec('gen_dice', global_weights if global_weights else None, eps)
+    return _eager_loss('gen_dice', y_true, y_pred, global_weights if global_weights else None, eps=eps)
 
 
 def iou_loss(true, pred):
-    raise NotImplementedError('iou_loss (utils/model_tools.py:131-140) is not built yet')
+    """utils/model_tools.py:131-140: 1 - sum(t*p) / sum(t + (1-t)*p) over the whole batch."""
+    if isinstance(pred, _LossArg):
+        return LossSpec('iou_loss')
+    return _eager_loss('iou_loss', true, pred, None)
 
 
 def mse_4d(y_true, y_pred, eps=1e-6):
-    raise NotImplementedError('mse_4d (utils/model_tools.py:142-166) is not built yet')
+    """utils/model_tools.py:142-166: mean squared error over the finite elements."""
+    if isinstance(y_pred, _LossArg):
+        return LossSpec('mse_4d')
+    return _eager_loss('mse_4d', y_true, y_pred, None)
 
 
 # ------------------------------------------------------------- optimizers / metrics
@@ -648,12 +685,20 @@ class Model:
     def _loss_launch(self, plan, st, grad_scale=1.0):
         rt = self.runtime
         h = plan.head
-        if getattr(self, '_loss_w', None) is None or self._loss_w_spec is not self._loss:
-            self._loss_w = torch.as_tensor(self._loss.weights).to(rt.dev)
+        if getattr(self, '_loss_w_spec', None) is not self._loss:
+            self._loss_w = None if self._loss.weights is None else torch.as_tensor(self._loss.weights).to(rt.dev)
             self._loss_w_spec = self._loss
         kind = ops.LOSS_KINDS[self._loss.kind]
-        if kind == 0 and self._loss_w.numel() != h['ncls']:
-            raise ValueError('weighted_categorical_crossentropy needs one weight per class')
+        if kind in (0, 2) and self._loss_w is not None and self._loss_w.numel() != h['ncls']:
+            raise ValueError(f'{self._loss.kind} needs one weight per class')
+        if kind >= 2:
+            if not hasattr(plan, 'loss_ws'):
+                plan.loss_ws = torch.zeros(plan.n * 3 * h['ncls'], dtype=torch.float32, device=rt.dev)
+            check(lib.satcv_loss_global_fwd_bwd(kind, h['probs'].data_ptr(), plan.y_true.data_ptr(),
+                                                self._loss_w.data_ptr() if self._loss_w is not None else None, h['ncls'], h['act'], plan.n,
+                                                h['r'].h * h['r'].w, self._loss.eps, grad_scale, plan.loss_ws.data_ptr(),
+                                                plan.loss_buf.data_ptr(), plan.dlogits.data_ptr(), st))
+            return
         check(lib.satcv_loss_fwd_bwd(kind, h['probs'].data_ptr(), plan.y_true.data_ptr(), self._loss_w.data_ptr(), h['ncls'], h['act'],
                                      plan.n * h['r'].h * h['r'].w, grad_scale, plan.loss_buf.data_ptr(), plan.dlogits.data_ptr(), st))
 

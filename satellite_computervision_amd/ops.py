@@ -80,7 +80,7 @@ def pack_weights(kernel_f32, cin_pad, dtype, transposed=False, want_dgrad=True, 
 # --------------------------------------------------------------------------- conv
 def make_conv_desc(*, x0, c0, w, y, ldy, n, h, w_, cout, cout_pad, dtype, x1=None, c1=0, in_scale=None, in_shift=None,
                    in_relu=0, bias=None, stats=None, stats_ld=0, kh=3, kw=3, dil=1, mode_in=0, mode_out=0, f=1,
-                   cstat=None, out_relu=0):
+                   cstat=None, out_relu=0, accumulate=0):
     d = ConvDesc()
     d.x0, d.x1, d.c0, d.c1 = x0, x1, c0, c1
     d.in_scale, d.in_shift, d.in_relu = in_scale, in_shift, int(in_relu)
@@ -91,7 +91,7 @@ def make_conv_desc(*, x0, c0, w, y, ldy, n, h, w_, cout, cout_pad, dtype, x1=Non
     d.kh, d.kw, d.dil = kh, kw, dil
     d.mode_in, d.mode_out, d.f = mode_in, mode_out, f
     d.cstat = cstat if cstat is not None else cout
-    d.out_relu, d.dtype = int(out_relu), dtype
+    d.out_relu, d.dtype, d.accumulate = int(out_relu), dtype, int(accumulate)
     return d
 
 
@@ -129,13 +129,13 @@ def conv2d_transpose(x, w_packed, cout, f, *, bias=None, in_scale=None, in_shift
     return y
 
 
-def conv2d_dgrad(dy, w_dgrad, cin, *, kh=3, kw=3, dil=1, out=None):
+def conv2d_dgrad(dy, w_dgrad, cin, *, kh=3, kw=3, dil=1, out=None, accumulate=False):
     """Data gradient of Conv2D: 'same' correlation of dy with the flipped, in/out-swapped kernel."""
     n, h, w_, cy = dy.shape
     dtype = DTYPE_CODE[dy.dtype]
     dx = out if out is not None else torch.empty(n, h, w_, rup(cin, 16), dtype=dy.dtype, device=dy.device)
     d = make_conv_desc(x0=_p(dy), c0=cy, w=_p(w_dgrad), y=_p(dx), ldy=dx.shape[-1], n=n, h=h, w_=w_, cout=cin,
-                       cout_pad=rup(cin, 32), dtype=dtype, kh=kh, kw=kw, dil=dil)
+                       cout_pad=rup(cin, 32), dtype=dtype, kh=kh, kw=kw, dil=dil, accumulate=accumulate)
     check(lib.satcv_conv2d_igemm(C.byref(d), stream_ptr()))
     return dx
 
@@ -292,15 +292,22 @@ def head_bwd(x, w, dlogits, in_scale=None, in_shift=None):
     return dx, dw, db
 
 
-LOSS_KINDS = {'weighted_categorical_crossentropy': 0, 'weighted_bce': 1}
+LOSS_KINDS = {'weighted_categorical_crossentropy': 0, 'weighted_bce': 1, 'gen_dice': 2, 'iou_loss': 3, 'mse_4d': 4}
 
 
-def loss_fwd_bwd(kind, probs, y_true, weights, activation='softmax', grad_scale=1.0):
+def loss_fwd_bwd(kind, probs, y_true, weights, activation='softmax', grad_scale=1.0, eps=1e-6):
     """Returns (loss scalar tensor, dL/dlogits)."""
     ncls = probs.shape[-1]
     npix = probs.numel() // ncls
     loss = torch.zeros(1, dtype=torch.float32, device=probs.device)
     dlogits = torch.empty_like(probs)
+    if LOSS_KINDS[kind] >= 2:
+        nimg = probs.shape[0]
+        ws = torch.empty(nimg * 3 * ncls, dtype=torch.float32, device=probs.device)
+        check(lib.satcv_loss_global_fwd_bwd(LOSS_KINDS[kind], ptr(probs), ptr(y_true.contiguous()), ptr(weights), ncls,
+                                            0 if activation == 'softmax' else 1, nimg, npix // nimg, eps, grad_scale, ptr(ws), ptr(loss),
+                                            ptr(dlogits), stream_ptr()))
+        return loss, dlogits
     check(lib.satcv_loss_fwd_bwd(LOSS_KINDS[kind], ptr(probs), ptr(y_true.contiguous()), ptr(weights), ncls,
                                  0 if activation == 'softmax' else 1, npix, grad_scale, ptr(loss), ptr(dlogits), stream_ptr()))
     return loss, dlogits

@@ -139,6 +139,9 @@ BWD_CASES = [
     (3, 8, 8, 64, 128),      # (1,4), TW=8 multi-image
     (1, 20, 24, 32, 32),     # ragged
     (1, 64, 64, 32, 32),     # many pixel tiles -> split-K
+    (2, 32, 32, 64, 64),     # (2,2) at TW=32
+    (2, 24, 24, 64, 64),     # ragged rows, TW=8
+    (2, 48, 48, 32, 32),     # 3 column tiles of 16
 ]
 
 
@@ -180,7 +183,8 @@ def test_wgrad_padded_input_and_affine(ops, td):
 
 # ------------------------------------------------------------------ transposed conv
 @pytest.mark.parametrize('td', DT)
-@pytest.mark.parametrize('case', [(2, 8, 8, 64, 32, 2), (1, 16, 16, 128, 64, 2), (2, 4, 4, 256, 128, 2), (1, 6, 6, 32, 32, 3)])
+@pytest.mark.parametrize('case', [(2, 8, 8, 64, 32, 2), (1, 16, 16, 128, 64, 2), (2, 4, 4, 256, 128, 2), (1, 6, 6, 32, 32, 3),
+                                  (2, 32, 32, 64, 32, 2), (2, 24, 24, 64, 32, 2), (1, 64, 64, 64, 32, 2), (2, 32, 32, 128, 64, 2)])
 def test_conv2d_transpose(ops, td, case):
     n, h, w, cin, cout, f = case
     rng = np.random.default_rng(hash(case) % 2**31)
@@ -324,3 +328,58 @@ def test_adam_keras_formulation(ops):
         pr = pr - alpha * mr / (np.sqrt(vr) + 1e-7)
     np.testing.assert_allclose(back(pd), pr, rtol=1e-5, atol=1e-6)
     assert state[1].item() == 3.0
+
+
+@pytest.mark.parametrize('ncls', [2, 4])
+def test_ratio_losses_dice_iou_mse(ops, ncls):
+    """gen_dice (global and per-image weights), iou_loss, mse_4d: loss and dL/dlogits vs the oracle."""
+    rng = np.random.default_rng(51 + ncls)
+    n, h, w = 3, 12, 10
+    logits = rng.standard_normal((n, h, w, ncls))
+    p = K.softmax(logits).astype(np.float32).astype(np.float64)
+    lab = rng.integers(0, ncls, (n, h, w)); lab[1][lab[1] == ncls - 1] = 0      # a class absent from one image
+    t = np.eye(ncls)[lab]
+    pd, td = f32dev(p), f32dev(t)
+    for gw in ([0.3, 0.5] + [0.1] * (ncls - 2), None):
+        l_ref, g_ref = OL.gen_dice(t, p, global_weights=gw)
+        loss, dl = ops.loss_fwd_bwd('gen_dice', pd, td, f32dev(np.array(gw)) if gw else None)
+        np.testing.assert_allclose(loss.item(), l_ref, rtol=2e-4)
+        ref = K.softmax_bwd(p, g_ref)
+        np.testing.assert_allclose(back(dl), ref, rtol=5e-3, atol=1e-6 * np.abs(ref).max())
+    l_ref, g_ref = OL.iou_loss(t, p)
+    loss, dl = ops.loss_fwd_bwd('iou_loss', pd, td, None)
+    np.testing.assert_allclose(loss.item(), l_ref, rtol=2e-4)
+    ref = K.softmax_bwd(p, g_ref)
+    np.testing.assert_allclose(back(dl), ref, rtol=5e-3, atol=1e-6 * np.abs(ref).max())
+    tn = rng.random((n, h, w, ncls)); tn[0, 0, 0, 0] = np.nan
+    l_ref, g_ref = OL.mse_4d(tn, p)
+    loss, dl = ops.loss_fwd_bwd('mse_4d', pd, f32dev(tn), None)
+    np.testing.assert_allclose(loss.item(), l_ref, rtol=2e-4)
+    ref = K.softmax_bwd(p, g_ref)
+    np.testing.assert_allclose(back(dl), ref, rtol=5e-3, atol=1e-6 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('td', DT)
+@pytest.mark.parametrize('case', [(2, 24, 24, 32, 64, 3, 3), (2, 24, 24, 32, 64, 3, 6), (2, 24, 24, 32, 64, 3, 12), (2, 24, 24, 256, 64, 1, 1),
+                                  (1, 32, 32, 128, 256, 3, 12), (2, 24, 24, 32, 64, 1, 1)])
+def test_aspp_shapes_backward_and_accumulate(ops, td, case):
+    """the ASPP convolutions (1x1 and 3x3 with rates 3/6/12) on a non-power-of-two map: dgrad, wgrad (incl. the
+    per-tap fallback for halo tiles that exceed the LDS) and the accumulate-into-output form of dgrad."""
+    n, h, w, cin, cout, k, dil = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (k, k, cin, cout), td, 0.2)
+    dy = rnd(rng, (n, h, w, cout), td)
+    y_ref = K.conv2d_same(x, kern, None, dil)
+    dx_ref, dk_ref, _ = K.conv2d_same_bwd(x, kern, dy, dil)
+    wf, wd = ops.pack_weights(f32dev(kern), cin, ops.DTYPE_CODE[td])
+    y = ops.conv2d(to_dev(x, td), wf, cout, kh=k, kw=k, dil=dil)
+    close(back(y, cout), y_ref, td, f'fwd {case}')
+    dx = ops.conv2d_dgrad(to_dev(dy, td), wd, cin, kh=k, kw=k, dil=dil)
+    close(back(dx, cin), dx_ref, td, f'dgrad {case}')
+    base = rnd(rng, (n, h, w, cin), td)
+    acc = to_dev(base, td)
+    ops.conv2d_dgrad(to_dev(dy, td), wd, cin, kh=k, kw=k, dil=dil, out=acc, accumulate=True)
+    close(back(acc, cin), dx_ref + base, td, f'dgrad accumulate {case}', k=2.0)
+    dk = ops.conv2d_wgrad(to_dev(x, td), to_dev(dy, td), cin, cout, kh=k, kw=k, dil=dil)
+    close(back(dk), dk_ref, td, f'wgrad {case}', k=(5.0 if td == torch.float32 else 0.5))

@@ -11,8 +11,9 @@ for dtype in ('float32', 'bfloat16'):
     o, m, names = build_pair(mt, dtype, 2, 4, filters, factors)
     rng = np.random.default_rng(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    x = rng.random((n, 32, 32, 4)).astype(np.float32)
-    lab = (rng.random((n, 32, 32)) < 0.3).astype(np.int64)
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    x = rng.random((n, S, S, 4)).astype(np.float32)
+    lab = (rng.random((n, S, S)) < 0.3).astype(np.int64)
     t = np.eye(2)[lab].astype(np.float32)
     m.compile(optimizer=mt.Adam(9e-4), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 20.0]))
     pr, _ = o.forward(x, training=True)
