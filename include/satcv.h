@@ -155,6 +155,18 @@ int satcv_bn_bwd_finalize(float* sums, int32_t sums_ld, int32_t c, float count, 
                           float* dbeta, float* coef, void* stream);
 int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream);
 
+/* ---------------------------------------------------------------- dropout
+ * layers.SpatialDropout2D / layers.Dropout (utils/model_tools.py:311, 351, 363, 402), training only.
+ * satcv_dropout_mask: counter-based Bernoulli mask, values 0 or 1/(1-rate).
+ * satcv_dropout_apply: out = act(x) * mask with act(x) = relu?(scale*x+shift) if scale else x;
+ *   mask_mode 0: mask is (n, ldm) [whole feature maps dropped], 1: mask is (n*hw, ldm) [per element];
+ *   ldm >= c lets a channel slice of a wider mask be applied.  With scale == NULL this is also the
+ *   backward (g * mask). */
+int satcv_dropout_mask(uint64_t seed, uint64_t offset, float rate, int64_t count, float* mask, void* stream);
+int satcv_dropout_apply(const void* x, int32_t ldx, const float* scale, const float* shift, int32_t relu,
+                        const float* mask, int32_t ldm, int32_t mask_mode, void* out, int32_t ldo, int32_t n,
+                        int32_t hw, int32_t c, int32_t dtype, void* stream);
+
 /* ------------------------------------------------------------------- head
  * Conv2D(ncls,(1,1),activation) + argmax/threshold (utils/model_tools.py:405-406, :660-661).
  * activation 0: softmax, classes = argmax (ties -> lowest index);

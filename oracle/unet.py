@@ -129,10 +129,17 @@ class UNetOracle:
         return dx
 
     # ----------------------------------------------------------------- forward
-    def forward(self, x, training=False):
-        """x (N,H,W,C).  Returns (probs, classes) -- get_unet_model outputs (:407)."""
+    def forward(self, x, training=False, masks=None):
+        """x (N,H,W,C).  Returns (probs, classes) -- get_unet_model outputs (:407).
+
+        masks (training only): dropout masks with values 0 or 1/(1-rate), keyed by position --
+        'pool0' SpatialDropout2D after the level-0 pool (:350-351), 'center' Dropout (:362-363),
+        'dec0' SpatialDropout2D inside the last decoder block (:310-311, :375), 'final'
+        SpatialDropout2D in front of the head (:401-402)."""
         x = np.asarray(x, self.dtype)
         p, c = self.params, {}
+        masks = masks or {}
+        c['masks'] = masks
         L = len(self.filters)
         h = x
         for i in range(L):
@@ -141,15 +148,23 @@ class UNetOracle:
             a = self._cba_fwd(f'enc{i}.conv', f'enc{i}.bn', h, training, c, updates=2)
             c[f'enc{i}'] = a
             h = K.maxpool(a, self.factors[i])
+            if i == 0 and 'pool0' in masks:
+                h = h * masks['pool0']
         h = self._cba_fwd('center.conv', 'center.bn', h, training, c, updates=2)
+        if 'center' in masks:
+            h = h * masks['center']
         for j in range(L - 1, -1, -1):
             up = K.conv2d_transpose_ks(h, p[f'dec{j}.up.kernel'], p[f'dec{j}.up.bias'])
             cat = np.concatenate([c[f'enc{j}'], up], axis=-1)        # skip first (:307)
             z, st = self._bn_fwd(f'dec{j}.bn0', cat, training, 1)
             a0 = K.relu(z)
             c[f'dec{j}.up'] = (h, cat, st, a0)
+            if j == 0 and 'dec0' in masks:
+                a0 = a0 * masks['dec0']
             a1 = self._cba_fwd(f'dec{j}.conv1', f'dec{j}.bn1', a0, training, c)
             h = self._cba_fwd(f'dec{j}.conv2', f'dec{j}.bn2', a1, training, c)
+        if 'final' in masks:
+            h = h * masks['final']
         logits = K.conv2d_same(h, p['probs.kernel'], p['probs.bias'])
         probs = K.softmax(logits)
         c['head'] = (h, probs)
@@ -165,10 +180,15 @@ class UNetOracle:
         h, probs = c['head']
         dlogits = K.softmax_bwd(probs, np.asarray(dprobs, self.dtype))
         dh, g['probs.kernel'], g['probs.bias'] = K.conv2d_same_bwd(h, p['probs.kernel'], dlogits)
+        masks = c.get('masks', {})
+        if 'final' in masks:
+            dh = dh * masks['final']
         dskip = {}
         for j in range(L):
             da1 = self._cba_bwd(f'dec{j}.conv2', f'dec{j}.bn2', dh, c, g)
             da0 = self._cba_bwd(f'dec{j}.conv1', f'dec{j}.bn1', da1, c, g)
+            if j == 0 and 'dec0' in masks:
+                da0 = da0 * masks['dec0']
             hin, cat, (mean, var), a0 = c[f'dec{j}.up']
             dz = K.relu_bwd(a0, da0)
             dcat, g[f'dec{j}.bn0.gamma'], g[f'dec{j}.bn0.beta'] = K.batchnorm_train_bwd(
@@ -179,9 +199,13 @@ class UNetOracle:
             dh, g[f'dec{j}.up.kernel'], g[f'dec{j}.up.bias'] = K.conv2d_transpose_ks_bwd(
                 hin, p[f'dec{j}.up.kernel'], dcat[..., f:])
             self.dbg[f'dx:dec{j}.up'] = dh
+        if 'center' in masks:
+            dh = dh * masks['center']
         dh = self._cba_bwd('center.conv', 'center.bn', dh, c, g)
         for i in range(L - 1, -1, -1):
             a = c[f'enc{i}']
+            if i == 0 and 'pool0' in masks:
+                dh = dh * masks['pool0']
             da = K.maxpool_bwd(a, self.factors[i], dh) + dskip[i]
             dh = self._cba_bwd(f'enc{i}.conv', f'enc{i}.bn', da, c, g)
         g['input'] = dh

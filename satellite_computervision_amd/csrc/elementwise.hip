@@ -693,6 +693,59 @@ extern "C" int satcv_head_bwd(const satcv_head_desc* d, void* stream) {
   return SATCV_OK;
 }
 
+// ----------------------------------------------------------------------- dropout
+// layers.SpatialDropout2D / layers.Dropout (utils/model_tools.py:311, 351, 363, 402), training only.
+// mask values are 0 or 1/(1-rate); mode 0: one value per (image, channel) [SpatialDropout2D], mode 1: per element.
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (idx + 1);          // splitmix64 finaliser (counter based)
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__global__ void dropout_mask_kernel(unsigned long long seed, unsigned long long offset, float rate, long long count, float* mask) {
+  const float keep = 1.f / (1.f - rate);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
+    mask[i] = hash_uniform(seed, offset + (unsigned long long)i) >= rate ? keep : 0.f;
+}
+extern "C" int satcv_dropout_mask(uint64_t seed, uint64_t offset, float rate, int64_t count, float* mask, void* stream) {
+  SATCV_CHECK(mask && count > 0 && rate >= 0.f && rate < 1.f, "dropout_mask: bad args");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid(count)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (unsigned long long)seed,
+                     (unsigned long long)offset, rate, (long long)count, mask);
+  LAUNCH_OK("dropout_mask");
+  return SATCV_OK;
+}
+// out = act(x) * mask, act(x) = relu?(scale*x+shift) when scale != NULL else x.  Also the backward (g*mask) with scale == NULL.
+template <typename T>
+__global__ void dropout_apply_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                     const float* __restrict__ mask, int ldm, int mode, T* __restrict__ out, int ldo, long long npix, int hw, int c) {
+  const int G = c / 8;
+  const long long total = npix * G;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+    const long long p = it / G; const int g = (int)(it % G);
+    float v[8];
+    load8<T>(x + p * ldx + g * 8, v);
+    const float* m = mode == 0 ? mask + (p / hw) * ldm + g * 8 : mask + p * ldm + g * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = v[e];
+      if (scale) { a = a * scale[g * 8 + e] + shift[g * 8 + e]; if (relu) a = fmaxf(a, 0.f); }
+      v[e] = a * m[e];
+    }
+    store8<T>(out + p * ldo + g * 8, v);
+  }
+}
+extern "C" int satcv_dropout_apply(const void* x, int32_t ldx, const float* scale, const float* shift, int32_t relu, const float* mask,
+                                   int32_t ldm, int32_t mask_mode, void* out, int32_t ldo, int32_t n, int32_t hw, int32_t c, int32_t dtype,
+                                   void* stream) {
+  SATCV_CHECK(x && mask && out && n > 0 && hw > 0 && c > 0 && c % 8 == 0 && ldm >= c && (mask_mode == 0 || mask_mode == 1), "dropout_apply: bad args");
+  const long long npix = (long long)n * hw;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(dropout_apply_kernel<T>, dim3(ew_grid(npix * (c / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)x, ldx,
+                                       scale, shift, relu, mask, ldm, mask_mode, (T*)out, ldo, npix, hw, c));
+  LAUNCH_OK("dropout_apply");
+  return SATCV_OK;
+}
+
 // ------------------------------------------------------------------------- losses
 __global__ void loss_kernel(int kind, const float* __restrict__ probs, const float* __restrict__ yt, const float* __restrict__ wts,
                             int nc, int activation, long long npix, float grad_scale, float* loss_out, float* dlogits) {

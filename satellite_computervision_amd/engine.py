@@ -130,6 +130,7 @@ class Runtime:
         self.adam_m = self.adam_v = None
         self.adam_state = torch.tensor([1e-3, 0.0, 1.0, 0.0], dtype=torch.float32, device=self.dev)
         self.lr_mul = None
+        self.dropout_seed = 0x5A7C0FFEE
         host = np.zeros(self.pflat.numel(), np.float32)
         hs = np.zeros(self.sflat.numel(), np.float32)
         for p in model.param_specs:
@@ -210,6 +211,8 @@ class Plan:
         self.rt, self.n, self.h, self.w, self.training = rt, n, h, w, training
         self.fwd, self.bwd = [], []
         self.keep = []                        # ctypes descriptors / tensors kept alive
+        self.dropouts = []                    # dropout masks (regenerated every training step)
+        self.step_count = 0
         self.outputs = {}
         self._build()
 
@@ -400,9 +403,38 @@ class Plan:
                 vals[tout.id] = TRef([ra.srcs[0], rb.srcs[0]], n, ra.h, ra.w, affine=aff, relu=True)
                 ctx[id(node)] = dict(ra=ra, rb=rb, aff=aff, ca=ca, cb=cb)
             elif op == 'dropout':
-                if training:
-                    raise NotImplementedError('dropout is not implemented in the training path yet')
-                vals[node.outputs[0].id] = vals[node.inputs[0].id]
+                tin, tout = node.inputs[0], node.outputs[0]
+                r = vals[tin.id]
+                if not training:                     # identity at inference (Keras semantics)
+                    vals[tout.id] = r
+                    if tin.id in acts:
+                        acts[tout.id] = acts[tin.id]
+                    continue
+                ctot = r.c
+                spatial = node.attrs['spatial']
+                hw = r.h * r.w
+                mask = self._z(*((n, ctot) if spatial else (n * hw, ctot)), dtype=torch.float32)
+                out = self._z(n, r.h, r.w, ctot)
+                rate = float(node.attrs['rate'])
+                slot = len(self.dropouts)
+                self.dropouts.append(dict(mask=mask, node=node))
+                cnt = mask.numel()
+
+                def gen(st, mask=mask, rate=rate, cnt=cnt, slot=slot):
+                    # a fresh mask every step: counter = (step, dropout slot)
+                    check(lib.satcv_dropout_mask(self.rt.dropout_seed, (self.step_count << 8) + slot, rate, cnt, mask.data_ptr(), st))
+                self.fwd.append(gen)
+                off = 0
+                mode = 0 if spatial else 1
+                for (src, cs) in r.srcs:             # dual-source (concat) inputs: one launch per source / channel slice
+                    a = r.affine
+                    self.fwd.append(lambda st, src=src, cs=cs, off=off, a=a, rl=1 if r.relu else 0, mask=mask, ctot=ctot, mode=mode, out=out,
+                                    hw=hw: check(lib.satcv_dropout_apply(
+                        src.data_ptr(), cs, _fp(a['scale'], off) if a else None, _fp(a['shift'], off) if a else None, rl,
+                        _fp(mask, off), ctot, mode, out.data_ptr() + off * es, ctot, n, hw, cs, dt, st)))
+                    off += cs
+                vals[tout.id] = TRef([(out, ctot)], n, r.h, r.w)
+                ctx[id(node)] = dict(mask=mask, spatial=spatial, ctot=ctot, hw=hw, r=r)
             elif op == 'head':
                 tin, tout = node.inputs[0], node.outputs[0]
                 r = vals[tin.id]
@@ -524,6 +556,18 @@ class Plan:
                                                     dil=cx['dil'], dtype=dt, accumulate=1 if prev is not None else 0))
                     gact[tin.id] = (gin, 0, cinp)
                     self.dbg['dx:' + lay.name] = gin
+            elif op == 'dropout':
+                tin, tout = node.inputs[0], node.outputs[0]
+                g = gact.get(tout.id)
+                if g is None or cx is None:
+                    continue
+                if g[1] != 0 or g[2] != cx['ctot']:
+                    raise NotImplementedError('dropout gradient in a channel slice')
+                gt, mask, ctot, hw = g[0], cx['mask'], cx['ctot'], cx['hw']
+                mode = 0 if cx['spatial'] else 1
+                self.bwd.append(lambda st, gt=gt, mask=mask, ctot=ctot, hw=hw, mode=mode: check(lib.satcv_dropout_apply(
+                    gt.data_ptr(), ctot, None, None, 0, _fp(mask), ctot, mode, gt.data_ptr(), ctot, n, hw, ctot, dt, st)))
+                gact[tin.id] = (gt, 0, ctot)
             elif op == 'concat':
                 g = gact.get(node.outputs[0].id)
                 if g is None:

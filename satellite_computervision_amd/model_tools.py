@@ -726,6 +726,7 @@ class Model:
         st = ops.stream_ptr()
         rt.gflat.zero_()
         plan.loss_buf.zero_()
+        plan.step_count += 1                     # fresh dropout masks every step
         plan.run_forward(st)
         self._loss_launch(plan, st)
         plan.run_backward(st)

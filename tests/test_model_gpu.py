@@ -328,3 +328,74 @@ def test_aspp_block_forward_backward(mt, dtype):
         if (f32 and (l2 > 2e-2 or cos < 0.9999)) or (not f32 and cos < 0.9):
             bad.append(f'{rname}: relL2 {l2:.2e} median {med:.2e} relmax {err:.2e} cos {cos:.5f}')
     assert not bad, '\n'.join(bad)
+
+
+def test_dropout_training_matches_oracle_given_masks(mt):
+    """get_unet_model(dropout=r): SpatialDropout2D after pool0, Dropout after the centre, SpatialDropout2D inside dec0 and in
+    front of the head (utils/model_tools.py:350-351, 362-363, 375, 401-402).  The device masks are read back and handed to
+    the oracle: loss and gradients must then agree; at inference dropout is the identity."""
+    filters, factors = [32, 64], [2, 2]
+    o, _, _ = build_pair(mt, 'float32', 2, 4, filters, factors, seed=21)
+    mt.reset_uids()
+    m = mt.get_unet_model(2, 4, filters, factors, dropout=0.25)
+    m.compute_dtype = 'float32'
+    mt.reset_uids()
+    names = mt.structural_names(mt.get_unet_model(2, 4, filters, factors))        # same layer names (dropout has no weights)
+    m.set_weights_dict({names[k]: v for k, v in o.params.items()})
+    rng = np.random.default_rng(5)
+    x = rng.random((4, 32, 32, 4)).astype(np.float32)
+    t = np.eye(2, dtype=np.float32)[(rng.random((4, 32, 32)) < 0.4).astype(np.int64)]
+    p_ref, _ = o.forward(x, training=False)
+    np.testing.assert_allclose(m.predict(x)[0], p_ref, atol=3e-5)                 # identity at inference
+    m.compile(optimizer=mt.Adam(1e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 2.0]))
+    loss = m.train_on_batch(x, t)
+    plan = m.runtime.plan(4, 32, 32, True)
+    assert len(plan.dropouts) == 4
+    dm = [d['mask'].cpu().numpy().astype(np.float64) for d in plan.dropouts]
+    keep = 1.0 / 0.75
+    for mk in dm:
+        assert set(np.unique(mk.round(6))) <= {0.0, round(keep, 6)}
+    assert 0.6 < (dm[1] > 0).mean() < 0.9                                        # element-wise mask: keep rate ~0.75
+    masks = {'pool0': dm[0].reshape(4, 1, 1, -1), 'center': dm[1].reshape(4, 8, 8, -1), 'dec0': dm[2].reshape(4, 1, 1, -1),
+             'final': dm[3].reshape(4, 1, 1, -1)}
+    pr, _ = o.forward(x, training=True, masks=masks)
+    loss_ref, dprobs, _ = OL.weighted_categorical_crossentropy(t.astype(np.float64), pr, [1.0, 2.0])
+    g_ref = o.backward(dprobs)
+    np.testing.assert_allclose(loss, loss_ref, rtol=3e-5)
+    rt = m.runtime
+    for k in ('probs.kernel', 'dec0.conv1.kernel', 'dec0.bn0.gamma', 'dec1.up.kernel', 'center.conv.kernel', 'enc1.conv.kernel', 'enc0.conv.kernel',
+              'enc0.bn.beta'):
+        g = rt.get_grad(names[k]).cpu().numpy().astype(np.float64)
+        l2 = np.linalg.norm(g - g_ref[k]) / np.linalg.norm(g_ref[k])
+        assert l2 < 1e-2, f'{k}: relL2 {l2:.3e}'
+    # a second step draws different masks
+    m.train_on_batch(x, t)
+    assert not np.array_equal(plan.dropouts[0]['mask'].cpu().numpy(), dm[0]) or not np.array_equal(plan.dropouts[1]['mask'].cpu().numpy(), dm[1])
+
+
+def test_config4_13_band_tiles_and_config5_1024_scene(mt):
+    """BASELINE configs 4 and 5 as parity cases: 13-band Sentinel-2 tiles (stored padded to 16 channels), and a
+    1024x1024 scene both one-shot (fully convolutional) and through the 384^2-chip sliding window of
+    utils/prediction_tools.py:87-156 (9 chips, centre 256^2 kept, border never predicted)."""
+    from satellite_computervision_amd import prediction_tools as pt
+    filters, factors = [32, 64], [2, 2]
+    o, m, _ = build_pair(mt, 'float32', 2, 13, filters, factors, seed=31)
+    rng = np.random.default_rng(4)
+    x = rng.random((2, 64, 64, 13)).astype(np.float32)
+    p_ref, c_ref = o.forward(x, training=False)
+    probs, classes = m.predict(x)
+    np.testing.assert_allclose(probs, p_ref, atol=3e-5)
+    ok = np.abs(p_ref[..., 0] - p_ref[..., 1]) > 1e-3
+    assert np.array_equal(classes[ok], c_ref[ok])
+
+    o4, m4, _ = build_pair(mt, 'float32', 2, 4, filters, factors, seed=32)
+    scene = rng.random((1024, 1024, 4)).astype(np.float32)
+    one_shot = m4.predict(scene[None])[0][0]                      # (1024,1024,2)
+    ref_one = o4.forward(scene[None], training=False)[0][0]
+    np.testing.assert_allclose(one_shot, ref_one, atol=5e-5)
+    idx = pt.generate_chip_indices(scene, buff=128, kernel=256)
+    assert idx == [(y, x_) for y in (64, 320, 576) for x_ in (64, 320, 576)]      # SURVEY Appendix D
+    got = pt.predict_chips(scene, idx, np.zeros(scene.shape[:2]), m4, kernel=256, buff=128, batch_size=9)
+    ref = OT.predict_chips(scene, idx, np.zeros(scene.shape[:2]), lambda chip: o4.forward(chip, training=False)[0], kernel=256, buff=128)
+    np.testing.assert_allclose(got, ref, atol=5e-5)
+    assert not got[:64].any() and not got[832:].any() and not got[:, :64].any() and not got[:, 832:].any()
