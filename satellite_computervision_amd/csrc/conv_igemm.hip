@@ -292,7 +292,7 @@ static int launch_t(IgemmArgs& a, hipStream_t st) {
 void satcv_prof_begin(int kind, double flops, hipStream_t st);
 void satcv_prof_end(int kind, hipStream_t st);
 
-extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
+static int igemm_fill_args(const satcv_conv_desc* d, IgemmArgs& a) {
   SATCV_CHECK(d && d->x0 && d->w && d->y, "igemm: null pointer");
   SATCV_CHECK(d->c0 > 0 && d->c0 % 16 == 0 && d->c1 % 16 == 0, "igemm: channels must be multiples of 16 (c0=%d c1=%d)", d->c0, d->c1);
   SATCV_CHECK((d->c1 == 0) == (d->x1 == nullptr), "igemm: x1/c1 mismatch");
@@ -302,7 +302,9 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   SATCV_CHECK((!d->mode_in && !d->mode_out) || (d->f >= 2 && d->kh == 1 && d->kw == 1), "igemm: s2d/d2s need 1x1 taps and f>=2");
   SATCV_CHECK(!(d->accumulate && d->stats), "igemm: accumulate with statistics");
   SATCV_CHECK(!(d->mode_in && d->in_scale), "igemm: s2d source cannot carry an input transform");
-  IgemmArgs a;
+  SATCV_CHECK(!d->bnr_sums || (d->bnr_y0 && d->bnr_scale && d->bnr_shift && d->bnr_mean && d->bnr_rstd && !d->mode_out && !d->accumulate &&
+                               d->bnr_c0 > 0 && d->bnr_c0 % 8 == 0 && (d->bnr_y1 || d->bnr_c0 >= d->cout)),
+              "igemm: incomplete bnr_* fusion fields");
   a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_relu = d->in_relu;
   a.w = d->w; a.bias = d->bias; a.y = d->y; a.ldy = d->ldy;
@@ -313,19 +315,40 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   a.kh = d->kh; a.kw = d->kw; a.dil = d->dil;
   a.mode_in = d->mode_in; a.mode_out = d->mode_out; a.f = d->f;
   a.cstat = d->cstat; a.out_relu = d->out_relu; a.accumulate = d->accumulate;
-  { static const int dbg = [] { const char* e = getenv("SATCV_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
+  a.bnr_y0 = d->bnr_y0; a.bnr_y1 = d->bnr_y1; a.bnr_c0 = d->bnr_c0; a.bnr_ld0 = d->bnr_ld0; a.bnr_ld1 = d->bnr_ld1;
+  a.bnr_scale = d->bnr_scale; a.bnr_shift = d->bnr_shift; a.bnr_mean = d->bnr_mean; a.bnr_rstd = d->bnr_rstd;
+  a.bnr_sums = d->bnr_sums; a.bnr_sums_ld = d->bnr_sums_ld;
+  a.dbg = 0;
   if (a.mode_in == 1) {
     // K = f*f*c0 virtual channels gathered from one source
     SATCV_CHECK(!d->x1, "igemm: s2d with dual source");
     a.c1 = a.c0 * (d->f * d->f - 1);   // so that c0+c1 = K; x1 unused in s2d mode
   }
+  return SATCV_OK;
+}
+
+static bool igemm_force_generic() {
+  static const bool v = [] { const char* e = getenv("SATCV_IGEMM"); return e && e[0] == 'g'; }();
+  return v;
+}
+
+extern "C" int satcv_conv2d_igemm_can_fuse(const satcv_conv_desc* d) {
+  IgemmArgs a;
+  if (igemm_fill_args(d, a) != SATCV_OK || igemm_force_generic()) return 0;
+  return igemm_fast_launch(a, d->dtype, nullptr, true) == SATCV_OK ? 1 : 0;
+}
+
+extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
+  IgemmArgs a;
+  int rc = igemm_fill_args(d, a);
+  if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * d->n * d->h * d->w_ * (double)d->cout * (double)(a.c0 + a.c1) * d->kh * d->kw;
   satcv_prof_begin(d->kh * d->kw > 1 ? 0 : 1, flops, st);
-  int rc = SATCV_ERR_UNSUPPORTED;
-  static const bool force_generic = [] { const char* e = getenv("SATCV_IGEMM"); return e && e[0] == 'g'; }();
-  if (!force_generic) rc = igemm_fast_launch(a, d->dtype, st);
+  rc = SATCV_ERR_UNSUPPORTED;
+  if (!igemm_force_generic()) rc = igemm_fast_launch(a, d->dtype, st);
   if (rc != SATCV_ERR_UNSUPPORTED) { /* launched (or failed hard) */ }
+  else if (d->bnr_sums) { satcv_set_error("igemm: the bnr_* fusion needs the pipelined kernel (check satcv_conv2d_igemm_can_fuse)"); rc = SATCV_ERR_UNSUPPORTED; }
   else if (d->dtype == SATCV_BF16) rc = launch_t<bf16>(a, st);
   else if (d->dtype == SATCV_F32) rc = launch_t<float>(a, st);
   else { satcv_set_error("igemm: bad dtype %d", d->dtype); rc = SATCV_ERR_INVALID; }

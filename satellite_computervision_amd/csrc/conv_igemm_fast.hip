@@ -11,6 +11,7 @@
 //   * blockIdx is remapped so that the workgroups sharing an activation tile / neighbouring
 //     halos run on the same XCD (private L2).
 #include "igemm_common.hpp"
+#include <cstdlib>
 
 // compile-time ablation switches for profiling builds (-DSATCV_ABLATE=bits): 1 skip global stores, 2 skip MFMA,
 // 4 skip activation loads, 8 skip weight loads, 16 skip the LDS fragment reads, 32 skip the whole epilogue
@@ -260,6 +261,26 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs
     const int ncols = min(BN, a.cout - nbase);      // valid columns of this tile
     int ij = 0, cbase = nbase;
     if (a.mode_out == 1) { ij = nbase / a.cstat; cbase = nbase - ij * a.cstat; }
+    // fused first pass of the consumer's BN+ReLU backward: this thread always handles vector column tid % VPR
+    float* ldsR = ldsS + WM * 2 * BN;                 // [2][BN]
+    const bool bnr = a.bnr_sums != nullptr;
+    const int vcol = tid % VPR;
+    float rsc[EPV], rsh[EPV], rmu[EPV], rrs[EPV], r1[EPV], r2[EPV];
+    const T* ry = nullptr; int rld = 0, rco = 0;
+    if (bnr) {
+      for (int i = tid; i < 2 * BN; i += NTHREADS) ldsR[i] = 0.f;
+      const int cg = cbase + vcol * EPV;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        const bool ok = cg + e < a.cout;
+        rsc[e] = ok ? a.bnr_scale[cg + e] : 0.f; rsh[e] = ok ? a.bnr_shift[cg + e] : 0.f;
+        rmu[e] = ok ? a.bnr_mean[cg + e] : 0.f; rrs[e] = ok ? a.bnr_rstd[cg + e] : 0.f;
+        r1[e] = 0.f; r2[e] = 0.f;
+      }
+      if (cg < a.bnr_c0) { ry = reinterpret_cast<const T*>(a.bnr_y0); rld = a.bnr_ld0; rco = cg; }
+      else { ry = reinterpret_cast<const T*>(a.bnr_y1); rld = a.bnr_ld1; rco = cg - a.bnr_c0; }
+      __syncthreads();
+    }
     for (int it = tid; it < BM * VPR; it += NTHREADS) {
       const int q = it / VPR, v = it % VPR;
       if (v * EPV >= ncols) continue;
@@ -271,6 +292,19 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs
       if (a.mode_out == 1) off = ((size_t)(nimg * ho + y * a.f + ij / a.f) * wo + x * a.f + ij % a.f) * a.ldy + cbase + v * EPV;
       else off = ((size_t)(nimg * ho + y) * wo + x) * a.ldy + cbase + v * EPV;
       const T* sp = ldsO + q * OPITCH + v * EPV;
+      if (bnr && v * EPV + EPV <= ncols) {
+        const T* rp = ry + ((size_t)(nimg * ho + y) * wo + x) * rld + rco;
+        const uint4 yq = *reinterpret_cast<const uint4*>(rp);           // one 16-byte load each (global, LDS)
+        const uint4 gq = *reinterpret_cast<const uint4*>(sp);
+        const T* yv = reinterpret_cast<const T*>(&yq);
+        const T* gv = reinterpret_cast<const T*>(&gq);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          const float yr = (float)yv[e];
+          const float g = (yr * rsc[e] + rsh[e] > 0.f) ? (float)gv[e] : 0.f;
+          r1[e] += g; r2[e] += g * ((yr - rmu[e]) * rrs[e]);
+        }
+      }
       if (ABL(1)) continue;
       if (a.accumulate) {
         const int ne = min(EPV, ncols - v * EPV);
@@ -281,12 +315,22 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs
         for (int e = 0; e < ncols - v * EPV; ++e) yp[off + e] = sp[e];
       }
     }
+    if (bnr) {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { atomicAdd(&ldsR[vcol * EPV + e], r1[e]); atomicAdd(&ldsR[BN + vcol * EPV + e], r2[e]); }
+      __syncthreads();
+      if (tid < BN && cbase + tid < a.cout) {
+        float* rowp = a.bnr_sums + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.bnr_sums_ld;
+        atomicAdd(rowp + cbase + tid, ldsR[tid]);
+        atomicAdd(rowp + a.bnr_sums_ld + cbase + tid, ldsR[BN + tid]);
+      }
+    }
   }
 }
 
 // ------------------------------------------------------------------ host side
 template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
-static int fast_cfg(IgemmArgs& a, hipStream_t st) {
+static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, KC = KS * 16, NTHREADS = WM * WN * 64;
   a.halh = a.dil * (a.kh - 1) / 2;
   a.halw = a.dil * (a.kw - 1) / 2;
@@ -313,9 +357,11 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st) {
   if (a.ldy % (16 / (int)sizeof(T)) != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;
   if (a.mode_out == 0 && a.cout % (16 / (int)sizeof(T)) != 0 && a.cout < a.ldy) { /* tail handled by scalar stores */ }
   const size_t lds_stage = ((size_t)(KC / 8) * a.rl * a.pitch * 8 + (size_t)TAPS * (KC / 8) * BN * 8) * sizeof(T);
-  const size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)WM * 2 * BN * sizeof(float);
+  const size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
   const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
+  if (a.bnr_sums && (a.cout % (16 / (int)sizeof(T)) != 0 || a.bnr_c0 % BN != 0 && a.bnr_y1)) return SATCV_ERR_UNSUPPORTED;
+  if (dry) return SATCV_OK;
   auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -330,7 +376,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st) {
 }
 
 template <typename T, int TW, int TAPS>
-static int fast_tw(IgemmArgs& a, hipStream_t st) {
+static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   const int cin = a.c0 + a.c1;
   const int nspace = a.mode_out ? a.cstat : a.cout;
   // 32-channel chunks only for 1x1 taps (the 9-tap weight slab of a 32-channel chunk would not leave
@@ -338,31 +384,40 @@ static int fast_tw(IgemmArgs& a, hipStream_t st) {
   if constexpr (TAPS == 1) {
     const bool ks2 = (cin % 32 == 0) && (!a.x1 || a.c0 % 32 == 0) && (a.mode_in != 1 || a.c0 % 32 == 0);
     if (ks2) {
-      if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS>(a, st);
-      if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 2, TAPS>(a, st);
-      return fast_cfg<T, TW, 4, 1, 2, 1, 2, TAPS>(a, st);
+      if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS>(a, st, dry);
+      if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 2, TAPS>(a, st, dry);
+      return fast_cfg<T, TW, 4, 1, 2, 1, 2, TAPS>(a, st, dry);
     }
   }
-  if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 1, TAPS>(a, st);
+  if (nspace >= 128 && nspace % 128 == 0) {
+    // 256-pixel tile (4x2 MFMA tiles per wave) when the grid still fills the chip twice over: fewer LDS bytes per MFMA
+    static const int big = [] { const char* e = getenv("SATCV_BIGTILE"); return e ? atoi(e) : 0; }();      // measured slower (15.9 vs 15.4 ms/step): off
+    const long long wgs256 = ((long long)a.n * a.h * a.w_ / 256) * (nspace / 128);
+    if (big && TAPS == 9 && TW >= 16 && wgs256 >= 512) {
+      const int rc = fast_cfg<T, TW, 2, 2, 4, 2, 1, TAPS>(a, st, dry);
+      if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+    }
+    return fast_cfg<T, TW, 2, 2, 2, 2, 1, TAPS>(a, st, dry);
+  }
   // (32-channel chunks for the thin 3x3 layers were measured SLOWER: 144 vs 113 us on enc1, 425 vs 351 us on
   //  dec0.conv1 -- fewer resident workgroups outweigh the halved barrier count)
-  if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 1, TAPS>(a, st);
-  return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS>(a, st);
+  if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 1, TAPS>(a, st, dry);
+  return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS>(a, st, dry);
 }
 
 template <typename T, int TAPS>
-static int fast_t(IgemmArgs& a, hipStream_t st) {
+static int fast_t(IgemmArgs& a, hipStream_t st, bool dry) {
   switch (igemm_pick_tw(a.w_)) {
-    case 32: return fast_tw<T, 32, TAPS>(a, st);
-    case 16: return fast_tw<T, 16, TAPS>(a, st);
-    default: return fast_tw<T, 8, TAPS>(a, st);
+    case 32: return fast_tw<T, 32, TAPS>(a, st, dry);
+    case 16: return fast_tw<T, 16, TAPS>(a, st, dry);
+    default: return fast_tw<T, 8, TAPS>(a, st, dry);
   }
 }
 
-int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st) {
+int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   const int taps = a.kh * a.kw;
   if (!(taps == 1 || (a.kh == 3 && a.kw == 3))) return SATCV_ERR_UNSUPPORTED;
-  if (dtype == SATCV_BF16) return taps == 1 ? fast_t<bf16, 1>(a, st) : fast_t<bf16, 9>(a, st);
-  if (dtype == SATCV_F32) return taps == 1 ? fast_t<float, 1>(a, st) : fast_t<float, 9>(a, st);
+  if (dtype == SATCV_BF16) return taps == 1 ? fast_t<bf16, 1>(a, st, dry) : fast_t<bf16, 9>(a, st, dry);
+  if (dtype == SATCV_F32) return taps == 1 ? fast_t<float, 1>(a, st, dry) : fast_t<float, 9>(a, st, dry);
   return SATCV_ERR_UNSUPPORTED;
 }

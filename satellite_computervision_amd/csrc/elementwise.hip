@@ -550,10 +550,15 @@ __global__ __launch_bounds__(EW_BLOCK) void head_fwd_fast_kernel(const satcv_hea
   }
 }
 
-template <typename T, int NC, int CIN>
+template <typename T, int NC, int CIN, bool BNR>
 __global__ __launch_bounds__(EW_BLOCK) void head_bwd_fast_kernel(const satcv_head_desc d) {
-  __shared__ float aw[CIN * NC + NC];
+  __shared__ float aw[CIN * NC + NC + 2 * CIN];
   float w[CIN][NC], sc[CIN], sh[CIN], acc[CIN][NC], accb[NC];
+  float mu[BNR ? CIN : 1], rs[BNR ? CIN : 1], r1[BNR ? CIN : 1], r2[BNR ? CIN : 1];
+  if constexpr (BNR) {
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) { mu[c] = d.bnr_mean[c]; rs[c] = d.bnr_rstd[c]; r1[c] = 0.f; r2[c] = 0.f; }
+  }
   const bool tr = d.in_scale != nullptr;
 #pragma unroll
   for (int c = 0; c < CIN; ++c) {
@@ -563,7 +568,7 @@ __global__ __launch_bounds__(EW_BLOCK) void head_bwd_fast_kernel(const satcv_hea
   }
 #pragma unroll
   for (int k = 0; k < NC; ++k) accb[k] = 0.f;
-  for (int i = threadIdx.x; i < CIN * NC + NC; i += blockDim.x) aw[i] = 0.f;
+  for (int i = threadIdx.x; i < CIN * NC + NC + 2 * CIN; i += blockDim.x) aw[i] = 0.f;
   __syncthreads();
   const T* x = (const T*)d.x; T* dx = (T*)d.dx;
   for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < d.npix; p += (long long)gridDim.x * blockDim.x) {
@@ -582,6 +587,10 @@ __global__ __launch_bounds__(EW_BLOCK) void head_bwd_fast_kernel(const satcv_hea
 #pragma unroll
         for (int k = 0; k < NC; ++k) { s += dl[k] * w[c][k]; acc[c][k] += a * dl[k]; }
         o[e] = s;
+        if constexpr (BNR) {      // first pass of the BN+ReLU backward of x, on the value as stored
+          const float gq = a > 0.f ? round_to<T>(s) : 0.f;
+          r1[c] += gq; r2[c] += gq * ((v[e] - mu[c]) * rs[c]);
+        }
       }
       if (dx) store8<T>(dx + p * d.lddx + g * 8, o);
     }
@@ -596,9 +605,23 @@ __global__ __launch_bounds__(EW_BLOCK) void head_bwd_fast_kernel(const satcv_hea
     }
 #pragma unroll
   for (int k = 0; k < NC; ++k) { const float s = wave_sum(accb[k]); if (lane == 0) atomicAdd(&aw[CIN * NC + k], s); }
+  if constexpr (BNR) {
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      const float s1 = wave_sum(r1[c]), s2 = wave_sum(r2[c]);
+      if (lane == 0) { atomicAdd(&aw[CIN * NC + NC + c], s1); atomicAdd(&aw[CIN * NC + NC + CIN + c], s2); }
+    }
+  }
   __syncthreads();
   if (d.dw) for (int i = threadIdx.x; i < CIN * NC; i += blockDim.x) atomicAdd(d.dw + i, aw[i]);
   if (d.db) for (int i = threadIdx.x; i < NC; i += blockDim.x) atomicAdd(d.db + i, aw[CIN * NC + i]);
+  if constexpr (BNR) {
+    float* rowp = d.bnr_sums + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * d.bnr_sums_ld;
+    for (int i = threadIdx.x; i < CIN; i += blockDim.x) {
+      atomicAdd(rowp + i, aw[CIN * NC + NC + i]);
+      atomicAdd(rowp + d.bnr_sums_ld + i, aw[CIN * NC + NC + CIN + i]);
+    }
+  }
 }
 
 template <typename T, bool BWD>
@@ -606,7 +629,8 @@ static bool head_fast_launch(const satcv_head_desc* d, hipStream_t st) {
   const int grid = ew_grid(d->npix, 1024);
 #define HEAD_CASE(NC_, CIN_)                                                                                      \
   if (d->ncls == NC_ && d->cin == CIN_) {                                                                         \
-    if (BWD) hipLaunchKernelGGL((head_bwd_fast_kernel<T, NC_, CIN_>), dim3(grid), dim3(EW_BLOCK), 0, st, *d);      \
+    if (BWD && d->bnr_sums) hipLaunchKernelGGL((head_bwd_fast_kernel<T, NC_, CIN_, true>), dim3(grid), dim3(EW_BLOCK), 0, st, *d); \
+    else if (BWD) hipLaunchKernelGGL((head_bwd_fast_kernel<T, NC_, CIN_, false>), dim3(grid), dim3(EW_BLOCK), 0, st, *d); \
     else hipLaunchKernelGGL((head_fwd_fast_kernel<T, NC_, CIN_>), dim3(grid), dim3(EW_BLOCK), 0, st, *d);         \
     return true;                                                                                                  \
   }
@@ -685,10 +709,12 @@ __global__ void head_bwd_kernel(const satcv_head_desc d) {
 }
 extern "C" int satcv_head_bwd(const satcv_head_desc* d, void* stream) {
   SATCV_CHECK(d && d->x && d->w && d->dlogits, "head_bwd: null pointer");
+  SATCV_CHECK(!d->bnr_sums || (d->bnr_mean && d->bnr_rstd && d->in_scale && d->dx && d->bnr_sums_ld >= d->cin), "head_bwd: incomplete bnr_* fields");
   SATCV_CHECK(d->cin > 0 && d->cin % 8 == 0 && d->ncls >= 1 && d->ncls <= HEAD_NCMAX && d->npix > 0, "head_bwd: bad dims");
   const size_t lds = (size_t)(2 * d->cin * d->ncls + d->ncls + 2 * d->cin) * sizeof(float);
   DISPATCH_T(d->dtype, { if (!head_fast_launch<T, true>(d, (hipStream_t)stream))
-      hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(ew_grid(d->npix, 1024)), dim3(EW_BLOCK), lds, (hipStream_t)stream, *d); });
+      { if (d->bnr_sums) { satcv_set_error("head_bwd: bnr fusion only on the register-resident kernel (cin in 16/32/64, small ncls)"); return SATCV_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(ew_grid(d->npix, 1024)), dim3(EW_BLOCK), lds, (hipStream_t)stream, *d); } });
   LAUNCH_OK("head_bwd");
   return SATCV_OK;
 }

@@ -15,6 +15,8 @@ struct IgemmArgs {
   int kh, kw, dil;
   int mode_in, mode_out, f;
   int cstat, out_relu, accumulate;
+  const void* bnr_y0; const void* bnr_y1; int bnr_c0, bnr_ld0, bnr_ld1;
+  const float* bnr_scale; const float* bnr_shift; const float* bnr_mean; const float* bnr_rstd; float* bnr_sums; int bnr_sums_ld;
   // derived tiling
   int tiles_x, tiles_y, ngroups;   // M tiles = ngroups * tiles_y * tiles_x
   int rpi, imgs, seg, rl, cl, pitch, halh, halw;
@@ -71,4 +73,4 @@ static inline int igemm_pick_tw(int w) {
 
 // software-pipelined variant (conv_igemm_fast.hip); returns SATCV_ERR_UNSUPPORTED when the
 // shape is outside its static limits so that the caller falls back to the generic kernel.
-int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st);
+int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run = false);

@@ -212,6 +212,7 @@ class Plan:
         self.fwd, self.bwd = [], []
         self.keep = []                        # ctypes descriptors / tensors kept alive
         self.dropouts = []                    # dropout masks (regenerated every training step)
+        self.side = torch.cuda.Stream() if (training and rt.model.wgrad_side_stream) else None
         self.step_count = 0
         self.outputs = {}
         self._build()
@@ -495,6 +496,40 @@ class Plan:
             app = lambda st: check(lib.satcv_bn_bwd_apply(C.byref(d), st))
             return red, fin, app
 
+        fused = {}      # tensor id -> sums buffer whose BN-backward reduce pass was done by the producer of the gradient
+        HEAD_FAST = {(1, 16), (2, 16), (1, 32), (2, 32), (3, 32), (4, 32), (1, 64), (2, 64)}
+
+        def fuse_target(t):
+            """bnr_* fields (and the sums buffer) if the BN+ReLU that produced tensor `t` can take its backward
+            reduction from the kernel that writes t's activation gradient; None otherwise."""
+            if not rt.model.fuse_bn_bwd or t.id in gact or len(consumers[t.id]) != 1:
+                return None
+            P, pc = t.node, ctx.get(id(t.node))
+            if P.op == 'cba':
+                if pc['yoff'] != 0 or pc['ldy'] != pc['cout']:
+                    return None                       # branch of a concatenation (ASPP)
+                c, aff = pc['cout'], pc['aff']
+                sums = self._z(STAT_ROWS, 2, c, dtype=torch.float32)
+                return dict(y0=pc['y'].data_ptr(), y1=None, c0=c, ld0=c, ld1=0, scale=_fp(aff['scale']), shift=_fp(aff['shift']),
+                            mean=_fp(aff['mean']), rstd=_fp(aff['rstd']), sums=_fp(sums), sums_ld=c), sums
+            if P.op == 'concat_bn_relu':
+                ra, rb, aff, ca, cb = pc['ra'], pc['rb'], pc['aff'], pc['ca'], pc['cb']
+                sums = self._z(STAT_ROWS, 2, ca + cb, dtype=torch.float32)
+                return dict(y0=ra.srcs[0][0].data_ptr(), y1=rb.srcs[0][0].data_ptr(), c0=ca, ld0=ca, ld1=cb, scale=_fp(aff['scale']),
+                            shift=_fp(aff['shift']), mean=_fp(aff['mean']), rstd=_fp(aff['rstd']), sums=_fp(sums), sums_ld=ca + cb), sums
+            return None
+
+        def dgrad_step(t, **kw):
+            """data-gradient launch writing the activation gradient of tensor t; fuses the consumer BN's reduce pass when possible"""
+            ft = fuse_target(t)
+            if ft is not None:
+                d = ops.make_conv_desc(bnr=ft[0], **kw)
+                if lib.satcv_conv2d_igemm_can_fuse(C.byref(d)):
+                    fused[t.id] = ft[1]
+                    self.keep.append(d)
+                    return lambda st, d=d: check(lib.satcv_conv2d_igemm(C.byref(d), st))
+            return self._conv_step(**kw)
+
         def wgrad_step(r, dy, lddy, lay, cin_real, cout, hh, ww, k, dil, f=0):
             nonlocal ws_need
             sa = self._src_args(r)
@@ -506,7 +541,18 @@ class Plan:
             ws_need = max(ws_need, nb)
             wdescs.append(d)
             self.keep.append(d)
-            return lambda st: check(lib.satcv_conv2d_wgrad(C.byref(d), st))
+            if self.side is None:
+                return lambda st: check(lib.satcv_conv2d_wgrad(C.byref(d), st))
+            # weight gradient and data gradient of a layer only share their INPUT (dy): run the weight gradients on a
+            # second HIP stream so that their load/MFMA/store phases interleave with the main stream's kernels
+            ev = torch.cuda.Event()
+            side, sptr = self.side, C.c_void_p(self.side.cuda_stream)
+
+            def run(st, d=d, ev=ev):
+                ev.record(torch.cuda.current_stream())
+                side.wait_event(ev)
+                check(lib.satcv_conv2d_wgrad(C.byref(d), sptr))
+            return run
 
         for node in reversed(m.nodes):
             op = node.op
@@ -516,12 +562,17 @@ class Plan:
                 (y, c) = r.srcs[0]
                 dx = self._z(n, r.h, r.w, c)
                 lay = node.layer
+                hb = None
+                ft = fuse_target(node.inputs[0]) if (cx['ncls'], c) in HEAD_FAST and r.affine else None
+                if ft is not None:
+                    hb = dict(mean=ft[0]['mean'], rstd=ft[0]['rstd'], sums=ft[0]['sums'], sums_ld=ft[0]['sums_ld'])
+                    fused[node.inputs[0].id] = ft[1]
                 hd = ops.make_head_desc(x=y.data_ptr(), ldx=c, cin=c, w=rt.pptr(lay.name + '/kernel'), b=rt.pptr(lay.name + '/bias'),
                                         ncls=cx['ncls'], activation=cx['act'], npix=n * r.h * r.w, dtype=dt,
                                         in_scale=_fp(r.affine['scale']) if r.affine else None,
                                         in_shift=_fp(r.affine['shift']) if r.affine else None,
                                         dlogits=self.dlogits.data_ptr(), dx=dx.data_ptr(), lddx=c,
-                                        dw=rt.gptr(lay.name + '/kernel'), db=rt.gptr(lay.name + '/bias'))
+                                        dw=rt.gptr(lay.name + '/kernel'), db=rt.gptr(lay.name + '/bias'), bnr=hb)
                 self.keep.append(hd)
                 self.bwd.append(lambda st, hd=hd: check(lib.satcv_head_bwd(C.byref(hd), st)))
                 gact[node.inputs[0].id] = (dx, 0, c)
@@ -533,14 +584,15 @@ class Plan:
                 lay, r, y, aff, cout = node.layer, cx['r'], cx['y'], cx['aff'], cx['cout']
                 yoff, ldy, aoff = cx['yoff'], cx['ldy'], cx['aoff']
                 hh, ww = r.h, r.w
-                sums = self._z(STAT_ROWS, 2, cout, dtype=torch.float32)
+                pre = fused.get(tout.id)
+                sums = pre if pre is not None else self._z(STAT_ROWS, 2, cout, dtype=torch.float32)
                 dy = self._z(n, hh, ww, cout)
                 da_ptr = da[0].data_ptr() + da[1] * es if da is not None else None
                 red, fin, app = bn_bwd_steps(da_ptr, da[2] if da is not None else 0, dp[0].data_ptr() if dp is not None else None,
                                              cout, gpool_f.get(tout.id, 1), y.data_ptr() + yoff * es, ldy, aff, aoff, sums, 0, cout, cout, hh, ww,
                                              dy.data_ptr(), cout, rt.gptr(lay.name + '/bias'),
                                              rt.gptr(lay.bn_name + '/gamma'), rt.gptr(lay.bn_name + '/beta'))
-                self.bwd += [red, fin, app]
+                self.bwd += [fin, app] if pre is not None else [red, fin, app]
                 self.dbg['dy:' + lay.name] = dy
                 self.dbg['_ctx:' + lay.name] = dict(da=da, dp=dp, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout)
                 pk = rt.packed[lay.name]
@@ -551,9 +603,9 @@ class Plan:
                     if prev is not None and (prev[1] != 0 or prev[2] != cinp):
                         raise NotImplementedError('gradient fan-in into a channel slice')
                     gin = prev[0] if prev is not None else self._z(n, hh, ww, cinp)
-                    self.bwd.append(self._conv_step(x0=dy.data_ptr(), c0=cout, w=pk['dgrad'].data_ptr(), y=gin.data_ptr(), ldy=cinp,
-                                                    n=n, h=hh, w_=ww, cout=cinp, cout_pad=rup(cinp, 32), kh=cx['k'], kw=cx['k'],
-                                                    dil=cx['dil'], dtype=dt, accumulate=1 if prev is not None else 0))
+                    self.bwd.append(dgrad_step(tin, x0=dy.data_ptr(), c0=cout, w=pk['dgrad'].data_ptr(), y=gin.data_ptr(), ldy=cinp,
+                                               n=n, h=hh, w_=ww, cout=cinp, cout_pad=rup(cinp, 32), kh=cx['k'], kw=cx['k'],
+                                               dil=cx['dil'], dtype=dt, accumulate=1 if prev is not None else 0))
                     gact[tin.id] = (gin, 0, cinp)
                     self.dbg['dx:' + lay.name] = gin
             elif op == 'dropout':
@@ -592,7 +644,8 @@ class Plan:
                 ra, rb, aff, ca, cb = cx['ra'], cx['rb'], cx['aff'], cx['ca'], cx['cb']
                 ctot = ca + cb
                 hh, ww = ra.h, ra.w
-                sums = self._z(STAT_ROWS, 2, ctot, dtype=torch.float32)
+                pre = fused.get(tout.id)
+                sums = pre if pre is not None else self._z(STAT_ROWS, 2, ctot, dtype=torch.float32)
                 dskip = self._z(n, hh, ww, ca)
                 du = self._z(n, hh, ww, cb)
                 bn = node.layer.name
@@ -605,7 +658,7 @@ class Plan:
                 rb_, fb_, ab_ = bn_bwd_steps(gptr_ + ca * es, ctot, None, 0, 1, rb.srcs[0][0].data_ptr(), cb, aff, ca, sums, ca, ctot, cb,
                                              hh, ww, du.data_ptr(), cb, rt.gptr(upl.name + '/bias') if tb.node.op == 'convT' else None,
                                              rt.gptr(bn + '/gamma') + 4 * ca, rt.gptr(bn + '/beta') + 4 * ca)
-                self.bwd += [ra_, rb_, fa_, fb_, aa_, ab_]
+                self.bwd += [fa_, fb_, aa_, ab_] if pre is not None else [ra_, rb_, fa_, fb_, aa_, ab_]
                 # the skip is the activated output of an encoder conv_batch_act block
                 gact[ta.id] = (dskip, 0, ca)
                 self.dbg['dskip:' + bn] = dskip
@@ -621,14 +674,21 @@ class Plan:
                 self.bwd.append(wgrad_step(r, du.data_ptr(), cout, lay, pk['cin'], cout, r.h, r.w, 1, 1, f=f))
                 cinp = r.c
                 gin = self._z(n, r.h, r.w, cinp)
-                self.bwd.append(self._conv_step(x0=du.data_ptr(), c0=cout, w=pk['dgrad'].data_ptr(), y=gin.data_ptr(), ldy=cinp, n=n, h=r.h,
-                                                w_=r.w, cout=cinp, cout_pad=rup(cinp, 32), kh=1, kw=1, dil=1, mode_in=1, f=f, dtype=dt))
+                self.bwd.append(dgrad_step(tin, x0=du.data_ptr(), c0=cout, w=pk['dgrad'].data_ptr(), y=gin.data_ptr(), ldy=cinp, n=n, h=r.h,
+                                           w_=r.w, cout=cinp, cout_pad=rup(cinp, 32), kh=1, kw=1, dil=1, mode_in=1, f=f, dtype=dt))
                 gact[tin.id] = (gin, 0, cinp)
                 self.dbg['dx:' + lay.name] = gin
         if ws_need:
             ws = self._z(max(ws_need // 4, 1), dtype=torch.float32)
             for d in wdescs:
                 d.workspace, d.workspace_bytes = ws.data_ptr(), ws_need
+        if self.side is not None:
+            evj = torch.cuda.Event()
+
+            def join(st, evj=evj):          # the optimizer (main stream) must see every weight gradient
+                evj.record(self.side)
+                torch.cuda.current_stream().wait_event(evj)
+            self.bwd.append(join)
 
     # -- execution
     def run_forward(self, st):

@@ -548,6 +548,8 @@ class Model:
                     self.param_specs += l.specs
         self.compute_dtype = dtype or _DEFAULT_DTYPE
         self.bn_bessel = False
+        self.fuse_bn_bwd = os.environ.get('SATCV_FUSE_BN_BWD', '0') == '1'   # BN-backward reduce pass inside the dgrad epilogues (measured: no gain, off)
+        self.wgrad_side_stream = os.environ.get('SATCV_WGRAD_STREAM', '1') != '0'      # weight gradients on a second HIP stream
         self._rt = None
         self.optimizer, self._loss, self._metrics = None, None, []
         self.metrics_names = []

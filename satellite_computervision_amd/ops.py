@@ -80,7 +80,7 @@ def pack_weights(kernel_f32, cin_pad, dtype, transposed=False, want_dgrad=True, 
 # --------------------------------------------------------------------------- conv
 def make_conv_desc(*, x0, c0, w, y, ldy, n, h, w_, cout, cout_pad, dtype, x1=None, c1=0, in_scale=None, in_shift=None,
                    in_relu=0, bias=None, stats=None, stats_ld=0, kh=3, kw=3, dil=1, mode_in=0, mode_out=0, f=1,
-                   cstat=None, out_relu=0, accumulate=0):
+                   cstat=None, out_relu=0, accumulate=0, bnr=None):
     d = ConvDesc()
     d.x0, d.x1, d.c0, d.c1 = x0, x1, c0, c1
     d.in_scale, d.in_shift, d.in_relu = in_scale, in_shift, int(in_relu)
@@ -92,6 +92,9 @@ def make_conv_desc(*, x0, c0, w, y, ldy, n, h, w_, cout, cout_pad, dtype, x1=Non
     d.mode_in, d.mode_out, d.f = mode_in, mode_out, f
     d.cstat = cstat if cstat is not None else cout
     d.out_relu, d.dtype, d.accumulate = int(out_relu), dtype, int(accumulate)
+    if bnr:
+        for k, v in bnr.items():
+            setattr(d, 'bnr_' + k, v)
     return d
 
 
@@ -252,7 +255,7 @@ def bn_relu_bwd(yraw, scale, shift, mean, rstd, da=None, dpool=None, f=1, want_d
 
 # ------------------------------------------------------------------------------ head
 def make_head_desc(*, x, ldx, cin, w, b, ncls, activation, npix, dtype, in_scale=None, in_shift=None, thresh=0.5,
-                   probs=None, classes=None, dlogits=None, dx=None, lddx=0, dw=None, db=None):
+                   probs=None, classes=None, dlogits=None, dx=None, lddx=0, dw=None, db=None, bnr=None):
     d = HeadDesc()
     d.x, d.ldx, d.cin = x, ldx, cin
     d.in_scale, d.in_shift, d.w, d.b = in_scale, in_shift, w, b
@@ -260,6 +263,9 @@ def make_head_desc(*, x, ldx, cin, w, b, ncls, activation, npix, dtype, in_scale
     d.probs, d.classes, d.dlogits = probs, classes, dlogits
     d.dx, d.lddx, d.dw, d.db = dx, lddx, dw, db
     d.npix, d.dtype = npix, dtype
+    if bnr:
+        for k, v in bnr.items():
+            setattr(d, 'bnr_' + k, v)
     return d
 
 
