@@ -96,6 +96,9 @@ typedef struct satcv_conv_desc {
   int32_t bnr_c0, bnr_ld0, bnr_ld1;
   const float* bnr_scale; const float* bnr_shift; const float* bnr_mean; const float* bnr_rstd;
   float* bnr_sums; int32_t bnr_sums_ld;
+  /* strided convolution (ResNet-style, symmetric zero padding dil*(k-1)/2): output grid (n,h,w_), input grid
+   * (n,hin,win) with h = (hin-1)/stride+1.  stride 0/1 = dense.  Generic kernel only. */
+  int32_t stride, hin, win;
 } satcv_conv_desc;
 int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream);
 /* 1 if the descriptor's shape runs on the pipelined kernel (needed for the bnr_* fusion), else 0; no launch. */
@@ -164,6 +167,21 @@ int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream);
 int satcv_bn_bwd_finalize(float* sums, int32_t sums_ld, int32_t c, float count, float* dgamma,
                           float* dbeta, float* coef, void* stream);
 int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream);
+
+/* ------------------------------------------ ResNet / DeepLab-v3 inference helpers
+ * The reference has no DeepLab-v3/ResNet-50 code (README.md:8 only names it); these ops serve the build-defined
+ * configuration of SURVEY.md section 8a row A9.
+ * satcv_maxpool: window k, stride s, symmetric padding (ResNet stem 3x3/2).
+ * satcv_add_act: out = relu?(affine?(y) + affine?(res)) -- the residual join of a bottleneck.
+ * satcv_upsample_head: bilinear x factor (half-pixel centres) of fp32 logits + softmax/argmax or sigmoid/threshold.
+ * (satcv_head_fwd with activation 2 writes the raw logits.) */
+int satcv_maxpool(const void* x, void* out, int32_t n, int32_t h, int32_t w_, int32_t c, int32_t k, int32_t s,
+                  int32_t pad, int32_t dtype, void* stream);
+int satcv_add_act(const void* y, const float* y_scale, const float* y_shift, const void* res,
+                  const float* res_scale, const float* res_shift, int32_t relu, void* out, int64_t npix,
+                  int32_t c, int32_t dtype, void* stream);
+int satcv_upsample_head(const float* logits, int32_t n, int32_t h, int32_t w_, int32_t ncls, int32_t factor,
+                        int32_t activation, float thresh, float* probs, int32_t* classes, void* stream);
 
 /* ---------------------------------------------------------------- dropout
  * layers.SpatialDropout2D / layers.Dropout (utils/model_tools.py:311, 351, 363, 402), training only.

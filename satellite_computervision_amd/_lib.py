@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
                 ('mode_in', c_i32), ('mode_out', c_i32), ('f', c_i32),
                 ('cstat', c_i32), ('out_relu', c_i32), ('dtype', c_i32), ('accumulate', c_i32),
                 ('bnr_y0', c_vp), ('bnr_y1', c_vp), ('bnr_c0', c_i32), ('bnr_ld0', c_i32), ('bnr_ld1', c_i32),
-                ('bnr_scale', c_vp), ('bnr_shift', c_vp), ('bnr_mean', c_vp), ('bnr_rstd', c_vp), ('bnr_sums', c_vp), ('bnr_sums_ld', c_i32)]
+                ('bnr_scale', c_vp), ('bnr_shift', c_vp), ('bnr_mean', c_vp), ('bnr_rstd', c_vp), ('bnr_sums', c_vp), ('bnr_sums_ld', c_i32), ('stride', c_i32), ('hin', c_i32), ('win', c_i32)]
 
 
 class WgradDesc(C.Structure):
@@ -82,6 +82,9 @@ _SIGS = {
     'satcv_bn_bwd_reduce': (C.c_int, [C.POINTER(BnBwdDesc), c_vp]),
     'satcv_bn_bwd_finalize': (C.c_int, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     'satcv_bn_bwd_apply': (C.c_int, [C.POINTER(BnBwdDesc), c_vp]),
+    'satcv_maxpool': (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'satcv_add_act': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    'satcv_upsample_head': (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
     'satcv_dropout_mask': (C.c_int, [C.c_uint64, C.c_uint64, c_f32, c_i64, c_vp, c_vp]),
     'satcv_dropout_apply': (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'satcv_head_fwd': (C.c_int, [C.POINTER(HeadDesc), c_vp]),

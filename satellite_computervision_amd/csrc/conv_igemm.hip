@@ -61,8 +61,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
     const int t = q / TW, cx = q % TW;
     const int k = t / a.rpi;
     // rows past the last image segment of the tile are never stored; keep their reads in range
-    const int l0 = (k < a.imgs) ? k * a.seg + (t - k * a.rpi) : 0;
-    a_off[m] = (l0 * a.pitch + cx) * 8;
+    const int l0 = (k < a.imgs) ? k * a.seg + (t - k * a.rpi) * a.stride : 0;
+    a_off[m] = (l0 * a.pitch + cx * a.stride) * 8;
   }
   const int slot_stride = a.rl * a.pitch * 8;
 
@@ -101,10 +101,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
         const int k = L / a.seg;
         const int yy = L - k * a.seg - a.halh;
         const int n = n0 + k;
-        const int y = y0 + yy;
-        const int x = x0 + c - a.halw;
+        const int y = y0 * a.stride + yy;          // input coordinates (stride 1: = output coordinates)
+        const int x = x0 * a.stride + c - a.halw;
         float v[8];
-        const bool valid = (n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_);
+        const int hlim = a.mode_in == 1 ? a.h : a.hs, wlim = a.mode_in == 1 ? a.w_ : a.ws;
+        const bool valid = (n < a.n) && (y >= 0) && (y < hlim) && (x >= 0) && (x < wlim);
         if (valid) {
           size_t off;
           if (a.mode_in == 1)
@@ -232,9 +233,9 @@ static int launch_cfg(IgemmArgs& a, hipStream_t st) {
   a.tiles_x = cdiv(a.w_, TW);
   if (a.h >= TH) { a.rpi = TH; a.imgs = 1; a.tiles_y = cdiv(a.h, TH); a.ngroups = a.n; }
   else { a.rpi = a.h; a.imgs = TH / a.h; a.tiles_y = 1; a.ngroups = cdiv(a.n, a.imgs); }
-  a.seg = a.rpi + 2 * a.halh;
+  a.seg = (a.rpi - 1) * a.stride + 1 + 2 * a.halh;
   a.rl = a.imgs * a.seg;
-  a.cl = TW + 2 * a.halw;
+  a.cl = (TW - 1) * a.stride + 1 + 2 * a.halw;
   // pitch chosen so that the 16-lane groups of ds_read_b128 hit distinct 16-byte slots
   if (TW == 32) a.pitch = a.cl;
   else if (TW == 16) a.pitch = cdiv(a.cl, 16) * 16;
@@ -277,6 +278,9 @@ static int launch_tw(IgemmArgs& a, hipStream_t st) {
     rc = ks2 ? launch_cfg<T, TW, 2, 2, 2, 1, 2>(a, st) : launch_cfg<T, TW, 2, 2, 2, 1, 1>(a, st);
   if (rc == SATCV_ERR_UNSUPPORTED)
     rc = ks2 ? launch_cfg<T, TW, 4, 1, 2, 1, 2>(a, st) : launch_cfg<T, TW, 4, 1, 2, 1, 1>(a, st);
+  if (rc == SATCV_ERR_UNSUPPORTED)          // many taps (7x7 stem) in fp32: halve the pixel tile as well
+    rc = launch_cfg<T, TW, 2, 1, 2, 1, 1>(a, st);
+  if (rc == SATCV_ERR_UNSUPPORTED) satcv_set_error("igemm: no tile configuration fits the LDS for this shape");
   return rc;
 }
 
@@ -315,6 +319,12 @@ static int igemm_fill_args(const satcv_conv_desc* d, IgemmArgs& a) {
   a.kh = d->kh; a.kw = d->kw; a.dil = d->dil;
   a.mode_in = d->mode_in; a.mode_out = d->mode_out; a.f = d->f;
   a.cstat = d->cstat; a.out_relu = d->out_relu; a.accumulate = d->accumulate;
+  a.stride = d->stride > 1 ? d->stride : 1;
+  if (a.stride > 1) {
+    SATCV_CHECK(!d->mode_in && !d->mode_out && d->hin > 0 && d->win > 0 && d->h == (d->hin - 1) / a.stride + 1 && d->w_ == (d->win - 1) / a.stride + 1,
+                "igemm: strided conv needs hin/win with h=(hin-1)/stride+1");
+    a.hs = d->hin; a.ws = d->win;
+  }
   a.bnr_y0 = d->bnr_y0; a.bnr_y1 = d->bnr_y1; a.bnr_c0 = d->bnr_c0; a.bnr_ld0 = d->bnr_ld0; a.bnr_ld1 = d->bnr_ld1;
   a.bnr_scale = d->bnr_scale; a.bnr_shift = d->bnr_shift; a.bnr_mean = d->bnr_mean; a.bnr_rstd = d->bnr_rstd;
   a.bnr_sums = d->bnr_sums; a.bnr_sums_ld = d->bnr_sums_ld;
@@ -344,6 +354,12 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   if (rc) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const double flops = 2.0 * d->n * d->h * d->w_ * (double)d->cout * (double)(a.c0 + a.c1) * d->kh * d->kw;
+  if (a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dil >= a.h && a.dil >= a.w_) {
+    // every off-centre tap of this dilated conv reads only zero padding: it IS the 1x1 conv of its centre tap
+    const size_t esz = d->dtype == SATCV_BF16 ? 2 : 4;
+    a.w = reinterpret_cast<const unsigned char*>(a.w) + (size_t)4 * ((a.c0 + a.c1) / 8) * a.cout_pad * 8 * esz;
+    a.kh = a.kw = 1; a.dil = 1;
+  }
   satcv_prof_begin(d->kh * d->kw > 1 ? 0 : 1, flops, st);
   rc = SATCV_ERR_UNSUPPORTED;
   if (!igemm_force_generic()) rc = igemm_fast_launch(a, d->dtype, st);

@@ -416,7 +416,7 @@ static int fast_t(IgemmArgs& a, hipStream_t st, bool dry) {
 
 int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   const int taps = a.kh * a.kw;
-  if (!(taps == 1 || (a.kh == 3 && a.kw == 3))) return SATCV_ERR_UNSUPPORTED;
+  if (!(taps == 1 || (a.kh == 3 && a.kw == 3)) || a.stride != 1) return SATCV_ERR_UNSUPPORTED;
   if (dtype == SATCV_BF16) return taps == 1 ? fast_t<bf16, 1>(a, st, dry) : fast_t<bf16, 9>(a, st, dry);
   if (dtype == SATCV_F32) return taps == 1 ? fast_t<float, 1>(a, st, dry) : fast_t<float, 9>(a, st, dry);
   return SATCV_ERR_UNSUPPORTED;

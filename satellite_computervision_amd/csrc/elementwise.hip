@@ -466,7 +466,10 @@ __global__ void head_fwd_kernel(const satcv_head_desc d) {
         for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) z[k] += a * lw[ch * nc + k];
       }
     }
-    if (d.activation == 0) {
+    if (d.activation == 2) {
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) d.probs[p * nc + k] = z[k];
+    } else if (d.activation == 0) {
       float mx = z[0]; int am = 0;
 #pragma unroll
       for (int k = 1; k < HEAD_NCMAX; ++k) if (k < nc && z[k] > mx) { mx = z[k]; }
@@ -523,7 +526,10 @@ __global__ __launch_bounds__(EW_BLOCK) void head_fwd_fast_kernel(const satcv_hea
         for (int k = 0; k < NC; ++k) z[k] += a * w[g * 8 + e][k];
       }
     }
-    if (d.activation == 0) {
+    if (d.activation == 2) {            // linear: raw logits (DeepLab head, upsampled later)
+#pragma unroll
+      for (int k = 0; k < NC; ++k) d.probs[p * NC + k] = z[k];
+    } else if (d.activation == 0) {
       float mx = z[0];
 #pragma unroll
       for (int k = 1; k < NC; ++k) mx = fmaxf(mx, z[k]);
@@ -716,6 +722,135 @@ extern "C" int satcv_head_bwd(const satcv_head_desc* d, void* stream) {
       { if (d->bnr_sums) { satcv_set_error("head_bwd: bnr fusion only on the register-resident kernel (cin in 16/32/64, small ncls)"); return SATCV_ERR_UNSUPPORTED; }
         hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(ew_grid(d->npix, 1024)), dim3(EW_BLOCK), lds, (hipStream_t)stream, *d); } });
   LAUNCH_OK("head_bwd");
+  return SATCV_OK;
+}
+
+// ------------------------------------------------- ResNet / DeepLab inference helpers (build-defined)
+// general max pooling on an activated NHWC tensor: window k, stride s, symmetric padding pad (-inf padded)
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ out, int n, int h, int w, int c, int k, int s, int pad, int ho, int wo) {
+  const int G = c / 8;
+  const long long total = (long long)n * ho * wo * G;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(it % G);
+    long long p = it / G;
+    const int ox = (int)(p % wo); p /= wo;
+    const int oy = (int)(p % ho);
+    const int img = (int)(p / ho);
+    float mx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
+    for (int i = 0; i < k; ++i) {
+      const int y = oy * s + i - pad; if (y < 0 || y >= h) continue;
+      for (int j = 0; j < k; ++j) {
+        const int xx = ox * s + j - pad; if (xx < 0 || xx >= w) continue;
+        float v[8];
+        load8<T>(x + ((size_t)(img * h + y) * w + xx) * c + g * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], v[e]);
+      }
+    }
+    store8<T>(out + ((size_t)(img * ho + oy) * wo + ox) * c + g * 8, mx);
+  }
+}
+extern "C" int satcv_maxpool(const void* x, void* out, int32_t n, int32_t h, int32_t w_, int32_t c, int32_t k, int32_t s, int32_t pad, int32_t dtype,
+                             void* stream) {
+  SATCV_CHECK(x && out && n > 0 && h > 0 && w_ > 0 && c > 0 && c % 8 == 0 && k >= 1 && s >= 1 && pad >= 0, "maxpool: bad args");
+  const int ho = (h + 2 * pad - k) / s + 1, wo = (w_ + 2 * pad - k) / s + 1;
+  SATCV_CHECK(ho > 0 && wo > 0, "maxpool: empty output");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_kernel<T>, dim3(ew_grid((long long)n * ho * wo * (c / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                                       (const T*)x, (T*)out, n, h, w_, c, k, s, pad, ho, wo));
+  LAUNCH_OK("maxpool");
+  return SATCV_OK;
+}
+// out = relu?( affine?(y) + affine?(res) ): the residual join of a bottleneck block
+template <typename T>
+__global__ void add_act_kernel(const T* __restrict__ y, const float* __restrict__ ysc, const float* __restrict__ ysh, const T* __restrict__ res,
+                               const float* __restrict__ rsc, const float* __restrict__ rsh, int relu, T* __restrict__ out, long long npix, int c) {
+  const int G = c / 8;
+  const long long total = npix * G;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(it % G);
+    const long long p = it / G;
+    float a[8], b[8];
+    load8<T>(y + p * c + g * 8, a);
+    load8<T>(res + p * c + g * 8, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = g * 8 + e;
+      float u = ysc ? a[e] * ysc[ch] + ysh[ch] : a[e];
+      const float r = rsc ? b[e] * rsc[ch] + rsh[ch] : b[e];
+      u += r;
+      a[e] = relu ? fmaxf(u, 0.f) : u;
+    }
+    store8<T>(out + p * c + g * 8, a);
+  }
+}
+extern "C" int satcv_add_act(const void* y, const float* y_scale, const float* y_shift, const void* res, const float* res_scale, const float* res_shift,
+                             int32_t relu, void* out, int64_t npix, int32_t c, int32_t dtype, void* stream) {
+  SATCV_CHECK(y && res && out && npix > 0 && c > 0 && c % 8 == 0, "add_act: bad args");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(add_act_kernel<T>, dim3(ew_grid(npix * (c / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)y, y_scale,
+                                       y_shift, (const T*)res, res_scale, res_shift, relu, (T*)out, (long long)npix, c));
+  LAUNCH_OK("add_act");
+  return SATCV_OK;
+}
+// bilinear upsampling (half-pixel centres, edge clamped -- tf.keras UpSampling2D(interpolation='bilinear')) of fp32 logits by an
+// integer factor, then softmax + argmax (or sigmoid + threshold)
+__global__ void upsample_head_kernel(const float* __restrict__ logits, int n, int h, int w, int nc, int f, int activation, float thresh,
+                                     float* __restrict__ probs, int32_t* __restrict__ classes) {
+  const int ho = h * f, wo = w * f;
+  const long long total = (long long)n * ho * wo;
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(p % wo);
+    const int oy = (int)((p / wo) % ho);
+    const int img = (int)(p / ((long long)wo * ho));
+    const float sy = fminf(fmaxf((oy + 0.5f) / f - 0.5f, 0.f), (float)(h - 1));
+    const float sx = fminf(fmaxf((ox + 0.5f) / f - 0.5f, 0.f), (float)(w - 1));
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float fy = sy - y0, fx = sx - x0;
+    const float* b = logits + (size_t)img * h * w * nc;
+    float z[HEAD_NCMAX];
+#pragma unroll
+    for (int k = 0; k < HEAD_NCMAX; ++k) {
+      z[k] = -INFINITY;
+      if (k < nc) {
+        const float v00 = b[((size_t)y0 * w + x0) * nc + k], v01 = b[((size_t)y0 * w + x1) * nc + k];
+        const float v10 = b[((size_t)y1 * w + x0) * nc + k], v11 = b[((size_t)y1 * w + x1) * nc + k];
+        z[k] = (v00 * (1.f - fx) + v01 * fx) * (1.f - fy) + (v10 * (1.f - fx) + v11 * fx) * fy;
+      }
+    }
+    if (activation == 0) {
+      float mx = z[0];
+#pragma unroll
+      for (int k = 1; k < HEAD_NCMAX; ++k) if (k < nc) mx = fmaxf(mx, z[k]);
+      float s = 0.f, ex[HEAD_NCMAX];
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) { ex[k] = k < nc ? expf(z[k] - mx) : 0.f; s += ex[k]; }
+      float best = -1.f; int am = 0;
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) {
+        const float pr = ex[k] / s;
+        probs[p * nc + k] = pr;
+        if (pr > best) { best = pr; am = k; }
+      }
+      if (classes) classes[p] = am;
+    } else {
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) {
+        const float pr = 1.f / (1.f + expf(-z[k]));
+        probs[p * nc + k] = pr;
+        if (classes) classes[p * nc + k] = pr > thresh ? 1 : 0;
+      }
+    }
+  }
+}
+extern "C" int satcv_upsample_head(const float* logits, int32_t n, int32_t h, int32_t w_, int32_t ncls, int32_t factor, int32_t activation, float thresh,
+                                   float* probs, int32_t* classes, void* stream) {
+  SATCV_CHECK(logits && probs && n > 0 && h > 0 && w_ > 0 && ncls >= 1 && ncls <= HEAD_NCMAX && factor >= 1, "upsample_head: bad args");
+  hipLaunchKernelGGL(upsample_head_kernel, dim3(ew_grid((long long)n * h * factor * w_ * factor)), dim3(EW_BLOCK), 0, (hipStream_t)stream, logits, n, h, w_,
+                     ncls, factor, activation, thresh, probs, classes);
+  LAUNCH_OK("upsample_head");
   return SATCV_OK;
 }
 

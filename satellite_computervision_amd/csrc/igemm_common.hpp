@@ -14,7 +14,7 @@ struct IgemmArgs {
   int cout, cout_pad;
   int kh, kw, dil;
   int mode_in, mode_out, f;
-  int cstat, out_relu, accumulate;
+  int cstat, out_relu, accumulate, stride;
   const void* bnr_y0; const void* bnr_y1; int bnr_c0, bnr_ld0, bnr_ld1;
   const float* bnr_scale; const float* bnr_shift; const float* bnr_mean; const float* bnr_rstd; float* bnr_sums; int bnr_sums_ld;
   // derived tiling

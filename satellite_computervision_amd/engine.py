@@ -260,6 +260,8 @@ class Plan:
         return a
 
     def _materialize(self, t, r, f=1, pooled=None, sink=None):
+        if not r.relu:
+            raise NotImplementedError('materialising a linear (no-ReLU) BatchNorm output')
         """relu(bn(raw)) -> dense activated tensor (and optional pooled / stats)."""
         (y, c) = r.srcs[0]
         hh, ww = r.h, r.w
@@ -334,6 +336,12 @@ class Plan:
                 if r.c != pk['cin_pad']:
                     raise ValueError(f'{lay.name}: input has {r.c} stored channels, kernel expects {pk["cin_pad"]}')
                 k, dil = node.attrs['k'], node.attrs['dil']
+                stride, relu_out = node.attrs.get('stride', 1), node.attrs.get('relu', True)
+                hin, win = r.h, r.w
+                if stride > 1:
+                    if training:
+                        raise NotImplementedError('strided convolutions are inference-only (DeepLab backbone)')
+                    r = TRef(r.srcs, r.n, (hin - 1) // stride + 1, (win - 1) // stride + 1, r.affine, r.relu)   # output grid
                 sl = slots.get(tout.id)
                 if sl is None:
                     y = self._z(n, r.h, r.w, cout)
@@ -343,10 +351,11 @@ class Plan:
                     y, stats, yoff, ldy, aoff, aff_in = sl['y'], sl['stats'], sl['off'], sl['ctot'], sl['off'], sl['aff']
                 self.fwd.append(self._conv_step(w=pk['fwd'].data_ptr(), bias=rt.pptr(lay.name + '/bias'), y=y.data_ptr() + yoff * es, ldy=ldy,
                                                 stats=_fp(stats, aoff), stats_ld=ldy, n=n, h=r.h, w_=r.w, cout=cout, cout_pad=rup(cout, 32),
-                                                kh=k, kw=k, dil=dil, dtype=dt, **self._src_args(r)))
+                                                kh=k, kw=k, dil=dil, dtype=dt, stride=stride, hin=hin if stride > 1 else 0,
+                                                win=win if stride > 1 else 0, **self._src_args(r)))
                 aff = self._bn_forward(lay.bn_name, stats, ldy, aoff, cout, n * r.h * r.w, node.attrs.get('bn_updates', 1), aff_in, aoff)
                 if sl is None:
-                    vals[tout.id] = TRef([(y, cout)], n, r.h, r.w, affine=aff, relu=True)
+                    vals[tout.id] = TRef([(y, cout)], n, r.h, r.w, affine=aff, relu=relu_out)
                 ctx[id(node)] = dict(r=r, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout, k=k, dil=dil)
             elif op == 'concat':
                 cx = ctx[id(node)]
@@ -403,6 +412,49 @@ class Plan:
                 aff = self._bn_forward(node.layer.name, st, ca + cb, 0, ca + cb, n * ra.h * ra.w, 1)
                 vals[tout.id] = TRef([ra.srcs[0], rb.srcs[0]], n, ra.h, ra.w, affine=aff, relu=True)
                 ctx[id(node)] = dict(ra=ra, rb=rb, aff=aff, ca=ca, cb=cb)
+            elif op == 'maxpool':
+                tin, tout = node.inputs[0], node.outputs[0]
+                r = vals[tin.id]
+                if r.affine:
+                    r = self._materialize(tin, r)
+                (src, c) = r.srcs[0]
+                kk, ss, pp = node.attrs['k'], node.attrs['s'], node.attrs['pad']
+                ho, wo = (r.h + 2 * pp - kk) // ss + 1, (r.w + 2 * pp - kk) // ss + 1
+                out = self._z(n, ho, wo, c)
+                self.fwd.append(lambda st, src=src, out=out, hh=r.h, ww=r.w, c=c, kk=kk, ss=ss, pp=pp: check(lib.satcv_maxpool(
+                    src.data_ptr(), out.data_ptr(), n, hh, ww, c, kk, ss, pp, dt, st)))
+                vals[tout.id] = TRef([(out, c)], n, ho, wo)
+            elif op == 'add_relu':
+                ty, tsc = node.inputs
+                tout = node.outputs[0]
+                ry, rs = vals[ty.id], vals[tsc.id]
+                if len(ry.srcs) != 1 or len(rs.srcs) != 1 or ry.relu or (rs.affine and rs.relu):
+                    raise NotImplementedError('residual join expects linear (BN without ReLU) branches')
+                (yb, c), (sb, c2) = ry.srcs[0], rs.srcs[0]
+                assert c == c2 and (ry.h, ry.w) == (rs.h, rs.w)
+                out = self._z(n, ry.h, ry.w, c)
+                ya, sa = ry.affine, rs.affine
+                npx = n * ry.h * ry.w
+                self.fwd.append(lambda st, yb=yb, sb=sb, out=out, ya=ya, sa=sa, npx=npx, c=c: check(lib.satcv_add_act(
+                    yb.data_ptr(), _fp(ya['scale']) if ya else None, _fp(ya['shift']) if ya else None, sb.data_ptr(),
+                    _fp(sa['scale']) if sa else None, _fp(sa['shift']) if sa else None, 1, out.data_ptr(), npx, c, dt, st)))
+                vals[tout.id] = TRef([(out, c)], n, ry.h, ry.w)
+            elif op == 'upsample_head':
+                tin, tout = node.inputs[0], node.outputs[0]
+                lg = self.outputs[tin.id]                         # fp32 logits written by the linear head
+                hctx = ctx[id(tin.node)]
+                f = node.attrs['factor']
+                act = 0 if node.attrs['activation'] == 'softmax' else 1
+                hh, ww, ncls = hctx['r'].h, hctx['r'].w, hctx['ncls']
+                probs = self._z(n, hh * f, ww * f, ncls, dtype=torch.float32)
+                classes = self._z(*((n, hh * f, ww * f) if act == 0 else (n, hh * f, ww * f, ncls)), dtype=torch.int32)
+                th = float(node.attrs.get('thresh', 0.5))
+                self.fwd.append(lambda st, lg=lg, probs=probs, classes=classes, hh=hh, ww=ww, ncls=ncls, f=f, act=act, th=th: check(
+                    lib.satcv_upsample_head(lg.data_ptr(), n, hh, ww, ncls, f, act, th, probs.data_ptr(), classes.data_ptr(), st)))
+                self.outputs[tout.id] = probs
+                ctx[id(node)] = dict(classes=classes)
+                if training:
+                    raise NotImplementedError('the up-sampling head is inference-only')
             elif op == 'dropout':
                 tin, tout = node.inputs[0], node.outputs[0]
                 r = vals[tin.id]
@@ -443,11 +495,11 @@ class Plan:
                     raise NotImplementedError('head on concatenated input')
                 lay = node.layer
                 ncls = tout.channels
-                act = 0 if node.attrs['activation'] == 'softmax' else 1
+                act = {'softmax': 0, 'sigmoid': 1, 'linear': 2}[node.attrs['activation']]
                 (y, c) = r.srcs[0]
                 npix = n * r.h * r.w
                 probs = self._z(n, r.h, r.w, ncls, dtype=torch.float32)
-                classes = self._z(*((n, r.h, r.w) if act == 0 else (n, r.h, r.w, ncls)), dtype=torch.int32)
+                classes = self._z(*((n, r.h, r.w) if act != 1 else (n, r.h, r.w, ncls)), dtype=torch.int32)
                 hd = ops.make_head_desc(x=y.data_ptr(), ldx=c, cin=c, w=rt.pptr(lay.name + '/kernel'), b=rt.pptr(lay.name + '/bias'),
                                         ncls=ncls, activation=act, npix=npix, dtype=dt,
                                         in_scale=_fp(r.affine['scale']) if r.affine else None,

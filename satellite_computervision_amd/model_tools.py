@@ -154,10 +154,12 @@ class conv_batch_act:
     Lowered to ONE node: implicit-GEMM conv kernel with BN statistics in its epilogue; the BN
     affine + ReLU is applied by the consumer's loader."""
 
-    def __init__(self, num_filters, kernel_size=(3, 3), dilation_rate=1, name='conv_batch_act', **kwargs):
+    def __init__(self, num_filters, kernel_size=(3, 3), dilation_rate=1, name='conv_batch_act', strides=1, activation='relu', **kwargs):
         self.name = name
         ks = _pair(kernel_size)
-        assert ks[0] == ks[1] and ks[0] in (1, 3), 'kernel_size must be (1,1) or (3,3)'
+        assert ks[0] == ks[1] and ks[0] % 2 == 1, 'kernel_size must be odd and square'
+        self.strides = strides if isinstance(strides, int) else strides[0]      # extension (ResNet backbone): strided / linear variants
+        self.activation = activation
         self.conv_layer = _ConvParams(_unique('conv2d'), num_filters, ks)
         self.bn_layer = _BNParams()
         self.conv_layer.bn_name = self.bn_layer.name
@@ -180,8 +182,8 @@ class conv_batch_act:
         self.conv_layer.build(inputs.channels)
         self.bn_layer.build(self.num_filters)
         node = E.Node('cba', [inputs], layer=self.conv_layer, k=self.conv_layer.kernel_size[0], dil=self.dilation_rate,
-                      bn_updates=bn_updates or self.bn_updates, owner=self)
-        return node.out(self.num_filters, inputs.down)
+                      bn_updates=bn_updates or self.bn_updates, owner=self, stride=self.strides, relu=self.activation == 'relu')
+        return node.out(self.num_filters, inputs.down / self.strides)
 
     call = __call__
 
@@ -351,6 +353,47 @@ def get_unet_model(nclasses, nchannels, filters=[32, 64, 128, 256, 512], factors
                           bias=bias, dropout=dropout, head_name=head_name, double_conv=double_conv)
     return model
 
+
+
+# ------------------------------------------------------------- DeepLab-v3 (build-defined)
+def _add_relu(y, shortcut):
+    node = E.Node('add_relu', [y, shortcut])
+    return node.out(y.channels, y.down)
+
+
+def _bottleneck(x, width, stride=1, dilation=1, downsample=False):
+    """ResNet-50 bottleneck: 1x1 -> 3x3 (stride / dilation) -> 1x1 (BN, no ReLU) + shortcut -> ReLU."""
+    y = conv_batch_act(width, (1, 1))(x)
+    y = conv_batch_act(width, (3, 3), dilation_rate=dilation, strides=stride)(y)
+    y = conv_batch_act(4 * width, (1, 1), activation=None)(y)
+    sc = conv_batch_act(4 * width, (1, 1), strides=stride, activation=None)(x) if downsample else x
+    return _add_relu(y, sc)
+
+
+def get_deeplabv3_model(nclasses, nchannels=4, aspp_filters=256, blocks=(3, 4, 6, 3), widths=(64, 128, 256, 512), head_name: str = ''):
+    """DeepLab-v3 with a ResNet-50 backbone at output stride 16 and the reference's ASPP block (BASELINE config 3).
+
+    The reference only NAMES this model (README.md:8): nothing of it exists under utils/.  It is therefore
+    build-defined: ResNet-50 v1.5 (stride on the 3x3, last stage dilated by 2),
+    a 4-band stem for NAIP RGBN tiles, DilatedSpatialPyramidPooling (utils/model_tools.py:533-574) on the
+    stride-16 features, a 1x1 classifier, x16 bilinear up-sampling, softmax and argmax.  Inference only."""
+    inputs = Input(shape=[None, None, nchannels])
+    x = conv_batch_act(64, (7, 7), strides=2)(inputs)
+    n_mp = E.Node('maxpool', [x], k=3, s=2, pad=1)
+    x = n_mp.out(x.channels, x.down / 2)
+    strides, dilations = (1, 2, 2, 1), (1, 1, 1, 2)
+    for stage, (nb, wdt) in enumerate(zip(blocks, widths)):
+        for b in range(nb):
+            x = _bottleneck(x, wdt, stride=strides[stage] if b == 0 else 1, dilation=dilations[stage], downsample=(b == 0))
+    x = DilatedSpatialPyramidPooling(aspp_filters)(x)
+    logits = _Head(nclasses, 'linear', None, 'logits')(x)
+    n_up = E.Node('upsample_head', [logits], factor=16, activation='softmax')
+    probs = n_up.out(nclasses, Fraction(1), 'probs')
+    classes = _classes(probs, f'{head_name}classes')
+    model = Model(inputs=inputs, outputs=[probs, classes])
+    model._builder = dict(fn='get_deeplabv3_model', nclasses=nclasses, nchannels=nchannels, aspp_filters=aspp_filters, blocks=list(blocks),
+                          widths=list(widths), head_name=head_name)
+    return model
 
 # ---------------------------------------------------------------------------- losses
 class LossSpec:

@@ -399,3 +399,45 @@ def test_config4_13_band_tiles_and_config5_1024_scene(mt):
     ref = OT.predict_chips(scene, idx, np.zeros(scene.shape[:2]), lambda chip: o4.forward(chip, training=False)[0], kernel=256, buff=128)
     np.testing.assert_allclose(got, ref, atol=5e-5)
     assert not got[:64].any() and not got[832:].any() and not got[:, :64].any() and not got[:, 832:].any()
+
+
+@pytest.mark.parametrize('dtype,size', [('float32', 64), ('bfloat16', 128)])
+def test_deeplabv3_resnet50_inference(mt, dtype, size):
+    """BASELINE config 3 (build-defined): DeepLab-v3 ResNet-50 (OS16) + the reference's ASPP on NAIP-like 4-band
+    tiles, inference.  Self-consistency against the PyTorch-CPU restatement of the same graph and weights."""
+    from oracle import torch_unet as TU
+    mt.reset_uids(); mt.set_seed(3)
+    m = mt.get_deeplabv3_model(3, 4)
+    m.compute_dtype = dtype
+    rng = np.random.default_rng(13)
+    w = {}
+    for ps in m.param_specs:
+        if ps.kind == 'kernel':
+            w[ps.name] = (rng.standard_normal(ps.shape) * np.sqrt(1.0 / np.prod(ps.shape[:3]))).astype(np.float32)
+        elif ps.kind == 'moving_var':
+            w[ps.name] = (0.5 + rng.random(ps.shape)).astype(np.float32)
+        elif ps.kind == 'gamma':
+            w[ps.name] = (1 + 0.1 * rng.standard_normal(ps.shape)).astype(np.float32)
+        else:
+            w[ps.name] = (0.1 * rng.standard_normal(ps.shape)).astype(np.float32)
+    m.set_weights_dict(w)
+    plist = []
+    for nd in m.nodes:
+        if nd.op == 'cba':
+            bn = nd.attrs['owner'].bn_layer.name
+            plist.append({'kernel': torch.tensor(w[nd.layer.name + '/kernel'], dtype=torch.float64), 'bias': torch.tensor(w[nd.layer.name + '/bias'], dtype=torch.float64),
+                          **{k: torch.tensor(w[f'{bn}/{k}'], dtype=torch.float64) for k in ('gamma', 'beta', 'moving_mean', 'moving_var')}})
+    head = (torch.tensor(w['logits/kernel'], dtype=torch.float64), torch.tensor(w['logits/bias'], dtype=torch.float64))
+    x = (rng.integers(0, 256, (2, size, size, 4)) / 255.0).astype(np.float32)            # NAIP uint8 / 255 (utils/processing.py:601)
+    with torch.no_grad():
+        p_ref, c_ref = TU.deeplab_forward(plist, head, torch.tensor(x, dtype=torch.float64))
+    probs, classes = m.predict(x)
+    assert probs.shape == (2, size, size, 3) and classes.shape == (2, size, size) and classes.dtype == np.int32
+    p_ref = p_ref.numpy()
+    np.testing.assert_allclose(probs, p_ref, atol=2e-4 if dtype == 'float32' else 6e-2)
+    srt = np.sort(p_ref, -1)
+    ok = (srt[..., -1] - srt[..., -2]) > (1e-3 if dtype == 'float32' else 0.15)
+    assert np.array_equal(classes[ok], c_ref.numpy()[ok])
+    with pytest.raises(NotImplementedError):
+        m.compile(optimizer=mt.Adam(), loss=lambda a, b: mt.weighted_categorical_crossentropy(a, b, [1, 1, 1]))
+        m.train_on_batch(x, np.zeros((2, size, size, 3), np.float32))
