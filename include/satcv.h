@@ -120,6 +120,7 @@ typedef struct satcv_wgrad_desc {
   int32_t transposed;                /* dw layout (f,f,cout,cin) */
   float* workspace; int64_t workspace_bytes;
   int32_t dtype;
+  int32_t accumulate;                /* dw += result (a layer applied to several inputs: shared weights) */
 } satcv_wgrad_desc;
 int64_t satcv_conv2d_wgrad_workspace(const satcv_wgrad_desc* d);
 int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream);
@@ -141,7 +142,7 @@ int satcv_bn_affine_infer(const float* gamma, const float* beta, const float* mo
 /* act = relu(scale*yraw+shift) (written if act != NULL), pooled = maxpool_f(act) ('valid'),
  * optional sum/sumsq rows of `act` (feeds the decoder's concat BatchNormalization).
  * Replaces Activation('relu') + MaxPooling2D (utils/model_tools.py:180,281). */
-int satcv_bn_relu_pool(const void* yraw, const float* scale, const float* shift, void* act,
+int satcv_bn_relu_pool(const void* yraw, const float* scale, const float* shift, void* act, int32_t act_ld,
                        void* pooled, float* stats, int32_t stats_ld, int32_t n, int32_t h,
                        int32_t w_, int32_t c, int32_t f, int32_t dtype, void* stream);
 
@@ -165,7 +166,7 @@ typedef struct satcv_bnbwd_desc {
 } satcv_bnbwd_desc;
 int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream);
 int satcv_bn_bwd_finalize(float* sums, int32_t sums_ld, int32_t c, float count, float* dgamma,
-                          float* dbeta, float* coef, void* stream);
+                          float* dbeta, float* coef, int32_t accumulate, void* stream);
 int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream);
 
 /* ------------------------------------------ ResNet / DeepLab-v3 inference helpers

@@ -143,3 +143,27 @@ def deeplab_forward(plist, head, x_nhwc, blocks=(3, 4, 6, 3), widths=(64, 128, 2
     logits = F.interpolate(logits, scale_factor=16, mode='bilinear', align_corners=False)
     probs = torch.softmax(logits, dim=1).permute(0, 2, 3, 1)
     return probs, torch.argmax(probs, dim=-1).to(torch.int32)
+
+
+def siamese_forward(p, xa_nhwc, xb_nhwc, filters, factors, training=False):
+    """Siamese U-Net of utils/model_tools.py:576-663 (shared encoder + shared ASPP, sigmoid head).
+    Parameter names: enc{i}.*, aspp.{cba,cba3_3,cba3_6,cba3_12,cba3}.*, dec{j}.{up,bn0,conv1,conv2}.*, probs.*"""
+    def cba(name, t, d=1):
+        return F.relu(_bn(_conv(t, p[f'{name}.kernel'], p[f'{name}.bias'], d), p, f'{name}.bn', training))
+
+    def aspp(t):
+        br = [cba('aspp.cba', t), cba('aspp.cba3_3', t, 3), cba('aspp.cba3_6', t, 6), cba('aspp.cba3_12', t, 12)]
+        return cba('aspp.cba3', torch.cat(br, dim=1))
+    a, b = xa_nhwc.permute(0, 3, 1, 2), xb_nhwc.permute(0, 3, 1, 2)
+    skips = []
+    for i in range(len(filters)):
+        ea, eb = cba(f'enc{i}', a), cba(f'enc{i}', b)
+        skips.append(torch.cat([eb, ea], dim=1))                      # Concatenate([encoded_b, encoded_a]) (:608)
+        a, b = F.max_pool2d(ea, factors[i], factors[i]), F.max_pool2d(eb, factors[i], factors[i])
+    h = torch.cat([aspp(b), aspp(a)], dim=1)                          # Concatenate([aspp_b, aspp_a]) (:624)
+    for j in range(len(filters) - 1, -1, -1):
+        up = F.conv_transpose2d(h, p[f'dec{j}.up.kernel'].permute(3, 2, 0, 1), p[f'dec{j}.up.bias'], stride=factors[j])
+        a0 = F.relu(_bn(torch.cat([skips[j], up], dim=1), p, f'dec{j}.bn0', training))
+        h = cba(f'dec{j}.conv2', cba(f'dec{j}.conv1', a0))
+    probs = torch.sigmoid(_conv(h, p['probs.kernel'], p['probs.bias'])).permute(0, 2, 3, 1)
+    return probs

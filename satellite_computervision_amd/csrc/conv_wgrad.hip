@@ -311,7 +311,7 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 2) void wgrad_kernel(const Wgra
 // dw (Keras layout) = sum over slabs in a fixed order (deterministic): 64 outputs x 4 split lanes
 // per block, each lane sums every 4th slab, LDS combines the 4 partial sums.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab, int taps, int kpad,
-                                                           int npad, int cin, int nvalid, int transposed) {
+                                                           int npad, int cin, int nvalid, int transposed, int accumulate) {
   __shared__ float part[4][64];
   const long long total = (long long)taps * cin * nvalid;
   const size_t slab = (size_t)taps * kpad * npad;
@@ -335,8 +335,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     __syncthreads();
     if (sl == 0 && it < total) {
       const float r = (part[0][ol] + part[1][ol]) + (part[2][ol] + part[3][ol]);
-      if (transposed) dw[(size_t)co * cin + ci] = r;
-      else dw[((size_t)tap * cin + ci) * nvalid + co] = r;
+      float* dst = transposed ? dw + (size_t)co * cin + ci : dw + ((size_t)tap * cin + ci) * nvalid + co;
+      *dst = accumulate ? *dst + r : r;
     }
     __syncthreads();
   }
@@ -454,7 +454,7 @@ static int wgrad_reduce_launch(const satcv_wgrad_desc* d, const WgradPlan& p, fl
   const long long total = (long long)p.ntaps * d->cin * nvalid;
   int grid = (int)((total + 63) / 64); if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, d->workspace, dw, p.nsplit, p.ntaps, p.kpad, p.npad, d->cin, nvalid,
-                     d->transposed);
+                     d->transposed, d->accumulate);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("wgrad reduce launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
   return SATCV_OK;

@@ -192,7 +192,7 @@ __device__ __forceinline__ void block_channel_reduce(float* lds, const float (&a
 template <typename T>
 __global__ void bn_relu_pool_kernel(const T* __restrict__ yraw, const float* __restrict__ scale, const float* __restrict__ shift,
                                     T* __restrict__ act, T* __restrict__ pooled, float* stats, int stats_ld,
-                                    int n, int h, int w, int c, int f) {
+                                    int n, int h, int w, int c, int f, int act_ld) {
   extern __shared__ float lds[];
   const int G = c / 8;
   const int hp = h / f, wp = w / f;               // 'valid' pooling
@@ -229,7 +229,7 @@ __global__ void bn_relu_pool_kernel(const T* __restrict__ yraw, const float* __r
             a = round_to<T>(a);
             v[e] = a; mx[e] = fmaxf(mx[e], a); s1[e] += a; s2[e] += a * a;
           }
-          if (act) store8<T>(act + off, v);
+          if (act) store8<T>(act + ((size_t)(img * h + y) * w + x) * act_ld + g * 8, v);
         }
       }
       if (pooled && py < hp && px < wp) store8<T>(pooled + ((size_t)(img * hp + py) * wp + px) * c + g * 8, mx);
@@ -237,12 +237,13 @@ __global__ void bn_relu_pool_kernel(const T* __restrict__ yraw, const float* __r
   }
   if (stats) block_channel_reduce(lds, s1, s2, g, active, c, stats, stats_ld);
 }
-extern "C" int satcv_bn_relu_pool(const void* yraw, const float* scale, const float* shift, void* act, void* pooled, float* stats,
+extern "C" int satcv_bn_relu_pool(const void* yraw, const float* scale, const float* shift, void* act, int32_t act_ld, void* pooled, float* stats,
                                   int32_t stats_ld, int32_t n, int32_t h, int32_t w_, int32_t c, int32_t f, int32_t dtype, void* stream) {
+  if (act_ld <= 0) act_ld = c;
   SATCV_CHECK(yraw && scale && shift && n > 0 && h > 0 && w_ > 0 && c > 0 && c % 8 == 0 && c <= 2048 && f >= 1, "bn_relu_pool: bad args");
   const long long items = (long long)n * cdiv(h, f) * cdiv(w_, f) * (c / 8);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_pool_kernel<T>, dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? 2 * c * sizeof(float) : 0, (hipStream_t)stream,
-                                       (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f));
+                                       (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld));
   LAUNCH_OK("bn_relu_pool");
   return SATCV_OK;
 }
@@ -418,7 +419,7 @@ extern "C" int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream) {
   LAUNCH_OK("bn_bwd_apply");
   return SATCV_OK;
 }
-__global__ void bn_bwd_finalize_kernel(float* sums, int ld, int c, float count, float* dgamma, float* dbeta, float* coef) {
+__global__ void bn_bwd_finalize_kernel(float* sums, int ld, int c, float count, float* dgamma, float* dbeta, float* coef, int accumulate) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
   float s1 = 0.f, s2 = 0.f;
@@ -427,13 +428,14 @@ __global__ void bn_bwd_finalize_kernel(float* sums, int ld, int c, float count, 
     s1 += row[ch]; s2 += row[ld + ch];
     row[ch] = 0.f; row[ld + ch] = 0.f;
   }
-  if (dbeta) dbeta[ch] = s1;
-  if (dgamma) dgamma[ch] = s2;
+  if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + s1 : s1;
+  if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + s2 : s2;
   coef[ch] = s1 / count; coef[c + ch] = s2 / count;
 }
-extern "C" int satcv_bn_bwd_finalize(float* sums, int32_t sums_ld, int32_t c, float count, float* dgamma, float* dbeta, float* coef, void* stream) {
+extern "C" int satcv_bn_bwd_finalize(float* sums, int32_t sums_ld, int32_t c, float count, float* dgamma, float* dbeta, float* coef, int32_t accumulate,
+                                     void* stream) {
   SATCV_CHECK(sums && coef && c > 0 && sums_ld >= c && count > 0, "bn_bwd_finalize: bad args");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 128)), dim3(128), 0, (hipStream_t)stream, sums, sums_ld, c, count, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 128)), dim3(128), 0, (hipStream_t)stream, sums, sums_ld, c, count, dgamma, dbeta, coef, accumulate);
   LAUNCH_OK("bn_bwd_finalize");
   return SATCV_OK;
 }

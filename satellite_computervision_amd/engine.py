@@ -212,6 +212,8 @@ class Plan:
         self.fwd, self.bwd = [], []
         self.keep = []                        # ctypes descriptors / tensors kept alive
         self.dropouts = []                    # dropout masks (regenerated every training step)
+        self.x_inputs = []                    # fp32 staging tensor of every model input
+        self.x_by_tid = {}
         self.side = torch.cuda.Stream() if (training and rt.model.wgrad_side_stream) else None
         self.step_count = 0
         self.outputs = {}
@@ -259,22 +261,28 @@ class Plan:
             self.fwd.append(lambda st: check(lib.satcv_bn_affine_infer(g, b, mm, mv, BN_EPS, c, _fp(a['scale'], aoff), _fp(a['shift'], aoff), st)))
         return a
 
-    def _materialize(self, t, r, f=1, pooled=None, sink=None):
+    def _materialize(self, t, r, f=1, pooled=None, sink=None, actslot=None):
+        """relu(bn(raw)) -> dense activated tensor (and optional pooled / stats).  actslot = (tensor, channel offset,
+        channel stride): write into a slice of a shared concatenation buffer instead of a fresh tensor."""
         if not r.relu:
             raise NotImplementedError('materialising a linear (no-ReLU) BatchNorm output')
-        """relu(bn(raw)) -> dense activated tensor (and optional pooled / stats)."""
         (y, c) = r.srcs[0]
         hh, ww = r.h, r.w
-        act = self._z(self.n, hh, ww, c)
+        if actslot is None:
+            act = self._z(self.n, hh, ww, c)
+            act_ptr, act_ld = act.data_ptr(), c
+        else:
+            act = actslot[0]
+            act_ptr, act_ld = actslot[0].data_ptr() + actslot[1] * self.rt.esize, actslot[2]
         st_ptr, ld = (None, 0)
         if sink is not None and self.training:
             st_ptr, ld = _fp(sink[0], sink[1]), sink[2]
         a = r.affine
         dt = self.rt.dtype
         self.fwd.append(lambda st: check(lib.satcv_bn_relu_pool(
-            y.data_ptr(), _fp(a['scale']), _fp(a['shift']), act.data_ptr(), pooled.data_ptr() if pooled is not None else None,
+            y.data_ptr(), _fp(a['scale']), _fp(a['shift']), act_ptr, act_ld, pooled.data_ptr() if pooled is not None else None,
             st_ptr, ld, self.n, hh, ww, c, f, dt, st)))
-        return TRef([(act, c)], self.n, hh, ww)
+        return TRef([(act, c)], self.n, hh, ww) if actslot is None else None
 
     # -- lowering
     def _build(self):
@@ -296,9 +304,24 @@ class Plan:
                 sinks[a.id] = (st, 0, ctot)
                 sinks[b.id] = (st, a.channels, ctot)
 
-        slots = {}
+        slots, actslots = {}, {}
         for node in m.nodes:
             if node.op == 'concat':
+                if all(t.node.op == 'cba' and len(consumers[t.id]) > 1 for t in node.inputs):
+                    # concatenation of ACTIVATED encoder outputs that are also pooled (Siamese skips): the pool kernels write
+                    # their activation straight into channel slices of one tensor
+                    ctot = sum(t.channels for t in node.inputs)
+                    hh, ww = self._dims(node.inputs[0])
+                    shared = self._z(n, hh, ww, ctot)
+                    off = 0
+                    for t in node.inputs:
+                        actslots[t.id] = (shared, off, ctot)
+                        if node.outputs[0].id in sinks:                      # statistics for the decoder's concat BatchNorm
+                            st_, so_, sl_ = sinks[node.outputs[0].id]
+                            sinks[t.id] = (st_, so_ + off, sl_)
+                        off += t.channels
+                    ctx[id(node)] = dict(act=shared, ctot=ctot)
+                    continue
                 if not all(t.node.op == 'cba' and len(consumers[t.id]) == 1 for t in node.inputs):
                     raise NotImplementedError('concatenate is supported for conv_batch_act outputs consumed only by the concat (ASPP)')
                 ctot = sum(t.channels for t in node.inputs)
@@ -321,6 +344,8 @@ class Plan:
                 x = self._z(n, self.h, self.w, cp)
                 xin = self._z(n, self.h, self.w, t.channels, dtype=torch.float32)
                 self.x_f32 = xin
+                self.x_inputs.append(xin)
+                self.x_by_tid[t.id] = xin
                 npix = n * self.h * self.w
                 cc = t.channels
                 self.fwd.append(lambda st, xin=xin, x=x, npix=npix, cc=cc, cp=cp: check(lib.satcv_ingest_nhwc(xin.data_ptr(), x.data_ptr(), npix, cc, cp, dt, st)))
@@ -360,7 +385,10 @@ class Plan:
             elif op == 'concat':
                 cx = ctx[id(node)]
                 hh, ww = self._dims(node.inputs[0])
-                vals[node.outputs[0].id] = TRef([(cx['y'], cx['ctot'])], n, hh, ww, affine=cx['aff'], relu=True)
+                if 'act' in cx:
+                    vals[node.outputs[0].id] = TRef([(cx['act'], cx['ctot'])], n, hh, ww)
+                else:
+                    vals[node.outputs[0].id] = TRef([(cx['y'], cx['ctot'])], n, hh, ww, affine=cx['aff'], relu=True)
             elif op == 'pool':
                 tin, tout = node.inputs[0], node.outputs[0]
                 r = vals[tin.id]
@@ -371,13 +399,13 @@ class Plan:
                 pooled = self._z(n, r.h // f, r.w // f, c)
                 others = [cn for cn in consumers[tin.id] if cn is not node]
                 if others:
-                    acts[tin.id] = self._materialize(tin, r, f, pooled, sinks.get(tin.id))
+                    acts[tin.id] = self._materialize(tin, r, f, pooled, sinks.get(tin.id), actslots.get(tin.id))
                 else:
                     (y, _) = r.srcs[0]
                     a = r.affine
                     hh, ww = r.h, r.w
                     self.fwd.append(lambda st, y=y, a=a, pooled=pooled, hh=hh, ww=ww, c=c, f=f: check(lib.satcv_bn_relu_pool(
-                        y.data_ptr(), _fp(a['scale']), _fp(a['shift']), None, pooled.data_ptr(), None, 0, n, hh, ww, c, f, dt, st)))
+                        y.data_ptr(), _fp(a['scale']), _fp(a['shift']), None, 0, pooled.data_ptr(), None, 0, n, hh, ww, c, f, dt, st)))
                 vals[tout.id] = TRef([(pooled, c)], n, r.h // f, r.w // f)
                 ctx[id(node)] = dict(f=f)
             elif op == 'convT':
@@ -535,7 +563,7 @@ class Plan:
         self.loss_buf = self._z(1, dtype=torch.float32)
 
         def bn_bwd_steps(da, ldda, dp, lddp, f, yraw, ldy, aff, aoff, sums, sums_off, sums_ld, c, hh, ww, dy, lddy, dbias,
-                         dgamma, dbeta):
+                         dgamma, dbeta, accum=0):
             coef = self._z(2, c, dtype=torch.float32)
             d = ops.make_bnbwd_desc(yraw=yraw, ldy=ldy, scale=_fp(aff['scale'], aoff), shift=_fp(aff['shift'], aoff),
                                     mean=_fp(aff['mean'], aoff), rstd=_fp(aff['rstd'], aoff), n=n, h=hh, w_=ww, c=c, dtype=dt,
@@ -544,10 +572,11 @@ class Plan:
             self.keep.append(d)
             cnt = float(n * hh * ww)
             red = lambda st: check(lib.satcv_bn_bwd_reduce(C.byref(d), st))
-            fin = lambda st: check(lib.satcv_bn_bwd_finalize(_fp(sums, sums_off), sums_ld, c, cnt, dgamma, dbeta, _fp(coef), st))
+            fin = lambda st: check(lib.satcv_bn_bwd_finalize(_fp(sums, sums_off), sums_ld, c, cnt, dgamma, dbeta, _fp(coef), accum, st))
             app = lambda st: check(lib.satcv_bn_bwd_apply(C.byref(d), st))
             return red, fin, app
 
+        seen_layers = set()     # layers applied more than once (shared weights): later visits accumulate their gradients
         fused = {}      # tensor id -> sums buffer whose BN-backward reduce pass was done by the producer of the gradient
         HEAD_FAST = {(1, 16), (2, 16), (1, 32), (2, 32), (3, 32), (4, 32), (1, 64), (2, 64)}
 
@@ -582,11 +611,11 @@ class Plan:
                     return lambda st, d=d: check(lib.satcv_conv2d_igemm(C.byref(d), st))
             return self._conv_step(**kw)
 
-        def wgrad_step(r, dy, lddy, lay, cin_real, cout, hh, ww, k, dil, f=0):
+        def wgrad_step(r, dy, lddy, lay, cin_real, cout, hh, ww, k, dil, f=0, accum=0):
             nonlocal ws_need
             sa = self._src_args(r)
             d = ops.make_wgrad_desc(dy=dy, lddy=lddy, dw=rt.gptr(lay.name + '/kernel'), cin=cin_real, cout=cout, n=n, h=hh, w_=ww,
-                                    dtype=dt, kh=k, kw=k, dil=dil, mode_dy=1 if f else 0, f=f if f else 1, transposed=1 if f else 0, **sa)
+                                    dtype=dt, kh=k, kw=k, dil=dil, mode_dy=1 if f else 0, f=f if f else 1, transposed=1 if f else 0, accumulate=accum, **sa)
             nb = lib.satcv_conv2d_wgrad_workspace(C.byref(d))
             if nb < 0:
                 raise RuntimeError(lib.satcv_last_error().decode())
@@ -639,16 +668,18 @@ class Plan:
                 pre = fused.get(tout.id)
                 sums = pre if pre is not None else self._z(STAT_ROWS, 2, cout, dtype=torch.float32)
                 dy = self._z(n, hh, ww, cout)
+                accum = 1 if lay.name in seen_layers else 0
+                seen_layers.add(lay.name)
                 da_ptr = da[0].data_ptr() + da[1] * es if da is not None else None
                 red, fin, app = bn_bwd_steps(da_ptr, da[2] if da is not None else 0, dp[0].data_ptr() if dp is not None else None,
                                              cout, gpool_f.get(tout.id, 1), y.data_ptr() + yoff * es, ldy, aff, aoff, sums, 0, cout, cout, hh, ww,
                                              dy.data_ptr(), cout, rt.gptr(lay.name + '/bias'),
-                                             rt.gptr(lay.bn_name + '/gamma'), rt.gptr(lay.bn_name + '/beta'))
+                                             rt.gptr(lay.bn_name + '/gamma'), rt.gptr(lay.bn_name + '/beta'), accum)
                 self.bwd += [fin, app] if pre is not None else [red, fin, app]
                 self.dbg['dy:' + lay.name] = dy
                 self.dbg['_ctx:' + lay.name] = dict(da=da, dp=dp, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout)
                 pk = rt.packed[lay.name]
-                self.bwd.append(wgrad_step(r, dy.data_ptr(), cout, lay, pk['cin'], cout, hh, ww, cx['k'], cx['dil']))
+                self.bwd.append(wgrad_step(r, dy.data_ptr(), cout, lay, pk['cin'], cout, hh, ww, cx['k'], cx['dil'], accum=accum))
                 if tin.node.op != 'input':
                     cinp = r.c
                     prev = gact.get(tin.id)

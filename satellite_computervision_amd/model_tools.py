@@ -355,6 +355,43 @@ def get_unet_model(nclasses, nchannels, filters=[32, 64, 128, 256, 512], factors
 
 
 
+
+# --------------------------------------------------------------------------- Siamese U-Net
+def get_siamese_layers(input_a, input_b, filters=[32, 64, 128], factors=[2, 2, 2]):
+    """utils/model_tools.py:576-636: shared-weight encoder on two dates, skips = concat([enc_b, enc_a]), shared ASPP on both
+    pooled tensors, squeezed = concat([aspp_b, aspp_a]), then the ordinary decoder."""
+    assert len(filters) == len(factors), 'filters and factors must be same length'
+    levels = len(filters)
+    net = {}
+    pooled_a, pooled_b = input_a, input_b
+    for i, filt in enumerate(filters):
+        encoder = encoder_block(filt, pool_size=(factors[i], factors[i]), name=f'encoder_{i}')
+        pooled_a, encoded_a = encoder(pooled_a)
+        pooled_b, encoded_b = encoder(pooled_b)
+        _unique('concatenate')
+        n_cat = E.Node('concat', [encoded_b, encoded_a])
+        net[f'encoder_{i}'] = n_cat.out(encoded_a.channels + encoded_b.channels, encoded_a.down)
+    aspp = DilatedSpatialPyramidPooling(filters[-1] * 2)
+    aspp_a = aspp(pooled_a)
+    aspp_b = aspp(pooled_b)
+    _unique('concatenate')
+    n_sq = E.Node('concat', [aspp_b, aspp_a])
+    decoder = n_sq.out(aspp_a.channels + aspp_b.channels, aspp_a.down)
+    for j in range(levels - 1, -1, -1):
+        decoder = decoder_block(decoder, net[f'encoder_{j}'], filters[j], up_size=(factors[j], factors[j]))
+    return decoder
+
+
+def make_siamese_unet(n_channels, filters, factors, bias=None, class_thresh=0.5):
+    """utils/model_tools.py:638-663: two inputs (T2 image a, T1 image b), sigmoid 1x1 head 'probs', classes = probs > class_thresh."""
+    bias_init = _Constant(bias) if bias is not None else None
+    input_a = Input((None, None, n_channels))
+    input_b = Input((None, None, n_channels))
+    decoder = get_siamese_layers(input_a, input_b, filters=filters, factors=factors)
+    probs = _Head(1, 'sigmoid', bias_init, 'probs')(decoder)
+    classes = _classes(probs, 'classes', thresh=class_thresh)
+    return Model(inputs=[input_a, input_b], outputs=[probs, classes])
+
 # ------------------------------------------------------------- DeepLab-v3 (build-defined, SURVEY A9)
 def _add_relu(y, shortcut):
     node = E.Node('add_relu', [y, shortcut])
@@ -550,13 +587,15 @@ class TensorBoard:
 # ----------------------------------------------------------------------------- Model
 def _as_batches(x, y, batch_size):
     """ndarray pair / Sequence / iterable of (x, y) -> generator of batches (possibly endless)."""
-    if y is not None or isinstance(x, (np.ndarray, torch.Tensor)):
-        n = x.shape[0]
+    multi = isinstance(x, (list, tuple)) and len(x) > 0 and all(isinstance(a, (np.ndarray, torch.Tensor)) for a in x)
+    if multi or y is not None or isinstance(x, (np.ndarray, torch.Tensor)):
+        n = x[0].shape[0] if multi else x.shape[0]
         bs = batch_size or 32
 
         def gen():
             for i in range(0, n, bs):
-                yield (x[i:i + bs], y[i:i + bs]) if y is not None else x[i:i + bs]
+                xb = [a[i:i + bs] for a in x] if multi else x[i:i + bs]
+                yield (xb, y[i:i + bs]) if y is not None else xb
         return gen(), (n + bs - 1) // bs
     if hasattr(x, '__getitem__') and hasattr(x, '__len__'):          # keras.utils.Sequence
 
@@ -576,8 +615,6 @@ class Model:
         self._single_output = not isinstance(outputs, (list, tuple))
         self.name = name
         self.nodes = E.topo_nodes(self.outputs)
-        if len(self.inputs) != 1:
-            raise NotImplementedError('multi-input models (Siamese) are not built yet')
         seen, self.layers, self.param_specs = set(), [], []
         for node in self.nodes:
             lay = node.layer
@@ -682,14 +719,23 @@ class Model:
         return self.runtime.plan(n, h, w, training)
 
     def _stage_x(self, plan, xb):
-        if isinstance(xb, torch.Tensor):
-            plan.x_f32.copy_(xb.to(torch.float32), non_blocking=True)
-        else:
-            plan.x_f32.copy_(torch.from_numpy(np.ascontiguousarray(xb, dtype=np.float32)), non_blocking=True)
+        xs = list(xb) if isinstance(xb, (list, tuple)) else [xb]
+        if len(xs) != len(self.inputs):
+            raise ValueError(f'model expects {len(self.inputs)} input array(s), got {len(xs)}')
+        for t, x in zip(self.inputs, xs):
+            dst = plan.x_by_tid[t.id]
+            if isinstance(x, torch.Tensor):
+                dst.copy_(x.to(torch.float32), non_blocking=True)
+            else:
+                dst.copy_(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)), non_blocking=True)
+
+    @staticmethod
+    def _shape_of(xb):
+        return (xb[0] if isinstance(xb, (list, tuple)) else xb).shape
 
     def predict_on_device(self, xb):
         """xb: (n,h,w,c) ndarray or device tensor -> list of device tensors [probs, classes] (no host sync)."""
-        n, h, w, _ = xb.shape
+        n, h, w, _ = self._shape_of(xb)
         plan = self._head_plan(n, h, w, False)
         self._stage_x(plan, xb)
         plan.run_forward(ops.stream_ptr())
@@ -700,10 +746,11 @@ class Model:
         inference-mode forward; ndarray or iterable of batches; list of arrays in output order."""
         batches, nb = _as_batches(x, None, batch_size or 32)
         outs = [[] for _ in self.outputs]
+        multi = len(self.inputs) > 1
         for i, xb in enumerate(batches):
             if steps is not None and i >= steps:
                 break
-            if isinstance(xb, (tuple, list)):
+            if isinstance(xb, (tuple, list)) and not multi:
                 xb = xb[0]
             res = self.predict_on_device(xb)
             for o, r in zip(outs, res):
@@ -764,7 +811,7 @@ class Model:
             raise RuntimeError('compile() the model before fit/train')
         rt = self.runtime
         rt.ensure_adam()
-        n, h, w, _ = xb.shape
+        n, h, w, _ = self._shape_of(xb)
         plan = self._head_plan(n, h, w, True)
         self._stage_x(plan, xb)
         self._stage_y(plan, yb)
@@ -813,7 +860,7 @@ class Model:
             if train:
                 plan = self.train_step_device(xb, yb, sync)
             else:
-                n, h, w, _ = xb.shape
+                n, h, w, _ = self._shape_of(xb)
                 plan = self._head_plan(n, h, w, False)
                 self._stage_x(plan, xb)
                 self._stage_y(plan, yb)

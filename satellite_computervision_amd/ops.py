@@ -158,14 +158,14 @@ def conv2d_transpose_dgrad(dy, w_dgrad, cin, cout, f, *, out=None):
 
 
 def make_wgrad_desc(*, x0, c0, dy, lddy, dw, cin, cout, n, h, w_, dtype, x1=None, c1=0, in_scale=None, in_shift=None,
-                    in_relu=0, kh=3, kw=3, dil=1, mode_dy=0, f=1, transposed=0, workspace=None, workspace_bytes=0):
+                    in_relu=0, kh=3, kw=3, dil=1, mode_dy=0, f=1, transposed=0, workspace=None, workspace_bytes=0, accumulate=0):
     d = WgradDesc()
     d.x0, d.x1, d.c0, d.c1 = x0, x1, c0, c1
     d.in_scale, d.in_shift, d.in_relu = in_scale, in_shift, int(in_relu)
     d.dy, d.lddy, d.dw, d.cin, d.cout = dy, lddy, dw, cin, cout
     d.n, d.h, d.w_, d.kh, d.kw, d.dil = n, h, w_, kh, kw, dil
     d.mode_dy, d.f, d.transposed = mode_dy, f, transposed
-    d.workspace, d.workspace_bytes, d.dtype = workspace, workspace_bytes, dtype
+    d.workspace, d.workspace_bytes, d.dtype, d.accumulate = workspace, workspace_bytes, dtype, int(accumulate)
     return d
 
 
@@ -216,7 +216,7 @@ def bn_relu_pool(yraw, scale, shift, f, want_act=True, want_pool=True, stats=Non
     n, h, w_, c = yraw.shape
     act = torch.empty_like(yraw) if want_act else None
     pooled = torch.empty(n, h // f, w_ // f, c, dtype=yraw.dtype, device=yraw.device) if want_pool else None
-    check(lib.satcv_bn_relu_pool(ptr(yraw), ptr(scale), ptr(shift), ptr(act), ptr(pooled), ptr(stats),
+    check(lib.satcv_bn_relu_pool(ptr(yraw), ptr(scale), ptr(shift), ptr(act), 0, ptr(pooled), ptr(stats),
                                  stats.shape[-1] if stats is not None else 0, n, h, w_, c, f, DTYPE_CODE[yraw.dtype], stream_ptr()))
     return act, pooled
 
@@ -249,7 +249,7 @@ def bn_relu_bwd(yraw, scale, shift, mean, rstd, da=None, dpool=None, f=1, want_d
                         lddp=dpool.shape[-1] if dpool is not None else 0, f=f, sums=_p(sums), sums_ld=c, coef=_p(coef),
                         dy=_p(dy), lddy_out=c, dbias=_p(dbias))
     check(lib.satcv_bn_bwd_reduce(C.byref(d), stream_ptr()))
-    check(lib.satcv_bn_bwd_finalize(ptr(sums), c, c, float(n * h * w_), ptr(dgamma), ptr(dbeta), ptr(coef), stream_ptr()))
+    check(lib.satcv_bn_bwd_finalize(ptr(sums), c, c, float(n * h * w_), ptr(dgamma), ptr(dbeta), ptr(coef), 0, stream_ptr()))
     check(lib.satcv_bn_bwd_apply(C.byref(d), stream_ptr()))
     return dy, dgamma, dbeta, dbias
 

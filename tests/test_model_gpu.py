@@ -441,3 +441,72 @@ def test_deeplabv3_resnet50_inference(mt, dtype, size):
     with pytest.raises(NotImplementedError):
         m.compile(optimizer=mt.Adam(), loss=lambda a, b: mt.weighted_categorical_crossentropy(a, b, [1, 1, 1]))
         m.train_on_batch(x, np.zeros((2, size, size, 3), np.float32))
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_siamese_unet_shared_weights_forward_backward(mt, dtype):
+    """make_siamese_unet (utils/model_tools.py:576-663): shared-weight encoder and ASPP applied to two dates, concatenated
+    skips, sigmoid head + threshold.  Predictions, weighted-BCE loss and the ACCUMULATED gradients of the shared layers
+    against the PyTorch-CPU restatement (autograd)."""
+    from oracle import torch_unet as TU
+    filters, factors = [32, 64], [2, 2]
+    mt.reset_uids(); mt.set_seed(4)
+    m = mt.make_siamese_unet(4, filters, factors, class_thresh=0.4)
+    m.compute_dtype = dtype
+    assert len(m.inputs) == 2 and [t.name for t in m.outputs] == ['probs', 'classes']
+    conv_of = {'enc0': 'conv2d', 'enc1': 'conv2d_2', 'aspp.cba': 'conv2d_4', 'aspp.cba3': 'conv2d_6', 'aspp.cba3_3': 'conv2d_7', 'aspp.cba3_6': 'conv2d_8',
+               'aspp.cba3_12': 'conv2d_9', 'dec1.conv1': 'conv2d_10', 'dec1.conv2': 'conv2d_11', 'dec0.conv1': 'conv2d_12', 'dec0.conv2': 'conv2d_13'}
+    ref_of = {'probs/kernel': 'probs.kernel', 'probs/bias': 'probs.bias', 'conv2d_transpose/kernel': 'dec1.up.kernel', 'conv2d_transpose/bias': 'dec1.up.bias',
+              'conv2d_transpose_1/kernel': 'dec0.up.kernel', 'conv2d_transpose_1/bias': 'dec0.up.bias'}
+    for rn, cn in conv_of.items():
+        ref_of[cn + '/kernel'] = rn + '.kernel'; ref_of[cn + '/bias'] = rn + '.bias'
+        idx = cn.split('_')[1] if '_' in cn else '0'
+        idx = {'10': '11', '11': '12', '12': '14', '13': '15'}.get(idx, idx)          # decoder convs follow a concat BN
+        bn = 'batch_normalization' if idx == '0' else f'batch_normalization_{idx}'
+        for s_ in ('gamma', 'beta', 'moving_mean', 'moving_var'):
+            ref_of[f'{bn}/{s_}'] = f'{rn}.bn.{s_}'
+    for bn, rn in (('batch_normalization_10', 'dec1.bn0'), ('batch_normalization_13', 'dec0.bn0')):
+        for s_ in ('gamma', 'beta', 'moving_mean', 'moving_var'):
+            ref_of[f'{bn}/{s_}'] = f'{rn}.{s_}'
+    assert set(ref_of) == {ps.name for ps in m.param_specs}, set(ref_of) ^ {ps.name for ps in m.param_specs}
+    rng = np.random.default_rng(17)
+    w = {}
+    for ps in m.param_specs:
+        if ps.kind == 'kernel':
+            w[ps.name] = (rng.standard_normal(ps.shape) * np.sqrt(2.0 / np.prod(ps.shape[:3]))).astype(np.float32)
+        elif ps.kind == 'moving_var':
+            w[ps.name] = (0.5 + rng.random(ps.shape)).astype(np.float32)
+        elif ps.kind == 'gamma':
+            w[ps.name] = (1 + 0.2 * rng.standard_normal(ps.shape)).astype(np.float32)
+        else:
+            w[ps.name] = (0.2 * rng.standard_normal(ps.shape)).astype(np.float32)
+    m.set_weights_dict(w)
+    tp = TU.params_to_torch({ref_of[k]: v for k, v in w.items()}, torch.float64)
+    xa = rng.random((2, 48, 48, 4)).astype(np.float32)
+    xb = rng.random((2, 48, 48, 4)).astype(np.float32)
+    t = (rng.random((2, 48, 48, 1)) < 0.3).astype(np.float32)
+    f32 = dtype == 'float32'
+    with torch.no_grad():
+        p_ref = TU.siamese_forward(tp, torch.tensor(xa, dtype=torch.float64), torch.tensor(xb, dtype=torch.float64), filters, factors).numpy()
+    probs, classes = m.predict([xa, xb])
+    assert probs.shape == (2, 48, 48, 1) and classes.shape == (2, 48, 48, 1) and classes.dtype == np.int32
+    np.testing.assert_allclose(probs, p_ref, atol=3e-5 if f32 else 5e-2)
+    ok = np.abs(p_ref - 0.4) > (1e-3 if f32 else 0.1)
+    assert np.array_equal(classes[ok], (p_ref > 0.4).astype(np.int32)[ok])
+    m.compile(optimizer=mt.Adam(1e-3), loss=lambda yt, yp: mt.weighted_bce(yt, yp, 5.0))
+    pr = TU.siamese_forward(tp, torch.tensor(xa, dtype=torch.float64), torch.tensor(xb, dtype=torch.float64), filters, factors, training=True)
+    lt = TU.weighted_bce_mean(torch.tensor(t, dtype=torch.float64), pr, 5.0); lt.backward()
+    loss = m.train_on_batch([xa, xb], t)
+    np.testing.assert_allclose(loss, lt.item(), rtol=3e-5 if f32 else 3e-2)
+    rt = m.runtime
+    bad = []
+    for k, rname in ref_of.items():
+        if 'moving' in k or (k.endswith('/bias') and not k.startswith('probs')):
+            continue
+        g = rt.get_grad(k).cpu().numpy().astype(np.float64)
+        r = tp[rname].grad.numpy()
+        cos = (g * r).sum() / (np.linalg.norm(g) * np.linalg.norm(r))
+        l2 = np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30)
+        if (f32 and (l2 > 2e-2 or cos < 0.9999)) or (not f32 and cos < 0.9):
+            bad.append(f'{rname}: relL2 {l2:.2e} cos {cos:.5f}')
+    assert not bad, '\\n'.join(bad)
