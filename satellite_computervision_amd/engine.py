@@ -20,7 +20,7 @@ from fractions import Fraction
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, parallel
 from ._lib import lib, check, F32, BF16, STAT_ROWS
 
 BN_EPS = 1e-3
@@ -217,6 +217,7 @@ class Plan:
         self.side = torch.cuda.Stream() if (training and rt.model.wgrad_side_stream) else None
         self.step_count = 0
         self.outputs = {}
+        self.sync_bn = bool(training and getattr(rt.model, 'sync_bn', False) and parallel.world_size() > 1)
         self._build()
 
     # -- helpers
@@ -254,6 +255,8 @@ class Plan:
         mm, mv = rt.sptr(bnname + '/moving_mean'), rt.sptr(bnname + '/moving_var')
         if self.training:
             bessel = 1 if rt.model.bn_bessel else 0
+            if self.sync_bn:            # SyncBN: [Σx, Σx²] averaged over replicas before the finalize
+                self.fwd.append(lambda st: parallel.allreduce_mean_(stats))
             self.fwd.append(lambda st: check(lib.satcv_bn_finalize_train(
                 _fp(stats, off), ld, c, float(count), g, b, BN_EPS, BN_MOMENTUM, updates, bessel, mm, mv,
                 _fp(a['scale'], aoff), _fp(a['shift'], aoff), _fp(a['mean'], aoff), _fp(a['rstd'], aoff), st)))
@@ -572,7 +575,13 @@ class Plan:
             self.keep.append(d)
             cnt = float(n * hh * ww)
             red = lambda st: check(lib.satcv_bn_bwd_reduce(C.byref(d), st))
-            fin = lambda st: check(lib.satcv_bn_bwd_finalize(_fp(sums, sums_off), sums_ld, c, cnt, dgamma, dbeta, _fp(coef), accum, st))
+            fin0 = lambda st: check(lib.satcv_bn_bwd_finalize(_fp(sums, sums_off), sums_ld, c, cnt, dgamma, dbeta, _fp(coef), accum, st))
+            if self.sync_bn:
+                def fin(st):            # SyncBN: Σdy, Σdy·x̂ averaged over replicas (linear + idempotent, so the whole buffer is reduced)
+                    parallel.allreduce_mean_(sums)
+                    fin0(st)
+            else:
+                fin = fin0
             app = lambda st: check(lib.satcv_bn_bwd_apply(C.byref(d), st))
             return red, fin, app
 

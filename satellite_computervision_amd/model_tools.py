@@ -630,6 +630,7 @@ class Model:
         self.bn_bessel = False
         self.fuse_bn_bwd = os.environ.get('SATCV_FUSE_BN_BWD', '0') == '1'   # BN-backward reduce pass inside the dgrad epilogues (measured: no gain, off)
         self.wgrad_side_stream = os.environ.get('SATCV_WGRAD_STREAM', '1') != '0'      # weight gradients on a second HIP stream
+        self.sync_bn = os.environ.get('SATCV_SYNC_BN', '0') == '1'      # data parallel: BatchNorm statistics over ALL replicas (parallel.py)
         self._rt = None
         self.optimizer, self._loss, self._metrics = None, None, []
         self.metrics_names = []

@@ -4,7 +4,10 @@ The reference has no multi-device code; this is the north-star
 extension of `Model.fit`: tiles are independent units, so
   * training shards the minibatch over ranks and has ONE exchange per step: an all-reduce (sum)
     of the flat fp32 gradient buffer, averaged by the optimizer's grad_scale = 1/world.
-    BatchNorm statistics stay per-replica (what tf.distribute does with plain BatchNormalization).
+    BatchNorm statistics stay per-replica by default (what tf.distribute does with plain
+    BatchNormalization); `model.sync_bn = True` (or SATCV_SYNC_BN=1) averages the per-channel
+    [Σx, Σx²] (forward) and [Σdy, Σdy·x̂] (backward) buffers over replicas, which makes N replicas of
+    batch B/N arithmetically one device with batch B.
   * inference shards the chip list; no collective on the data path (templates are disjoint and
     are summed once at the end).
 The helpers work on any device so the N>1 logic is covered by gloo tests on CPU.
@@ -27,6 +30,22 @@ def init_from_env(backend=None):
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     dist.init_process_group(backend)
     return dist.get_rank(), dist.get_world_size()
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def allreduce_mean_(t, group=None):
+    """In-place mean over ranks (RCCL has a native AVG; gloo sums then scales)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if dist.get_backend(group) == 'nccl':
+        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.div_(dist.get_world_size(group))
+    return t
 
 
 class GradSync:

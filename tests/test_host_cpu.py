@@ -112,6 +112,9 @@ assert sorted(allc[0] + allc[1]) == sorted(chips) and not set(allc[0]) & set(all
 t = torch.zeros(4, 4); t[rank] = rank + 1
 parallel.reduce_templates(t)
 assert t[0].eq(1).all() and t[1].eq(2).all() and t[2:].eq(0).all()
+s = torch.tensor([1.0, 2.0]) * (rank + 1)
+parallel.allreduce_mean_(s)
+assert torch.allclose(s, torch.tensor([1.5, 3.0])) and parallel.world_size() == 2
 dist.barrier(); dist.destroy_process_group()
 print("OK", rank)
 '''
