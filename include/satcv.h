@@ -88,21 +88,11 @@ typedef struct satcv_conv_desc {
   int32_t out_relu;        /* clamp outputs at 0 before storing                        */
   int32_t dtype;
   int32_t accumulate;      /* y += result instead of y = result (fan-out of a tensor into several convs) */
-  /* Optional fused first pass of the CONSUMER's BatchNorm+ReLU backward (data-gradient launches): y is the gradient
-   * w.r.t. a = relu(scale*r+shift) where r = concat(bnr_y0[.., bnr_c0], bnr_y1); the epilogue accumulates, per channel,
-   * sum(g) and sum(g*xhat) with g = y*(a>0), xhat = (r-mean)*rstd into bnr_sums ([SATCV_STAT_ROWS][2][bnr_sums_ld]),
-   * which replaces satcv_bn_bwd_reduce for that tensor.  Only on the pipelined kernel (satcv_conv2d_igemm_can_fuse). */
-  const void* bnr_y0; const void* bnr_y1;
-  int32_t bnr_c0, bnr_ld0, bnr_ld1;
-  const float* bnr_scale; const float* bnr_shift; const float* bnr_mean; const float* bnr_rstd;
-  float* bnr_sums; int32_t bnr_sums_ld;
   /* strided convolution (ResNet-style, symmetric zero padding dil*(k-1)/2): output grid (n,h,w_), input grid
    * (n,hin,win) with h = (hin-1)/stride+1.  stride 0/1 = dense.  Generic kernel only. */
   int32_t stride, hin, win;
 } satcv_conv_desc;
 int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream);
-/* 1 if the descriptor's shape runs on the pipelined kernel (needed for the bnr_* fusion), else 0; no launch. */
-int satcv_conv2d_igemm_can_fuse(const satcv_conv_desc* d);
 
 /* Weight gradient of the same convolutions: dW[tap][ci][co] = sum_p X[p+tap][ci]*dY[p][co],
  * written as Keras HWIO fp32.  X is staged with the same optional affine+ReLU as the
@@ -212,7 +202,9 @@ typedef struct satcv_head_desc {
   const float* dlogits;      /* bwd: (npix, ncls) fp32 */
   void* dx; int32_t lddx;    /* bwd: grad w.r.t. the activated input, storage dtype */
   float* dw; float* db;      /* bwd: fp32, atomically accumulated */
-  /* bwd, optional: fused first pass of the BatchNorm+ReLU backward of x (see satcv_conv_desc.bnr_*) */
+  /* bwd, optional: fused first pass of the BatchNorm+ReLU backward of x: with g = dx*(a>0), xhat = (x-mean)*rstd the kernel
+   * accumulates per channel sum(g), sum(g*xhat) into bnr_sums ([SATCV_STAT_ROWS][2][bnr_sums_ld]) -- replaces
+   * satcv_bn_bwd_reduce for that tensor (register-resident head kernel only) */
   const float* bnr_mean; const float* bnr_rstd; float* bnr_sums; int32_t bnr_sums_ld;
   int64_t npix;
   int32_t dtype;

@@ -29,8 +29,7 @@ class ConvDesc(C.Structure):
                 ('kh', c_i32), ('kw', c_i32), ('dil', c_i32),
                 ('mode_in', c_i32), ('mode_out', c_i32), ('f', c_i32),
                 ('cstat', c_i32), ('out_relu', c_i32), ('dtype', c_i32), ('accumulate', c_i32),
-                ('bnr_y0', c_vp), ('bnr_y1', c_vp), ('bnr_c0', c_i32), ('bnr_ld0', c_i32), ('bnr_ld1', c_i32),
-                ('bnr_scale', c_vp), ('bnr_shift', c_vp), ('bnr_mean', c_vp), ('bnr_rstd', c_vp), ('bnr_sums', c_vp), ('bnr_sums_ld', c_i32), ('stride', c_i32), ('hin', c_i32), ('win', c_i32)]
+                ('stride', c_i32), ('hin', c_i32), ('win', c_i32)]
 
 
 class WgradDesc(C.Structure):
@@ -72,7 +71,6 @@ _SIGS = {
     'satcv_ingest_chw': (C.c_int, [c_vp, c_i32, c_f32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'satcv_pack_weights': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'satcv_conv2d_igemm': (C.c_int, [C.POINTER(ConvDesc), c_vp]),
-    'satcv_conv2d_igemm_can_fuse': (C.c_int, [C.POINTER(ConvDesc)]),
     'satcv_conv2d_wgrad_workspace': (c_i64, [C.POINTER(WgradDesc)]),
     'satcv_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), c_vp]),
     'satcv_bn_finalize_train': (C.c_int, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32,

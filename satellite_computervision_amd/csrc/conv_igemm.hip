@@ -306,9 +306,6 @@ static int igemm_fill_args(const satcv_conv_desc* d, IgemmArgs& a) {
   SATCV_CHECK((!d->mode_in && !d->mode_out) || (d->f >= 2 && d->kh == 1 && d->kw == 1), "igemm: s2d/d2s need 1x1 taps and f>=2");
   SATCV_CHECK(!(d->accumulate && d->stats), "igemm: accumulate with statistics");
   SATCV_CHECK(!(d->mode_in && d->in_scale), "igemm: s2d source cannot carry an input transform");
-  SATCV_CHECK(!d->bnr_sums || (d->bnr_y0 && d->bnr_scale && d->bnr_shift && d->bnr_mean && d->bnr_rstd && !d->mode_out && !d->accumulate &&
-                               d->bnr_c0 > 0 && d->bnr_c0 % 8 == 0 && (d->bnr_y1 || d->bnr_c0 >= d->cout)),
-              "igemm: incomplete bnr_* fusion fields");
   a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_relu = d->in_relu;
   a.w = d->w; a.bias = d->bias; a.y = d->y; a.ldy = d->ldy;
@@ -325,9 +322,6 @@ static int igemm_fill_args(const satcv_conv_desc* d, IgemmArgs& a) {
                 "igemm: strided conv needs hin/win with h=(hin-1)/stride+1");
     a.hs = d->hin; a.ws = d->win;
   }
-  a.bnr_y0 = d->bnr_y0; a.bnr_y1 = d->bnr_y1; a.bnr_c0 = d->bnr_c0; a.bnr_ld0 = d->bnr_ld0; a.bnr_ld1 = d->bnr_ld1;
-  a.bnr_scale = d->bnr_scale; a.bnr_shift = d->bnr_shift; a.bnr_mean = d->bnr_mean; a.bnr_rstd = d->bnr_rstd;
-  a.bnr_sums = d->bnr_sums; a.bnr_sums_ld = d->bnr_sums_ld;
   a.dbg = 0;
   if (a.mode_in == 1) {
     // K = f*f*c0 virtual channels gathered from one source
@@ -340,12 +334,6 @@ static int igemm_fill_args(const satcv_conv_desc* d, IgemmArgs& a) {
 static bool igemm_force_generic() {
   static const bool v = [] { const char* e = getenv("SATCV_IGEMM"); return e && e[0] == 'g'; }();
   return v;
-}
-
-extern "C" int satcv_conv2d_igemm_can_fuse(const satcv_conv_desc* d) {
-  IgemmArgs a;
-  if (igemm_fill_args(d, a) != SATCV_OK || igemm_force_generic()) return 0;
-  return igemm_fast_launch(a, d->dtype, nullptr, true) == SATCV_OK ? 1 : 0;
 }
 
 extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
@@ -364,7 +352,6 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   rc = SATCV_ERR_UNSUPPORTED;
   if (!igemm_force_generic()) rc = igemm_fast_launch(a, d->dtype, st);
   if (rc != SATCV_ERR_UNSUPPORTED) { /* launched (or failed hard) */ }
-  else if (d->bnr_sums) { satcv_set_error("igemm: the bnr_* fusion needs the pipelined kernel (check satcv_conv2d_igemm_can_fuse)"); rc = SATCV_ERR_UNSUPPORTED; }
   else if (d->dtype == SATCV_BF16) rc = launch_t<bf16>(a, st);
   else if (d->dtype == SATCV_F32) rc = launch_t<float>(a, st);
   else { satcv_set_error("igemm: bad dtype %d", d->dtype); rc = SATCV_ERR_INVALID; }

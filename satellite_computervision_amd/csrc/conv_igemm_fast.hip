@@ -1,5 +1,11 @@
 // Software-pipelined implicit-GEMM convolution (the hot variant of conv_igemm.hip).
 //
+// Thin-layer note (measured, round 1): the 16..96-channel full-resolution layers are bound by bytes in flight, not by MFMA
+// or LDS (2.0-2.9 TB/s algorithmic vs 5.4 TB/s of a copy kernel).  What helped: 4 waves/SIMD for the small-accumulator
+// configurations (+10-15 %).  What did not: persistent workgroups with the next tile's loads in flight during the
+// epilogue (-DSATCV_PERSIST_THIN=1: the extra live state costs one wave/SIMD, net +-0), 32-channel chunks, 256-pixel x
+// 128-channel tiles.
+//
 // Same math, LDS images and MFMA fragment addressing as igemm_kernel, plus:
 //   * the halo-tile gather table (LDS offset + source pixel per staged 16-byte item) is computed
 //     ONCE per workgroup and kept in registers -- no integer divisions in the K loop;
@@ -19,9 +25,20 @@
 #define SATCV_ABLATE 0
 #endif
 #define ABL(bit) ((SATCV_ABLATE & (bit)) != 0)
+#ifndef SATCV_PERSIST_THIN
+#define SATCV_PERSIST_THIN 0
+#endif
 
 template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs a) {
+struct FastCfg {
+  // persistent workgroups (several tiles each, cross-tile prefetch) only where the accumulators are small: the extra live
+  // state would halve the occupancy of the 128x128 configuration
+  static constexpr bool PERS = (MT * NT <= 2) && SATCV_PERSIST_THIN;
+};
+
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
+__global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (SATCV_PERSIST_THIN ? 3 : 4) : 1)) void igemm_fast_kernel(const IgemmArgs a) {
+  constexpr bool PERS = FastCfg<T, TW, WM, WN, MT, NT, KS, TAPS>::PERS;
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int BM = WM * MT * 32;
   constexpr int BN = WN * NT * 32;
@@ -45,33 +62,29 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, hh = lane >> 5;
 
-  // ---- XCD-aware tile id: blocks b and b+8 share an XCD, give each XCD a contiguous tile range
+  // ---- persistent workgroups: this one owns tiles v = bid, bid + G, bid + 2G, ...  (G is a multiple of the number of
+  //      N tiles, so its channel block is fixed).  XCD-aware id: blocks b and b+8 share an XCD (private L2); give each
+  //      XCD a contiguous range so that the workgroups running side by side read neighbouring halos.
+  const int G = gridDim.x;
   int bid;
   {
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, rem = nwg & 7;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = G >> 3, rem = G & 7;
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
   }
-  const int nt = bid % a.n_tiles;
-  int mt = bid / a.n_tiles;
-  const int tx = mt % a.tiles_x; mt /= a.tiles_x;
-  const int ty = mt % a.tiles_y;
-  const int grp = mt / a.tiles_y;
-  const int n0 = grp * a.imgs;
-  const int y0 = ty * TH;
-  const int x0 = tx * TW;
-  const int nbase = nt * BN;
+  const int total = a.total_tiles;
+  const int nbase = (bid % a.n_tiles) * BN;
   const int cin = a.c0 + a.c1;
   const int fs = a.mode_in == 1 ? a.f : 1;
   const int slot_t = tid % SLOTS;                  // NTHREADS % SLOTS == 0: a thread's slot is fixed
 
-  // ---- gather tables (registers)
-  int a_l[AI], a_p[AI];
+  // ---- tile-independent gather tables (registers): LDS offset and halo coordinates of every staged 16-byte item
+  int a_l[AI], a_pk[AI], a_p[AI];
   const int a_items = a.rl * a.cl * SLOTS;
 #pragma unroll
   for (int j = 0; j < AI; ++j) {
     const int it = tid + j * NTHREADS;
-    a_l[j] = -1; a_p[j] = -1;
+    a_l[j] = -1; a_pk[j] = 0; a_p[j] = -1;
     if (it < a_items) {
       const int pix = it / SLOTS;
       int c, L;
@@ -82,10 +95,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs
         c = pix % a.cl; L = pix / a.cl;
       }
       const int k = (a.imgs == 1) ? 0 : L / a.seg;
-      const int yy = L - k * a.seg - a.halh;
-      const int n = n0 + k, y = y0 + yy, x = x0 + c - a.halw;
       a_l[j] = ((slot_t * a.rl + L) * a.pitch + c) * 8;
-      if ((n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_)) a_p[j] = (n * a.hs + y * fs) * a.ws + x * fs;
+      a_pk[j] = (k << 24) | ((L - k * a.seg) << 12) | c;
     }
   }
   constexpr int b_items = TAPS * SLOTS * BN;
@@ -108,17 +119,23 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs
   }
   const int slot_stride = a.rl * a.pitch * 8;
 
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-
   const T* wp = reinterpret_cast<const T*>(a.w);
   Raw8<T> ra[AI], rb[BI];
 
+  auto tile_origin = [&](int v, int& n0, int& y0, int& x0) {
+    int mt = v / a.n_tiles;
+    const int tx = mt % a.tiles_x; mt /= a.tiles_x;
+    const int ty = mt % a.tiles_y;
+    n0 = (mt / a.tiles_y) * a.imgs; y0 = ty * TH; x0 = tx * TW;
+  };
+  auto gather_pixels = [&](int n0, int y0, int x0) {      // source pixel of every staged item of the tile at (n0, y0, x0)
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      const int k = a_pk[j] >> 24, yy = ((a_pk[j] >> 12) & 0xfff) - a.halh, c = (a_pk[j] & 0xfff) - a.halw;
+      const int n = n0 + k, y = y0 + yy, x = x0 + c;
+      a_p[j] = ((a_l[j] >= 0) && (n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_)) ? (n * a.hs + y * fs) * a.ws + x * fs : -1;
+    }
+  };
   auto load_regs = [&](int chunk) {
     const int cg0 = chunk * KC;
     const T* src; int cs, coff, sadd = 0;
@@ -160,175 +177,202 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_fast_kernel(const IgemmArgs
     }
   };
 
+  float st1[NT], st2[NT];                 // BN statistics of all tiles of this workgroup (flushed once at the end)
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { st1[n] = 0.f; st2[n] = 0.f; }
+
+  int v = bid;
+  if (v >= total) return;
+  int n0, y0, x0;
+  tile_origin(v, n0, y0, x0);
+  gather_pixels(n0, y0, x0);
   load_regs(0);
   store_lds(0);
   __syncthreads();
-  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-    const bool more = chunk + 1 < a.nchunks;
-    if (more) load_regs(chunk + 1);
+  for (;;) {
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap % 3;
-      const int tap_off = (ky * a.dil * a.pitch + kx * a.dil) * 8;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int slot = s * 2 + hh;
-        FragT<T> af[MT], bf[NT];
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) af[m] = lds_frag<T>(ldsA + (ABL(16) ? 0 : slot * slot_stride + a_off[m] + tap_off));
-#pragma unroll
-        for (int n = 0; n < NT; ++n) bf[n] = lds_frag<T>(ldsB + ((tap * SLOTS + slot) * BN + (wn * NT + n) * 32 + r) * 8);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) { if (!ABL(2)) mma32<T>(acc[m][n], af[m], bf[n]); }
+        for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    const int vnext = PERS ? v + G : total;
+    int n0n = 0, y0n = 0, x0n = 0;
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+      const bool more = chunk + 1 < a.nchunks;
+      if (more) {
+        load_regs(chunk + 1);
+      } else if (vnext < total) {           // first chunk of the NEXT tile: its loads fly during these MFMAs and the epilogue
+        tile_origin(vnext, n0n, y0n, x0n);
+        gather_pixels(n0n, y0n, x0n);
+        load_regs(0);
       }
-    }
-    __syncthreads();
-    if (more) {
-      store_lds(chunk + 1);
-      __syncthreads();
-    }
-  }
-
-  // ---------------------------------------------------------------- epilogue
-  if (ABL(32)) { if (acc[0][0][0] == 123.456f) reinterpret_cast<T*>(a.y)[0] = (T)1.f; return; }
-  // 1) bias, optional ReLU, rounding, BN statistics from registers; stage the tile in LDS [BM][OPITCH]
-  unsigned pvmask[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    pvmask[m] = 0;
-    if (a.stats) {
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap % 3;
+        const int tap_off = (ky * a.dil * a.pitch + kx * a.dil) * 8;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int q = (wm * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const int t = q / TW, cx = q % TW;
-        const int k = (a.imgs == 1) ? 0 : t / a.rpi;
-        const bool pv = (k < a.imgs) && (n0 + k < a.n) && (y0 + (t - k * a.rpi) < a.h) && (x0 + cx < a.w_);
-        pvmask[m] |= (pv ? 1u : 0u) << i;
-      }
-    }
-  }
+        for (int s = 0; s < KS; ++s) {
+          const int slot = s * 2 + hh;
+          FragT<T> af[MT], bf[NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int cl_ = (wn * NT + n) * 32 + r;          // column inside the tile
-    const int cn = nbase + cl_;
-    const bool cvalid = cn < a.cout;
-    const int cch = cvalid ? cn % a.cstat : 0;
-    const float bv = (a.bias && cvalid) ? a.bias[cch] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+          for (int m = 0; m < MT; ++m) af[m] = lds_frag<T>(ldsA + (ABL(16) ? 0 : slot * slot_stride + a_off[m] + tap_off));
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+          for (int n = 0; n < NT; ++n) bf[n] = lds_frag<T>(ldsB + ((tap * SLOTS + slot) * BN + (wn * NT + n) * 32 + r) * 8);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const int q = (wm * MT + m) * 32 + row;
-        float v = acc[m][n][i] + bv;
-        if (a.out_relu) v = fmaxf(v, 0.f);
-        const T tv = (T)v;
-        ldsO[q * OPITCH + cl_] = tv;
-        const float fv = ((pvmask[m] >> i) & 1u) ? (float)tv : 0.f;
-        s1 += fv; s2 += fv * fv;
-      }
-    }
-    if (a.stats) {
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (hh == 0) { ldsS[(wm * 2 + 0) * BN + cl_] = s1; ldsS[(wm * 2 + 1) * BN + cl_] = s2; }
-    }
-  }
-  __syncthreads();
-  if (a.stats && tid < BN) {
-    // one pair of atomics per output channel per workgroup (fixed wave order)
-    const int cn = nbase + tid;
-    if (cn < a.cout) {
-      float t1 = 0.f, t2 = 0.f;
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int w = 0; w < WM; ++w) { t1 += ldsS[(w * 2 + 0) * BN + tid]; t2 += ldsS[(w * 2 + 1) * BN + tid]; }
-      const int cch = cn % a.cstat;
-      float* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
-      atomicAdd(rowp + cch, t1);
-      atomicAdd(rowp + a.stats_ld + cch, t2);
-    }
-  }
-  // 2) coalesced 16-byte stores of whole channel rows
-  {
-    constexpr int EPV = 16 / (int)sizeof(T);        // elements per 16-byte vector
-    constexpr int VPR = BN / EPV;                   // vectors per tile row
-    T* yp = reinterpret_cast<T*>(a.y);
-    const int ho = a.mode_out ? a.h * a.f : a.h;
-    const int wo = a.mode_out ? a.w_ * a.f : a.w_;
-    const int ncols = min(BN, a.cout - nbase);      // valid columns of this tile
-    int ij = 0, cbase = nbase;
-    if (a.mode_out == 1) { ij = nbase / a.cstat; cbase = nbase - ij * a.cstat; }
-    // fused first pass of the consumer's BN+ReLU backward: this thread always handles vector column tid % VPR
-    float* ldsR = ldsS + WM * 2 * BN;                 // [2][BN]
-    const bool bnr = a.bnr_sums != nullptr;
-    const int vcol = tid % VPR;
-    float rsc[EPV], rsh[EPV], rmu[EPV], rrs[EPV], r1[EPV], r2[EPV];
-    const T* ry = nullptr; int rld = 0, rco = 0;
-    if (bnr) {
-      for (int i = tid; i < 2 * BN; i += NTHREADS) ldsR[i] = 0.f;
-      const int cg = cbase + vcol * EPV;
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) {
-        const bool ok = cg + e < a.cout;
-        rsc[e] = ok ? a.bnr_scale[cg + e] : 0.f; rsh[e] = ok ? a.bnr_shift[cg + e] : 0.f;
-        rmu[e] = ok ? a.bnr_mean[cg + e] : 0.f; rrs[e] = ok ? a.bnr_rstd[cg + e] : 0.f;
-        r1[e] = 0.f; r2[e] = 0.f;
-      }
-      if (cg < a.bnr_c0) { ry = reinterpret_cast<const T*>(a.bnr_y0); rld = a.bnr_ld0; rco = cg; }
-      else { ry = reinterpret_cast<const T*>(a.bnr_y1); rld = a.bnr_ld1; rco = cg - a.bnr_c0; }
-      __syncthreads();
-    }
-    for (int it = tid; it < BM * VPR; it += NTHREADS) {
-      const int q = it / VPR, v = it % VPR;
-      if (v * EPV >= ncols) continue;
-      const int t = q / TW, cx = q % TW;
-      const int k = (a.imgs == 1) ? 0 : t / a.rpi;
-      const int nimg = n0 + k, y = y0 + (t - k * a.rpi), x = x0 + cx;
-      if (!((k < a.imgs) && (nimg < a.n) && (y < a.h) && (x < a.w_))) continue;
-      size_t off;
-      if (a.mode_out == 1) off = ((size_t)(nimg * ho + y * a.f + ij / a.f) * wo + x * a.f + ij % a.f) * a.ldy + cbase + v * EPV;
-      else off = ((size_t)(nimg * ho + y) * wo + x) * a.ldy + cbase + v * EPV;
-      const T* sp = ldsO + q * OPITCH + v * EPV;
-      if (bnr && v * EPV + EPV <= ncols) {
-        const T* rp = ry + ((size_t)(nimg * ho + y) * wo + x) * rld + rco;
-        const uint4 yq = *reinterpret_cast<const uint4*>(rp);           // one 16-byte load each (global, LDS)
-        const uint4 gq = *reinterpret_cast<const uint4*>(sp);
-        const T* yv = reinterpret_cast<const T*>(&yq);
-        const T* gv = reinterpret_cast<const T*>(&gq);
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-          const float yr = (float)yv[e];
-          const float g = (yr * rsc[e] + rsh[e] > 0.f) ? (float)gv[e] : 0.f;
-          r1[e] += g; r2[e] += g * ((yr - rmu[e]) * rrs[e]);
+            for (int n = 0; n < NT; ++n) { if (!ABL(2)) mma32<T>(acc[m][n], af[m], bf[n]); }
         }
       }
-      if (ABL(1)) continue;
-      if (a.accumulate) {
-        const int ne = min(EPV, ncols - v * EPV);
-        for (int e = 0; e < ne; ++e) yp[off + e] = (T)((float)yp[off + e] + (float)sp[e]);
-      } else if (ncols - v * EPV >= EPV) {
-        *reinterpret_cast<uint4*>(yp + off) = *reinterpret_cast<const uint4*>(sp);
-      } else {
-        for (int e = 0; e < ncols - v * EPV; ++e) yp[off + e] = sp[e];
+      __syncthreads();
+      if (more) {
+        store_lds(chunk + 1);
+        __syncthreads();
       }
     }
-    if (bnr) {
+
+    // ---------------------------------------------------------------- epilogue of tile v
+    // (thread coordinates re-derived from an opaque copy of threadIdx so that the per-tile address arithmetic below is
+    //  NOT hoisted out of the persistent loop -- hoisting it costs >100 VGPRs and the occupancy with them)
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wave_e = tid_e >> 6;
+    const int wm_e = wave_e / WN, wn_e = wave_e % WN, r_e = lane_e & 31, hh_e = lane_e >> 5;
+    if (ABL(32)) { if (acc[0][0][0] == 123.456f) reinterpret_cast<T*>(a.y)[0] = (T)1.f; }
+    else {
+    // 1) bias, optional ReLU, rounding, BN statistics from registers; stage the tile in LDS [BM][OPITCH]
+    // validity of the 16 accumulator rows of each MFMA tile (pixels outside the image must not enter the statistics):
+    // rows of one MFMA tile span 32/TW tile rows; the column test needs no division
+    unsigned pvmask[MT];
+    {
+      const int xlim = a.w_ - x0;
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) { atomicAdd(&ldsR[vcol * EPV + e], r1[e]); atomicAdd(&ldsR[BN + vcol * EPV + e], r2[e]); }
-      __syncthreads();
-      if (tid < BN && cbase + tid < a.cout) {
-        float* rowp = a.bnr_sums + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.bnr_sums_ld;
-        atomicAdd(rowp + cbase + tid, ldsR[tid]);
-        atomicAdd(rowp + a.bnr_sums_ld + cbase + tid, ldsR[BN + tid]);
+      for (int m = 0; m < MT; ++m) {
+        pvmask[m] = 0;
+        if (a.stats) {
+          unsigned rowok = 0;
+#pragma unroll
+          for (int u = 0; u < 32 / TW; ++u) {
+            const int t = (wm_e * MT + m) * (32 / TW) + u;
+            const int k = (a.imgs == 1) ? 0 : t / a.rpi;
+            const bool ok = (k < a.imgs) && (n0 + k < a.n) && (y0 + (t - k * a.rpi) < a.h);
+            rowok |= (ok ? 1u : 0u) << u;
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * hh_e;
+            const bool pv = ((rowok >> ((8 * (i >> 2)) / TW)) & 1u) && ((row % TW) < xlim);
+            pvmask[m] |= (pv ? 1u : 0u) << i;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int cl_ = (wn_e * NT + n) * 32 + r_e;          // column inside the tile
+      const int cn = nbase + cl_;
+      const bool cvalid = cn < a.cout;
+      const int cch = cvalid ? cn % a.cstat : 0;
+      const float bv = (a.bias && cvalid) ? a.bias[cch] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * hh_e;
+          const int q = (wm_e * MT + m) * 32 + row;
+          float vv = acc[m][n][i] + bv;
+          if (a.out_relu) vv = fmaxf(vv, 0.f);
+          const T tv = (T)vv;
+          ldsO[q * OPITCH + cl_] = tv;
+          const float fv = ((pvmask[m] >> i) & 1u) ? (float)tv : 0.f;
+          s1 += fv; s2 += fv * fv;
+        }
+      }
+      st1[n] += s1; st2[n] += s2;
+    }
+    __syncthreads();
+    // 2) coalesced 16-byte stores of whole channel rows
+    {
+      constexpr int EPV = 16 / (int)sizeof(T);        // elements per 16-byte vector
+      constexpr int VPR = BN / EPV;                   // vectors per tile row
+      T* yp = reinterpret_cast<T*>(a.y);
+      const int ho = a.mode_out ? a.h * a.f : a.h;
+      const int wo = a.mode_out ? a.w_ * a.f : a.w_;
+      const int ncols = min(BN, a.cout - nbase);      // valid columns of this tile
+      int ij = 0, cbase = nbase;
+      if (a.mode_out == 1) { ij = nbase / a.cstat; cbase = nbase - ij * a.cstat; }
+      for (int it = tid_e; it < BM * VPR; it += NTHREADS) {
+        const int q = it / VPR, vq = it % VPR;
+        if (vq * EPV >= ncols) continue;
+        const int t = q / TW, cx = q % TW;
+        const int k = (a.imgs == 1) ? 0 : t / a.rpi;
+        const int nimg = n0 + k, y = y0 + (t - k * a.rpi), x = x0 + cx;
+        if (!((k < a.imgs) && (nimg < a.n) && (y < a.h) && (x < a.w_))) continue;
+        size_t off;
+        if (a.mode_out == 1) off = ((size_t)(nimg * ho + y * a.f + ij / a.f) * wo + x * a.f + ij % a.f) * a.ldy + cbase + vq * EPV;
+        else off = ((size_t)(nimg * ho + y) * wo + x) * a.ldy + cbase + vq * EPV;
+        const T* sp = ldsO + q * OPITCH + vq * EPV;
+        if (ABL(1)) continue;
+        if (a.accumulate) {
+          const int ne = min(EPV, ncols - vq * EPV);
+          for (int e = 0; e < ne; ++e) yp[off + e] = (T)((float)yp[off + e] + (float)sp[e]);
+        } else if (ncols - vq * EPV >= EPV) {
+          *reinterpret_cast<uint4*>(yp + off) = *reinterpret_cast<const uint4*>(sp);
+        } else {
+          for (int e = 0; e < ncols - vq * EPV; ++e) yp[off + e] = sp[e];
+        }
+      }
+    }
+    }
+    if (vnext >= total) break;
+    __syncthreads();                      // every wave is done with the staged output before the LDS images are rewritten
+    store_lds(0);
+    __syncthreads();
+    v = vnext; n0 = n0n; y0 = y0n; x0 = x0n;
+  }
+
+  // ---- BN statistics of all tiles of this workgroup: one pair of atomics per output channel (fixed wave order)
+  if (a.stats) {
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int cl_ = (wn * NT + n) * 32 + r;
+      const float s1 = st1[n] + __shfl_xor(st1[n], 32, 64);
+      const float s2 = st2[n] + __shfl_xor(st2[n], 32, 64);
+      if (hh == 0) { ldsS[(wm * 2 + 0) * BN + cl_] = s1; ldsS[(wm * 2 + 1) * BN + cl_] = s2; }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int cn = nbase + tid;
+      if (cn < a.cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { t1 += ldsS[(w * 2 + 0) * BN + tid]; t2 += ldsS[(w * 2 + 1) * BN + tid]; }
+        const int cch = cn % a.cstat;
+        float* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
+        atomicAdd(rowp + cch, t1);
+        atomicAdd(rowp + a.stats_ld + cch, t2);
       }
     }
   }
 }
 
 // ------------------------------------------------------------------ host side
+static bool igemm_persist() {
+  static const bool on = [] { const char* e = getenv("SATCV_PERSIST"); return !e || atoi(e) != 0; }();
+  return on;
+}
+static int igemm_num_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    return v;
+  }();
+  return n;
+}
 template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
 static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, KC = KS * 16, NTHREADS = WM * WN * 64;
@@ -360,7 +404,6 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   const size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
   const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
-  if (a.bnr_sums && (a.cout % (16 / (int)sizeof(T)) != 0 || a.bnr_c0 % BN != 0 && a.bnr_y1)) return SATCV_ERR_UNSUPPORTED;
   if (dry) return SATCV_OK;
   auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS>;
   if (lds > 48 * 1024) {
@@ -369,7 +412,23 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   }
   const long long blocks = (long long)a.ngroups * a.tiles_y * a.tiles_x * a.n_tiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return SATCV_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHREADS), lds, st, a);
+  a.total_tiles = (int)blocks;
+  // persistent launch: as many workgroups as fit on the chip at once (a multiple of the N-tile count so that a
+  // workgroup keeps its channel block); each walks the tiles bid, bid+G, ... with the next tile's loads in flight
+  // during the current tile's epilogue
+  long long grid = blocks;
+  if (FastCfg<T, TW, WM, WN, MT, NT, KS, TAPS>::PERS && igemm_persist()) {
+    static int occ_lds = -1, occ = 0;
+    if (occ_lds != (int)lds) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), NTHREADS, lds) != hipSuccess || nb < 1) nb = 1;
+      occ = nb; occ_lds = (int)lds;
+    }
+    long long g = (long long)occ * igemm_num_cus();
+    g -= g % a.n_tiles;
+    if (g >= a.n_tiles && g < blocks) grid = g;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("igemm_fast launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
   return SATCV_OK;
@@ -399,6 +458,10 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
     }
     return fast_cfg<T, TW, 2, 2, 2, 2, 1, TAPS>(a, st, dry);
   }
+  // 96 output channels (data gradient of dec0's concatenated input): one N tile of exactly that width instead of two tiles of
+  // 64 that would each re-read the activation tile (559 -> 533 us).  The same idea for 192 channels (128x192 tile, one
+  // workgroup per CU) was measured SLOWER than three 64-wide tiles: 584 vs 379 us.
+  if (TAPS == 9 && nspace % 96 == 0 && nspace % 64 != 0) return fast_cfg<T, TW, 4, 1, 2, 3, 1, TAPS>(a, st, dry);
   // (32-channel chunks for the thin 3x3 layers were measured SLOWER: 144 vs 113 us on enc1, 425 vs 351 us on
   //  dec0.conv1 -- fewer resident workgroups outweigh the halved barrier count)
   if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 1, TAPS>(a, st, dry);

@@ -15,13 +15,12 @@ struct IgemmArgs {
   int kh, kw, dil;
   int mode_in, mode_out, f;
   int cstat, out_relu, accumulate, stride;
-  const void* bnr_y0; const void* bnr_y1; int bnr_c0, bnr_ld0, bnr_ld1;
-  const float* bnr_scale; const float* bnr_shift; const float* bnr_mean; const float* bnr_rstd; float* bnr_sums; int bnr_sums_ld;
   // derived tiling
   int tiles_x, tiles_y, ngroups;   // M tiles = ngroups * tiles_y * tiles_x
   int rpi, imgs, seg, rl, cl, pitch, halh, halw;
   int n_tiles;                     // N tiles
   int nchunks;
+  int total_tiles;                 // M tiles x N tiles (persistent workgroups stride over them)
   int dbg;                         // ablation bits (env SATCV_DBG): 1 skip stores, 2 skip MFMA, 4 skip A loads, 8 skip B loads
 };
 

@@ -590,34 +590,19 @@ class Plan:
         HEAD_FAST = {(1, 16), (2, 16), (1, 32), (2, 32), (3, 32), (4, 32), (1, 64), (2, 64)}
 
         def fuse_target(t):
-            """bnr_* fields (and the sums buffer) if the BN+ReLU that produced tensor `t` can take its backward
-            reduction from the kernel that writes t's activation gradient; None otherwise."""
-            if not rt.model.fuse_bn_bwd or t.id in gact or len(consumers[t.id]) != 1:
+            """bnr_* fields (and the sums buffer) if the head's backward kernel can also do the reduce pass of the BN+ReLU
+            that produced its input tensor `t` (the raw values are in its registers anyway); None otherwise."""
+            if not rt.model.fuse_head_bn_bwd or t.id in gact or len(consumers[t.id]) != 1:
                 return None
             P, pc = t.node, ctx.get(id(t.node))
-            if P.op == 'cba':
-                if pc['yoff'] != 0 or pc['ldy'] != pc['cout']:
-                    return None                       # branch of a concatenation (ASPP)
-                c, aff = pc['cout'], pc['aff']
-                sums = self._z(STAT_ROWS, 2, c, dtype=torch.float32)
-                return dict(y0=pc['y'].data_ptr(), y1=None, c0=c, ld0=c, ld1=0, scale=_fp(aff['scale']), shift=_fp(aff['shift']),
-                            mean=_fp(aff['mean']), rstd=_fp(aff['rstd']), sums=_fp(sums), sums_ld=c), sums
-            if P.op == 'concat_bn_relu':
-                ra, rb, aff, ca, cb = pc['ra'], pc['rb'], pc['aff'], pc['ca'], pc['cb']
-                sums = self._z(STAT_ROWS, 2, ca + cb, dtype=torch.float32)
-                return dict(y0=ra.srcs[0][0].data_ptr(), y1=rb.srcs[0][0].data_ptr(), c0=ca, ld0=ca, ld1=cb, scale=_fp(aff['scale']),
-                            shift=_fp(aff['shift']), mean=_fp(aff['mean']), rstd=_fp(aff['rstd']), sums=_fp(sums), sums_ld=ca + cb), sums
-            return None
+            if P.op != 'cba' or pc['yoff'] != 0 or pc['ldy'] != pc['cout']:
+                return None
+            c, aff = pc['cout'], pc['aff']
+            sums = self._z(STAT_ROWS, 2, c, dtype=torch.float32)
+            return dict(mean=_fp(aff['mean']), rstd=_fp(aff['rstd']), sums=_fp(sums), sums_ld=c), sums
 
         def dgrad_step(t, **kw):
-            """data-gradient launch writing the activation gradient of tensor t; fuses the consumer BN's reduce pass when possible"""
-            ft = fuse_target(t)
-            if ft is not None:
-                d = ops.make_conv_desc(bnr=ft[0], **kw)
-                if lib.satcv_conv2d_igemm_can_fuse(C.byref(d)):
-                    fused[t.id] = ft[1]
-                    self.keep.append(d)
-                    return lambda st, d=d: check(lib.satcv_conv2d_igemm(C.byref(d), st))
+            """data-gradient launch writing the activation gradient of tensor t"""
             return self._conv_step(**kw)
 
         def wgrad_step(r, dy, lddy, lay, cin_real, cout, hh, ww, k, dil, f=0, accum=0):

@@ -628,7 +628,7 @@ class Model:
                     self.param_specs += l.specs
         self.compute_dtype = dtype or _DEFAULT_DTYPE
         self.bn_bessel = False
-        self.fuse_bn_bwd = os.environ.get('SATCV_FUSE_BN_BWD', '0') == '1'   # BN-backward reduce pass inside the dgrad epilogues (measured: no gain, off)
+        self.fuse_head_bn_bwd = os.environ.get('SATCV_FUSE_HEAD_BN_BWD', '1') != '0'   # head backward also does the reduce pass of the last BN
         self.wgrad_side_stream = os.environ.get('SATCV_WGRAD_STREAM', '1') != '0'      # weight gradients on a second HIP stream
         self.sync_bn = os.environ.get('SATCV_SYNC_BN', '0') == '1'      # data parallel: BatchNorm statistics over ALL replicas (parallel.py)
         self._rt = None
