@@ -33,6 +33,21 @@ TILE, CH, NCLS, BATCH = 256, 4, 2, 64
 FWD_GFLOP_PER_TILE = 22.641
 TRAIN_GFLOP_PER_TILE = 67.77
 PEAK_BF16_TFLOPS = 2500.0
+# algorithmic HBM bytes of the 3x3 conv launches of one training step at batch 64 (each launch reads its input once and
+# writes its output once, bf16, weights once): forward 11 layers + data gradient 10 layers, see DESIGN.md section 3
+def _alg_3x3_bytes(batch, esize=2, tile=TILE, filters=(32, 64, 128, 256, 512), cin0=16):
+    L, cin = [], cin0
+    for i, c in enumerate(filters):
+        L.append((batch * (tile >> i) ** 2, cin, c)); cin = c
+    L.append((batch * (tile >> len(filters)) ** 2, filters[-1], 2 * filters[-1]))
+    for j in range(len(filters) - 1, -1, -1):
+        px = batch * (tile >> j) ** 2
+        L += [(px, 3 * filters[j], filters[j]), (px, filters[j], filters[j])]
+    one = lambda px, ci, co: px * (ci + co) * esize + 9 * ci * co * esize
+    return sum(one(*l) for l in L) + sum(one(*l) for l in L[1:])        # forward + data gradient (none for the first layer)
+
+
+ALG_3X3_BYTES_PER_STEP = _alg_3x3_bytes(BATCH)                          # 7.50 GB at batch 64: 16 forward + 15 dgrad launches
 
 
 def synth_batch(rng, n):
@@ -46,6 +61,18 @@ def synth_batch(rng, n):
             lab[i, y0:y0 + h, x0:x0 + w] = 1
     y = np.eye(NCLS, dtype=np.float32)[lab]
     return x, y
+
+
+def pmc_traffic_per_launch():
+    """HBM bytes per 3x3 implicit-GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this same
+    command (profiles/r01_pmc_traffic.json, produced by tools/pmc_summary.py with the gfx950 FETCH_SIZE x2 correction).
+    PMC counters cannot be collected from inside the timed run; None when the summary is absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['classes']
+        c = d.get('igemm_3x3') or d.get('igemm_3x3_1x1_convT')
+        return round(c['hbm_bytes_per_launch'] / 1e6, 1)
+    except Exception:
+        return None
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -165,6 +192,29 @@ def main():
             model.predict_on_device(xb)
         barrier()
         extra['infer_tiles_per_s'] = round(world * B * 10 / (time.perf_counter() - t1), 1)
+        # BASELINE configs[4]: sliding-window inference on 1024^2 scenes = 9 chips of 384^2 per scene (buff 128, kernel 256,
+        # utils/prediction_tools.py:87-156), bf16 plan vs folded fp8 (e4m3) plan; output "kernel tiles" = 256^2 centres kept
+        chips = torch.from_numpy(np.random.default_rng(5).beta(2, 5, (36, 384, 384, CH)).astype(np.float32)).cuda()      # 4 scenes
+        for tag in ('bf16', 'fp8'):
+            if tag == 'fp8':
+                model.enable_fp8_inference(chips[:8])
+            for _ in range(3):
+                model.predict_on_device(chips)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                model.predict_on_device(chips)
+            barrier()
+            extra[f'config5_{tag}_kernel_tiles_per_s'] = round(world * 36 * 10 / (time.perf_counter() - t1), 1)
+        for _ in range(3):
+            model.predict_on_device(xb)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            model.predict_on_device(xb)
+        barrier()
+        extra['infer_fp8_tiles_per_s'] = round(world * B * 10 / (time.perf_counter() - t1), 1)
+        model.disable_fp8_inference()
 
     if rank == 0:
         tiles = world * B * args.steps
@@ -181,7 +231,9 @@ def main():
                        'optimizer': 'adam(9e-4)'},
             'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS if args.dtype == 'bfloat16' else 157.3,
                          'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16_TFLOPS if args.dtype == 'bfloat16' else 157.3), 4),
-                         'traffic': None, 'kernel': 'igemm_kernel (3x3 conv fwd + dgrad)',
+                         'traffic': pmc_traffic_per_launch(), 'traffic_unit': 'MB per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)',
+                         'algorithmic_bytes_per_launch_MB': round(ALG_3X3_BYTES_PER_STEP / max(d['launches'] / args.steps, 1) / 1e6, 1),
+                         'kernel': 'igemm_fast_kernel (3x3 conv fwd + dgrad)',
                          'avg_launch_us': round(1000 * d['ms'] / max(d['launches'], 1), 2)},
             'model_tflops': round(value * TRAIN_GFLOP_PER_TILE / 1000, 2),
             'extra': extra,

@@ -27,7 +27,9 @@ extern "C" {
 #endif
 
 enum { SATCV_OK = 0, SATCV_ERR_INVALID = -1, SATCV_ERR_HIP = -2, SATCV_ERR_UNSUPPORTED = -3 };
-enum { SATCV_F32 = 0, SATCV_BF16 = 1 };
+enum { SATCV_F32 = 0, SATCV_BF16 = 1,
+       SATCV_FP8 = 2 /* OCP e4m3fn storage, inference only: ingest, pack_weights, conv2d_igemm (pipelined kernel), maxpool,
+                        affine_requant, head_fwd */ };
 /* rows of replicated per-channel accumulators (sum rows in order to consume) */
 #define SATCV_STAT_ROWS 32
 
@@ -41,6 +43,8 @@ int satcv_device_info(int32_t* out4);
  * Replaces the implicit float32 feed of Model.predict/fit (utils/prediction_tools.py:152). */
 int satcv_ingest_nhwc(const float* src, void* dst, int64_t npix, int32_t c, int32_t cpad,
                       int32_t dtype, void* stream);
+/* same with a multiplier (the fp8 path feeds x/q_in so that the reflectances use the upper e4m3 range) */
+int satcv_ingest_nhwc_scaled(const float* src, void* dst, int64_t npix, int32_t c, int32_t cpad, float mul, int32_t dtype, void* stream);
 /* planar CHW (c,h,w) per tile, any of u8/u16/f32 (src_kind 0/1/2), scaled by `scale`
  * -> dtype NHWC (n,h,w,cpad).  Mirrors the CHW->HWC + rescale of utils/processing.py:544-613. */
 int satcv_ingest_chw(const void* src, int32_t src_kind, float scale, void* dst, int32_t n,
@@ -91,6 +95,9 @@ typedef struct satcv_conv_desc {
   /* strided convolution (ResNet-style, symmetric zero padding dil*(k-1)/2): output grid (n,h,w_), input grid
    * (n,hin,win) with h = (hin-1)/stride+1.  stride 0/1 = dense.  Generic kernel only. */
   int32_t stride, hin, win;
+  /* optional per-channel multiplier of the accumulator (indexed like bias): y = act(acc*out_scale + bias).  The folded
+   * inference path puts BatchNorm and the fp8 quantisation scales here (q_in*w_scale*bn_scale/q_out). */
+  const float* out_scale;
 } satcv_conv_desc;
 int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream);
 
@@ -171,6 +178,13 @@ int satcv_maxpool(const void* x, void* out, int32_t n, int32_t h, int32_t w_, in
 int satcv_add_act(const void* y, const float* y_scale, const float* y_shift, const void* res,
                   const float* res_scale, const float* res_shift, int32_t relu, void* out, int64_t npix,
                   int32_t c, int32_t dtype, void* stream);
+/* out = Q(relu?(scale[c]*x + shift[c])) channel-wise between two NHWC tensors with their own channel strides; dtype_out is
+ * dtype or SATCV_FP8.  Uses in the folded fp8 inference path: the skip half of concat([skip, up]) -> BN -> ReLU with the
+ * requantisation q_skip/q_cat folded into scale/shift (utils/model_tools.py:307-309), and BN+ReLU+quantisation of the
+ * first conv block, which is computed in bf16 because the e4m3 rounding of the INPUT bands costs the most accuracy. */
+int satcv_affine_requant(const void* x, int32_t ldx, const float* scale, const float* shift, int32_t relu, void* out, int32_t ldo,
+                         int64_t npix, int32_t c, int32_t dtype, int32_t dtype_out, void* stream);
+
 int satcv_upsample_head(const float* logits, int32_t n, int32_t h, int32_t w_, int32_t ncls, int32_t factor,
                         int32_t activation, float thresh, float* probs, int32_t* classes, void* stream);
 

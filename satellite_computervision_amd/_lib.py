@@ -13,7 +13,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SATCV_LIB') or os.path.join(_HERE, 'libsatcv.so')     # SATCV_LIB: profiling variants only
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 STAT_ROWS = 32
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ('kh', c_i32), ('kw', c_i32), ('dil', c_i32),
                 ('mode_in', c_i32), ('mode_out', c_i32), ('f', c_i32),
                 ('cstat', c_i32), ('out_relu', c_i32), ('dtype', c_i32), ('accumulate', c_i32),
-                ('stride', c_i32), ('hin', c_i32), ('win', c_i32)]
+                ('stride', c_i32), ('hin', c_i32), ('win', c_i32), ('out_scale', c_vp)]
 
 
 class WgradDesc(C.Structure):
@@ -68,6 +68,7 @@ _SIGS = {
     'satcv_last_error': (C.c_char_p, []),
     'satcv_device_info': (C.c_int, [C.POINTER(c_i32)]),
     'satcv_ingest_nhwc': (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    'satcv_ingest_nhwc_scaled': (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_vp]),
     'satcv_ingest_chw': (C.c_int, [c_vp, c_i32, c_f32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'satcv_pack_weights': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'satcv_conv2d_igemm': (C.c_int, [C.POINTER(ConvDesc), c_vp]),
@@ -81,6 +82,7 @@ _SIGS = {
     'satcv_bn_bwd_finalize': (C.c_int, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'satcv_bn_bwd_apply': (C.c_int, [C.POINTER(BnBwdDesc), c_vp]),
     'satcv_maxpool': (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'satcv_affine_requant': (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp]),
     'satcv_add_act': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp]),
     'satcv_upsample_head': (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
     'satcv_dropout_mask': (C.c_int, [C.c_uint64, C.c_uint64, c_f32, c_i64, c_vp, c_vp]),

@@ -1,11 +1,13 @@
 // Shared device/host helpers for the satcv HIP library (gfx950 / MI355X only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp8.h>
 #include <stdint.h>
 #include <type_traits>
 #include "../../include/satcv.h"
 
 typedef __bf16 bf16;
+typedef __hip_fp8_e4m3 fp8;          // OCP e4m3fn on gfx950 (hardware v_cvt_pk_fp8_f32 / v_cvt_f32_fp8, saturating)
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using short4v = __attribute__((ext_vector_type(4))) short;
@@ -50,6 +52,11 @@ __device__ __forceinline__ void load8(const T* p, float (&out)[8]) {
     bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
     for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+  } else if constexpr (std::is_same<T, fp8>::value) {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    const fp8* b = reinterpret_cast<const fp8*>(&q);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (float)b[i];
   } else {
     float4 a = reinterpret_cast<const float4*>(p)[0];
     float4 b = reinterpret_cast<const float4*>(p)[1];
@@ -65,6 +72,12 @@ __device__ __forceinline__ void store8(T* p, const float (&in)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (bf16)in[i];
     *reinterpret_cast<bf16x8*>(p) = v;
+  } else if constexpr (std::is_same<T, fp8>::value) {
+    uint2 q;
+    fp8* b = reinterpret_cast<fp8*>(&q);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = (fp8)in[i];
+    *reinterpret_cast<uint2*>(p) = q;
   } else {
     reinterpret_cast<float4*>(p)[0] = make_float4(in[0], in[1], in[2], in[3]);
     reinterpret_cast<float4*>(p)[1] = make_float4(in[4], in[5], in[6], in[7]);
@@ -77,24 +90,40 @@ struct Raw8 {
   static constexpr int NQ = sizeof(T) / 2;      // 16-byte quads per 8 elements
   uint4 q[NQ];
 };
+template <>
+struct Raw8<fp8> {
+  uint2 q;                                      // 8 bytes
+};
 
 template <typename T>
 __device__ __forceinline__ Raw8<T> gload8(const T* p) {
   Raw8<T> r;
+  if constexpr (std::is_same<T, fp8>::value) {
+    r.q = *reinterpret_cast<const uint2*>(p);
+  } else {
 #pragma unroll
-  for (int i = 0; i < Raw8<T>::NQ; ++i) r.q[i] = reinterpret_cast<const uint4*>(p)[i];
+    for (int i = 0; i < Raw8<T>::NQ; ++i) r.q[i] = reinterpret_cast<const uint4*>(p)[i];
+  }
   return r;
 }
 template <typename T>
 __device__ __forceinline__ void lstore8(T* p, const Raw8<T>& r) {
+  if constexpr (std::is_same<T, fp8>::value) {
+    *reinterpret_cast<uint2*>(p) = r.q;
+  } else {
 #pragma unroll
-  for (int i = 0; i < Raw8<T>::NQ; ++i) reinterpret_cast<uint4*>(p)[i] = r.q[i];
+    for (int i = 0; i < Raw8<T>::NQ; ++i) reinterpret_cast<uint4*>(p)[i] = r.q[i];
+  }
 }
 template <typename T>
 __device__ __forceinline__ Raw8<T> zero8() {
   Raw8<T> r;
+  if constexpr (std::is_same<T, fp8>::value) {
+    r.q = make_uint2(0, 0);
+  } else {
 #pragma unroll
-  for (int i = 0; i < Raw8<T>::NQ; ++i) r.q[i] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < Raw8<T>::NQ; ++i) r.q[i] = make_uint4(0, 0, 0, 0);
+  }
   return r;
 }
 template <typename T>
@@ -110,6 +139,14 @@ __device__ __forceinline__ Raw8<T> affine8(const Raw8<T>& r, const float* sc, co
       w[e] = (bf16)t;
     }
     o.q[0] = __builtin_bit_cast(uint4, w);
+  } else if constexpr (std::is_same<T, fp8>::value) {
+    const fp8* f = reinterpret_cast<const fp8*>(&r.q);
+    fp8* g = reinterpret_cast<fp8*>(&o.q);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (float)f[e] * sc[e] + sh[e];
+      g[e] = (fp8)(relu ? fmaxf(t, 0.f) : t);
+    }
   } else {
     const float* f = reinterpret_cast<const float*>(&r.q[0]);
     float* g = reinterpret_cast<float*>(&o.q[0]);
@@ -126,6 +163,7 @@ __device__ __forceinline__ Raw8<T> affine8(const Raw8<T>& r, const float* sc, co
 template <typename T>
 __device__ __forceinline__ float round_to(float x) {
   if constexpr (std::is_same<T, bf16>::value) return (float)(bf16)x;
+  else if constexpr (std::is_same<T, fp8>::value) return (float)(fp8)x;
   else return x;
 }
 

@@ -308,7 +308,7 @@ static int igemm_fill_args(const satcv_conv_desc* d, IgemmArgs& a) {
   SATCV_CHECK(!(d->mode_in && d->in_scale), "igemm: s2d source cannot carry an input transform");
   a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_relu = d->in_relu;
-  a.w = d->w; a.bias = d->bias; a.y = d->y; a.ldy = d->ldy;
+  a.w = d->w; a.bias = d->bias; a.out_scale = d->out_scale; a.y = d->y; a.ldy = d->ldy;
   a.stats = d->stats; a.stats_ld = d->stats_ld;
   a.n = d->n; a.h = d->h; a.w_ = d->w_;
   a.hs = d->mode_in ? d->h * d->f : d->h; a.ws = d->mode_in ? d->w_ * d->f : d->w_;
@@ -352,6 +352,8 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   rc = SATCV_ERR_UNSUPPORTED;
   if (!igemm_force_generic()) rc = igemm_fast_launch(a, d->dtype, st);
   if (rc != SATCV_ERR_UNSUPPORTED) { /* launched (or failed hard) */ }
+  else if (d->dtype == SATCV_FP8) { satcv_set_error("igemm: this fp8 shape is outside the pipelined kernel's limits"); rc = SATCV_ERR_UNSUPPORTED; }
+  else if (d->out_scale) { satcv_set_error("igemm: out_scale needs the pipelined kernel"); rc = SATCV_ERR_UNSUPPORTED; }
   else if (d->dtype == SATCV_BF16) rc = launch_t<bf16>(a, st);
   else if (d->dtype == SATCV_F32) rc = launch_t<float>(a, st);
   else { satcv_set_error("igemm: bad dtype %d", d->dtype); rc = SATCV_ERR_INVALID; }

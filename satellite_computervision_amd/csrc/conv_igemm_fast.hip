@@ -276,6 +276,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (SATCV_PERSIST_THIN ? 
       const bool cvalid = cn < a.cout;
       const int cch = cvalid ? cn % a.cstat : 0;
       const float bv = (a.bias && cvalid) ? a.bias[cch] : 0.f;
+      const float osc = (a.out_scale && cvalid) ? a.out_scale[cch] : 1.f;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (SATCV_PERSIST_THIN ? 
         for (int i = 0; i < 16; ++i) {
           const int row = (i & 3) + 8 * (i >> 2) + 4 * hh_e;
           const int q = (wm_e * MT + m) * 32 + row;
-          float vv = acc[m][n][i] + bv;
+          float vv = acc[m][n][i] * osc + bv;
           if (a.out_relu) vv = fmaxf(vv, 0.f);
           const T tv = (T)vv;
           ldsO[q * OPITCH + cl_] = tv;
@@ -482,5 +483,6 @@ int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   if (!(taps == 1 || (a.kh == 3 && a.kw == 3)) || a.stride != 1) return SATCV_ERR_UNSUPPORTED;
   if (dtype == SATCV_BF16) return taps == 1 ? fast_t<bf16, 1>(a, st, dry) : fast_t<bf16, 9>(a, st, dry);
   if (dtype == SATCV_F32) return taps == 1 ? fast_t<float, 1>(a, st, dry) : fast_t<float, 9>(a, st, dry);
+  if (dtype == SATCV_FP8) return taps == 1 ? fast_t<fp8, 1>(a, st, dry) : fast_t<fp8, 9>(a, st, dry);
   return SATCV_ERR_UNSUPPORTED;
 }

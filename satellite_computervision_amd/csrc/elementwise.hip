@@ -25,23 +25,38 @@ static inline int ew_grid(long long items, int cap = 256 * 8) {
     else { satcv_set_error("bad dtype %d", (int)(dtype)); return SATCV_ERR_INVALID; } \
   } while (0)
 
+// storage dtypes of the inference-only kernels (adds OCP fp8 e4m3)
+#define DISPATCH_T8(dtype, ...)                                                  \
+  do {                                                                           \
+    if ((dtype) == SATCV_BF16) { using T = bf16; __VA_ARGS__; }                  \
+    else if ((dtype) == SATCV_F32) { using T = float; __VA_ARGS__; }             \
+    else if ((dtype) == SATCV_FP8) { using T = fp8; __VA_ARGS__; }               \
+    else { satcv_set_error("bad dtype %d", (int)(dtype)); return SATCV_ERR_INVALID; } \
+  } while (0)
+
 // ------------------------------------------------------------------------ ingest
 template <typename T>
-__global__ void ingest_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, long long npix, int c, int cpad) {
+__global__ void ingest_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, long long npix, int c, int cpad, float mul) {
   const int G = cpad / 8;
   const long long total = npix * G;
   for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
     const long long p = it / G; const int g = (int)(it % G);
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const int ch = g * 8 + e; v[e] = ch < c ? src[p * c + ch] : 0.f; }
+    for (int e = 0; e < 8; ++e) { const int ch = g * 8 + e; v[e] = ch < c ? src[p * c + ch] * mul : 0.f; }
     store8<T>(dst + p * cpad + g * 8, v);
   }
 }
 extern "C" int satcv_ingest_nhwc(const float* src, void* dst, int64_t npix, int32_t c, int32_t cpad, int32_t dtype, void* stream) {
   SATCV_CHECK(src && dst && npix > 0 && c > 0 && cpad >= c && cpad % 8 == 0, "ingest_nhwc: bad args");
-  DISPATCH_T(dtype, hipLaunchKernelGGL(ingest_nhwc_kernel<T>, dim3(ew_grid(npix * (cpad / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, src, (T*)dst, (long long)npix, c, cpad));
+  DISPATCH_T8(dtype, hipLaunchKernelGGL(ingest_nhwc_kernel<T>, dim3(ew_grid(npix * (cpad / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, src, (T*)dst, (long long)npix, c, cpad, 1.0f));
   LAUNCH_OK("ingest_nhwc");
+  return SATCV_OK;
+}
+extern "C" int satcv_ingest_nhwc_scaled(const float* src, void* dst, int64_t npix, int32_t c, int32_t cpad, float mul, int32_t dtype, void* stream) {
+  SATCV_CHECK(src && dst && npix > 0 && c > 0 && cpad >= c && cpad % 8 == 0, "ingest_nhwc_scaled: bad args");
+  DISPATCH_T8(dtype, hipLaunchKernelGGL(ingest_nhwc_kernel<T>, dim3(ew_grid(npix * (cpad / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, src, (T*)dst, (long long)npix, c, cpad, mul));
+  LAUNCH_OK("ingest_nhwc_scaled");
   return SATCV_OK;
 }
 
@@ -107,7 +122,7 @@ extern "C" int satcv_pack_weights(const float* src, void* dst_fwd, void* dst_dgr
   SATCV_CHECK(src && cin > 0 && cout > 0 && cin_pad >= cin && cin_pad % 16 == 0, "pack_weights: bad args");
   const int taps = kh * kw;
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_T(dtype, {
+  DISPATCH_T8(dtype, {
     if (!transposed) {
       if (dst_fwd) { const int kp = cin_pad, np = rup(cout, 32);
         hipLaunchKernelGGL(pack_kernel<T>, dim3(ew_grid((long long)taps * (kp / 8) * np)), dim3(EW_BLOCK), 0, st, src, (T*)dst_fwd, 0, taps, cin, cout, kp, np); }
@@ -637,9 +652,10 @@ static bool head_fast_launch(const satcv_head_desc* d, hipStream_t st) {
   const int grid = ew_grid(d->npix, 1024);
 #define HEAD_CASE(NC_, CIN_)                                                                                      \
   if (d->ncls == NC_ && d->cin == CIN_) {                                                                         \
-    if (BWD && d->bnr_sums) hipLaunchKernelGGL((head_bwd_fast_kernel<T, NC_, CIN_, true>), dim3(grid), dim3(EW_BLOCK), 0, st, *d); \
-    else if (BWD) hipLaunchKernelGGL((head_bwd_fast_kernel<T, NC_, CIN_, false>), dim3(grid), dim3(EW_BLOCK), 0, st, *d); \
-    else hipLaunchKernelGGL((head_fwd_fast_kernel<T, NC_, CIN_>), dim3(grid), dim3(EW_BLOCK), 0, st, *d);         \
+    if constexpr (BWD) {                                                                                          \
+      if (d->bnr_sums) hipLaunchKernelGGL((head_bwd_fast_kernel<T, NC_, CIN_, true>), dim3(grid), dim3(EW_BLOCK), 0, st, *d); \
+      else hipLaunchKernelGGL((head_bwd_fast_kernel<T, NC_, CIN_, false>), dim3(grid), dim3(EW_BLOCK), 0, st, *d); \
+    } else hipLaunchKernelGGL((head_fwd_fast_kernel<T, NC_, CIN_>), dim3(grid), dim3(EW_BLOCK), 0, st, *d);       \
     return true;                                                                                                  \
   }
   HEAD_CASE(1, 16) HEAD_CASE(2, 16) HEAD_CASE(1, 32) HEAD_CASE(2, 32) HEAD_CASE(3, 32) HEAD_CASE(4, 32) HEAD_CASE(1, 64) HEAD_CASE(2, 64)
@@ -650,7 +666,7 @@ extern "C" int satcv_head_fwd(const satcv_head_desc* d, void* stream) {
   SATCV_CHECK(d && d->x && d->w && d->b && d->probs, "head_fwd: null pointer");
   SATCV_CHECK(d->cin > 0 && d->cin % 8 == 0 && d->ncls >= 1 && d->ncls <= HEAD_NCMAX && d->npix > 0, "head_fwd: bad dims (cin=%d ncls=%d)", d->cin, d->ncls);
   const size_t lds = (size_t)(d->cin * d->ncls + d->ncls + 2 * d->cin) * sizeof(float);
-  DISPATCH_T(d->dtype, { if (!head_fast_launch<T, false>(d, (hipStream_t)stream))
+  DISPATCH_T8(d->dtype, { if (!head_fast_launch<T, false>(d, (hipStream_t)stream))
       hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(ew_grid(d->npix)), dim3(EW_BLOCK), lds, (hipStream_t)stream, *d); });
   LAUNCH_OK("head_fwd");
   return SATCV_OK;
@@ -760,9 +776,41 @@ extern "C" int satcv_maxpool(const void* x, void* out, int32_t n, int32_t h, int
   SATCV_CHECK(x && out && n > 0 && h > 0 && w_ > 0 && c > 0 && c % 8 == 0 && k >= 1 && s >= 1 && pad >= 0, "maxpool: bad args");
   const int ho = (h + 2 * pad - k) / s + 1, wo = (w_ + 2 * pad - k) / s + 1;
   SATCV_CHECK(ho > 0 && wo > 0, "maxpool: empty output");
-  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_kernel<T>, dim3(ew_grid((long long)n * ho * wo * (c / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+  DISPATCH_T8(dtype, hipLaunchKernelGGL(maxpool_kernel<T>, dim3(ew_grid((long long)n * ho * wo * (c / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream,
                                        (const T*)x, (T*)out, n, h, w_, c, k, s, pad, ho, wo));
   LAUNCH_OK("maxpool");
+  return SATCV_OK;
+}
+// out = Q(relu?(scale*x + shift)) with separate channel strides (skip half of the folded concat -> BN -> ReLU)
+template <typename T, typename TO>
+__global__ void affine_requant_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                      TO* __restrict__ out, int ldo, long long npix, int c) {
+  const int G = c / 8;
+  const long long total = npix * G;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+    const long long p = it / G; const int g = (int)(it % G);
+    float v[8];
+    load8<T>(x + p * ldx + g * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = v[e] * scale[g * 8 + e] + shift[g * 8 + e];
+      v[e] = relu ? fmaxf(a, 0.f) : a;
+    }
+    store8<TO>(out + p * ldo + g * 8, v);
+  }
+}
+extern "C" int satcv_affine_requant(const void* x, int32_t ldx, const float* scale, const float* shift, int32_t relu, void* out, int32_t ldo,
+                                    int64_t npix, int32_t c, int32_t dtype, int32_t dtype_out, void* stream) {
+  SATCV_CHECK(x && scale && shift && out && npix > 0 && c > 0 && c % 8 == 0 && ldx >= c && ldo >= c, "affine_requant: bad args");
+  SATCV_CHECK(dtype_out == dtype || dtype_out == SATCV_FP8, "affine_requant: output dtype must equal the input dtype or be fp8");
+  if (dtype_out == dtype) {
+    DISPATCH_T8(dtype, hipLaunchKernelGGL((affine_requant_kernel<T, T>), dim3(ew_grid(npix * (c / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)x, ldx,
+                                          scale, shift, relu, (T*)out, ldo, (long long)npix, c));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((affine_requant_kernel<T, fp8>), dim3(ew_grid(npix * (c / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)x, ldx,
+                                         scale, shift, relu, (fp8*)out, ldo, (long long)npix, c));
+  }
+  LAUNCH_OK("affine_requant");
   return SATCV_OK;
 }
 // out = relu?( affine?(y) + affine?(res) ): the residual join of a bottleneck block

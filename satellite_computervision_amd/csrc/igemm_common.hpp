@@ -6,7 +6,7 @@ struct IgemmArgs {
   const void* x0; const void* x1;
   int c0, c1;
   const float* in_scale; const float* in_shift; int in_relu;
-  const void* w; const float* bias;
+  const void* w; const float* bias; const float* out_scale;
   void* y; int ldy;
   float* stats; int stats_ld;
   int n, h, w_;            // GEMM pixel grid
@@ -30,12 +30,16 @@ template <>
 struct FragT<bf16> { bf16x8 v; };
 template <>
 struct FragT<float> { float4 lo, hi; };
+template <>
+struct FragT<fp8> { long v; };
 
 template <typename T>
 __device__ __forceinline__ FragT<T> lds_frag(const T* p) {
   FragT<T> f;
   if constexpr (std::is_same<T, bf16>::value) {
     f.v = *reinterpret_cast<const bf16x8*>(p);
+  } else if constexpr (std::is_same<T, fp8>::value) {
+    f.v = *reinterpret_cast<const long*>(p);
   } else {
     f.lo = reinterpret_cast<const float4*>(p)[0];
     f.hi = reinterpret_cast<const float4*>(p)[1];
@@ -47,6 +51,8 @@ template <typename T>
 __device__ __forceinline__ void mma32(f32x16& acc, const FragT<T>& a, const FragT<T>& b) {
   if constexpr (std::is_same<T, bf16>::value) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+  } else if constexpr (std::is_same<T, fp8>::value) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a.v, b.v, acc, 0, 0, 0);      // bf16 rate, half the operand bytes
   } else {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.x, b.lo.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.y, b.lo.y, acc, 0, 0, 0);

@@ -550,6 +550,7 @@ class Plan:
             else:
                 raise NotImplementedError(f'op {op}')
         self.vals = vals
+        self.node_ctx = ctx
         if training:
             self._build_backward(consumers, vals, acts, ctx, cat_stats)
 

@@ -719,6 +719,28 @@ class Model:
     def _head_plan(self, n, h, w, training):
         return self.runtime.plan(n, h, w, training)
 
+    def enable_fp8_inference(self, calibration_tiles):
+        """Switch predict / predict_on_device / predict_chips to the folded fp8 (e4m3) graph of fp8_infer.py.  The
+        per-tensor activation scales come from one regular inference run on `calibration_tiles` (NHWC); the weights
+        are re-quantised from the current fp32 parameters here, so call it again after training or load_weights."""
+        from . import fp8_infer
+        self._fp8_q = fp8_infer.calibrate(self, calibration_tiles)
+        self._fp8_plans = {}
+        return self
+
+    def disable_fp8_inference(self):
+        self._fp8_q = None
+        self._fp8_plans = {}
+
+    def _infer_plan(self, n, h, w):
+        if getattr(self, '_fp8_q', None) is not None:
+            from . import fp8_infer
+            key = (n, h, w)
+            if key not in self._fp8_plans:
+                self._fp8_plans[key] = fp8_infer.Fp8Plan(self, n, h, w, self._fp8_q)
+            return self._fp8_plans[key]
+        return self._head_plan(n, h, w, False)
+
     def _stage_x(self, plan, xb):
         xs = list(xb) if isinstance(xb, (list, tuple)) else [xb]
         if len(xs) != len(self.inputs):
@@ -737,7 +759,7 @@ class Model:
     def predict_on_device(self, xb):
         """xb: (n,h,w,c) ndarray or device tensor -> list of device tensors [probs, classes] (no host sync)."""
         n, h, w, _ = self._shape_of(xb)
-        plan = self._head_plan(n, h, w, False)
+        plan = self._infer_plan(n, h, w)
         self._stage_x(plan, xb)
         plan.run_forward(ops.stream_ptr())
         return [plan.outputs[t.id] for t in self.outputs]

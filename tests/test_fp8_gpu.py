@@ -1,0 +1,125 @@
+"""FP8 (OCP e4m3fn) inference path, BASELINE config 5.  The reference has no reduced-precision path: parity is against
+this build's fp32 path / the float64 oracle.  Operator tests use values that are exactly representable, so the fp8
+MFMA operand layout, the folded epilogue and the e4m3 rounding are checked BIT-EXACTLY; the model test states its
+tolerance (IoU of the fp8 mask vs the oracle's, both against ground truth)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    from satellite_computervision_amd import ops, model_tools as mt
+    from satellite_computervision_amd._lib import lib, check, FP8
+    return dict(ops=ops, mt=mt, lib=lib, check=check, FP8=FP8)
+
+
+def _to_f8(t):
+    return t.to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize('cin,cout,k,dil', [(32, 32, 3, 1), (16, 64, 3, 1), (64, 96, 3, 1), (128, 128, 3, 1), (64, 32, 1, 1), (32, 32, 3, 2)])
+def test_fp8_conv_bit_exact(env, cin, cout, k, dil):
+    ops, lib, check, FP8 = env['ops'], env['lib'], env['check'], env['FP8']
+    rng = np.random.default_rng(cin * 7 + cout + k)
+    n, h, w = 3, 20, 40
+    x = torch.tensor(rng.integers(-3, 4, (n, h, w, cin)), dtype=torch.float32)
+    kern = torch.tensor(rng.integers(-2, 3, (k, k, cin, cout)), dtype=torch.float32)
+    osc = torch.tensor(2.0 ** rng.integers(-6, -3, cout), dtype=torch.float32)
+    bias = torch.tensor(rng.integers(-4, 5, cout), dtype=torch.float32)
+    pad = dil * (k - 1) // 2
+    acc = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), kern.permute(3, 2, 0, 1).double(), padding=pad, dilation=dil).permute(0, 2, 3, 1)
+    ref = _to_f8((acc * osc.double() + bias.double()).clamp_min(0).clamp_max(448).float())
+    xd = _to_f8(x).cuda()
+    w8, _ = ops.pack_weights(kern.cuda(), cin, FP8, want_dgrad=False)
+    y = torch.zeros(n, h, w, cout, dtype=torch.uint8, device='cuda')
+    oscd, bd = osc.cuda(), bias.cuda()
+    d = ops.make_conv_desc(x0=xd.data_ptr(), c0=cin, w=w8.data_ptr(), bias=bd.data_ptr(), out_scale=oscd.data_ptr(), y=y.data_ptr(), ldy=cout, n=n, h=h, w_=w,
+                           cout=cout, cout_pad=ops.rup(cout, 32), kh=k, kw=k, dil=dil, dtype=FP8, out_relu=1)
+    check(lib.satcv_conv2d_igemm(C.byref(d), ops.stream_ptr()))
+    got = y.cpu()
+    assert torch.equal(got, ref.view(torch.uint8)), (got.view(torch.float8_e4m3fn).float() - ref.float()).abs().max()
+
+
+def test_fp8_transposed_conv_into_concat_slice_and_requant(env):
+    ops, lib, check, FP8 = env['ops'], env['lib'], env['check'], env['FP8']
+    rng = np.random.default_rng(3)
+    n, h, w, cin, cout, f, ca = 2, 8, 16, 64, 32, 2, 32
+    x = torch.tensor(rng.integers(-3, 4, (n, h, w, cin)), dtype=torch.float32)
+    kern = torch.tensor(rng.integers(-2, 3, (f, f, cout, cin)), dtype=torch.float32)          # Keras Conv2DTranspose layout
+    osc = torch.tensor(2.0 ** rng.integers(-5, -2, cout), dtype=torch.float32)
+    bias = torch.tensor(rng.integers(-4, 5, cout), dtype=torch.float32)
+    up = torch.nn.functional.conv_transpose2d(x.permute(0, 3, 1, 2).double(), kern.permute(3, 2, 0, 1).double(), stride=f).permute(0, 2, 3, 1)
+    ref_up = _to_f8((up * osc.double() + bias.double()).clamp_min(0).clamp_max(448).float())
+    skip = torch.tensor(rng.integers(0, 9, (n, h * f, w * f, ca)), dtype=torch.float32)
+    rs = torch.tensor(2.0 ** rng.integers(-2, 2, ca), dtype=torch.float32)
+    rsh = torch.tensor(rng.integers(-3, 4, ca), dtype=torch.float32)
+    ref_skip = _to_f8((skip * rs + rsh).clamp_min(0))
+    cat = torch.zeros(n, h * f, w * f, ca + cout, dtype=torch.uint8, device='cuda')
+    xd, sd = _to_f8(x).cuda(), _to_f8(skip).cuda()
+    w8, _ = ops.pack_weights(kern.cuda(), cin, FP8, transposed=True, want_dgrad=False)
+    oscd, bd, rsd, rshd = osc.cuda(), bias.cuda(), rs.cuda(), rsh.cuda()
+    d = ops.make_conv_desc(x0=xd.data_ptr(), c0=cin, w=w8.data_ptr(), bias=bd.data_ptr(), out_scale=oscd.data_ptr(), y=cat.data_ptr() + ca, ldy=ca + cout,
+                           n=n, h=h, w_=w, cout=f * f * cout, cout_pad=ops.rup(f * f * cout, 32), kh=1, kw=1, dil=1, mode_out=1, f=f, cstat=cout,
+                           dtype=FP8, out_relu=1)
+    check(lib.satcv_conv2d_igemm(C.byref(d), ops.stream_ptr()))
+    check(lib.satcv_affine_requant(sd.data_ptr(), ca, rsd.data_ptr(), rshd.data_ptr(), 1, cat.data_ptr(), ca + cout, n * h * f * w * f, ca, FP8, FP8, ops.stream_ptr()))
+    got = cat.cpu()
+    assert torch.equal(got[..., ca:], ref_up.view(torch.uint8))
+    assert torch.equal(got[..., :ca], ref_skip.view(torch.uint8))
+    # max-pool on the fp8 values
+    pooled = torch.zeros(n, h, w, ca + cout, dtype=torch.uint8, device='cuda')
+    check(lib.satcv_maxpool(cat.data_ptr(), pooled.data_ptr(), n, h * f, w * f, ca + cout, 2, 2, 0, FP8, ops.stream_ptr()))
+    refp = torch.nn.functional.max_pool2d(got.view(torch.float8_e4m3fn).float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert torch.equal(pooled.cpu().view(torch.float8_e4m3fn).float(), refp)
+
+
+def test_fp8_unet_inference_iou(env):
+    """Trained small U-Net: fp8 (e4m3 weights + activations, fp32 accumulate) mask vs the float64 oracle's mask, both scored
+    against ground truth.  Stated tolerance for the fp8 path (3 mantissa bits, per-tensor activation scales): |IoU_fp8 - IoU_oracle| <= 5e-3,
+    >= 98.5 % identical pixels, >= 99.5 % where the oracle's probability is beyond 0.5 +- 0.25."""
+    from oracle.unet import UNetOracle
+    mt = env['mt']
+    mt.reset_uids(); mt.set_seed(1)
+    filters, factors = [32, 64], [2, 2]
+    m = mt.get_unet_model(2, 4, filters=filters, factors=factors)
+    m.compute_dtype = 'float32'
+    rng = np.random.default_rng(7)
+
+    def make(n):
+        lo = torch.tensor(rng.random((n, 4, 8, 8)), dtype=torch.float32)
+        x = torch.nn.functional.interpolate(lo, size=(64, 64), mode='bilinear', align_corners=False)
+        x = (x.permute(0, 2, 3, 1).numpy() + 0.05 * rng.standard_normal((n, 64, 64, 4))).astype(np.float32)
+        return x, (x[..., 0] + x[..., 3] > 1.0).astype(np.int64)
+    x, lab = make(32)
+    m.compile(optimizer=mt.Adam(2e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 1.0]))
+    m.fit(x, np.eye(2, dtype=np.float32)[lab], batch_size=8, epochs=100, verbose=0)
+    xt, labt = make(8)
+    w = m.get_weights_dict()
+    names = mt.structural_names(m)
+    o = UNetOracle(2, 4, filters, factors, dtype=np.float64)
+    for k in o.params:
+        o.params[k] = w[names[k]].astype(np.float64)
+    p_ref, c_ref = o.forward(xt, training=False)
+
+    def iou(a, b):
+        return (np.logical_and(a == 1, b == 1).sum()) / max(np.logical_or(a == 1, b == 1).sum(), 1)
+    iou_ref = iou(c_ref, labt)
+    assert iou_ref > 0.85
+    m.enable_fp8_inference(x[:8])
+    p8, c8 = m.predict(xt)
+    m.disable_fp8_inference()
+    p32, c32 = m.predict(xt)
+    assert np.array_equal(c32, c_ref) or (c32 == c_ref).mean() > 0.9999
+    agree, d_iou, d_p = (c8 == c_ref).mean(), abs(iou(c8, labt) - iou_ref), np.abs(p8 - p_ref).mean()
+    print(f'fp8 vs oracle: pixel agreement {agree:.4f}, IoU {iou(c8, labt):.4f} vs {iou_ref:.4f}, mean |dp| {d_p:.4f}')
+    margin = np.abs(p_ref[..., 1] - 0.5) > 0.25                 # confidently classified pixels must not flip
+    assert (c8[margin] == c_ref[margin]).mean() > 0.995, (c8[margin] == c_ref[margin]).mean()
+    assert agree >= 0.985 and d_iou <= 5e-3 and d_p < 0.015, (agree, d_iou, d_p)
