@@ -226,6 +226,37 @@ typedef struct satcv_head_desc {
 int satcv_head_fwd(const satcv_head_desc* d, void* stream);
 int satcv_head_bwd(const satcv_head_desc* d, void* stream);
 
+/* ------------------------------------------------------------------ tile input pipeline
+ * Device version of UNETDataGenerator.__getitem__ (utils/processing.py:456-755) for one source / the labels of one batch.
+ * src: planes (n, c, hin, win) of kind 0 u8, 1 u16, 2 f32, 3 i16, 4 f64, 5 i32, 6 i64 (what np.load returned).
+ *   x / rescale (float64; 0 = none)                                     -- :551-552, 601, 613 (255 / 10000 / 100 / 2000)
+ *   nan_mask: append the mask channel; with replace (to_fit) values that are NaN or < -5000 -- in this channel or an
+ *   EARLIER one of the image, as coded -- become N(0,1) draws (counter RNG on seed) and the mask is 1     -- :553-583
+ *   centre trim to (h, w_)                                                                                 -- :586-590
+ *   ch_mean != NULL: (x - mean)*contra_mul + mean*bright_mul, mean = nanmean over (h, w_) per image and channel from
+ *   satcv_tile_channel_mean                                             -- utils/array_tools.py:159-186
+ *   flip_v, flip_h, rot (np.rot90 k) of the stacked batch               -- utils/array_tools.py:188-213, processing.py:748
+ * dst: fp32 NHWC (n, ho, wo, ldc) written at channel offset coff (ho, wo = w_, h when rot is odd). */
+typedef struct {
+  const void* src; int32_t src_kind;
+  int32_t n, c, hin, win, h, w_;
+  double rescale;
+  int32_t nan_mask, replace;
+  uint64_t seed;
+  const double* ch_mean;
+  double contra_mul, bright_mul;
+  int32_t flip_v, flip_h, rot;
+  float* dst; int32_t ldc, coff;
+} satcv_tile_desc;
+int satcv_tile_channel_mean(const satcv_tile_desc* d, double* mean_out /* (n, c) */, void* stream);
+int satcv_tile_ingest(const satcv_tile_desc* d, void* stream);
+/* labels (n, 1, hin, win) -> merge_classes (utils/array_tools.py:26-44) as 256-entry look-up tables (-1 = keep): lut on the
+ * land-cover value, then lu_lut on the optional land-use array -> trim -> morph -> tf.one_hot(depth nclasses) fp32
+ * (utils/processing.py:656-704). */
+int satcv_label_onehot(const void* lc, int32_t lc_kind, const int32_t* lut, const void* lu, int32_t lu_kind, const int32_t* lu_lut,
+                       int32_t n, int32_t hin, int32_t win, int32_t h, int32_t w_, int32_t nclasses, int32_t flip_v, int32_t flip_h,
+                       int32_t rot, float* dst, int32_t ldc, int32_t coff, void* stream);
+
 /* ------------------------------------------------------------------ losses
  * Each writes loss_out[0] += mean loss contribution (caller zeroes) and
  * dlogits = dL/dlogits (through the head activation).

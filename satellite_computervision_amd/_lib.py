@@ -32,6 +32,13 @@ class ConvDesc(C.Structure):
                 ('stride', c_i32), ('hin', c_i32), ('win', c_i32), ('out_scale', c_vp)]
 
 
+class TileDesc(C.Structure):
+    _fields_ = [('src', c_vp), ('src_kind', c_i32), ('n', c_i32), ('c', c_i32), ('hin', c_i32), ('win', c_i32), ('h', c_i32), ('w_', c_i32),
+                ('rescale', C.c_double), ('nan_mask', c_i32), ('replace', c_i32), ('seed', C.c_uint64), ('ch_mean', c_vp),
+                ('contra_mul', C.c_double), ('bright_mul', C.c_double), ('flip_v', c_i32), ('flip_h', c_i32), ('rot', c_i32),
+                ('dst', c_vp), ('ldc', c_i32), ('coff', c_i32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [('x0', c_vp), ('x1', c_vp), ('c0', c_i32), ('c1', c_i32),
                 ('in_scale', c_vp), ('in_shift', c_vp), ('in_relu', c_i32),
@@ -87,6 +94,9 @@ _SIGS = {
     'satcv_upsample_head': (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
     'satcv_dropout_mask': (C.c_int, [C.c_uint64, C.c_uint64, c_f32, c_i64, c_vp, c_vp]),
     'satcv_dropout_apply': (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'satcv_tile_channel_mean': (C.c_int, [C.POINTER(TileDesc), c_vp, c_vp]),
+    'satcv_tile_ingest': (C.c_int, [C.POINTER(TileDesc), c_vp]),
+    'satcv_label_onehot': (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
     'satcv_head_fwd': (C.c_int, [C.POINTER(HeadDesc), c_vp]),
     'satcv_head_bwd': (C.c_int, [C.POINTER(HeadDesc), c_vp]),
     'satcv_loss_fwd_bwd': (C.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_f32, c_vp, c_vp, c_vp]),

@@ -1,0 +1,160 @@
+"""Device-side tile input pipeline: `UNETDataGenerator` of the reference (utils/processing.py:456-755) with the per-pixel
+work (rescale, NaN mask channel, centre trim, colour augmentation, label merging + one-hot, flip/rot90 augmentation) done by
+the HIP kernels of csrc/input_pipeline.hip instead of NumPy.  Same constructor arguments and Keras `Sequence` protocol
+(`__len__`, `__getitem__`, `on_epoch_end`); `__getitem__` returns DEVICE tensors (features NHWC fp32, one-hot labels fp32)
+that `Model.fit` consumes without a host round trip.  File entries may be `.npy` paths (np.load, as the reference) or
+in-memory arrays.
+
+Random draws use Python's `random` in the reference's order (per colour-augmented source: contrast, brightness; then
+vertical flip, horizontal flip, rot90 count), so `random.seed(k)` reproduces the reference's augmentation choices; the
+N(0,1) replacement values of masked pixels come from a counter-based device generator (the reference's np.random.randn
+stream cannot be reproduced on the device)."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import lib, check, TileDesc
+
+_KIND = {np.dtype('uint8'): 0, np.dtype('uint16'): 1, np.dtype('float32'): 2, np.dtype('int16'): 3, np.dtype('float64'): 4,
+         np.dtype('int32'): 5, np.dtype('int64'): 6}
+
+
+def merge_lut(trans, device):
+    """merge_classes (utils/array_tools.py:26-44) as a 256-entry table: rules test the ORIGINAL value, the last one wins."""
+    lut = np.full(256, -1, np.int32)
+    for x, y in trans or []:
+        if 0 <= int(x) < 256:
+            lut[int(x)] = int(y)
+    return torch.from_numpy(lut).to(device)
+
+
+def _load(item):
+    if isinstance(item, (str, os.PathLike)):
+        return np.load(item)
+    return np.asarray(item)
+
+
+def _stack_chw(items):
+    arrays = [_load(f) for f in items]
+    assert len(arrays) > 0 and all(a.ndim == 3 for a in arrays), 'all arrays not 3D'
+    chw = [np.moveaxis(a, -1, 0) if a.shape[-1] < a.shape[0] else a for a in arrays]          # utils/processing.py:549
+    batch = np.stack(chw, axis=0)
+    if batch.dtype not in _KIND:
+        batch = batch.astype(np.float64)
+    return np.ascontiguousarray(batch)
+
+
+def device_source(batch_chw, unet_dim, dst, coff, *, rescale_val=0.0, add_nan_mask=False, to_fit=True, color=None, morph=(0, 0, 0), seed=0):
+    """One source of one batch -> channels [coff, coff + C (+1)) of the NHWC fp32 tensor `dst`.  color = (contra_mul, bright_mul)
+    or None; morph = (flip_v, flip_h, rot)."""
+    src = torch.from_numpy(batch_chw).to(dst.device, non_blocking=True)
+    n, c, hin, win = batch_chw.shape
+    d = TileDesc(src=src.data_ptr(), src_kind=_KIND[batch_chw.dtype], n=n, c=c, hin=hin, win=win, h=unet_dim[0], w_=unet_dim[1],
+                 rescale=float(rescale_val or 0.0), nan_mask=int(bool(add_nan_mask)), replace=int(bool(to_fit)), seed=int(seed),
+                 flip_v=int(bool(morph[0])), flip_h=int(bool(morph[1])), rot=int(morph[2]) % 4,
+                 dst=dst.data_ptr(), ldc=dst.shape[-1], coff=coff)
+    st = ops.stream_ptr()
+    keep = [src]
+    if color is not None:
+        mean = torch.empty(n * c, dtype=torch.float64, device=dst.device)
+        check(lib.satcv_tile_channel_mean(C.byref(d), mean.data_ptr(), st))
+        d.ch_mean, d.contra_mul, d.bright_mul = mean.data_ptr(), float(color[0]), float(color[1])
+        keep.append(mean)
+    check(lib.satcv_tile_ingest(C.byref(d), st))
+    return keep
+
+
+def device_labels(lc_b1hw, unet_dim, n_classes, dst, coff, lut, lu_b1hw=None, lu_lut=None, morph=(0, 0, 0)):
+    lc = torch.from_numpy(np.ascontiguousarray(lc_b1hw)).to(dst.device, non_blocking=True)
+    lu = torch.from_numpy(np.ascontiguousarray(lu_b1hw)).to(dst.device, non_blocking=True) if lu_b1hw is not None else None
+    n, _, hin, win = lc_b1hw.shape
+    check(lib.satcv_label_onehot(lc.data_ptr(), _KIND[lc_b1hw.dtype], lut.data_ptr() if lut is not None else None,
+                                 lu.data_ptr() if lu is not None else None, _KIND[lu_b1hw.dtype] if lu is not None else 0,
+                                 lu_lut.data_ptr() if lu is not None else None, n, hin, win, unet_dim[0], unet_dim[1], n_classes,
+                                 int(bool(morph[0])), int(bool(morph[1])), int(morph[2]) % 4, dst.data_ptr(), dst.shape[-1], coff, ops.stream_ptr()))
+    return [lc, lu]
+
+
+class UNETDataGenerator:
+    """Same arguments as utils/processing.py:460-468.  `splits` / `moments` are accepted and unused, as in the reference's
+    __getitem__."""
+
+    # (attribute, rescale_val, nan mask follows self.mask, colour augmentation when fitting) in the reference's order (:716-744)
+    _SOURCES = (('s2files', 10000.0, False, True), ('naipfiles', 255.0, False, True), ('hagfiles', 100, True, False),
+                ('demfiles', 2000.0, True, False), ('ssurgofiles', 0.0, False, False), ('lidarfiles', 100, True, False))
+
+    def __init__(self, labelfiles=None, s2files=None, naipfiles=None, hagfiles=None, lidarfiles=None, lufiles=None, demfiles=None,
+                 ssurgofiles=None, to_fit=True, batch_size=32, unet_dim=(256, 256), n_channels=4, n_classes=8, shuffle=True,
+                 splits=None, moments=None, lc_transitions=[(12, 3), (11, 3), (10, 3), (9, 8), (255, 0)],
+                 lu_transitions=[(82, 9), (84, 10)], device=None):
+        self.s2files, self.naipfiles, self.hagfiles, self.demfiles = s2files, naipfiles, hagfiles, demfiles
+        self.ssurgofiles, self.lidarfiles, self.labelfiles, self.lufiles = ssurgofiles, lidarfiles, labelfiles, lufiles
+        self.to_fit, self.batch_size, self.unet_dim = to_fit, batch_size, tuple(unet_dim)
+        self.n_channels, self.n_classes, self.shuffle = n_channels, n_classes, shuffle
+        self.splits, self.moments = splits, moments
+        self.lc_trans, self.lu_trans = lc_transitions, lu_transitions
+        self.device = device or torch.device('cuda', torch.cuda.current_device())
+        first = labelfiles if labelfiles is not None else next(getattr(self, a) for a, *_ in self._SOURCES if getattr(self, a))
+        self.indexes = np.arange(len(first))
+        self.mask = bool(to_fit)                                   # :498-500
+        self.on_epoch_end()
+        if self.shuffle:
+            np.random.shuffle(self.indexes)
+        self._lut = merge_lut(self.lc_trans, self.device)
+        self._lu_lut = merge_lut(self.lu_trans, self.device)
+        self._batch_counter = 0
+
+    def __len__(self):
+        return int(np.floor(len(self.indexes) / self.batch_size))
+
+    def on_epoch_end(self):
+        self.indexes = np.arange(len(self.indexes))
+        if self.shuffle:
+            np.random.shuffle(self.indexes)
+
+    def __getitem__(self, index):
+        idx = self.indexes[index * self.batch_size:(index + 1) * self.batch_size]
+        plan = []
+        for attr, rescale, masked, colored in self._SOURCES:
+            files = getattr(self, attr)
+            if not files:
+                continue
+            batch = _stack_chw([files[k] for k in idx])
+            color = None
+            if colored and self.to_fit:                            # aug_array_color draws (utils/array_tools.py:180-182)
+                color = (random.uniform(1 - 0.05, 1 + 0.05), random.uniform(1 - 0.05, 1 + 0.05))
+            plan.append((batch, rescale, masked and self.mask, color))
+        nch = sum(b.shape[1] + (1 if m else 0) for b, _, m, _ in plan)
+        morph = (0, 0, 0)
+        if self.to_fit:                                            # aug_array_morph draws (utils/array_tools.py:202-207)
+            morph = (random.uniform(0, 1) < 0.5, random.uniform(0, 1) < 0.5, random.randint(0, 3))
+        h, w = self.unet_dim
+        ho, wo = (w, h) if morph[2] % 2 else (h, w)
+        n = len(idx)
+        x = torch.empty(n, ho, wo, nch, dtype=torch.float32, device=self.device)
+        keep, off = [], 0
+        self._batch_counter += 1
+        for batch, rescale, masked, color in plan:
+            keep += device_source(batch, self.unet_dim, x, off, rescale_val=rescale, add_nan_mask=masked, to_fit=self.to_fit, color=color,
+                                  morph=morph, seed=(self._batch_counter << 20) + off)
+            off += batch.shape[1] + (1 if masked else 0)
+        if not self.to_fit:
+            torch.cuda.current_stream().synchronize()
+            return x
+        lc = np.stack([_load(self.labelfiles[k]) for k in idx], axis=0)
+        assert lc.shape[1] == 1, 'labels must be (1, H, W)'
+        if lc.dtype not in _KIND:
+            lc = lc.astype(np.int64)
+        lu = None
+        if self.lufiles:
+            lu = np.stack([_load(self.lufiles[k]) for k in idx], axis=0)
+            if lu.dtype not in _KIND:
+                lu = lu.astype(np.float64)
+        y = torch.empty(n, ho, wo, self.n_classes, dtype=torch.float32, device=self.device)
+        keep += device_labels(lc, self.unet_dim, self.n_classes, y, 0, self._lut if self.lc_trans else None, lu, self._lu_lut, morph)
+        torch.cuda.current_stream().synchronize()                  # the staged host batches may be released
+        return x[..., :self.n_channels], y

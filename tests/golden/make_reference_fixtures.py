@@ -85,6 +85,19 @@ def main():
     a['rescale_moments'] = at.rescale_array(img, moments=[(0, 3000)] * 4)
     a['rescale_axes01'] = at.rescale_array(img, axes=(0, 1))
     a['normalize_axes01'] = at.normalize_array(img, axes=(0, 1))
+    # aug_array_color draws two uniform(0.95, 1.05) multipliers from `random`; seed it and record the draws
+    import random
+    img4 = rng.random((3, 12, 10, 4)).astype(np.float32)
+    img4[1, 2, 3, 1] = np.nan                                  # nanmean path
+    a['color_in'] = img4
+    for seed in (0, 1):
+        random.seed(seed)
+        a[f'color_out_{seed}'] = at.aug_array_color(img4)
+        random.seed(seed)
+        a[f'color_mul_{seed}'] = np.array([random.uniform(0.95, 1.05), random.uniform(0.95, 1.05)])
+    lab = np.arange(256).reshape(1, 1, 16, 16)
+    a['merge_lc_default'] = at.merge_classes(lab, [(12, 3), (11, 3), (10, 3), (9, 8), (255, 0)], lab)
+    a['merge_dup_rule'] = at.merge_classes(lab, [(5, 1), (1, 7), (5, 2)], lab)          # rules test the ORIGINAL values; later wins
     np.savez_compressed(f'{OUT}/array_tools_reference.npz', **a)
     print('wrote fixtures:', len(out), len(a))
 

@@ -210,3 +210,28 @@ def test_aspp_shapes():
         params[n] = rng.standard_normal(shape) * 0.1 if kind in ('kernel', 'bias', 'beta', 'mm') else np.ones(shape)
     y = aspp_forward(params, rng.standard_normal((1, 32, 32, 8)))
     assert y.shape == (1, 32, 32, 16) and (y >= 0).all()
+
+
+def test_input_pipeline_restatement_matches_reference_array_tools():
+    """oracle/input_pipeline.py against outputs of the REAL utils/array_tools.py (generated by
+    tests/golden/make_reference_fixtures.py): 16 flip/rot90 cases, the colour augmentation with the recorded random draws,
+    merge_classes rule order."""
+    from oracle import input_pipeline as ip
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'array_tools_reference.npz'))
+    x = z['morph_in']
+    for v in (0, 1):
+        for h in (0, 1):
+            for r in range(4):
+                assert np.array_equal(ip.aug_array_morph(x, bool(v), bool(h), r), z[f'morph_{v}{h}{r}'])
+    for seed in (0, 1):
+        c, b = (float(v_) for v_ in z[f'color_mul_{seed}'])          # python floats, as random.uniform returns
+        got = ip.aug_array_color(z['color_in'], c, b)
+        np.testing.assert_array_equal(got, z[f'color_out_{seed}'])
+    lab = np.arange(256).reshape(1, 1, 16, 16)
+    lc = [(12, 3), (11, 3), (10, 3), (9, 8), (255, 0)]
+    assert np.array_equal(ip.merge_classes(lab, lc, lab), z['merge_lc_default'])
+    lut = ip.merge_lut(lc)
+    assert np.array_equal(np.where(lut[lab] >= 0, lut[lab], lab), z['merge_lc_default'])
+    dup = [(5, 1), (1, 7), (5, 2)]
+    lut = ip.merge_lut(dup)
+    assert np.array_equal(np.where(lut[lab] >= 0, lut[lab], lab), z['merge_dup_rule'])
