@@ -208,22 +208,30 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (SATCV_PERSIST_THIN ? 
         gather_pixels(n0n, y0n, x0n);
         load_regs(0);
       }
+      // software-pipelined fragment reads: the LDS reads of step s+1 are issued before the MFMAs of step s (the compiler
+      // otherwise waits for every read right before its MFMAs and the matrix pipe idles for the LDS latency)
+      {
+        constexpr int STEPS = TAPS * KS;
+        FragT<T> af[2][MT], bf[2][NT];
+        auto read_step = [&](int st, int buf) {
+          const int tap = st / KS, ks = st % KS;
+          const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap % 3;
+          const int tap_off = (ky * a.dil * a.pitch + kx * a.dil) * 8;
+          const int slot = ks * 2 + hh;
 #pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
-        const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap % 3;
-        const int tap_off = (ky * a.dil * a.pitch + kx * a.dil) * 8;
+          for (int m = 0; m < MT; ++m) af[buf][m] = lds_frag<T>(ldsA + (ABL(16) ? 0 : slot * slot_stride + a_off[m] + tap_off));
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const int slot = s * 2 + hh;
-          FragT<T> af[MT], bf[NT];
+          for (int n = 0; n < NT; ++n) bf[buf][n] = lds_frag<T>(ldsB + ((tap * SLOTS + slot) * BN + (wn * NT + n) * 32 + r) * 8);
+        };
+        read_step(0, 0);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) af[m] = lds_frag<T>(ldsA + (ABL(16) ? 0 : slot * slot_stride + a_off[m] + tap_off));
-#pragma unroll
-          for (int n = 0; n < NT; ++n) bf[n] = lds_frag<T>(ldsB + ((tap * SLOTS + slot) * BN + (wn * NT + n) * 32 + r) * 8);
+        for (int st = 0; st < STEPS; ++st) {
+          if (st + 1 < STEPS) read_step(st + 1, (st + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this step's MFMAs
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) { if (!ABL(2)) mma32<T>(acc[m][n], af[m], bf[n]); }
+            for (int n = 0; n < NT; ++n) { if (!ABL(2)) mma32<T>(acc[m][n], af[st & 1][m], bf[st & 1][n]); }
         }
       }
       __syncthreads();
@@ -459,10 +467,8 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
     }
     return fast_cfg<T, TW, 2, 2, 2, 2, 1, TAPS>(a, st, dry);
   }
-  // 96 output channels (data gradient of dec0's concatenated input): one N tile of exactly that width instead of two tiles of
-  // 64 that would each re-read the activation tile (559 -> 533 us).  The same idea for 192 channels (128x192 tile, one
-  // workgroup per CU) was measured SLOWER than three 64-wide tiles: 584 vs 379 us.
-  if (TAPS == 9 && nspace % 96 == 0 && nspace % 64 != 0) return fast_cfg<T, TW, 4, 1, 2, 3, 1, TAPS>(a, st, dry);
+  // (a 96-wide N tile for the 32->96 data gradient needs 171+96 registers = one workgroup per CU: 836 vs 559 us with two 64-wide tiles;
+  //  a 192-wide one: 584 vs 379 us)
   // (32-channel chunks for the thin 3x3 layers were measured SLOWER: 144 vs 113 us on enc1, 425 vs 351 us on
   //  dec0.conv1 -- fewer resident workgroups outweigh the halved barrier count)
   if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 1, TAPS>(a, st, dry);

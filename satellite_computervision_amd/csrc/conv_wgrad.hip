@@ -223,13 +223,20 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 2) void wgrad_kernel(const Wgra
         bf16x8 bfr = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
         const int xoa = tab[qa] + wci * 32 + chb;
         const int xob = tab[qb] + wci * 32 + chb;
+        // the transposing reads of tap t+1 are issued before the MFMA of tap t (see conv_igemm_fast.hip)
+        bf16x4 alo[2], ahi[2];
+        alo[0] = tr_read(ldsX + xoa);
+        ahi[0] = tr_read(ldsX + xob);
 #pragma unroll
         for (int tap = 0; tap < NTAPS; ++tap) {
-          const int ky = tap / 3, kx = tap % 3;
-          const int toff = (NTAPS == 1) ? 0 : ((ky * a.dil) * a.cl + kx * a.dil) * XP;
-          bf16x4 alo = tr_read(ldsX + xoa + toff);
-          bf16x4 ahi = tr_read(ldsX + xob + toff);
-          bf16x8 afr = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+          if (tap + 1 < NTAPS) {
+            const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
+            const int toff = ((ky * a.dil) * a.cl + kx * a.dil) * XP;
+            alo[(tap + 1) & 1] = tr_read(ldsX + xoa + toff);
+            ahi[(tap + 1) & 1] = tr_read(ldsX + xob + toff);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          bf16x8 afr = __builtin_shufflevector(alo[tap & 1], ahi[tap & 1], 0, 1, 2, 3, 4, 5, 6, 7);
           acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[tap], 0, 0, 0);
         }
       } else {
