@@ -471,6 +471,8 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   //  a 192-wide one: 584 vs 379 us)
   // (32-channel chunks for the thin 3x3 layers were measured SLOWER: 144 vs 113 us on enc1, 425 vs 351 us on
   //  dec0.conv1 -- fewer resident workgroups outweigh the halved barrier count)
+  // (8-wave variants of the thin tiles -- 16 accumulator registers, 6 waves/SIMD -- were measured 8-20 % SLOWER: occupancy is
+  //  no longer what limits the bytes in flight)
   if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 1, TAPS>(a, st, dry);
   return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS>(a, st, dry);
 }

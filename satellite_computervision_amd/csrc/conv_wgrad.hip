@@ -11,6 +11,7 @@
 // the pixel tiles (split-K) and writes an fp32 partial slab; a second kernel sums the slabs
 // in fixed order (deterministic) into the Keras-layout gradient.
 #include "common.hpp"
+#include <cstdlib>
 
 struct WgradArgs {
   const void* x0; const void* x1; int c0, c1;
@@ -44,11 +45,11 @@ __device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
 
 // NCI x NCO waves own distinct (ci, co) 32x32 tiles; NKS waves share a tile and split the
 // k-steps (pixels) of every staged tile, each writing its own partial slab.
-template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS>
+template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS, int PIX>
 __global__ __launch_bounds__(NCI* NCO* NKS * 64, 2) void wgrad_kernel(const WgradArgs a) {
   using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
   constexpr int NTHREADS = NCI * NCO * NKS * 64;
-  constexpr int BMPIX = 128;
+  constexpr int BMPIX = PIX;               // pixels per staged tile: 128, or 256 for the thin layers (more bytes in flight)
   constexpr int CI_T = G::CI_T, CO_T = G::CO_T, XP = G::XP, DP = G::DP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* ldsX = reinterpret_cast<T*>(smem_raw);
@@ -59,8 +60,15 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 2) void wgrad_kernel(const Wgra
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wci = wave % NCI, wco = (wave / NCI) % NCO, wks = wave / (NCI * NCO);
   const int r = lane & 31, hh = lane >> 5;
-  const int ci_blk = blockIdx.x % a.n_ci_blk, co_blk = blockIdx.x / a.n_ci_blk;
-  const int sp = blockIdx.y;
+  // 1-D grid; the (ci, co) blocks that read the SAME pixel tiles get ids congruent mod 8, i.e. run on one XCD and share its
+  // L2 (each block re-reads dY / X: with the plain x-fastest order the re-reads of a tile came from 3-8 different L2s)
+  int blk, sp;
+  {
+    const int nblk = a.n_ci_blk * a.n_co_blk, id = blockIdx.x;
+    if ((a.nsplit & 7) == 0) { const int xcd = id & 7, j = id >> 3; blk = j % nblk; sp = (j / nblk) * 8 + xcd; }
+    else { blk = id % nblk; sp = id / nblk; }
+  }
+  const int ci_blk = blk % a.n_ci_blk, co_blk = blk / a.n_ci_blk;
   const int ci0 = ci_blk * CI_T, co0 = co_blk * CO_T;
 
   f32x16 acc[NTAPS];
@@ -350,7 +358,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ host side
-struct WgradPlan { int tw, nci, nco, nks, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk; size_t ws_bytes; };
+struct WgradPlan { int tw, nci, nco, nks, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk, pix; size_t ws_bytes; };
+
+static bool wgrad_pix256() {
+  static const bool on = [] { const char* e = getenv("SATCV_WGRAD_PIX256"); return !e || atoi(e) != 0; }();
+  return on;
+}
 
 static int pick_tw_w(int w) {
   int best = 8, bestpad = cdiv(w, 8) * 8;
@@ -373,7 +386,9 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   const int ci_t = 32 * p.nci, co_t = 32 * p.nco;
   p.n_ci_blk = cdiv(cinx, ci_t); p.n_co_blk = cdiv(nspace, co_t);
   p.kpad = p.n_ci_blk * ci_t; p.npad = p.n_co_blk * co_t;
-  const int th = 128 / p.tw;
+  // thin layers (a handful of (ci, co) blocks at full resolution) are bound by bytes in flight: stage 256 pixels per step
+  p.pix = (p.ntaps == 9 && p.tw == 32 && p.n_ci_blk * p.n_co_blk <= 3 && d->h >= 8 && d->w_ >= 256 && d->dil == 1 && wgrad_pix256()) ? 256 : 128;
+  const int th = p.pix / p.tw;
   const int tiles_x = cdiv(d->w_, p.tw);
   long long ptiles;
   if (d->h >= th) ptiles = (long long)d->n * cdiv(d->h, th) * tiles_x;
@@ -382,6 +397,7 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   if (ns > ptiles) ns = ptiles;
   if (ns > 768) ns = 768;
   if (ns < 1) ns = 1;
+  if (ns >= 8) ns -= ns % 8;                               // XCD-aware block order needs a multiple of 8
   p.nsplit = (int)ns;
   p.ws_bytes = (size_t)p.nsplit * p.ntaps * p.kpad * p.npad * sizeof(float);
   return SATCV_OK;
@@ -400,10 +416,10 @@ extern "C" int64_t satcv_conv2d_wgrad_workspace(const satcv_wgrad_desc* d) {
   return (int64_t)need;
 }
 
-template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS>
+template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS, int PIX = 128>
 static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy = 0, int sx = 0) {
   using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
-  constexpr int TH = 128 / TW;
+  constexpr int TH = PIX / TW;
   WgradArgs a;
   a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_relu = d->in_relu;
@@ -420,15 +436,15 @@ static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream
   a.seg = a.rpi + 2 * a.halh; a.rl = a.imgs * a.seg; a.cl = TW + 2 * a.halw;
   a.n_ci_blk = p.n_ci_blk; a.n_co_blk = p.n_co_blk; a.nsplit = p.nsplit;
   a.total_ptiles = a.ngroups * a.tiles_y * a.tiles_x;
-  size_t lds = ((size_t)a.rl * a.cl * G::XP + 128 * G::DP) * sizeof(T) + (128 + (size_t)a.rl * a.cl) * sizeof(int);
+  size_t lds = ((size_t)a.rl * a.cl * G::XP + PIX * G::DP) * sizeof(T) + (PIX + (size_t)a.rl * a.cl) * sizeof(int);
   if (lds < 3 * 4096) lds = 3 * 4096;          // k-slice reduction scratch
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
-  auto kern = wgrad_kernel<T, TW, NCI, NCO, NKS, NTAPS>;
+  auto kern = wgrad_kernel<T, TW, NCI, NCO, NKS, NTAPS, PIX>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
   }
-  hipLaunchKernelGGL(kern, dim3(p.n_ci_blk * p.n_co_blk, p.nsplit), dim3(NCI * NCO * NKS * 64), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(p.n_ci_blk * p.n_co_blk * p.nsplit), dim3(NCI * NCO * NKS * 64), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("wgrad launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
   return SATCV_OK;
@@ -439,6 +455,14 @@ static int wgrad_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t 
   if (p.ntaps == 1) return wgrad_launch<T, TW, 1, 4, 1, 1>(d, p, st, sy, sx);
   if (p.nci == 1 && p.nco == 4) return wgrad_launch<T, TW, 1, 4, 1, 9>(d, p, st);
   if (p.nci == 2 && p.nco == 2) return wgrad_launch<T, TW, 2, 2, 1, 9>(d, p, st);
+  if constexpr (TW == 32) {
+    if (p.pix == 256) {
+      if (p.nci == 2 && p.nco == 2) return wgrad_launch<T, TW, 2, 2, 1, 9, 256>(d, p, st);
+      if (p.nci == 1 && p.nco == 2) return wgrad_launch<T, TW, 1, 2, 2, 9, 256>(d, p, st);
+      if (p.nci == 2 && p.nco == 1) return wgrad_launch<T, TW, 2, 1, 2, 9, 256>(d, p, st);
+      if (p.nci == 1 && p.nco == 1) return wgrad_launch<T, TW, 1, 1, 4, 9, 256>(d, p, st);
+    }
+  }
   if (p.nci == 1 && p.nco == 2) return wgrad_launch<T, TW, 1, 2, 2, 9>(d, p, st);
   if (p.nci == 2 && p.nco == 1) return wgrad_launch<T, TW, 2, 1, 2, 9>(d, p, st);
   return wgrad_launch<T, TW, 1, 1, 4, 9>(d, p, st);

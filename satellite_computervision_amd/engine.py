@@ -630,7 +630,35 @@ class Plan:
                 check(lib.satcv_conv2d_wgrad(C.byref(d), sptr))
             return run
 
+        # data-parallel overlap: after every parameter-bearing node tell the gradient exchange which tail of the flat
+        # gradient buffer is final (parallel.GradSync.ready_above)
+        pending = {}                                   # layer name -> remaining visits
+        for node in m.nodes:
+            if node.layer is not None and any(ps.name in rt.offsets for ps in node.layer.specs):
+                pending[node.layer.name] = pending.get(node.layer.name, 0) + 1
+        layer_hi = {l.name: max(rt.offsets[ps.name] + ps.size for ps in l.specs if ps.name in rt.offsets)
+                    for l in m.layers if l.name in pending}
+
+        def grads_ready(node):
+            lay = node.layer
+            if lay is None or lay.name not in pending:
+                return
+            pending[lay.name] -= 1
+            if pending[lay.name] == 0:
+                del pending[lay.name]
+            lo = max((layer_hi[k] for k in pending), default=0)
+
+            def ckpt(st, lo=lo):
+                sync = getattr(m, '_sync_grads', None)
+                if sync is not None and hasattr(sync, 'ready_above'):
+                    sync.ready_above(rt.gflat, lo, self.side)
+            self.bwd.append(ckpt)
+
+        prev_node = None
         for node in reversed(m.nodes):
+            if prev_node is not None:
+                grads_ready(prev_node)                 # (the branches below `continue`: bookkeeping of the node just finished)
+            prev_node = node
             op = node.op
             cx = ctx.get(id(node))
             if op == 'head':
@@ -756,6 +784,8 @@ class Plan:
                                            w_=r.w, cout=cinp, cout_pad=rup(cinp, 32), kh=1, kw=1, dil=1, mode_in=1, f=f, dtype=dt))
                 gact[tin.id] = (gin, 0, cinp)
                 self.dbg['dx:' + lay.name] = gin
+        if prev_node is not None:
+            grads_ready(prev_node)
         if ws_need:
             ws = self._z(max(ws_need // 4, 1), dtype=torch.float32)
             for d in wdescs:

@@ -3,7 +3,8 @@
 The reference has no multi-device code; this is the north-star's data-parallel
 extension of `Model.fit`: tiles are independent units, so
   * training shards the minibatch over ranks and has ONE exchange per step: an all-reduce (sum)
-    of the flat fp32 gradient buffer, averaged by the optimizer's grad_scale = 1/world.
+    of the flat fp32 gradient buffer (bucketed, started while the encoder's backward still runs),
+    averaged by the optimizer's grad_scale = 1/world.
     BatchNorm statistics stay per-replica by default (what tf.distribute does with plain
     BatchNormalization); `model.sync_bn = True` (or SATCV_SYNC_BN=1) averages the per-channel
     [Σx, Σx²] (forward) and [Σdy, Σdy·x̂] (backward) buffers over replicas, which makes N replicas of
@@ -49,23 +50,60 @@ def allreduce_mean_(t, group=None):
 
 
 class GradSync:
-    """All-reduce of a flat gradient buffer in buckets.
+    """All-reduce of a flat gradient buffer in buckets, overlapped with the rest of the backward pass.
 
-    xGMI is point-to-point (7 links x ~153 GB/s per GPU); the 74 MB fp32 gradient is sent as a few
-    large buckets (default 32 MiB) rather than per-layer tensors so that each collective is
-    bandwidth- not latency-bound."""
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU); the 74 MB fp32 gradient is sent as a few large buckets (default
+    16 MiB) rather than per-layer tensors so that each collective is bandwidth- not latency-bound.  Buckets are cut from the
+    END of the buffer: backward finishes the layers in decreasing offset order (head, dec0 .. dec4, center, enc4 .. enc0), so
+    `ready_above(flat, lo, stream)` -- called by the engine after every layer -- can start the collectives of all buckets that
+    lie above the highest still-pending offset while the encoder's backward is still running; `__call__` sends what is left
+    (the first ~10 MB) and makes the current stream wait for everything."""
 
-    def __init__(self, numel, bucket_bytes=32 << 20, group=None):
-        self.group = group
+    def __init__(self, numel, bucket_bytes=16 << 20, group=None, overlap=True):
+        self.group, self.overlap = group, overlap
         per = max(bucket_bytes // 4, 1)
-        self.bounds = [(s, min(s + per, numel)) for s in range(0, numel, per)]
+        self.bounds = []
+        hi = numel
+        while hi > 0:
+            lo = max(hi - per, 0)
+            self.bounds.append((lo, hi))
+            hi = lo
+        self.bounds.reverse()
+        self._next = len(self.bounds) - 1          # highest bucket not yet launched
+        self._works = []
+
+    def _active(self):
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def ready_above(self, flat, lo, stream=None):
+        """every gradient element at offset >= lo is final once the work queued so far on the current stream and on `stream`
+        (the weight-gradient stream, or None) has run: start the collectives of the buckets inside [lo, numel)."""
+        if not (self.overlap and self._active() and flat.is_cuda):
+            return
+        if self._next < 0 or self.bounds[self._next][0] < lo:
+            return
+        cur = torch.cuda.current_stream()
+        run_on = stream if stream is not None else cur
+        if stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            stream.wait_event(ev)
+        with torch.cuda.stream(run_on):
+            while self._next >= 0 and self.bounds[self._next][0] >= lo:
+                a, b = self.bounds[self._next]
+                self._works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._next -= 1
 
     def __call__(self, flat):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
-            return
-        works = [dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for a, b in self.bounds]
-        for w in works:
-            w.wait()
+        if self._active():
+            while self._next >= 0:
+                a, b = self.bounds[self._next]
+                self._works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._next -= 1
+            for w in self._works:
+                w.wait()                           # the CURRENT stream waits for the collective
+        self._works = []
+        self._next = len(self.bounds) - 1
 
 
 def broadcast_state(tensors, src=0, group=None):
@@ -74,7 +112,7 @@ def broadcast_state(tensors, src=0, group=None):
             dist.broadcast(t, src, group=group)
 
 
-def make_grad_sync(model, bucket_bytes=32 << 20):
+def make_grad_sync(model, bucket_bytes=16 << 20, overlap=None):
     """Replicate rank 0's weights, set the optimizer's gradient scale to 1/world and return the
     callable that `Model.train_step_device` runs between backward and Adam."""
     rt = model.runtime
@@ -82,7 +120,9 @@ def make_grad_sync(model, bucket_bytes=32 << 20):
     broadcast_state([rt.pflat, rt.sflat])
     rt.repack()
     rt.adam_state[2:3].fill_(1.0 / world)
-    sync = GradSync(rt.gflat.numel(), bucket_bytes)
+    if overlap is None:
+        overlap = os.environ.get('SATCV_OVERLAP_ALLREDUCE', '1') != '0'
+    sync = GradSync(rt.gflat.numel(), bucket_bytes, overlap=overlap)
     model._sync_grads = sync
     return sync
 

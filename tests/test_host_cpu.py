@@ -98,9 +98,13 @@ rank, world = parallel.init_from_env("gloo")
 assert world == 2
 g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
 sync = parallel.GradSync(g.numel(), bucket_bytes=1024)
-assert len(sync.bounds) == 4
+assert len(sync.bounds) == 4 and sync.bounds[0][0] == 0 and sync.bounds[-1] == (744, 1000)        # cut from the end
+sync.ready_above(g, 0)                                   # CPU tensors: no early launch, everything goes in __call__
 sync(g)
 assert torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3)
+g2 = torch.ones(1000) * (rank + 1)
+sync(g2)                                                 # state resets between steps
+assert torch.equal(g2, torch.full((1000,), 3.0))
 w = torch.full((7,), float(rank))
 parallel.broadcast_state([w], 0)
 assert torch.equal(w, torch.zeros(7))

@@ -30,6 +30,8 @@ def run(n, h, w, cin, cout, stats=True, reps=40, k=3):
 print('lib', os.environ.get('SATCV_LIB'))
 SHAPES = [(64, 256, 256, 16, 32), (64, 256, 256, 32, 32), (64, 256, 256, 96, 32), (64, 256, 256, 32, 96), (64, 128, 128, 32, 64), (64, 128, 128, 64, 64),
             (64, 128, 128, 192, 64), (64, 128, 128, 64, 192), (64, 128, 128, 64, 32), (64, 64, 64, 128, 128), (64, 32, 32, 256, 256), (64, 16, 16, 512, 512)]
+if os.environ.get('PROBE_1X1'):
+    SHAPES = [(64, 256, 256, 32, 32, True, 40, 1), (64, 256, 256, 32, 32, False, 40, 1), (64, 256, 256, 64, 64, True, 40, 1), (64, 256, 256, 32, 32, True, 40, 3), (64, 256, 256, 32, 32, False, 40, 3)]
 if os.environ.get('PROBE_DEEP'):
     SHAPES = [(64, 64, 64, 128, 128), (64, 32, 32, 256, 256), (64, 32, 32, 768, 256), (64, 16, 16, 512, 512)]
 for shp in SHAPES:
