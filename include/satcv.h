@@ -60,6 +60,13 @@ int satcv_ingest_chw(const void* src, int32_t src_kind, float scale, void* dst, 
 int satcv_pack_weights(const float* src, void* dst_fwd, void* dst_dgrad, int32_t kh, int32_t kw,
                        int32_t cin, int32_t cout, int32_t cin_pad, int32_t transposed,
                        int32_t dtype, void* stream);
+/* All layers in one launch: a DEVICE array of jobs (mode 0 conv fwd, 1 conv dgrad, 2 transposed-conv fwd, 3 transposed-conv dgrad;
+ * kpad / npad = K and N paddings of the image exactly as satcv_pack_weights derives them) and the exclusive prefix sum of
+ * satcv_pack_job_items() over the jobs. */
+typedef struct { const float* src; void* dst; int32_t mode, taps, cin, cout, kpad, npad; } satcv_pack_job;
+int64_t satcv_pack_job_items(const satcv_pack_job* job);
+int satcv_pack_weights_batched(const satcv_pack_job* jobs_dev, const int64_t* prefix_dev, int32_t njobs, int64_t total_items, int32_t dtype,
+                               void* stream);
 
 /* ------------------------------------------------------------ implicit-GEMM conv
  * One descriptor drives Conv2D forward, its data gradient, Conv2DTranspose(k==s)

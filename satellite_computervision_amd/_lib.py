@@ -32,6 +32,10 @@ class ConvDesc(C.Structure):
                 ('stride', c_i32), ('hin', c_i32), ('win', c_i32), ('out_scale', c_vp)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [('src', c_vp), ('dst', c_vp), ('mode', c_i32), ('taps', c_i32), ('cin', c_i32), ('cout', c_i32), ('kpad', c_i32), ('npad', c_i32)]
+
+
 class TileDesc(C.Structure):
     _fields_ = [('src', c_vp), ('src_kind', c_i32), ('n', c_i32), ('c', c_i32), ('hin', c_i32), ('win', c_i32), ('h', c_i32), ('w_', c_i32),
                 ('rescale', C.c_double), ('nan_mask', c_i32), ('replace', c_i32), ('seed', C.c_uint64), ('ch_mean', c_vp),
@@ -78,6 +82,8 @@ _SIGS = {
     'satcv_ingest_nhwc_scaled': (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_vp]),
     'satcv_ingest_chw': (C.c_int, [c_vp, c_i32, c_f32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'satcv_pack_weights': (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'satcv_pack_job_items': (c_i64, [C.POINTER(PackJob)]),
+    'satcv_pack_weights_batched': (C.c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     'satcv_conv2d_igemm': (C.c_int, [C.POINTER(ConvDesc), c_vp]),
     'satcv_conv2d_wgrad_workspace': (c_i64, [C.POINTER(WgradDesc)]),
     'satcv_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), c_vp]),

@@ -117,6 +117,46 @@ __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, 
     store8<T>(dst + it * 8, v);
   }
 }
+// every layer's operand images in ONE launch (the per-layer form costs ~40 tiny launches on the critical path of a step):
+// a device table of pack jobs + the exclusive prefix sum of their 16-byte output items; each thread finds its job by binary
+// search and does what pack_kernel does.
+template <typename T>
+__global__ void pack_batched_kernel(const satcv_pack_job* __restrict__ jobs, const long long* __restrict__ prefix, int njobs, long long total) {
+  for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= g) lo = mid; else hi = mid - 1; }
+    const satcv_pack_job j = jobs[lo];
+    const long long it = g - prefix[lo];
+    const int nn = (int)(it % j.npad);
+    const int k8 = (int)((it / j.npad) % (j.kpad / 8));
+    const int tap = (int)(it / ((long long)j.npad * (j.kpad / 8)));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k8 * 8 + e;
+      float x = 0.f;
+      if (j.mode == 0) { if (k < j.cin && nn < j.cout) x = j.src[((size_t)tap * j.cin + k) * j.cout + nn]; }
+      else if (j.mode == 1) { if (k < j.cout && nn < j.cin) x = j.src[((size_t)(j.taps - 1 - tap) * j.cin + nn) * j.cout + k]; }
+      else if (j.mode == 2) { if (k < j.cin && nn < j.taps * j.cout) x = j.src[(size_t)nn * j.cin + k]; }
+      else { if (k < j.taps * j.cout && nn < j.cin) x = j.src[(size_t)k * j.cin + nn]; }
+      v[e] = x;
+    }
+    store8<T>(reinterpret_cast<T*>(j.dst) + it * 8, v);
+  }
+}
+extern "C" int64_t satcv_pack_job_items(const satcv_pack_job* j) {
+  if (!j || j->kpad <= 0 || j->kpad % 8 || j->npad <= 0 || j->mode < 0 || j->mode > 3) return -1;
+  return (int64_t)(j->mode >= 2 ? 1 : j->taps) * (j->kpad / 8) * j->npad;
+}
+extern "C" int satcv_pack_weights_batched(const satcv_pack_job* jobs_dev, const int64_t* prefix_dev, int32_t njobs, int64_t total_items, int32_t dtype,
+                                          void* stream) {
+  SATCV_CHECK(jobs_dev && prefix_dev && njobs > 0 && total_items > 0, "pack_weights_batched: bad args");
+  DISPATCH_T8(dtype, hipLaunchKernelGGL(pack_batched_kernel<T>, dim3(ew_grid(total_items)), dim3(EW_BLOCK), 0, (hipStream_t)stream, jobs_dev,
+                                        (const long long*)prefix_dev, njobs, (long long)total_items));
+  LAUNCH_OK("pack_weights_batched");
+  return SATCV_OK;
+}
+
 static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 extern "C" int satcv_pack_weights(const float* src, void* dst_fwd, void* dst_dgrad, int32_t kh, int32_t kw, int32_t cin, int32_t cout, int32_t cin_pad, int32_t transposed, int32_t dtype, void* stream) {
   SATCV_CHECK(src && cin > 0 && cout > 0 && cin_pad >= cin && cin_pad % 16 == 0, "pack_weights: bad args");

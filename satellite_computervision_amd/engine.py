@@ -158,6 +158,7 @@ class Runtime:
                     fwd=torch.zeros(ef, dtype=self.tdtype, device=self.dev),
                     dgrad=torch.zeros(ed, dtype=self.tdtype, device=self.dev),
                     k=(ks[0], ks[1]), cin=cin, cout=cout, cin_pad=cin_pad, transposed=tr)
+        self._ptab = None
         self.repack()
         self.plans = {}
 
@@ -184,13 +185,36 @@ class Runtime:
     def set_param(self, name, value):
         self.get_param(name).copy_(torch.as_tensor(np.asarray(value, np.float32)).to(self.dev).view(self.specs[name].shape))
 
-    def repack(self):
-        """fp32 Keras-layout kernels -> MFMA operand images (after every weight update)."""
-        st = ops.stream_ptr()
+    def _pack_table(self):
+        """device table of every layer's pack jobs (forward + data-gradient image) for satcv_pack_weights_batched"""
+        from ._lib import PackJob
+        jobs = []
         for lname, pk in self.packed.items():
-            check(lib.satcv_pack_weights(self.pptr(lname + '/kernel'), pk['fwd'].data_ptr(), pk['dgrad'].data_ptr(),
-                                         pk['k'][0], pk['k'][1], pk['cin'], pk['cout'], pk['cin_pad'],
-                                         1 if pk['transposed'] else 0, self.dtype, st))
+            taps, cin, cout, cp = pk['k'][0] * pk['k'][1], pk['cin'], pk['cout'], pk['cin_pad']
+            src = self.pptr(lname + '/kernel')
+            if not pk['transposed']:
+                jobs.append(PackJob(src, pk['fwd'].data_ptr(), 0, taps, cin, cout, cp, rup(cout, 32)))
+                jobs.append(PackJob(src, pk['dgrad'].data_ptr(), 1, taps, cin, cout, rup(cout, 16), rup(cin, 32)))
+            else:
+                jobs.append(PackJob(src, pk['fwd'].data_ptr(), 2, taps, cin, cout, cp, rup(taps * cout, 32)))
+                jobs.append(PackJob(src, pk['dgrad'].data_ptr(), 3, taps, cin, cout, rup(taps * cout, 16), rup(cin, 32)))
+        prefix, tot = [], 0
+        for j in jobs:
+            prefix.append(tot)
+            tot += int(lib.satcv_pack_job_items(C.byref(j)))
+        arr = (PackJob * len(jobs))(*jobs)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+        pre = torch.tensor(prefix, dtype=torch.int64, device=self.dev)
+        return dict(jobs=raw, prefix=pre, n=len(jobs), total=tot)
+
+    def repack(self):
+        """fp32 Keras-layout kernels -> MFMA operand images (after every weight update), one launch for all layers."""
+        if not self.packed:
+            return
+        if self._ptab is None:
+            self._ptab = self._pack_table()
+        t = self._ptab
+        check(lib.satcv_pack_weights_batched(t['jobs'].data_ptr(), t['prefix'].data_ptr(), t['n'], t['total'], self.dtype, ops.stream_ptr()))
 
     def ensure_adam(self):
         if self.adam_m is None:
