@@ -233,6 +233,10 @@ typedef struct satcv_head_desc {
 int satcv_head_fwd(const satcv_head_desc* d, void* stream);
 int satcv_head_bwd(const satcv_head_desc* d, void* stream);
 
+/* CRC-32C (Castagnoli) of a HOST buffer, continuing from crc_in (0 to start): the checksum of the TFRecord framing that
+ * tf.io.TFRecordWriter / tf.data.TFRecordDataset use (utils/prediction_tools.py:221, 404; utils/processing.py:416). */
+uint32_t satcv_crc32c(const void* data, uint64_t nbytes, uint32_t crc_in);
+
 /* ------------------------------------------------------------------ tile input pipeline
  * Device version of UNETDataGenerator.__getitem__ (utils/processing.py:456-755) for one source / the labels of one batch.
  * src: planes (n, c, hin, win) of kind 0 u8, 1 u16, 2 f32, 3 i16, 4 f64, 5 i32, 6 i64 (what np.load returned).

@@ -103,6 +103,7 @@ _SIGS = {
     'satcv_tile_channel_mean': (C.c_int, [C.POINTER(TileDesc), c_vp, c_vp]),
     'satcv_tile_ingest': (C.c_int, [C.POINTER(TileDesc), c_vp]),
     'satcv_label_onehot': (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp]),
+    'satcv_crc32c': (C.c_uint32, [c_vp, C.c_uint64, C.c_uint32]),
     'satcv_head_fwd': (C.c_int, [C.POINTER(HeadDesc), c_vp]),
     'satcv_head_bwd': (C.c_int, [C.POINTER(HeadDesc), c_vp]),
     'satcv_loss_fwd_bwd': (C.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_f32, c_vp, c_vp, c_vp]),

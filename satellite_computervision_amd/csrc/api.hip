@@ -1,6 +1,7 @@
 // C-ABI plumbing: error string, device info, hipGraph capture helpers, per-kernel-class
 // HIP-event profiling used by bench.py for the roofline numbers.
 #include "common.hpp"
+#include <cstring>
 #include <cstdarg>
 #include <cstdio>
 #include <mutex>
@@ -104,4 +105,33 @@ extern "C" int satcv_prof_collect(int32_t kind, double* total_ms, int64_t* launc
   *total_ms = ms; *launches = (int64_t)g_prof[kind].size(); *flops = fl;
   g_prof[kind].clear();
   return SATCV_OK;
+}
+
+// ------------------------------------------------------------------ CRC32C (host)
+// TFRecord framing (utils/prediction_tools.py:221, 404; tf.io.TFRecordWriter / TFRecordDataset) protects the length and
+// the payload of every record with a masked CRC-32C (Castagnoli, reflected polynomial 0x82F63B78).  Slice-by-8 tables.
+static uint32_t g_crc_tab[8][256];
+static bool g_crc_init = [] {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+    g_crc_tab[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; ++i)
+    for (int t = 1; t < 8; ++t) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xff];
+  return true;
+}();
+extern "C" uint32_t satcv_crc32c(const void* data, uint64_t nbytes, uint32_t crc_in) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(data);
+  uint32_t c = ~crc_in;
+  while (nbytes >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = g_crc_tab[7][lo & 0xff] ^ g_crc_tab[6][(lo >> 8) & 0xff] ^ g_crc_tab[5][(lo >> 16) & 0xff] ^ g_crc_tab[4][lo >> 24] ^
+        g_crc_tab[3][hi & 0xff] ^ g_crc_tab[2][(hi >> 8) & 0xff] ^ g_crc_tab[1][(hi >> 16) & 0xff] ^ g_crc_tab[0][hi >> 24];
+    p += 8; nbytes -= 8;
+  }
+  while (nbytes--) c = (c >> 8) ^ g_crc_tab[0][(c ^ *p++) & 0xff];
+  return ~c;
 }

@@ -665,6 +665,8 @@ class Model:
     def set_weights_dict(self, d, skip_mismatch=False):
         rt = self.runtime
         for k, v in d.items():
+            if k.endswith('/moving_variance'):               # tf.keras variable name (tools/keras_to_npz.py)
+                k = k[:-len('moving_variance')] + 'moving_var'
             if k not in rt.specs:
                 if skip_mismatch:
                     continue
@@ -675,8 +677,11 @@ class Model:
                 raise ValueError(f'{k}: shape {np.shape(v)} != {rt.specs[k].shape}')
             rt.set_param(k, v)
         rt.repack()
+        if getattr(self, '_fp8_plans', None):
+            self._fp8_plans = {}                             # fp8 weight images are re-quantised when the plans are rebuilt
 
-    # ---- persistence (own .npz container; Keras HDF5 import is a later row of SURVEY §8f)
+    # ---- persistence: own .npz container keyed '<layer>/<variable>' with Keras' auto-generated layer names; a real
+    # tf.keras model converts to/from it with tools/keras_to_npz.py on a TensorFlow host (HDF5 itself is not read here)
     def save_weights(self, path):
         np.savez(path if path.endswith('.npz') else path + '.npz', **self.get_weights_dict())
 

@@ -1,0 +1,269 @@
+"""Earth-Engine TFRecord tile IO around the prediction path, without TensorFlow.
+
+On-disk format (what `tf.data.TFRecordDataset(files, compression_type='GZIP')` reads and `tf.io.TFRecordWriter` writes,
+utils/prediction_tools.py:221, 404; utils/processing.py:416):
+  record  = uint64 length | uint32 masked_crc32c(length) | payload | uint32 masked_crc32c(payload)      (little endian)
+  masked  = ((crc >> 15) | (crc << 17)) + 0xa282ead8   (mod 2^32)
+  payload = serialized tf.train.Example: Example{1: Features{1: map<string, Feature>}},
+            Feature{1: BytesList{1: bytes}, 2: FloatList{1: packed float32}, 3: Int64List{1: packed varint}}
+The whole file may be GZIP-compressed.  The protobuf wire format is hand-parsed (no generated classes needed); the CRC
+runs in libsatcv (`satcv_crc32c`).  Mirrors of the reference's callers:
+  make_pred_dataset            utils/prediction_tools.py:159-226   (FixedLenFeature float32 [H+buf, W+buf] per band)
+  make_array_predictions       utils/prediction_tools.py:293-373   (mixer.json mosaic; pinned by a fixture of the real body)
+  write_tfrecord_predictions   utils/prediction_tools.py:375-445   (b1..bC float lists of the cropped patch)
+"""
+import gzip
+import json
+import struct
+from os.path import join
+
+import numpy as np
+
+from ._lib import lib
+
+_MASK_DELTA = 0xa282ead8
+
+
+def crc32c(data, crc=0):
+    buf = bytes(data)
+    return int(lib.satcv_crc32c(buf, len(buf), crc))
+
+
+def masked_crc(data):
+    c = crc32c(data)
+    return (((c >> 15) | (c << 17)) + _MASK_DELTA) & 0xffffffff
+
+
+# ------------------------------------------------------------------ record framing
+def _open(path, mode):
+    if 'r' in mode:
+        with open(path, 'rb') as f:
+            magic = f.read(2)
+        return gzip.open(path, 'rb') if magic == b'\x1f\x8b' else open(path, 'rb')
+    return open(path, mode)
+
+
+def read_records(path, check_crc=True):
+    """Yield the payload bytes of every record of a (possibly GZIP-compressed) TFRecord file."""
+    with _open(path, 'rb') as f:
+        while True:
+            head = f.read(12)
+            if not head:
+                return
+            if len(head) != 12:
+                raise IOError(f'{path}: truncated record header')
+            (length,), (lcrc,) = struct.unpack('<Q', head[:8]), struct.unpack('<I', head[8:])
+            if check_crc and masked_crc(head[:8]) != lcrc:
+                raise IOError(f'{path}: corrupt record length')
+            data = f.read(length)
+            tail = f.read(4)
+            if len(data) != length or len(tail) != 4:
+                raise IOError(f'{path}: truncated record')
+            if check_crc and masked_crc(data) != struct.unpack('<I', tail)[0]:
+                raise IOError(f'{path}: corrupt record payload')
+            yield data
+
+
+class TFRecordWriter:
+    """tf.io.TFRecordWriter(path) semantics (uncompressed unless compression='GZIP')."""
+
+    def __init__(self, path, compression=None):
+        self._f = gzip.open(path, 'wb') if compression == 'GZIP' else open(path, 'wb')
+
+    def write(self, payload):
+        head = struct.pack('<Q', len(payload))
+        self._f.write(head + struct.pack('<I', masked_crc(head)) + payload + struct.pack('<I', masked_crc(payload)))
+
+    def close(self):
+        self._f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+# ------------------------------------------------------------------ tf.train.Example wire format
+def _varint(n):
+    out = bytearray()
+    n &= (1 << 64) - 1
+    while True:
+        b = n & 0x7f
+        n >>= 7
+        out.append(b | (0x80 if n else 0))
+        if not n:
+            return bytes(out)
+
+
+def _read_varint(buf, pos):
+    shift = val = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        val |= (b & 0x7f) << shift
+        if not b & 0x80:
+            return val, pos
+        shift += 7
+
+
+def _ld(field, payload):
+    return _varint((field << 3) | 2) + _varint(len(payload)) + payload
+
+
+def encode_example(features):
+    """{name: ndarray} -> serialized tf.train.Example.  float arrays -> FloatList, integer arrays -> Int64List, bytes -> BytesList."""
+    entries = b''
+    for key in features:
+        v = features[key]
+        if isinstance(v, (bytes, bytearray)):
+            feat = _ld(1, _ld(1, bytes(v)))
+        else:
+            a = np.asarray(v)
+            if a.dtype.kind == 'f':
+                feat = _ld(2, _ld(1, np.ascontiguousarray(a, '<f4').tobytes()))
+            else:
+                feat = _ld(3, _ld(1, b''.join(_varint(int(x)) for x in a.reshape(-1))))
+        entries += _ld(1, _ld(1, key.encode()) + _ld(2, feat))
+    return _ld(1, entries)
+
+
+def _fields(buf):
+    pos = 0
+    while pos < len(buf):
+        tag, pos = _read_varint(buf, pos)
+        wt = tag & 7
+        if wt == 2:
+            n, pos = _read_varint(buf, pos)
+            yield tag >> 3, wt, buf[pos:pos + n]
+            pos += n
+        elif wt == 0:
+            v, pos = _read_varint(buf, pos)
+            yield tag >> 3, wt, v
+        elif wt == 5:
+            yield tag >> 3, wt, buf[pos:pos + 4]
+            pos += 4
+        elif wt == 1:
+            yield tag >> 3, wt, buf[pos:pos + 8]
+            pos += 8
+        else:
+            raise ValueError(f'unsupported protobuf wire type {wt}')
+
+
+def decode_example(payload):
+    """serialized tf.train.Example -> {name: float32 ndarray | int64 ndarray | [bytes]}"""
+    out = {}
+    buf = memoryview(payload)
+    for f1, _, features in _fields(buf):
+        if f1 != 1:
+            continue
+        for f2, _, entry in _fields(features):
+            if f2 != 1:
+                continue
+            key, feat = None, None
+            for f3, _, val in _fields(entry):
+                if f3 == 1:
+                    key = bytes(val).decode()
+                elif f3 == 2:
+                    feat = val
+            value = None
+            for kind, _, lst in _fields(feat if feat is not None else b''):
+                if kind == 2:                                        # FloatList: packed (or repeated fixed32)
+                    chunks = [bytes(v) for f, wt, v in _fields(lst) if f == 1]
+                    value = np.frombuffer(b''.join(chunks), '<f4')
+                elif kind == 3:
+                    vals = []
+                    for f, wt, v in _fields(lst):
+                        if f != 1:
+                            continue
+                        if wt == 0:
+                            vals.append(v)
+                        else:
+                            pos = 0
+                            while pos < len(v):
+                                x, pos = _read_varint(v, pos)
+                                vals.append(x)
+                    value = np.array(vals, dtype=np.uint64).astype(np.int64)
+                elif kind == 1:
+                    value = [bytes(v) for f, wt, v in _fields(lst) if f == 1]
+            out[key] = value
+    return out
+
+
+# ------------------------------------------------------------------ mirrors of the reference's callers
+def rescale_tensor(img, axes=[2], epsilon=1e-8, moments=None, splits=None):
+    """utils/processing.py:281-322 (NumPy; same arithmetic as utils/array_tools.rescale_array)."""
+    def rescale(x):
+        if moments:
+            mn = np.array([t[0] for t in moments], dtype='float32')
+            mx = np.array([t[1] for t in moments], dtype='float32')
+        else:
+            mn = x.min(axis=tuple(axes), keepdims=True)
+            mx = x.max(axis=tuple(axes), keepdims=True)
+        return (x - mn) / ((mx - mn) + epsilon)
+    if splits:
+        parts = np.split(img, np.cumsum(splits)[:-1], axis=2)
+        return np.concatenate([rescale(p) for p in parts], axis=2)
+    return rescale(img)
+
+
+def make_pred_dataset(file_list, features, kernel_shape=[256, 256], kernel_buffer=[128, 128], axes=[2], splits=None, moments=None,
+                      one_hot=None, **kwargs):
+    """utils/prediction_tools.py:159-226: generator of (1, H+buf, W+buf, C) float32 batches, files in sorted order."""
+    file_list = sorted(file_list)
+    shape = (kernel_shape[0] + kernel_buffer[0], kernel_shape[1] + kernel_buffer[1])
+
+    def gen():
+        for path in file_list:
+            for payload in read_records(path):
+                dic = {k: v.reshape(shape).astype(np.float32) for k, v in decode_example(payload).items() if k in features}
+                missing = [k for k in features if k not in dic]
+                if missing:
+                    raise KeyError(f'{path}: features {missing} not in the record')
+                feat = [dic[k] for k in features if not (one_hot and k in one_hot)]
+                bands = np.transpose(np.stack(feat, axis=0), [1, 2, 0])
+                bands = rescale_tensor(bands, axes=axes, moments=moments, splits=splits)
+                for fxn in kwargs.values():
+                    bands = np.concatenate([bands, np.expand_dims(fxn(dic), 2)], axis=2)
+                if one_hot:
+                    hot = [(dic[k].astype(np.uint8)[..., None] == np.arange(d)).astype(np.float32) for k, d in one_hot.items()]
+                    bands = np.concatenate([bands] + hot, axis=2)
+                yield bands[None].astype(np.float32)
+    return gen()
+
+
+def make_array_predictions(imageDataset, model, jsonFile, kernel_shape=[256, 256], kernel_buffer=[128, 128]):
+    """utils/prediction_tools.py:293-373: run the model over the patches and rebuild the mosaic described by the Earth-Engine
+    mixer file (row-major, `patchesPerRow` columns); the buffer is cropped from every patch exactly as coded (x/y naming of the
+    reference kept)."""
+    with open(jsonFile) as f:
+        mixer = json.load(f)
+    patches, cols = mixer['totalPatches'], mixer['patchesPerRow']
+    predictions = model.predict(imageDataset, steps=patches, verbose=1)
+    if type(predictions) == list:
+        predictions = np.concatenate([p if p.ndim == 4 else p[..., None] for p in predictions], axis=3)
+    x_buffer, y_buffer = int(kernel_buffer[0] / 2), int(kernel_buffer[1] / 2)
+    x_size, y_size = kernel_shape[0] + y_buffer, kernel_shape[1] + x_buffer
+    rows_out, row = None, None
+    for x, prediction in enumerate(predictions, start=1):
+        patch = prediction[y_buffer:y_size, x_buffer:x_size, :]
+        row = patch if x % cols == 1 or cols == 1 else np.append(row, patch, axis=1)
+        if x % cols == 0:
+            rows_out = row if x <= cols else np.append(rows_out, row, axis=0)
+    return rows_out
+
+
+def write_tfrecord_predictions(predictions, pred_path, out_image_base, kernel_shape=[256, 256], kernel_buffer=[128, 128]):
+    """utils/prediction_tools.py:375-445: one uncompressed TFRecord of tf.train.Examples with float lists b1..bC of the patch
+    cropped by the buffer."""
+    if type(predictions) == list:
+        predictions = np.concatenate([p if p.ndim == 4 else p[..., None] for p in predictions], axis=3)
+    C = predictions.shape[-1]
+    out_image_file = join(pred_path, f'{out_image_base}.tfrecords')
+    x_buffer, y_buffer = int(kernel_buffer[0] / 2), int(kernel_buffer[1] / 2)
+    x_size, y_size = x_buffer + kernel_shape[1], y_buffer + kernel_shape[0]
+    with TFRecordWriter(out_image_file) as w:
+        for prediction in predictions:
+            patch = prediction[y_buffer:y_size, x_buffer:x_size, :]
+            w.write(encode_example({f'b{i + 1}': np.ndarray.flatten(patch[:, :, i]).astype(np.float32) for i in range(C)}))
+    return out_image_file

@@ -68,8 +68,31 @@ def main():
     chips = pt['extract_chips'](sq, 16, 32)
     out['ec_arr'] = sq
     out['ec_chips'] = np.stack(chips)
-    np.savez_compressed(f'{OUT}/tiling_reference.npz', **out)
 
+    # make_array_predictions (utils/prediction_tools.py:293-373) only needs json + numpy + model.predict: run the real body
+    import json, tempfile
+    mp = extract_functions(f'{REF}/utils/prediction_tools.py', {'make_array_predictions'})
+    mp['json'] = json
+
+    class StackModel:
+        def __init__(self, preds):
+            self.preds = preds
+
+        def predict(self, dataset, steps=None, verbose=0):
+            return self.preds
+    rngm = np.random.default_rng(42)
+    for tag, (kernel, buff, cols, rows_) in {'a': ((8, 8), (4, 4), 3, 2), 'b': ((6, 10), (4, 2), 2, 3)}.items():
+        n = cols * rows_
+        preds = rngm.random((n, kernel[0] + buff[0], kernel[1] + buff[1], 2)).astype(np.float32)
+        with tempfile.NamedTemporaryFile('w', suffix='.json', delete=False) as f:
+            json.dump({'totalPatches': n, 'patchesPerRow': cols}, f)
+        with contextlib.redirect_stdout(io.StringIO()):
+            mosaic = mp['make_array_predictions'](None, StackModel(preds), f.name, list(kernel), list(buff))
+        out[f'mosaic_{tag}_preds'] = preds
+        out[f'mosaic_{tag}_cfg'] = np.array([kernel[0], kernel[1], buff[0], buff[1], cols, n])
+        out[f'mosaic_{tag}_out'] = mosaic
+        os.unlink(f.name)
+    np.savez_compressed(f'{OUT}/tiling_reference.npz', **out)
     sys.path.insert(0, f'{REF}/utils')
     import array_tools as at
     a = {}
