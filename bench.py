@@ -124,6 +124,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('SATCV_BENCH_BACKEND') == 'gloo':   # test hook: several ranks on ONE GPU (RCCL refuses that), see tests/test_dp_gpu.py
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or 'RANK' in os.environ:              # launched by torch.distributed.run: one rank per GPU over RCCL
@@ -132,7 +134,9 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29500')
         # (no device_id=: the eager communicator init it triggers was measured to slow EVERY kernel launch of the process,
         #  14.7 vs 13.05 ms/step; the lazy init on the first collective does not)
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get('SATCV_BENCH_BACKEND', 'nccl'), rank=rank, world_size=world)
+
+    BARRIER_KW = dict(device_ids=[local_rank]) if (dist is not None and dist.get_backend() == 'nccl') else {}
 
     from satellite_computervision_amd import model_tools as mt
     from satellite_computervision_amd import parallel
@@ -155,7 +159,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(**BARRIER_KW)
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -244,7 +248,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(**BARRIER_KW)
         dist.destroy_process_group()
 
 

@@ -89,3 +89,21 @@ def test_two_replicas_per_replica_bn_stay_in_lockstep(tmp_path):
     worker) but not equal to the single-device run."""
     dw, ds, dl, dg = _run(tmp_path, False)
     assert dg > 1e-3 and dw < 0.5, (dw, dg)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_end_to_end(tmp_path):
+    """bench.py exactly as the driver launches it for N=2 (torch.distributed.run, one JSON line from rank 0), with the two
+    ranks sharing the only GPU over gloo: barriers, max-over-ranks timing, overlapped gradient exchange, whole-job value."""
+    import json
+    env = dict(os.environ, SATCV_BENCH_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29655',
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2', '--batch', '8']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['config']['global_batch'] == 16 and out['scaling'] == 'weak'
+    assert out['value'] > 0 and np.isfinite(out['extra']['loss_last']) and 'cpu_baseline' not in out
+    assert abs(out['value'] - 16 * 3 / (out['ms_per_step'] * 3 / 1000)) / out['value'] < 1e-3
