@@ -3,8 +3,8 @@
 // Thin-layer note (measured, round 1): the 16..96-channel full-resolution layers are bound by bytes in flight, not by MFMA
 // or LDS (2.0-2.9 TB/s algorithmic vs 5.4 TB/s of a copy kernel).  What helped: 4 waves/SIMD for the small-accumulator
 // configurations (+10-15 %).  What did not: persistent workgroups with the next tile's loads in flight during the
-// epilogue (-DSATCV_PERSIST_THIN=1: the extra live state costs one wave/SIMD, net +-0), 32-channel chunks, 256-pixel x
-// 128-channel tiles.
+// epilogue (the extra live state costs one wave/SIMD, net +-0; removed), 32-channel chunks, 256-pixel x 128-channel tiles,
+// 8-wave thin tiles, de-phasing the workgroups of a CU with s_sleep.
 //
 // Same math, LDS images and MFMA fragment addressing as igemm_kernel, plus:
 //   * the halo-tile gather table (LDS offset + source pixel per staged 16-byte item) is computed
@@ -25,20 +25,9 @@
 #define SATCV_ABLATE 0
 #endif
 #define ABL(bit) ((SATCV_ABLATE & (bit)) != 0)
-#ifndef SATCV_PERSIST_THIN
-#define SATCV_PERSIST_THIN 0
-#endif
-
 template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
-struct FastCfg {
-  // persistent workgroups (several tiles each, cross-tile prefetch) only where the accumulators are small: the extra live
-  // state would halve the occupancy of the 128x128 configuration
-  static constexpr bool PERS = (MT * NT <= 2) && SATCV_PERSIST_THIN;
-};
-
-template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
-__global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (SATCV_PERSIST_THIN ? 3 : 4) : 1)) void igemm_fast_kernel(const IgemmArgs a) {
-  constexpr bool PERS = FastCfg<T, TW, WM, WN, MT, NT, KS, TAPS>::PERS;
+// thin configurations (<= 32 accumulator registers) request 4 waves/SIMD
+__global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? 4 : 1)) void igemm_fast_kernel(const IgemmArgs a) {
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int BM = WM * MT * 32;
   constexpr int BN = WN * NT * 32;
@@ -62,9 +51,8 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (SATCV_PERSIST_THIN ? 
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, hh = lane >> 5;
 
-  // ---- persistent workgroups: this one owns tiles v = bid, bid + G, bid + 2G, ...  (G is a multiple of the number of
-  //      N tiles, so its channel block is fixed).  XCD-aware id: blocks b and b+8 share an XCD (private L2); give each
-  //      XCD a contiguous range so that the workgroups running side by side read neighbouring halos.
+  // ---- XCD-aware tile id: blocks b and b+8 share an XCD (private L2); give each XCD a contiguous tile range so that the
+  //      workgroups running side by side read neighbouring halos
   const int G = gridDim.x;
   int bid;
   {
@@ -72,7 +60,6 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (SATCV_PERSIST_THIN ? 
     const int xcd = orig & 7, q = G >> 3, rem = G & 7;
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
   }
-  const int total = a.total_tiles;
   const int nbase = (bid % a.n_tiles) * BN;
   const int cin = a.c0 + a.c1;
   const int fs = a.mode_in == 1 ? a.f : 1;
@@ -177,19 +164,17 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (SATCV_PERSIST_THIN ? 
     }
   };
 
-  float st1[NT], st2[NT];                 // BN statistics of all tiles of this workgroup (flushed once at the end)
+  float st1[NT], st2[NT];                 // BN statistics of the tile (flushed after the stores)
 #pragma unroll
   for (int n = 0; n < NT; ++n) { st1[n] = 0.f; st2[n] = 0.f; }
 
-  int v = bid;
-  if (v >= total) return;
   int n0, y0, x0;
-  tile_origin(v, n0, y0, x0);
+  tile_origin(bid, n0, y0, x0);
   gather_pixels(n0, y0, x0);
   load_regs(0);
   store_lds(0);
   __syncthreads();
-  for (;;) {
+  {
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -197,16 +182,10 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (SATCV_PERSIST_THIN ? 
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-    const int vnext = PERS ? v + G : total;
-    int n0n = 0, y0n = 0, x0n = 0;
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
       const bool more = chunk + 1 < a.nchunks;
       if (more) {
         load_regs(chunk + 1);
-      } else if (vnext < total) {           // first chunk of the NEXT tile: its loads fly during these MFMAs and the epilogue
-        tile_origin(vnext, n0n, y0n, x0n);
-        gather_pixels(n0n, y0n, x0n);
-        load_regs(0);
       }
       // software-pipelined fragment reads: the LDS reads of step s+1 are issued before the MFMAs of step s (the compiler
       // otherwise waits for every read right before its MFMAs and the matrix pipe idles for the LDS latency)
@@ -336,14 +315,9 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (SATCV_PERSIST_THIN ? 
       }
     }
     }
-    if (vnext >= total) break;
-    __syncthreads();                      // every wave is done with the staged output before the LDS images are rewritten
-    store_lds(0);
-    __syncthreads();
-    v = vnext; n0 = n0n; y0 = y0n; x0 = x0n;
   }
 
-  // ---- BN statistics of all tiles of this workgroup: one pair of atomics per output channel (fixed wave order)
+  // ---- BN statistics of the tile: one pair of atomics per output channel (waves summed in fixed order)
   if (a.stats) {
     __syncthreads();
 #pragma unroll
@@ -370,18 +344,6 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (SATCV_PERSIST_THIN ? 
 }
 
 // ------------------------------------------------------------------ host side
-static bool igemm_persist() {
-  static const bool on = [] { const char* e = getenv("SATCV_PERSIST"); return !e || atoi(e) != 0; }();
-  return on;
-}
-static int igemm_num_cus() {
-  static const int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
-    return v;
-  }();
-  return n;
-}
 template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
 static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, KC = KS * 16, NTHREADS = WM * WN * 64;
@@ -421,23 +383,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   }
   const long long blocks = (long long)a.ngroups * a.tiles_y * a.tiles_x * a.n_tiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return SATCV_ERR_UNSUPPORTED;
-  a.total_tiles = (int)blocks;
-  // persistent launch: as many workgroups as fit on the chip at once (a multiple of the N-tile count so that a
-  // workgroup keeps its channel block); each walks the tiles bid, bid+G, ... with the next tile's loads in flight
-  // during the current tile's epilogue
-  long long grid = blocks;
-  if (FastCfg<T, TW, WM, WN, MT, NT, KS, TAPS>::PERS && igemm_persist()) {
-    static int occ_lds = -1, occ = 0;
-    if (occ_lds != (int)lds) {
-      int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), NTHREADS, lds) != hipSuccess || nb < 1) nb = 1;
-      occ = nb; occ_lds = (int)lds;
-    }
-    long long g = (long long)occ * igemm_num_cus();
-    g -= g % a.n_tiles;
-    if (g >= a.n_tiles && g < blocks) grid = g;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHREADS), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("igemm_fast launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
   return SATCV_OK;
@@ -458,13 +404,8 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
     }
   }
   if (nspace >= 128 && nspace % 128 == 0) {
-    // 256-pixel tile (4x2 MFMA tiles per wave) when the grid still fills the chip twice over: fewer LDS bytes per MFMA
-    static const int big = [] { const char* e = getenv("SATCV_BIGTILE"); return e ? atoi(e) : 0; }();      // measured slower (15.9 vs 15.4 ms/step): off
-    const long long wgs256 = ((long long)a.n * a.h * a.w_ / 256) * (nspace / 128);
-    if (big && TAPS == 9 && TW >= 16 && wgs256 >= 512) {
-      const int rc = fast_cfg<T, TW, 2, 2, 4, 2, 1, TAPS>(a, st, dry);
-      if (rc != SATCV_ERR_UNSUPPORTED) return rc;
-    }
+    // (a 256x128 tile -- 4x2 MFMA tiles per wave, 128 accumulator registers, one workgroup per CU -- was measured slower:
+    //  15.9 vs 15.4 ms/step)
     return fast_cfg<T, TW, 2, 2, 2, 2, 1, TAPS>(a, st, dry);
   }
   // (a 96-wide N tile for the 32->96 data gradient needs 171+96 registers = one workgroup per CU: 836 vs 559 us with two 64-wide tiles;

@@ -20,7 +20,6 @@ struct IgemmArgs {
   int rpi, imgs, seg, rl, cl, pitch, halh, halw;
   int n_tiles;                     // N tiles
   int nchunks;
-  int total_tiles;                 // M tiles x N tiles (persistent workgroups stride over them)
   int dbg;                         // ablation bits (env SATCV_DBG): 1 skip stores, 2 skip MFMA, 4 skip A loads, 8 skip B loads
 };
 
