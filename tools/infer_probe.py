@@ -15,7 +15,7 @@ def timeit(x, reps=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
 
 
-for (n, s) in ((64, 256), (36, 384), (4, 1024)):
+for (n, s) in ((8, 256), (16, 256), (32, 256), (64, 256), (128, 256), (36, 384), (4, 1024)):
     x = torch.from_numpy(rng.beta(2, 5, (n, s, s, 4)).astype(np.float32)).cuda()
     m.disable_fp8_inference()
     tb = timeit(x)
