@@ -29,7 +29,10 @@ extern "C" {
 enum { SATCV_OK = 0, SATCV_ERR_INVALID = -1, SATCV_ERR_HIP = -2, SATCV_ERR_UNSUPPORTED = -3 };
 enum { SATCV_F32 = 0, SATCV_BF16 = 1,
        SATCV_FP8 = 2 /* OCP e4m3fn storage, inference only: ingest, pack_weights, conv2d_igemm (pipelined kernel), maxpool,
-                        affine_requant, head_fwd */ };
+                        affine_requant, head_fwd */,
+       SATCV_FP8X = 3 /* same NHWC e4m3 activations, but weights packed in 16-channel granules ([tap][K/16][Npad][16]) and
+                         the convolution on the block-scaled K=64 MFMA (2x the bf16 rate); needs channels % 64 == 0.
+                         Only pack_weights and conv2d_igemm take it. */ };
 /* rows of replicated per-channel accumulators (sum rows in order to consume) */
 #define SATCV_STAT_ROWS 32
 

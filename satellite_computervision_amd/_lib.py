@@ -13,7 +13,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SATCV_LIB') or os.path.join(_HERE, 'libsatcv.so')     # SATCV_LIB: profiling variants only
 
-F32, BF16, FP8 = 0, 1, 2
+F32, BF16, FP8, FP8X = 0, 1, 2, 3
 STAT_ROWS = 32
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p

@@ -8,6 +8,15 @@
 
 typedef __bf16 bf16;
 typedef __hip_fp8_e4m3 fp8;          // OCP e4m3fn on gfx950 (hardware v_cvt_pk_fp8_f32 / v_cvt_f32_fp8, saturating)
+// same storage, but staged in 16-channel items for the block-scaled K=64 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, 2x the bf16 rate)
+struct fp8s : public __hip_fp8_e4m3 { using __hip_fp8_e4m3::__hip_fp8_e4m3; };
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+
+// K granularity of the implicit-GEMM staging: EL elements per staged 16-byte (bf16 / fp8s), 32-byte (f32) or 8-byte (fp8) item,
+// SUB items per lane half per MFMA step (a lane half feeds 8 k to the 32x32x16 forms, 32 k to the scaled 32x32x64 form)
+template <typename T> struct KTraits { static constexpr int EL = 8, SUB = 1; };
+template <> struct KTraits<fp8s> { static constexpr int EL = 16, SUB = 2; };
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using short4v = __attribute__((ext_vector_type(4))) short;
@@ -94,6 +103,11 @@ template <>
 struct Raw8<fp8> {
   uint2 q;                                      // 8 bytes
 };
+template <>
+struct Raw8<fp8s> {
+  static constexpr int NQ = 1;                  // 16 elements = 16 bytes
+  uint4 q[NQ];
+};
 
 template <typename T>
 __device__ __forceinline__ Raw8<T> gload8(const T* p) {
@@ -144,6 +158,14 @@ __device__ __forceinline__ Raw8<T> affine8(const Raw8<T>& r, const float* sc, co
     fp8* g = reinterpret_cast<fp8*>(&o.q);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+      float t = (float)f[e] * sc[e] + sh[e];
+      g[e] = (fp8)(relu ? fmaxf(t, 0.f) : t);
+    }
+  } else if constexpr (std::is_same<T, fp8s>::value) {
+    const fp8* f = reinterpret_cast<const fp8*>(&r.q[0]);
+    fp8* g = reinterpret_cast<fp8*>(&o.q[0]);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
       float t = (float)f[e] * sc[e] + sh[e];
       g[e] = (fp8)(relu ? fmaxf(t, 0.f) : t);
     }

@@ -299,6 +299,7 @@ void satcv_prof_end(int kind, hipStream_t st);
 static int igemm_fill_args(const satcv_conv_desc* d, IgemmArgs& a) {
   SATCV_CHECK(d && d->x0 && d->w && d->y, "igemm: null pointer");
   SATCV_CHECK(d->c0 > 0 && d->c0 % 16 == 0 && d->c1 % 16 == 0, "igemm: channels must be multiples of 16 (c0=%d c1=%d)", d->c0, d->c1);
+  SATCV_CHECK(d->dtype != SATCV_FP8X || (d->c0 % 64 == 0 && d->c1 % 64 == 0 && !d->in_scale), "igemm: the scaled fp8 path needs channels %% 64 == 0 and no input transform");
   SATCV_CHECK((d->c1 == 0) == (d->x1 == nullptr), "igemm: x1/c1 mismatch");
   SATCV_CHECK(d->kh >= 1 && d->kw >= 1 && (d->kh & 1) && (d->kw & 1) && d->dil >= 1, "igemm: bad taps");
   SATCV_CHECK(d->n > 0 && d->h > 0 && d->w_ > 0 && d->cout > 0, "igemm: bad dims");
@@ -352,7 +353,7 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   rc = SATCV_ERR_UNSUPPORTED;
   if (!igemm_force_generic()) rc = igemm_fast_launch(a, d->dtype, st);
   if (rc != SATCV_ERR_UNSUPPORTED) { /* launched (or failed hard) */ }
-  else if (d->dtype == SATCV_FP8) { satcv_set_error("igemm: this fp8 shape is outside the pipelined kernel's limits"); rc = SATCV_ERR_UNSUPPORTED; }
+  else if (d->dtype == SATCV_FP8 || d->dtype == SATCV_FP8X) { satcv_set_error("igemm: this fp8 shape is outside the pipelined kernel's limits"); rc = SATCV_ERR_UNSUPPORTED; }
   else if (d->out_scale) { satcv_set_error("igemm: out_scale needs the pipelined kernel"); rc = SATCV_ERR_UNSUPPORTED; }
   else if (d->dtype == SATCV_BF16) rc = launch_t<bf16>(a, st);
   else if (d->dtype == SATCV_F32) rc = launch_t<float>(a, st);

@@ -25,15 +25,24 @@
 #define SATCV_ABLATE 0
 #endif
 #define ABL(bit) ((SATCV_ABLATE & (bit)) != 0)
-template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
-// thin configurations (<= 32 accumulator registers) request 4 waves/SIMD
-__global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? 4 : 1)) void igemm_fast_kernel(const IgemmArgs a) {
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool DYN>
+// thin configurations (<= 32 accumulator registers) request 4 waves/SIMD; the scaled-fp8 fragments are 8 registers each, so
+// that path asks for 2
+__global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 ? 2 : 4) : 1)) void igemm_fast_kernel(const IgemmArgs a) {
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int BM = WM * MT * 32;
   constexpr int BN = WN * NT * 32;
   constexpr int TH = BM / TW;
-  constexpr int KC = KS * 16;
-  constexpr int SLOTS = KC / 8;
+  constexpr int EL = KTraits<T>::EL, SUB = KTraits<T>::SUB;      // elements per staged item, items per lane half per MFMA
+  // DYN = dilated 3x3 taps: halo width and LDS pitch come from the arguments.  Otherwise they are compile-time functions of the
+  // tile width, which turns every tap / sub-slot offset of the fragment reads into an instruction immediate (no address VGPRs).
+  constexpr int CLc = TW + (TAPS == 9 ? 2 : 0);
+  constexpr int PITCHc = TW == 32 ? CLc : (TW == 16 ? ((CLc + 15) / 16) * 16 : (CLc <= 8 ? 8 : ((CLc - 8 + 15) / 16) * 16 + 8));
+  const int pitch = DYN ? a.pitch : PITCHc;
+  const int cl = DYN ? a.cl : CLc;
+  const int dil = DYN ? a.dil : 1;
+  constexpr int KC = KS * 2 * SUB * EL;                          // channels per chunk (16 per K-step; 64 for scaled fp8)
+  constexpr int SLOTS = KC / EL;
   // staged A items per thread: halo tile of a 3x3 / dilation-1 conv incl. the several-images-per-tile case
   constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
   constexpr int AI = (XMAXPIX * SLOTS + NTHREADS - 1) / NTHREADS;
@@ -41,7 +50,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? 4 : 1)) void igemm_fas
   constexpr int OPITCH = BN + 16 / (int)sizeof(T);                   // output staging pitch (elements)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* ldsA = reinterpret_cast<T*>(smem_raw);
-  T* ldsB = ldsA + SLOTS * a.rl * a.pitch * 8;
+  T* ldsB = ldsA + SLOTS * a.rl * pitch * EL;
   T* ldsO = reinterpret_cast<T*>(smem_raw);
   float* ldsS = reinterpret_cast<float*>(smem_raw + (size_t)BM * OPITCH * sizeof(T));   // [WM][2][BN] partial BN sums
 
@@ -67,22 +76,16 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? 4 : 1)) void igemm_fas
 
   // ---- tile-independent gather tables (registers): LDS offset and halo coordinates of every staged 16-byte item
   int a_l[AI], a_pk[AI], a_p[AI];
-  const int a_items = a.rl * a.cl * SLOTS;
+  const int a_items = a.rl * cl * SLOTS;
 #pragma unroll
   for (int j = 0; j < AI; ++j) {
     const int it = tid + j * NTHREADS;
     a_l[j] = -1; a_pk[j] = 0; a_p[j] = -1;
     if (it < a_items) {
       const int pix = it / SLOTS;
-      int c, L;
-      if (a.dil == 1) {                      // compile-time halo width: division by a constant
-        constexpr int CL1 = TW + (TAPS == 9 ? 2 : 0);
-        c = pix % CL1; L = pix / CL1;
-      } else {
-        c = pix % a.cl; L = pix / a.cl;
-      }
+      const int c = pix % cl, L = pix / cl;          // (division by a constant unless DYN)
       const int k = (a.imgs == 1) ? 0 : L / a.seg;
-      a_l[j] = ((slot_t * a.rl + L) * a.pitch + c) * 8;
+      a_l[j] = ((slot_t * a.rl + L) * pitch + c) * EL;
       a_pk[j] = (k << 24) | ((L - k * a.seg) << 12) | c;
     }
   }
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? 4 : 1)) void igemm_fas
   for (int j = 0; j < BI; ++j) {
     const int it = tid + j * NTHREADS;
     const int co = it % BN, run = it / BN;
-    b_g[j] = ((run / SLOTS) * (cin / 8) + (run % SLOTS)) * a.cout_pad + nbase + co;
+    b_g[j] = ((run / SLOTS) * (cin / EL) + (run % SLOTS)) * a.cout_pad + nbase + co;
   }
 
   int a_off[MT];
@@ -102,9 +105,9 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? 4 : 1)) void igemm_fas
     const int t = q / TW, cx = q % TW;
     const int k = (a.imgs == 1) ? 0 : t / a.rpi;
     const int l0 = (k < a.imgs) ? k * a.seg + (t - k * a.rpi) : 0;
-    a_off[m] = (l0 * a.pitch + cx) * 8;
+    a_off[m] = (l0 * pitch + cx) * EL;
   }
-  const int slot_stride = a.rl * a.pitch * 8;
+  const int slot_stride = a.rl * pitch * EL;
 
   const T* wp = reinterpret_cast<const T*>(a.w);
   Raw8<T> ra[AI], rb[BI];
@@ -137,18 +140,18 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? 4 : 1)) void igemm_fas
     }
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
-      if (a_p[j] >= 0 && !ABL(4)) ra[j] = gload8<T>(src + (size_t)(a_p[j] + sadd) * cs + coff + slot_t * 8);
+      if (a_p[j] >= 0 && !ABL(4)) ra[j] = gload8<T>(src + (size_t)(a_p[j] + sadd) * cs + coff + slot_t * EL);
       else ra[j] = zero8<T>();
     }
     const size_t cadd = (size_t)chunk * SLOTS * a.cout_pad;
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
-      if (tid + j * NTHREADS < b_items && !ABL(8)) rb[j] = gload8<T>(wp + ((size_t)b_g[j] + cadd) * 8);
+      if (tid + j * NTHREADS < b_items && !ABL(8)) rb[j] = gload8<T>(wp + ((size_t)b_g[j] + cadd) * EL);
       else rb[j] = zero8<T>();
     }
   };
   auto store_lds = [&](int chunk) {
-    const int cg0 = chunk * KC + slot_t * 8;
+    const int cg0 = chunk * KC + slot_t * EL;
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
       if (a_l[j] >= 0) {
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? 4 : 1)) void igemm_fas
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
       const int it = tid + j * NTHREADS;
-      if (it < b_items) lstore8<T>(ldsB + (size_t)it * 8, rb[j]);
+      if (it < b_items) lstore8<T>(ldsB + (size_t)it * EL, rb[j]);
     }
   };
 
@@ -195,22 +198,31 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? 4 : 1)) void igemm_fas
         auto read_step = [&](int st, int buf) {
           const int tap = st / KS, ks = st % KS;
           const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap % 3;
-          const int tap_off = (ky * a.dil * a.pitch + kx * a.dil) * 8;
-          const int slot = ks * 2 + hh;
+          const int tap_off = (ky * dil * pitch + kx * dil) * EL;
+          const int slot = (ks * 2 + hh) * SUB;
 #pragma unroll
-          for (int m = 0; m < MT; ++m) af[buf][m] = lds_frag<T>(ldsA + (ABL(16) ? 0 : slot * slot_stride + a_off[m] + tap_off));
+          for (int m = 0; m < MT; ++m) af[buf][m] = lds_frag<T>(ldsA + (ABL(16) ? 0 : slot * slot_stride + a_off[m] + tap_off), slot_stride);
 #pragma unroll
-          for (int n = 0; n < NT; ++n) bf[buf][n] = lds_frag<T>(ldsB + ((tap * SLOTS + slot) * BN + (wn * NT + n) * 32 + r) * 8);
+          for (int n = 0; n < NT; ++n) bf[buf][n] = lds_frag<T>(ldsB + ((tap * SLOTS + slot) * BN + (wn * NT + n) * 32 + r) * EL, BN * EL);
         };
         read_step(0, 0);
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
+          asm volatile("" ::: "memory");              // IR-level fence: later steps' LDS reads must not be hoisted up here
           if (st + 1 < STEPS) read_step(st + 1, (st + 1) & 1);
           __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this step's MFMAs
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) { if (!ABL(2)) mma32<T>(acc[m][n], af[st & 1][m], bf[st & 1][n]); }
+        }
+        // pin this chunk's MFMAs before the barrier: nothing else orders them, and the compiler otherwise sinks all of them below
+        // the LDS restaging of the next chunk, which keeps every fragment of the chunk live (seen with the scaled-fp8 form: spills)
+        if constexpr (SUB == 2) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(acc[m][n]));
         }
       }
       __syncthreads();
@@ -346,7 +358,8 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? 4 : 1)) void igemm_fas
 // ------------------------------------------------------------------ host side
 template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
 static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
-  constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, KC = KS * 16, NTHREADS = WM * WN * 64;
+  constexpr int EL = KTraits<T>::EL, SUB = KTraits<T>::SUB;
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, KC = KS * 2 * SUB * EL, NTHREADS = WM * WN * 64;
   a.halh = a.dil * (a.kh - 1) / 2;
   a.halw = a.dil * (a.kw - 1) / 2;
   a.tiles_x = cdiv(a.w_, TW);
@@ -366,17 +379,24 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   if (a.cout_pad < a.n_tiles * BN) return SATCV_ERR_UNSUPPORTED;
   {
     constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
-    constexpr int AI = (XMAXPIX * (KC / 8) + NTHREADS - 1) / NTHREADS;
-    if (a.rl * a.cl * (KC / 8) > AI * NTHREADS) return SATCV_ERR_UNSUPPORTED;     // register-staged items per thread
+    constexpr int AI = (XMAXPIX * (KC / EL) + NTHREADS - 1) / NTHREADS;
+    if (a.rl * a.cl * (KC / EL) > AI * NTHREADS) return SATCV_ERR_UNSUPPORTED;     // register-staged items per thread
   }
   if (a.ldy % (16 / (int)sizeof(T)) != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;
   if (a.mode_out == 0 && a.cout % (16 / (int)sizeof(T)) != 0 && a.cout < a.ldy) { /* tail handled by scalar stores */ }
-  const size_t lds_stage = ((size_t)(KC / 8) * a.rl * a.pitch * 8 + (size_t)TAPS * (KC / 8) * BN * 8) * sizeof(T);
+  const size_t lds_stage = ((size_t)KC * a.rl * a.pitch + (size_t)TAPS * KC * BN) * sizeof(T);
   const size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
   const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
   if (dry) return SATCV_OK;
-  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS>;
+  const bool dyn = TAPS == 9 && a.dil != 1;
+  if (!dyn) {            // the kernel hard-codes these for the undilated case: keep the two derivations in lock step
+    constexpr int CLc = TW + (TAPS == 9 ? 2 : 0);
+    constexpr int PITCHc = TW == 32 ? CLc : (TW == 16 ? ((CLc + 15) / 16) * 16 : (CLc <= 8 ? 8 : ((CLc - 8 + 15) / 16) * 16 + 8));
+    if (a.cl != CLc || a.pitch != PITCHc) { satcv_set_error("igemm_fast: internal pitch mismatch (%d/%d vs %d/%d)", a.cl, a.pitch, CLc, PITCHc); return SATCV_ERR_INVALID; }
+  }
+  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, false>;
+  if constexpr (TAPS == 9) { if (dyn) kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, true>; }
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
@@ -395,7 +415,13 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   const int nspace = a.mode_out ? a.cstat : a.cout;
   // 32-channel chunks only for 1x1 taps (the 9-tap weight slab of a 32-channel chunk would not leave
   // room for 2-3 workgroups per CU)
-  if constexpr (TAPS == 1) {
+  if constexpr (KTraits<T>::SUB == 2) {
+    // scaled fp8: a chunk is 64 channels, so the 9-tap weight slab of a 128-wide N tile (74 KB) would leave one workgroup per CU
+    // (a 256x64 tile was measured 10-30 % slower than 128x64 here)
+    if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 1, TAPS>(a, st, dry);
+    return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS>(a, st, dry);
+  }
+  if constexpr (TAPS == 1 && KTraits<T>::SUB == 1) {
     const bool ks2 = (cin % 32 == 0) && (!a.x1 || a.c0 % 32 == 0) && (a.mode_in != 1 || a.c0 % 32 == 0);
     if (ks2) {
       if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS>(a, st, dry);
@@ -403,7 +429,7 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
       return fast_cfg<T, TW, 4, 1, 2, 1, 2, TAPS>(a, st, dry);
     }
   }
-  if (nspace >= 128 && nspace % 128 == 0) {
+  if (nspace >= 128 && nspace % 128 == 0) {      // (128x64 tiles on these layers: 5-10 % slower)
     // (a 256x128 tile -- 4x2 MFMA tiles per wave, 128 accumulator registers, one workgroup per CU -- was measured slower:
     //  15.9 vs 15.4 ms/step)
     return fast_cfg<T, TW, 2, 2, 2, 2, 1, TAPS>(a, st, dry);
@@ -433,5 +459,6 @@ int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   if (dtype == SATCV_BF16) return taps == 1 ? fast_t<bf16, 1>(a, st, dry) : fast_t<bf16, 9>(a, st, dry);
   if (dtype == SATCV_F32) return taps == 1 ? fast_t<float, 1>(a, st, dry) : fast_t<float, 9>(a, st, dry);
   if (dtype == SATCV_FP8) return taps == 1 ? fast_t<fp8, 1>(a, st, dry) : fast_t<fp8, 9>(a, st, dry);
+  if (dtype == SATCV_FP8X) return taps == 1 ? fast_t<fp8s, 1>(a, st, dry) : fast_t<fp8s, 9>(a, st, dry);
   return SATCV_ERR_UNSUPPORTED;
 }

@@ -90,23 +90,25 @@ extern "C" int satcv_ingest_chw(const void* src, int32_t src_kind, float scale, 
   return SATCV_OK;
 }
 
+static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
+
 // ------------------------------------------------------------------ weight packing
 // mode 0: conv fwd    dst[tap][k8][npad][8], k = ci, n = co          src HWIO (tap,ci,co)
 // mode 1: conv dgrad  dst[tap'][k8][npad][8], k = co, n = ci, tap' flipped
 // mode 2: convT fwd   dst[0][k8][npad][8], k = ci, n = (ij)*cout+o   src (ij,o,ci)
 // mode 3: convT dgrad dst[0][k8][npad][8], k = (ij)*cout+o, n = ci
-template <typename T>
+template <typename T, int EL = 8>
 __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int mode, int taps, int cin, int cout, int kpad, int npad) {
   const int ptaps = (mode >= 2) ? 1 : taps;
-  const long long total = (long long)ptaps * (kpad / 8) * npad;
+  const long long total = (long long)ptaps * (kpad / EL) * npad;
   for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
     const int nn = (int)(it % npad);
-    const int k8 = (int)((it / npad) % (kpad / 8));
-    const int tap = (int)(it / ((long long)npad * (kpad / 8)));
-    float v[8];
+    const int k8 = (int)((it / npad) % (kpad / EL));
+    const int tap = (int)(it / ((long long)npad * (kpad / EL)));
+    float v[EL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = k8 * 8 + e;
+    for (int e = 0; e < EL; ++e) {
+      const int k = k8 * EL + e;
       float x = 0.f;
       if (mode == 0) { if (k < cin && nn < cout) x = src[((size_t)tap * cin + k) * cout + nn]; }
       else if (mode == 1) { if (k < cout && nn < cin) x = src[((size_t)(taps - 1 - tap) * cin + nn) * cout + k]; }
@@ -114,7 +116,15 @@ __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, 
       else { if (k < taps * cout && nn < cin) x = src[(size_t)k * cin + nn]; }
       v[e] = x;
     }
-    store8<T>(dst + it * 8, v);
+    if constexpr (EL == 8) {
+      store8<T>(dst + it * 8, v);
+    } else {
+      float lo[8], hi[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { lo[e] = v[e]; hi[e] = v[8 + e]; }
+      store8<T>(dst + it * 16, lo);
+      store8<T>(dst + it * 16 + 8, hi);
+    }
   }
 }
 // every layer's operand images in ONE launch (the per-layer form costs ~40 tiny launches on the critical path of a step):
@@ -157,11 +167,18 @@ extern "C" int satcv_pack_weights_batched(const satcv_pack_job* jobs_dev, const 
   return SATCV_OK;
 }
 
-static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 extern "C" int satcv_pack_weights(const float* src, void* dst_fwd, void* dst_dgrad, int32_t kh, int32_t kw, int32_t cin, int32_t cout, int32_t cin_pad, int32_t transposed, int32_t dtype, void* stream) {
   SATCV_CHECK(src && cin > 0 && cout > 0 && cin_pad >= cin && cin_pad % 16 == 0, "pack_weights: bad args");
   const int taps = kh * kw;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == SATCV_FP8X) {          // scaled fp8: 16-channel granules, forward images only (inference)
+    SATCV_CHECK(dst_fwd && !dst_dgrad && cin_pad % 16 == 0, "pack_weights: the scaled fp8 image is forward-only, cin_pad %% 16 == 0");
+    const int kp = cin_pad, np = rup(transposed ? taps * cout : cout, 32);
+    const long long items = (long long)(transposed ? 1 : taps) * (kp / 16) * np;
+    hipLaunchKernelGGL((pack_kernel<fp8, 16>), dim3(ew_grid(items)), dim3(EW_BLOCK), 0, st, src, (fp8*)dst_fwd, transposed ? 2 : 0, taps, cin, cout, kp, np);
+    LAUNCH_OK("pack_weights");
+    return SATCV_OK;
+  }
   DISPATCH_T8(dtype, {
     if (!transposed) {
       if (dst_fwd) { const int kp = cin_pad, np = rup(cout, 32);

@@ -31,11 +31,17 @@ template <>
 struct FragT<float> { float4 lo, hi; };
 template <>
 struct FragT<fp8> { long v; };
+template <>
+struct FragT<fp8s> { i32x4 lo, hi; };
 
+// p: the lane's item of sub-slot 0; sub_stride: element distance to its item of sub-slot 1 (fp8s only)
 template <typename T>
-__device__ __forceinline__ FragT<T> lds_frag(const T* p) {
+__device__ __forceinline__ FragT<T> lds_frag(const T* p, int sub_stride = 0) {
   FragT<T> f;
-  if constexpr (std::is_same<T, bf16>::value) {
+  if constexpr (std::is_same<T, fp8s>::value) {
+    f.lo = *reinterpret_cast<const i32x4*>(p);
+    f.hi = *reinterpret_cast<const i32x4*>(p + sub_stride);
+  } else if constexpr (std::is_same<T, bf16>::value) {
     f.v = *reinterpret_cast<const bf16x8*>(p);
   } else if constexpr (std::is_same<T, fp8>::value) {
     f.v = *reinterpret_cast<const long*>(p);
@@ -52,6 +58,12 @@ __device__ __forceinline__ void mma32(f32x16& acc, const FragT<T>& a, const Frag
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
   } else if constexpr (std::is_same<T, fp8>::value) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a.v, b.v, acc, 0, 0, 0);      // bf16 rate, half the operand bytes
+  } else if constexpr (std::is_same<T, fp8s>::value) {
+    // K = 64 per instruction, unit block scales (e8m0 127): twice the bf16 rate.  Any k order is fine as long as A and B agree
+    // (tools/probes/mfma_scale_layout.hip): a lane half holds the 32 consecutive channels of its two 16-byte items.
+    const i32x8 av = __builtin_shufflevector(a.lo, a.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    const i32x8 bv = __builtin_shufflevector(b.lo, b.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
   } else {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.x, b.lo.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo.y, b.lo.y, acc, 0, 0, 0);

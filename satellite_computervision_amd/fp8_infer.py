@@ -18,7 +18,12 @@ import ctypes as C
 import torch
 
 from . import ops
-from ._lib import lib, check, FP8, BF16
+import os
+
+from ._lib import lib, check, FP8, FP8X, BF16
+
+# layers whose input channels are a multiple of 64 run on the block-scaled K=64 MFMA (2x the bf16 rate)
+USE_SCALED_MFMA = os.environ.get('SATCV_FP8_SCALED', '1') != '0'
 
 E4M3_MAX = 448.0
 BN_EPS = 1e-3
@@ -98,12 +103,13 @@ class Fp8Plan:
             amax = kernel.abs().amax(dim=(0, 1, 2))
             wscale = amax.clamp_min(1e-12) / E4M3_MAX
             kq = kernel / wscale.view(1, 1, 1, -1)
-        fwd, _ = ops.pack_weights(kq.contiguous(), cin_pad, FP8, transposed=transposed, want_dgrad=False)
+        dt = FP8X if (USE_SCALED_MFMA and cin_pad % 64 == 0) else FP8
+        fwd, _ = ops.pack_weights(kq.contiguous(), cin_pad, dt, transposed=transposed, want_dgrad=False)
         self.keep.append(fwd)
-        return fwd, wscale
+        return fwd, wscale, dt
 
-    def _conv(self, **kw):
-        d = ops.make_conv_desc(dtype=FP8, out_relu=1, **kw)
+    def _conv(self, dtype=FP8, **kw):
+        d = ops.make_conv_desc(dtype=dtype, out_relu=1, **kw)
         self.keep.append(d)
         self.fwd.append(lambda st, d=d: check(lib.satcv_conv2d_igemm(C.byref(d), st)))
 
@@ -164,7 +170,7 @@ class Fp8Plan:
                         lib.satcv_affine_requant(yb.data_ptr(), cout, rs.data_ptr(), rsh.data_ptr(), 1, y8.data_ptr(), cout, npix, cout, BF16, FP8, st)))
                     vals[tout.id] = (y8, cout, hh, ww, qo)
                     continue
-                w8, wscale = self._pack(kernel, cin_s, False)
+                w8, wscale, cdt = self._pack(kernel, cin_s, False)
                 s, t_ = self._bn(lay.bn_name)
                 qo = q[tout.id]
                 oscale = self._f32(qin * wscale * s / qo)
@@ -172,7 +178,7 @@ class Fp8Plan:
                 y8 = self._z(n, hh, ww, cout)
                 k = node.attrs['k']
                 self._conv(x0=x8.data_ptr(), c0=cin_s, w=w8.data_ptr(), bias=obias.data_ptr(), out_scale=oscale.data_ptr(), y=y8.data_ptr(), ldy=cout,
-                           n=n, h=hh, w_=ww, cout=cout, cout_pad=_rup(cout, 32), kh=k, kw=k, dil=node.attrs['dil'])
+                           n=n, h=hh, w_=ww, cout=cout, cout_pad=_rup(cout, 32), kh=k, kw=k, dil=node.attrs['dil'], dtype=cdt)
                 vals[tout.id] = (y8, cout, hh, ww, qo)
             elif op == 'pool':
                 tin, tout = node.inputs[0], node.outputs[0]
@@ -196,7 +202,7 @@ class Fp8Plan:
                 if cb % 32 or ca % 16:
                     raise NotImplementedError(f'{lay.name}: unsupported channel counts for the fp8 path')
                 kernel = rt.get_param(lay.name + '/kernel')
-                w8, wscale = self._pack(kernel, cin_s, True)
+                w8, wscale, cdt = self._pack(kernel, cin_s, True)
                 s0, t0 = self._bn(cat.layer.name)
                 qc = q[cat.outputs[0].id]
                 cat8 = self._z(n, hh * f, ww * f, ca + cb)
@@ -204,7 +210,7 @@ class Fp8Plan:
                 obias = self._f32((s0[ca:] * rt.get_param(lay.name + '/bias') + t0[ca:]) / qc)
                 self._conv(x0=x8.data_ptr(), c0=cin_s, w=w8.data_ptr(), bias=obias.data_ptr(), out_scale=oscale.data_ptr(),
                            y=cat8.data_ptr() + ca, ldy=ca + cb, n=n, h=hh, w_=ww, cout=f * f * cb, cout_pad=_rup(f * f * cb, 32),
-                           kh=1, kw=1, dil=1, mode_out=1, f=f, cstat=cb)
+                           kh=1, kw=1, dil=1, mode_out=1, f=f, cstat=cb, dtype=cdt)
                 cats[id(cat)] = (cat8, ca, cb, qc, s0, t0, hh * f, ww * f)
             elif op == 'concat_bn_relu':
                 ta, tout = node.inputs[0], node.outputs[0]

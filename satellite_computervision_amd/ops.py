@@ -8,9 +8,9 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import lib, check, ConvDesc, WgradDesc, BnBwdDesc, HeadDesc, F32, BF16, FP8, STAT_ROWS
+from ._lib import lib, check, ConvDesc, WgradDesc, BnBwdDesc, HeadDesc, F32, BF16, FP8, FP8X, STAT_ROWS
 
-TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, FP8: torch.float8_e4m3fn}
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, FP8: torch.float8_e4m3fn, FP8X: torch.float8_e4m3fn}
 DTYPE_CODE = {torch.float32: F32, torch.bfloat16: BF16, torch.float8_e4m3fn: FP8}
 
 

@@ -25,9 +25,13 @@ def _to_f8(t):
     return t.to(torch.float8_e4m3fn)
 
 
-@pytest.mark.parametrize('cin,cout,k,dil', [(32, 32, 3, 1), (16, 64, 3, 1), (64, 96, 3, 1), (128, 128, 3, 1), (64, 32, 1, 1), (32, 32, 3, 2)])
-def test_fp8_conv_bit_exact(env, cin, cout, k, dil):
-    ops, lib, check, FP8 = env['ops'], env['lib'], env['check'], env['FP8']
+@pytest.mark.parametrize('cin,cout,k,dil,scaled', [(32, 32, 3, 1, 0), (16, 64, 3, 1, 0), (64, 96, 3, 1, 0), (128, 128, 3, 1, 0), (64, 32, 1, 1, 0), (32, 32, 3, 2, 0),
+                                                  (64, 64, 3, 1, 1), (128, 128, 3, 1, 1), (192, 64, 3, 1, 1), (256, 32, 3, 1, 1), (64, 128, 1, 1, 1), (128, 96, 3, 2, 1)])
+def test_fp8_conv_bit_exact(env, cin, cout, k, dil, scaled):
+    """scaled=1: SATCV_FP8X -- weights in 16-channel granules, block-scaled K=64 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4)"""
+    ops, lib, check = env['ops'], env['lib'], env['check']
+    from satellite_computervision_amd._lib import FP8X
+    FP8 = FP8X if scaled else env['FP8']
     rng = np.random.default_rng(cin * 7 + cout + k)
     n, h, w = 3, 20, 40
     x = torch.tensor(rng.integers(-3, 4, (n, h, w, cin)), dtype=torch.float32)
