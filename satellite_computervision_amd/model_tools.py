@@ -773,17 +773,34 @@ class Model:
         """Model.predict semantics used by the reference (utils/prediction_tools.py:152, 251, 333, 515):
         inference-mode forward; ndarray or iterable of batches; list of arrays in output order."""
         batches, nb = _as_batches(x, None, batch_size or 32)
-        outs = [[] for _ in self.outputs]
         multi = len(self.inputs) > 1
+        # results go D2H asynchronously into page-locked host arrays (one per output, grown as batches arrive): no per-batch
+        # synchronisation and no final concatenation; the copy of batch i overlaps the staging and compute of batch i+1
+        pinned, filled = None, 0
         for i, xb in enumerate(batches):
             if steps is not None and i >= steps:
                 break
             if isinstance(xb, (tuple, list)) and not multi:
                 xb = xb[0]
             res = self.predict_on_device(xb)
-            for o, r in zip(outs, res):
-                o.append(r.cpu().numpy())
-        arrays = [np.concatenate(o, axis=0) for o in outs]
+            nb_i = res[0].shape[0]
+            if pinned is None:
+                total = (self._shape_of(x)[0] if isinstance(x, (np.ndarray, torch.Tensor)) or multi else (steps or nb or 1) * nb_i)
+                rows = max(total, nb_i)
+                big = sum(rows * r[0].numel() * r.element_size() for r in res) >= (16 << 20)      # page-locking small buffers costs more than it saves
+                pinned = [torch.empty((rows,) + tuple(r.shape[1:]), dtype=r.dtype, pin_memory=big) for r in res]
+            if filled + nb_i > pinned[0].shape[0]:               # iterable of unknown length: grow geometrically
+                torch.cuda.current_stream().synchronize()
+                grown = [torch.empty((2 * (filled + nb_i),) + tuple(p_.shape[1:]), dtype=p_.dtype, pin_memory=p_.is_pinned()) for p_ in pinned]
+                for g_, p_ in zip(grown, pinned):
+                    g_[:filled].copy_(p_[:filled])
+                pinned = grown
+            for p_, r in zip(pinned, res):
+                p_[filled:filled + nb_i].copy_(r, non_blocking=p_.is_pinned())
+            filled += nb_i
+            # the plan's output buffers are rewritten by the next batch: that launch is stream-ordered after the copy above
+        torch.cuda.current_stream().synchronize()
+        arrays = [p_[:filled].numpy() for p_ in (pinned or [])]
         return arrays[0] if self._single_output else arrays
 
     __call__ = predict_on_device
