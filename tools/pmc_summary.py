@@ -5,7 +5,7 @@ coalesced stream, i.e. HALF the bytes -> doubled here; WRITE_SIZE is exact for 1
 Counter unit: KiB."""
 import csv, glob, json, sys, collections
 fdir, wdir, out = sys.argv[1], sys.argv[2], sys.argv[3]
-CLASSES = (('Li9EEv9IgemmArgs', 'igemm_3x3'), ('igemm_fast', 'igemm_1x1_convT'), ('igemm_kernel', 'igemm_generic'), ('wgrad_kernel', 'wgrad'), ('wgrad_reduce', 'wgrad_reduce'),
+CLASSES = (('Li9ELb', 'igemm_3x3'), ('igemm_fast', 'igemm_1x1_convT'), ('igemm_kernel', 'igemm_generic'), ('wgrad_kernel', 'wgrad'), ('wgrad_reduce', 'wgrad_reduce'),
            ('bn_bwd', 'bn_bwd'), ('bn_relu_pool', 'bn_relu_pool'), ('head_', 'head'), ('adam', 'adam'), ('pack_kernel', 'pack'))
 
 def load(d):
