@@ -423,6 +423,8 @@ class Plan:
                 if not (r.affine and len(r.srcs) == 1):
                     raise NotImplementedError('max-pool expects the output of a conv_batch_act block')
                 c = r.c
+                if r.h % f or r.w % f:
+                    raise ValueError(f'input {self.h}x{self.w} is not divisible by the model downsampling (a {r.h}x{r.w} map meets a {f}x{f} pool)')
                 pooled = self._z(n, r.h // f, r.w // f, c)
                 others = [cn for cn in consumers[tin.id] if cn is not node]
                 if others:
@@ -460,6 +462,8 @@ class Plan:
                     ra0 = vals[ta.id]
                     acts[ta.id] = self._materialize(ta, ra0, 1, None, sinks.get(ta.id)) if ra0.affine else ra0
                 ra, rb = acts[ta.id], vals[tb.id]
+                if (ra.h, ra.w) != (rb.h, rb.w):
+                    raise ValueError(f'concatenation of a {ra.h}x{ra.w} skip with a {rb.h}x{rb.w} up-sampled map: the input size must be divisible by the model downsampling')
                 if rb.affine or len(rb.srcs) != 1 or len(ra.srcs) != 1:
                     raise NotImplementedError('concat+BN expects (activated skip, transposed-conv output)')
                 ca, cb = ra.c, rb.c

@@ -184,6 +184,8 @@ class Fp8Plan:
                 tin, tout = node.inputs[0], node.outputs[0]
                 x8, c, hh, ww, qin = vals[tin.id]
                 f = node.attrs['f']
+                if hh % f or ww % f:
+                    raise ValueError(f'input {self.h}x{self.w} is not divisible by the model downsampling')
                 p8 = self._z(n, hh // f, ww // f, c)
                 self.fwd.append(lambda st, x8=x8, p8=p8, hh=hh, ww=ww, c=c, f=f: check(
                     lib.satcv_maxpool(x8.data_ptr(), p8.data_ptr(), n, hh, ww, c, f, f, 0, FP8, st)))
@@ -216,7 +218,8 @@ class Fp8Plan:
                 ta, tout = node.inputs[0], node.outputs[0]
                 cat8, ca, cb, qc, s0, t0, hh, ww = cats[id(node)]
                 a8, c, ha, wa, qa = vals[ta.id]
-                assert c == ca and (ha, wa) == (hh, ww)
+                if c != ca or (ha, wa) != (hh, ww):
+                    raise ValueError(f'concatenation of a {ha}x{wa}x{c} skip with a {hh}x{ww} up-sampled map')
                 rs = self._f32(s0[:ca] * qa / qc)
                 rsh = self._f32(t0[:ca] / qc)
                 npix = n * hh * ww

@@ -611,3 +611,36 @@ def test_full_size_training_step_permutation_property(mt):
     # them; a wrong tile mapping or a dropped slab would show up as O(1)
     assert rel < 1e-2 and rel_same < 1e-2, (rel, rel_same)
     assert torch.isfinite(g1).all() and g1.abs().max() > 0
+
+
+@pytest.mark.parametrize('n,h,w', [(1, 4, 4), (5, 12, 20), (3, 40, 72), (2, 100, 36), (7, 8, 264)])
+def test_ragged_shapes_forward_and_gradients(mt, n, h, w):
+    """tile sizes that are not multiples of any kernel tile (partial tiles in x and y, several images per workgroup, a 1x1
+    deepest level, more pixels per row than one tile): fp32 predictions and every gradient against the float64 oracle."""
+    filters, factors = [32, 64], [2, 2]
+    o, m, names = build_pair(mt, 'float32', 2, 4, filters, factors, seed=n + h)
+    rng = np.random.default_rng(h * w)
+    x = rng.random((n, h, w, 4)).astype(np.float32)
+    lab = (rng.random((n, h, w)) < 0.4).astype(np.int64)
+    t = np.eye(2)[lab].astype(np.float32)
+    p_ref, c_ref = o.forward(x, training=False)
+    probs, classes = m.predict(x, batch_size=n)
+    np.testing.assert_allclose(probs, p_ref, atol=3e-5)
+    ok = np.abs(p_ref[..., 0] - p_ref[..., 1]) > 1e-4
+    assert np.array_equal(classes[ok], c_ref[ok])
+    if n * h * w < 64:
+        return                                        # BN batch statistics of a handful of pixels: forward only
+    m.compile(optimizer=mt.Adam(1e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 3.0]))
+    pr, _ = o.forward(x, training=True)
+    loss_ref, dprobs, _ = OL.weighted_categorical_crossentropy(t.astype(np.float64), pr, [1.0, 3.0])
+    g_ref = o.backward(dprobs)
+    loss = m.train_on_batch(x, t)
+    np.testing.assert_allclose(loss, loss_ref, rtol=3e-5)
+    for k in o.trainable:
+        if k.endswith('.bias') and not k.startswith('probs'):
+            continue
+        g = m.runtime.get_grad(names[k]).cpu().numpy().astype(np.float64)
+        l2 = np.linalg.norm(g - g_ref[k]) / max(np.linalg.norm(g_ref[k]), 1e-30)
+        assert l2 < 2e-2, f'{k}: relL2 {l2:.2e} at {(n, h, w)}'
+    with pytest.raises(ValueError):
+        m.predict(rng.random((1, h + 2, w, 4)).astype(np.float32))      # not divisible by the down-sampling
