@@ -644,3 +644,35 @@ def test_ragged_shapes_forward_and_gradients(mt, n, h, w):
         assert l2 < 2e-2, f'{k}: relL2 {l2:.2e} at {(n, h, w)}'
     with pytest.raises(ValueError):
         m.predict(rng.random((1, h + 2, w, 4)).astype(np.float32))      # not divisible by the down-sampling
+
+
+@pytest.mark.parametrize('filters,factors,ncls,nch,hw', [([32, 64, 128], [2, 2, 2], 8, 1, (24, 40)), ([32, 64], [3, 3], 3, 5, (18, 27)),
+                                                          ([32, 32, 64, 64, 128], [2, 2, 2, 2, 2], 2, 17, (32, 64)), ([64, 32], [2, 4], 4, 3, (16, 48))])
+def test_model_variants_forward_and_gradients(mt, filters, factors, ncls, nch, hw):
+    """get_unet_model's free parameters (utils/model_tools.py:394): class count, band count (not a multiple of the channel
+    padding), depth, pool / up-sampling factors other than 2, non-monotone filter lists -- fp32 against the float64 oracle."""
+    o, m, names = build_pair(mt, 'float32', ncls, nch, filters, factors, seed=ncls + nch)
+    rng = np.random.default_rng(ncls * 7 + nch)
+    n, (h, w) = 4, hw
+    x = rng.random((n, h, w, nch)).astype(np.float32)
+    lab = rng.integers(0, ncls, (n, h, w))
+    t = np.eye(ncls)[lab].astype(np.float32)
+    p_ref, c_ref = o.forward(x, training=False)
+    probs, classes = m.predict(x)
+    np.testing.assert_allclose(probs, p_ref, atol=3e-5)
+    srt = np.sort(p_ref, axis=-1)
+    ok = (srt[..., -1] - srt[..., -2]) > 1e-4
+    assert np.array_equal(classes[ok], c_ref[ok])
+    wts = list(np.linspace(1.0, 2.0, ncls))
+    m.compile(optimizer=mt.Adam(1e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, wts))
+    pr, _ = o.forward(x, training=True)
+    loss_ref, dprobs, _ = OL.weighted_categorical_crossentropy(t.astype(np.float64), pr, wts)
+    g_ref = o.backward(dprobs)
+    loss = m.train_on_batch(x, t)
+    np.testing.assert_allclose(loss, loss_ref, rtol=3e-5)
+    for k in o.trainable:
+        if k.endswith('.bias') and not k.startswith('probs'):
+            continue
+        g = m.runtime.get_grad(names[k]).cpu().numpy().astype(np.float64)
+        l2 = np.linalg.norm(g - g_ref[k]) / max(np.linalg.norm(g_ref[k]), 1e-30)
+        assert l2 < 2e-2, f'{k}: relL2 {l2:.2e}'
