@@ -13,6 +13,13 @@
 #include "common.hpp"
 #include <cstdlib>
 
+// compile-time ablation for profiling builds (-DSATCV_WABLATE=bits): 1 skip the global loads, 2 skip the MFMAs, 4 read every
+// fragment from LDS offset 0 (no address arithmetic / bank pattern), 8 skip the LDS staging stores
+#ifndef SATCV_WABLATE
+#define SATCV_WABLATE 0
+#endif
+#define WABL(bit) ((SATCV_WABLATE & (bit)) != 0)
+
 struct WgradArgs {
   const void* x0; const void* x1; int c0, c1;
   const float* in_scale; const float* in_shift; int in_relu;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 2) void wgrad_kernel(const Wgra
           const T* src; int cs, coff;
           if (cg < a.c0) { src = reinterpret_cast<const T*>(a.x0); cs = a.c0; coff = cg; }
           else { src = reinterpret_cast<const T*>(a.x1); cs = a.c1; coff = cg - a.c0; }
-          xr[j] = gload8<T>(src + ((size_t)(n * a.h + y) * a.w_ + x) * cs + coff);
+          if (!WABL(1)) xr[j] = gload8<T>(src + ((size_t)(n * a.h + y) * a.w_ + x) * cs + coff);
           xv[j] = true;
         }
       }
@@ -150,12 +157,13 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 2) void wgrad_kernel(const Wgra
         } else {
           off = ((size_t)(nimg * a.h + y) * a.w_ + x) * a.lddy + cv;
         }
-        dr[j] = gload8<T>(dyp + off);
+        if (!WABL(1)) dr[j] = gload8<T>(dyp + off);
       }
     }
   };
   // BN affine + ReLU of the producing layer (in registers), then LDS
   auto store_tile = [&]() {
+    if (WABL(8)) return;
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
       const int it = tid + j * NTHREADS;
@@ -240,12 +248,13 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 2) void wgrad_kernel(const Wgra
           if (tap + 1 < NTAPS) {
             const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
             const int toff = ((ky * a.dil) * a.cl + kx * a.dil) * XP;
-            alo[(tap + 1) & 1] = tr_read(ldsX + xoa + toff);
-            ahi[(tap + 1) & 1] = tr_read(ldsX + xob + toff);
+            alo[(tap + 1) & 1] = tr_read(ldsX + (WABL(4) ? 0 : xoa + toff));
+            ahi[(tap + 1) & 1] = tr_read(ldsX + (WABL(4) ? 64 : xob + toff));
           }
           __builtin_amdgcn_sched_barrier(0);
           bf16x8 afr = __builtin_shufflevector(alo[tap & 1], ahi[tap & 1], 0, 1, 2, 3, 4, 5, 6, 7);
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[tap], 0, 0, 0);
+          if (!WABL(2)) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[tap], 0, 0, 0);
+          else acc[tap][0] += (float)afr[0] + (float)bfr[0];
         }
       } else {
 #pragma unroll
