@@ -66,17 +66,30 @@ def calibrate(model, x):
     return q
 
 
+class _Ones:
+    """scale table of the unquantised (bf16) folded graph"""
+
+    def __getitem__(self, k):
+        return 1.0
+
+
 class Fp8Plan:
     """Static launch list of the folded fp8 forward for one (n, h, w)."""
 
-    def __init__(self, model, n, h, w, q, first_bf16=True):
-        self.model, self.n, self.h, self.w, self.q, self.first_bf16 = model, n, h, w, q, first_bf16
+    def __init__(self, model, n, h, w, q, first_bf16=True, store=FP8):
+        # store = BF16: the same folded graph with bf16 tensors and no quantisation (every scale 1) -- BatchNorm in the conv epilogues
+        # instead of the consumers' loaders, activations written once
+        self.model, self.n, self.h, self.w, self.first_bf16, self.store = model, n, h, w, first_bf16, store
+        self.q = q if store == FP8 else _Ones()
+        self.tdt = torch.bfloat16 if store == BF16 else torch.float8_e4m3fn
         self.rt = model.runtime
         self.dev = self.rt.dev
         self.fwd, self.keep, self.outputs, self.x_by_tid = [], [], {}, {}
+        self.esz = 2 if self.store == BF16 else 1
         self._build()
 
-    def _z(self, *shape, dtype=torch.float8_e4m3fn):
+    def _z(self, *shape, dtype=None):
+        dtype = dtype or self.tdt
         t = torch.zeros(*shape, dtype=torch.uint8 if dtype == torch.float8_e4m3fn else dtype, device=self.dev)
         self.keep.append(t)
         return t
@@ -95,6 +108,11 @@ class Fp8Plan:
 
     def _pack(self, kernel, cin_pad, transposed):
         """fp8 operand image + per-output-channel scale of a Keras kernel."""
+        if self.store == BF16:
+            fwd, _ = ops.pack_weights(kernel.contiguous(), cin_pad, BF16, transposed=transposed, want_dgrad=False)
+            self.keep.append(fwd)
+            nout = kernel.shape[2] if transposed else kernel.shape[3]
+            return fwd, torch.ones(nout, device=self.dev), BF16
         if transposed:                                  # (f, f, cout, cin)
             amax = kernel.abs().amax(dim=(0, 1, 3))
             wscale = amax.clamp_min(1e-12) / E4M3_MAX
@@ -108,7 +126,8 @@ class Fp8Plan:
         self.keep.append(fwd)
         return fwd, wscale, dt
 
-    def _conv(self, dtype=FP8, **kw):
+    def _conv(self, dtype=None, **kw):
+        dtype = dtype if dtype is not None else self.store
         d = ops.make_conv_desc(dtype=dtype, out_relu=1, **kw)
         self.keep.append(d)
         self.fwd.append(lambda st, d=d: check(lib.satcv_conv2d_igemm(C.byref(d), st)))
@@ -129,13 +148,13 @@ class Fp8Plan:
                 xin = self._z(n, self.h, self.w, t.channels, dtype=torch.float32)
                 self.x_by_tid[t.id] = xin
                 npix, cc = n * self.h * self.w, t.channels
-                if self.first_bf16:
+                if self.first_bf16 or self.store == BF16:
                     # the input bands stay bf16 and the first conv block runs on the bf16 kernel: e4m3's 3 mantissa bits on
                     # the reflectances themselves were measured to flip ~1 % of confidently classified pixels
                     xb = self._z(n, self.h, self.w, cp, dtype=torch.bfloat16)
                     self.fwd.append(lambda st, xin=xin, xb=xb, npix=npix, cc=cc, cp=cp: check(
                         lib.satcv_ingest_nhwc(xin.data_ptr(), xb.data_ptr(), npix, cc, cp, BF16, st)))
-                    vals[t.id] = (xb, cp, self.h, self.w, None)
+                    vals[t.id] = (xb, cp, self.h, self.w, None if self.store == FP8 else 1.0)
                 else:
                     x8 = self._z(n, self.h, self.w, cp)
                     inv = 1.0 / q[t.id]
@@ -188,7 +207,7 @@ class Fp8Plan:
                     raise ValueError(f'input {self.h}x{self.w} is not divisible by the model downsampling')
                 p8 = self._z(n, hh // f, ww // f, c)
                 self.fwd.append(lambda st, x8=x8, p8=p8, hh=hh, ww=ww, c=c, f=f: check(
-                    lib.satcv_maxpool(x8.data_ptr(), p8.data_ptr(), n, hh, ww, c, f, f, 0, FP8, st)))
+                    lib.satcv_maxpool(x8.data_ptr(), p8.data_ptr(), n, hh, ww, c, f, f, 0, self.store, st)))
                 vals[tout.id] = (p8, c, hh // f, ww // f, qin)
             elif op == 'dropout':
                 vals[node.outputs[0].id] = vals[node.inputs[0].id]           # identity at inference
@@ -211,7 +230,7 @@ class Fp8Plan:
                 oscale = self._f32(qin * wscale * s0[ca:] / qc)
                 obias = self._f32((s0[ca:] * rt.get_param(lay.name + '/bias') + t0[ca:]) / qc)
                 self._conv(x0=x8.data_ptr(), c0=cin_s, w=w8.data_ptr(), bias=obias.data_ptr(), out_scale=oscale.data_ptr(),
-                           y=cat8.data_ptr() + ca, ldy=ca + cb, n=n, h=hh, w_=ww, cout=f * f * cb, cout_pad=_rup(f * f * cb, 32),
+                           y=cat8.data_ptr() + ca * self.esz, ldy=ca + cb, n=n, h=hh, w_=ww, cout=f * f * cb, cout_pad=_rup(f * f * cb, 32),
                            kh=1, kw=1, dil=1, mode_out=1, f=f, cstat=cb, dtype=cdt)
                 cats[id(cat)] = (cat8, ca, cb, qc, s0, t0, hh * f, ww * f)
             elif op == 'concat_bn_relu':
@@ -224,7 +243,7 @@ class Fp8Plan:
                 rsh = self._f32(t0[:ca] / qc)
                 npix = n * hh * ww
                 self.fwd.append(lambda st, a8=a8, cat8=cat8, rs=rs, rsh=rsh, ca=ca, ld=ca + cb, npix=npix: check(
-                    lib.satcv_affine_requant(a8.data_ptr(), ca, rs.data_ptr(), rsh.data_ptr(), 1, cat8.data_ptr(), ld, npix, ca, FP8, FP8, st)))
+                    lib.satcv_affine_requant(a8.data_ptr(), ca, rs.data_ptr(), rsh.data_ptr(), 1, cat8.data_ptr(), ld, npix, ca, self.store, self.store, st)))
                 vals[tout.id] = (cat8, ca + cb, hh, ww, qc)
             elif op == 'head':
                 tin, tout = node.inputs[0], node.outputs[0]
@@ -237,7 +256,7 @@ class Fp8Plan:
                 sc = self._f32(torch.full((c,), qin, device=self.dev))
                 sh = self._f32(torch.zeros(c, device=self.dev))
                 hd = ops.make_head_desc(x=x8.data_ptr(), ldx=c, cin=c, w=rt.pptr(lay.name + '/kernel'), b=rt.pptr(lay.name + '/bias'),
-                                        ncls=ncls, activation=act, npix=n * hh * ww, dtype=FP8, in_scale=sc.data_ptr(), in_shift=sh.data_ptr(),
+                                        ncls=ncls, activation=act, npix=n * hh * ww, dtype=self.store, in_scale=sc.data_ptr(), in_shift=sh.data_ptr(),
                                         thresh=node.attrs.get('thresh', 0.5), probs=probs.data_ptr(), classes=classes.data_ptr())
                 self.keep.append(hd)
                 self.fwd.append(lambda st, hd=hd: check(lib.satcv_head_fwd(C.byref(hd), st)))

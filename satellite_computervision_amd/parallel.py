@@ -119,6 +119,7 @@ def make_grad_sync(model, bucket_bytes=16 << 20, overlap=None):
     world = dist.get_world_size() if dist.is_initialized() else 1
     broadcast_state([rt.pflat, rt.sflat])
     rt.repack()
+    model._weights_version = getattr(model, '_weights_version', 0) + 1
     rt.adam_state[2:3].fill_(1.0 / world)
     if overlap is None:
         overlap = os.environ.get('SATCV_OVERLAP_ALLREDUCE', '1') != '0'

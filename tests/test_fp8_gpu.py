@@ -127,3 +127,60 @@ def test_fp8_unet_inference_iou(env):
     margin = np.abs(p_ref[..., 1] - 0.5) > 0.25                 # confidently classified pixels must not flip
     assert (c8[margin] == c_ref[margin]).mean() > 0.995, (c8[margin] == c_ref[margin]).mean()
     assert agree >= 0.985 and d_iou <= 5e-3 and d_p < 0.015, (agree, d_iou, d_p)
+
+
+def test_folded_bf16_inference_matches_regular_plan(env):
+    """the folded graph with bf16 tensors (no quantisation) against the regular bf16 plan and the float64 oracle"""
+    from oracle.unet import UNetOracle
+    mt = env['mt']
+    mt.reset_uids(); mt.set_seed(6)
+    filters, factors = [32, 64, 128], [2, 2, 2]
+    m = mt.get_unet_model(2, 4, filters=filters, factors=factors)
+    m.compute_dtype = 'bfloat16'
+    rng = np.random.default_rng(3)
+    w = m.get_weights_dict()
+    for k in w:                                   # non-trivial BN statistics and biases
+        if k.endswith('moving_mean') or k.endswith('/bias') or k.endswith('/beta'):
+            w[k] = (0.2 * rng.standard_normal(w[k].shape)).astype(np.float32)
+        elif k.endswith('moving_var') or k.endswith('/gamma'):
+            w[k] = (0.5 + rng.random(w[k].shape)).astype(np.float32)
+    m.set_weights_dict(w)
+    names = mt.structural_names(m)
+    o = UNetOracle(2, 4, filters, factors, dtype=np.float64)
+    for k in o.params:
+        o.params[k] = w[names[k]].astype(np.float64)
+    x = rng.random((3, 48, 80, 4)).astype(np.float32)
+    p_ref, _ = o.forward(x, training=False)
+    p_reg, _ = m.predict(x)
+    m.enable_folded_inference()
+    p_fold, c_fold = m.predict(x)
+    m.disable_folded_inference()
+    assert np.abs(p_fold - p_ref).max() < 0.05 and np.abs(p_reg - p_ref).max() < 0.05
+    assert np.abs(p_fold - p_ref).mean() < 1.5 * np.abs(p_reg - p_ref).mean() + 1e-4      # same bf16 noise level as the regular plan
+    assert c_fold.shape == (3, 48, 80)
+
+
+def test_folded_inference_tracks_weight_updates(env):
+    """the default bf16 inference plan bakes BatchNorm / bias / weight images in at build time: it must follow training steps
+    and weight loads (no stale predictions), and SATCV-regular and folded paths must agree after them."""
+    mt = env['mt']
+    mt.reset_uids(); mt.set_seed(8)
+    m = mt.get_unet_model(2, 4, filters=[32, 64], factors=[2, 2])
+    m.compute_dtype = 'bfloat16'
+    m.compile(optimizer=mt.Adam(5e-3), loss=lambda t, p: mt.weighted_categorical_crossentropy(t, p, [1.0, 1.0]))
+    rng = np.random.default_rng(1)
+    x = rng.random((4, 32, 32, 4)).astype(np.float32)
+    y = np.eye(2, dtype=np.float32)[(x[..., 0] > 0.5).astype(np.int64)]
+    p0, _ = m.predict(x)
+    for _ in range(20):
+        m.train_on_batch(x, y)
+    p1, _ = m.predict(x)
+    assert np.abs(p1 - p0).max() > 0.05                       # the model moved, and predict saw it
+    plan = m._head_plan(4, 32, 32, False)                      # regular (training-style) inference plan on the same weights
+    m._stage_x(plan, x); plan.run_forward(env['ops'].stream_ptr())
+    p_reg = plan.outputs[m.outputs[0].id].cpu().numpy()
+    assert np.abs(p1 - p_reg).max() < 0.06 and np.abs(p1 - p_reg).mean() < 0.01
+    w = m.get_weights_dict()
+    m.set_weights_dict({k: np.zeros_like(v) if k == 'probs/kernel' else v for k, v in w.items()})
+    p2, _ = m.predict(x)
+    assert np.allclose(p2[..., 0], p2[0, 0, 0, 0], atol=1e-6)  # zero head kernel -> constant output: the load was seen

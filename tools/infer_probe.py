@@ -19,7 +19,9 @@ for (n, s) in ((8, 256), (16, 256), (32, 256), (64, 256), (128, 256), (36, 384),
     x = torch.from_numpy(rng.beta(2, 5, (n, s, s, 4)).astype(np.float32)).cuda()
     m.disable_fp8_inference()
     tb = timeit(x)
+    m.enable_folded_inference()
+    tf = timeit(x)
     m.enable_fp8_inference(x[:min(n, 8)])
     t8 = timeit(x)
     k = (s // 256) ** 2 if s != 384 else 1
-    print(f'n{n} {s}x{s}: bf16 {tb*1e3:7.2f} ms ({n/tb:8.1f} img/s)   fp8 {t8*1e3:7.2f} ms ({n/t8:8.1f} img/s)   speed-up {tb/t8:.2f}', flush=True)
+    print(f'n{n} {s}x{s}: bf16 {tb*1e3:7.2f} ms ({n/tb:8.1f} img/s)  folded-bf16 {tf*1e3:7.2f} ms ({n/tf:8.1f} img/s)   fp8 {t8*1e3:7.2f} ms ({n/t8:8.1f} img/s)   speed-up {tb/t8:.2f}', flush=True)
