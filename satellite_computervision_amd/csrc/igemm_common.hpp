@@ -77,6 +77,125 @@ __device__ __forceinline__ void mma32(f32x16& acc, const FragT<T>& a, const Frag
 }
 
 
+// ------------------------------------------------------------------ shared epilogue of the implicit-GEMM kernels
+// acc[MT][NT] (32x32 MFMA tiles of this wave) -> y: per-channel multiplier / bias / ReLU, rounding to T, BN sum / sum-of-squares of
+// the STORED values, tile staged in LDS [BM][BN+pad] and written with 16-byte coalesced stores (NHWC rows; depth-to-space rows
+// for the transposed conv).  Call with every wave past its last LDS fragment read (the staging aliases the operand images).
+template <typename T, int TW, int WM, int WN, int MT, int NT, bool SKIP_STORES = false>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[MT][NT], int n0, int y0, int x0, int nbase, unsigned char* smem_raw) {
+  constexpr int NTHREADS = WM * WN * 64, BM = WM * MT * 32, BN = WN * NT * 32;
+  constexpr int OPITCH = BN + 16 / (int)sizeof(T);                   // output staging pitch (elements)
+  T* ldsO = reinterpret_cast<T*>(smem_raw);
+  float* ldsS = reinterpret_cast<float*>(smem_raw + (size_t)BM * OPITCH * sizeof(T));   // [WM][2][BN] partial BN sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, r = lane & 31, hh = lane >> 5;
+  // validity of the 16 accumulator rows of each MFMA tile (pixels outside the image must not enter the statistics): rows of one
+  // MFMA tile span 32/TW tile rows; the column test needs no division
+  unsigned pvmask[MT];
+  {
+    const int xlim = a.w_ - x0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      pvmask[m] = 0;
+      if (a.stats) {
+        unsigned rowok = 0;
+#pragma unroll
+        for (int u = 0; u < 32 / TW; ++u) {
+          const int t = (wm * MT + m) * (32 / TW) + u;
+          const int k = (a.imgs == 1) ? 0 : t / a.rpi;
+          const bool ok = (k < a.imgs) && (n0 + k < a.n) && (y0 + (t - k * a.rpi) < a.h);
+          rowok |= (ok ? 1u : 0u) << u;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+          const bool pv = ((rowok >> ((8 * (i >> 2)) / TW)) & 1u) && ((row % TW) < xlim);
+          pvmask[m] |= (pv ? 1u : 0u) << i;
+        }
+      }
+    }
+  }
+  float st1[NT], st2[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int cl_ = (wn * NT + n) * 32 + r;          // column inside the tile
+    const int cn = nbase + cl_;
+    const bool cvalid = cn < a.cout;
+    const int cch = cvalid ? cn % a.cstat : 0;
+    const float bv = (a.bias && cvalid) ? a.bias[cch] : 0.f;
+    const float osc = (a.out_scale && cvalid) ? a.out_scale[cch] : 1.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const int q = (wm * MT + m) * 32 + row;
+        float vv = acc[m][n][i] * osc + bv;
+        if (a.out_relu) vv = fmaxf(vv, 0.f);
+        const T tv = (T)vv;
+        ldsO[q * OPITCH + cl_] = tv;
+        const float fv = ((pvmask[m] >> i) & 1u) ? (float)tv : 0.f;
+        s1 += fv; s2 += fv * fv;
+      }
+    }
+    st1[n] = s1; st2[n] = s2;
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int cl_ = (wn * NT + n) * 32 + r;
+      const float s1 = st1[n] + __shfl_xor(st1[n], 32, 64);
+      const float s2 = st2[n] + __shfl_xor(st2[n], 32, 64);
+      if (hh == 0) { ldsS[(wm * 2 + 0) * BN + cl_] = s1; ldsS[(wm * 2 + 1) * BN + cl_] = s2; }
+    }
+  }
+  __syncthreads();
+  if (a.stats && tid < BN) {
+    // one pair of atomics per output channel per workgroup (waves summed in fixed order)
+    const int cn = nbase + tid;
+    if (cn < a.cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { t1 += ldsS[(w * 2 + 0) * BN + tid]; t2 += ldsS[(w * 2 + 1) * BN + tid]; }
+      const int cch = cn % a.cstat;
+      float* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
+      atomicAdd(rowp + cch, t1);
+      atomicAdd(rowp + a.stats_ld + cch, t2);
+    }
+  }
+  // coalesced 16-byte stores of whole channel rows
+  constexpr int EPV = 16 / (int)sizeof(T);        // elements per 16-byte vector
+  constexpr int VPR = BN / EPV;                   // vectors per tile row
+  T* yp = reinterpret_cast<T*>(a.y);
+  const int ho = a.mode_out ? a.h * a.f : a.h;
+  const int wo = a.mode_out ? a.w_ * a.f : a.w_;
+  const int ncols = min(BN, a.cout - nbase);      // valid columns of this tile
+  int ij = 0, cbase = nbase;
+  if (a.mode_out == 1) { ij = nbase / a.cstat; cbase = nbase - ij * a.cstat; }
+  for (int it = tid; it < BM * VPR; it += NTHREADS) {
+    const int q = it / VPR, vq = it % VPR;
+    if (vq * EPV >= ncols) continue;
+    const int t = q / TW, cx = q % TW;
+    const int k = (a.imgs == 1) ? 0 : t / a.rpi;
+    const int nimg = n0 + k, y = y0 + (t - k * a.rpi), x = x0 + cx;
+    if (!((k < a.imgs) && (nimg < a.n) && (y < a.h) && (x < a.w_))) continue;
+    size_t off;
+    if (a.mode_out == 1) off = ((size_t)(nimg * ho + y * a.f + ij / a.f) * wo + x * a.f + ij % a.f) * a.ldy + cbase + vq * EPV;
+    else off = ((size_t)(nimg * ho + y) * wo + x) * a.ldy + cbase + vq * EPV;
+    const T* sp = ldsO + q * OPITCH + vq * EPV;
+    if (SKIP_STORES) continue;
+    if (a.accumulate) {
+      const int ne = min(EPV, ncols - vq * EPV);
+      for (int e = 0; e < ne; ++e) yp[off + e] = (T)((float)yp[off + e] + (float)sp[e]);
+    } else if (ncols - vq * EPV >= EPV) {
+      *reinterpret_cast<uint4*>(yp + off) = *reinterpret_cast<const uint4*>(sp);
+    } else {
+      for (int e = 0; e < ncols - vq * EPV; ++e) yp[off + e] = sp[e];
+    }
+  }
+}
+
 static inline int igemm_pick_tw(int w) {
   int best = 8, bestpad = cdiv(w, 8) * 8;
   const int cands[2] = {16, 32};
