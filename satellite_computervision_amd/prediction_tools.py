@@ -48,3 +48,23 @@ def predict_chips(arr, chip_indices, template, m, kernel=256, buff=128, batch_si
         for k, (y, x) in enumerate(part):
             template[y:y + kernel, x:x + kernel] += preds[k, y_buff:(kernel + y_buff), x_buff:(kernel + x_buff), channel]
     return template
+
+
+def predict_chips_sharded(arr, chip_indices, template, m, kernel=256, buff=128, batch_size=16, channel=0):
+    """Multi-GPU form of `predict_chips` (one process per GPU): the chip list of `generate_chip_indices` is split
+    round-robin over the ranks, every rank predicts its share into a zero template -- no collective on the data path, the chips
+    are independent units (utils/prediction_tools.py:147-154 loops over them one by one) -- and the per-rank templates are
+    summed once (disjoint centres, so the sum equals the single-process result).  Every rank returns the full template.
+    Without an initialised process group it is `predict_chips`."""
+    import torch
+    from . import parallel
+    rank, world = (parallel.dist.get_rank(), parallel.dist.get_world_size()) if parallel.dist.is_initialized() else (0, 1)
+    if world == 1:
+        return predict_chips(arr, chip_indices, template, m, kernel, buff, batch_size, channel)
+    mine = parallel.shard_list(list(chip_indices), rank, world)
+    part = predict_chips(arr, mine, np.zeros_like(template), m, kernel, buff, batch_size, channel)
+    dev = 'cuda' if parallel.dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.from_numpy(np.ascontiguousarray(part)).to(dev)
+    parallel.reduce_templates(t)
+    template += t.cpu().numpy().astype(template.dtype)
+    return template

@@ -107,3 +107,39 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['config']['global_batch'] == 16 and out['scaling'] == 'weak'
     assert out['value'] > 0 and np.isfinite(out['extra']['loss_last']) and 'cpu_baseline' not in out
     assert abs(out['value'] - 16 * 3 / (out['ms_per_step'] * 3 / 1000)) / out['value'] < 1e-3
+
+
+CHIP_WORKER = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ["REPO"])
+import torch.distributed as dist
+from satellite_computervision_amd import model_tools as mt, parallel, prediction_tools as pt
+rank, world = parallel.init_from_env("gloo")
+torch.cuda.set_device(0)
+mt.reset_uids(); mt.set_seed(3)
+m = mt.get_unet_model(2, 4, filters=[32, 64], factors=[2, 2])
+rng = np.random.default_rng(0)
+scene = rng.random((224, 288, 4)).astype(np.float32)
+idx = pt.generate_chip_indices(scene, buff=32, kernel=64)
+assert len(idx) >= 4
+out = pt.predict_chips_sharded(scene, idx, np.zeros(scene.shape[:2]), m, kernel=64, buff=32, batch_size=3, channel=1)
+if rank == 0:
+    ref = pt.predict_chips(scene, idx, np.zeros(scene.shape[:2]), m, kernel=64, buff=32, batch_size=5, channel=1)
+    print("RESULT", float(np.abs(out - ref).max()), float(np.abs(ref).max()), len(idx))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_sharded_chip_inference_equals_single_process(tmp_path):
+    """inference partitioning (SURVEY 8e): chips split round-robin over two ranks, templates summed once"""
+    script = tmp_path / 'chip_worker.py'
+    script.write_text(CHIP_WORKER)
+    env = dict(os.environ, REPO=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT='29671', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK='0'),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    err, mag, nchips = [float(v) for v in [l for l in outs[0].splitlines() if l.startswith('RESULT')][0].split()[1:]]
+    assert err == 0.0 and mag > 0 and nchips >= 4          # inference is bit-identical across batch splits
