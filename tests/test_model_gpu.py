@@ -676,3 +676,38 @@ def test_model_variants_forward_and_gradients(mt, filters, factors, ncls, nch, h
         g = m.runtime.get_grad(names[k]).cpu().numpy().astype(np.float64)
         l2 = np.linalg.norm(g - g_ref[k]) / max(np.linalg.norm(g_ref[k]), 1e-30)
         assert l2 < 2e-2, f'{k}: relL2 {l2:.2e}'
+
+
+def test_training_trajectory_matches_oracle_over_steps(mt):
+    """twelve fp32 optimisation steps (forward, loss, backward, Keras-Adam, BN moving statistics incl. the reference's double
+    update) on the device vs the float64 oracle doing the same twelve steps: loss per step and final parameters."""
+    filters, factors = [32, 64], [2, 2]
+    o, m, names = build_pair(mt, 'float32', 2, 4, filters, factors, seed=9)
+    rng = np.random.default_rng(33)
+    x = rng.random((4, 32, 32, 4)).astype(np.float32)
+    lab = (x[..., 0] + x[..., 2] > 1.0).astype(np.int64)
+    t = np.eye(2)[lab].astype(np.float32)
+    m.compile(optimizer=mt.Adam(2e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 2.0]))
+    p_start = {k: v.copy() for k, v in o.params.items()}
+    dev_losses, ref_losses = [], []
+    for step in range(1, 13):
+        pr, _ = o.forward(x, training=True)
+        loss_ref, dprobs, _ = OL.weighted_categorical_crossentropy(t.astype(np.float64), pr, [1.0, 2.0])
+        g = o.backward(dprobs)
+        o.adam_step(g, lr=2e-3)
+        ref_losses.append(float(loss_ref))
+        dev_losses.append(m.train_on_batch(x, t))
+    np.testing.assert_allclose(dev_losses, ref_losses, rtol=2e-3)
+    assert ref_losses[-1] < ref_losses[0]
+    w = m.get_weights_dict()
+    for k in o.params:
+        if k.endswith('.bias') and not k.startswith('probs'):
+            continue                                   # ~zero gradients: Adam steps of rounding-noise sign (see test_dp_gpu.py)
+        # Adam moves an element whose gradient is rounding noise by +-lr per step, so single elements may differ by up to
+        # 12*lr; the tensors as a whole must agree
+        ref, got = o.params[k], w[names[k]].astype(np.float64)
+        if k.endswith('moving_mean') or k.endswith('moving_var'):
+            continue                                   # batch statistics of weights that differ by that noise (step 1 is checked exactly
+                                                       # in test_tiny_unet_predict_and_train_step)
+        upd = np.linalg.norm(ref - p_start[k])
+        assert np.linalg.norm(got - ref) < 0.3 * max(upd, 1e-9), f'{k}: {np.linalg.norm(got - ref):.3e} vs update {upd:.3e}'
