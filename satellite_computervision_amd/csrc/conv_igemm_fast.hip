@@ -49,7 +49,13 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
   constexpr int BI = (TAPS * SLOTS * BN + NTHREADS - 1) / NTHREADS;  // staged B items per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* ldsA = reinterpret_cast<T*>(smem_raw);
-  T* ldsB = ldsA + SLOTS * a.rl * pitch * EL;
+  // padding between the slot planes: ds_write_b128 is serviced in groups of 8 lanes over 32 banks (128 B).  With 4+ slots the
+  // 8 lanes of a group store 2 pixels x 4 slots, so the plane stride must be 32 B modulo 128 B for the eight 16-byte stores to
+  // fall on distinct banks (unpadded 1x1 / 32-channel-chunk planes are multiples of 512 B: measured 43 % bank-conflict cycles)
+  const int plane = a.rl * pitch * EL;
+  const int spad = SLOTS > 2 ? ((32 - (plane * (int)sizeof(T)) % 128 + 128) % 128) / (int)sizeof(T) : 0;
+  const int slot_stride = plane + spad;
+  T* ldsB = ldsA + SLOTS * slot_stride;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
       const int pix = it / SLOTS;
       const int c = pix % cl, L = pix / cl;          // (division by a constant unless DYN)
       const int k = (a.imgs == 1) ? 0 : L / a.seg;
-      a_l[j] = ((slot_t * a.rl + L) * pitch + c) * EL;
+      a_l[j] = slot_t * slot_stride + (L * pitch + c) * EL;
       a_pk[j] = (k << 24) | ((L - k * a.seg) << 12) | c;
     }
   }
@@ -104,7 +110,6 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
     const int l0 = (k < a.imgs) ? k * a.seg + (t - k * a.rpi) : 0;
     a_off[m] = (l0 * pitch + cx) * EL;
   }
-  const int slot_stride = a.rl * pitch * EL;
 
   const T* wp = reinterpret_cast<const T*>(a.w);
   Raw8<T> ra[AI], rb[BI];
@@ -258,7 +263,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   }
   if (a.ldy % (16 / (int)sizeof(T)) != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;
   if (a.mode_out == 0 && a.cout % (16 / (int)sizeof(T)) != 0 && a.cout < a.ldy) { /* tail handled by scalar stores */ }
-  const size_t lds_stage = ((size_t)KC * a.rl * a.pitch + (size_t)TAPS * KC * BN) * sizeof(T);
+  const size_t lds_stage = ((size_t)KC * a.rl * a.pitch + (size_t)TAPS * KC * BN) * sizeof(T) + (size_t)(KC / EL) * 128;      // + slot padding (< 128 B per plane)
   const size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
   const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
