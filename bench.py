@@ -42,12 +42,12 @@ def _alg_3x3_bytes(batch, esize=2, tile=TILE, filters=(32, 64, 128, 256, 512), c
     L.append((batch * (tile >> len(filters)) ** 2, filters[-1], 2 * filters[-1]))
     for j in range(len(filters) - 1, -1, -1):
         px = batch * (tile >> j) ** 2
-        L += [(px, 3 * filters[j], filters[j]), (px, filters[j], filters[j])]
+        L += [(px, 2 * filters[j], filters[j]), (px, filters[j], filters[j])]       # conv1 reads concat([skip f, up f])
     one = lambda px, ci, co: px * (ci + co) * esize + 9 * ci * co * esize
     return sum(one(*l) for l in L) + sum(one(*l) for l in L[1:])        # forward + data gradient (none for the first layer)
 
 
-ALG_3X3_BYTES_PER_STEP = _alg_3x3_bytes(BATCH)                          # 7.50 GB at batch 64: 16 forward + 15 dgrad launches
+ALG_3X3_BYTES_PER_STEP = _alg_3x3_bytes(BATCH)                          # 6.45 GB at batch 64: 16 forward + 15 dgrad launches
 
 
 def synth_batch(rng, n):

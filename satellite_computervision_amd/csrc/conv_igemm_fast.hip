@@ -1,6 +1,6 @@
 // Software-pipelined implicit-GEMM convolution (the hot variant of conv_igemm.hip).
 //
-// Thin-layer note (measured, round 1): the 16..96-channel full-resolution layers are bound by bytes in flight, not by MFMA
+// Thin-layer note (measured, round 1): the 16..64-channel full- and half-resolution layers are bound by bytes in flight, not by MFMA
 // or LDS (2.0-2.9 TB/s algorithmic vs 5.4 TB/s of a copy kernel).  What helped: 4 waves/SIMD for the small-accumulator
 // configurations (+10-15 %).  What did not: persistent workgroups with the next tile's loads in flight during the
 // epilogue (the extra live state costs one wave/SIMD, net +-0; removed), 32-channel chunks, 256-pixel x 128-channel tiles,
@@ -313,8 +313,7 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
     //  15.9 vs 15.4 ms/step)
     return fast_cfg<T, TW, 2, 2, 2, 2, 1, TAPS>(a, st, dry);
   }
-  // (a 96-wide N tile for the 32->96 data gradient needs 171+96 registers = one workgroup per CU: 836 vs 559 us with two 64-wide tiles;
-  //  a 192-wide one: 584 vs 379 us)
+  // (N tiles wider than 128 -- tried on synthetic 96 / 192-channel outputs -- leave one workgroup per CU and were slower)
   // (32-channel chunks for the thin 3x3 layers were measured SLOWER: 144 vs 113 us on enc1, 425 vs 351 us on
   //  dec0.conv1 -- fewer resident workgroups outweigh the halved barrier count)
   // (8-wave variants of the thin tiles -- 16 accumulator registers, 6 waves/SIMD -- were measured 8-20 % SLOWER: occupancy is

@@ -396,7 +396,9 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   p.n_ci_blk = cdiv(cinx, ci_t); p.n_co_blk = cdiv(nspace, co_t);
   p.kpad = p.n_ci_blk * ci_t; p.npad = p.n_co_blk * co_t;
   // thin layers (a handful of (ci, co) blocks at full resolution) are bound by bytes in flight: stage 256 pixels per step
-  p.pix = (p.ntaps == 9 && p.tw == 32 && p.n_ci_blk * p.n_co_blk <= 3 && d->h >= 8 && d->w_ >= 256 && d->dil == 1 && wgrad_pix256()) ? 256 : 128;
+  // (only with 32-channel X blocks: the 256-pixel halo tile of a 64-channel block is 65 KB and leaves ONE workgroup per CU --
+  //  measured 842 us on dec0.conv1 (64->32), the slowest kernel of the step)
+  p.pix = (p.ntaps == 9 && p.tw == 32 && p.nci == 1 && p.n_ci_blk * p.n_co_blk <= 3 && d->h >= 8 && d->w_ >= 256 && d->dil == 1 && wgrad_pix256()) ? 256 : 128;
   const int th = p.pix / p.tw;
   const int tiles_x = cdiv(d->w_, p.tw);
   long long ptiles;

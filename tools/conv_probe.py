@@ -28,8 +28,9 @@ def run(n, h, w, cin, cout, stats=True, reps=40, k=3):
     by = n * h * w * (cin + cout) * 2
     print(f'  n{n} {h}x{w} {cin}->{cout} k{k} stats={int(stats)}: gpu {t*1e6:8.1f} us (host {th*1e6:6.1f} us/call)  {fl/t/1e12:7.1f} TF/s  {by/t/1e12:5.2f} TB/s(alg)', flush=True)
 print('lib', os.environ.get('SATCV_LIB'))
-SHAPES = [(64, 256, 256, 16, 32), (64, 256, 256, 32, 32), (64, 256, 256, 96, 32), (64, 256, 256, 32, 96), (64, 128, 128, 32, 64), (64, 128, 128, 64, 64),
-            (64, 128, 128, 192, 64), (64, 128, 128, 64, 192), (64, 128, 128, 64, 32), (64, 64, 64, 128, 128), (64, 32, 32, 256, 256), (64, 16, 16, 512, 512)]
+# the 3x3 shapes of get_unet_model(2, 4) at batch 64 (forward and data gradient), thin to deep
+SHAPES = [(64, 256, 256, 16, 32), (64, 256, 256, 32, 32), (64, 256, 256, 64, 32), (64, 256, 256, 32, 64), (64, 128, 128, 32, 64), (64, 128, 128, 64, 64),
+            (64, 128, 128, 128, 64), (64, 128, 128, 64, 128), (64, 128, 128, 64, 32), (64, 64, 64, 128, 128), (64, 32, 32, 256, 256), (64, 16, 16, 512, 512)]
 if os.environ.get('PROBE_1X1'):
     SHAPES = [(64, 256, 256, 32, 32, True, 40, 1), (64, 256, 256, 32, 32, False, 40, 1), (64, 256, 256, 64, 64, True, 40, 1), (64, 256, 256, 32, 32, True, 40, 3), (64, 256, 256, 32, 32, False, 40, 3)]
 if os.environ.get('PROBE_DEEP'):

@@ -24,7 +24,7 @@ def run(n, h, w, cin, cout, reps=20):
     print(f'  n{n} {h}x{w} {cin}->{cout}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e12:5.2f} TB/s(alg)', flush=True)
 
 
-SH = [(64, 256, 256, 16, 32), (64, 256, 256, 32, 32), (64, 256, 256, 96, 32), (64, 128, 128, 32, 64), (64, 128, 128, 64, 64), (64, 128, 128, 192, 64),
+SH = [(64, 256, 256, 16, 32), (64, 256, 256, 32, 32), (64, 256, 256, 64, 32), (64, 128, 128, 32, 64), (64, 128, 128, 64, 64), (64, 128, 128, 128, 64),
             (64, 64, 64, 64, 128), (64, 64, 64, 128, 128), (64, 64, 64, 384, 128), (64, 32, 32, 256, 256), (64, 32, 32, 768, 256), (64, 16, 16, 512, 512),
             (64, 16, 16, 1536, 512), (64, 8, 8, 512, 1024)]
 if os.environ.get('PROBE_DEEP'):
