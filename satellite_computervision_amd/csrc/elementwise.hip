@@ -630,68 +630,73 @@ __global__ __launch_bounds__(EW_BLOCK) void head_fwd_fast_kernel(const satcv_hea
   }
 }
 
+// One thread per (pixel, 8-channel group): the per-thread state (8 x NC weights and dW accumulators, 8 BN coefficients and sums) stays
+// small enough for 4+ waves/SIMD.  (The first version kept all CIN channels of a pixel in one thread: 255 VGPRs, one wave per SIMD,
+// 2.3 TB/s.)
 template <typename T, int NC, int CIN, bool BNR>
 __global__ __launch_bounds__(EW_BLOCK) void head_bwd_fast_kernel(const satcv_head_desc d) {
+  constexpr int G = CIN / 8;                       // threads per pixel; EW_BLOCK * gridDim is a multiple of G, so a thread's group is fixed
   __shared__ float aw[CIN * NC + NC + 2 * CIN];
-  float w[CIN][NC], sc[CIN], sh[CIN], acc[CIN][NC], accb[NC];
-  float mu[BNR ? CIN : 1], rs[BNR ? CIN : 1], r1[BNR ? CIN : 1], r2[BNR ? CIN : 1];
-  if constexpr (BNR) {
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) { mu[c] = d.bnr_mean[c]; rs[c] = d.bnr_rstd[c]; r1[c] = 0.f; r2[c] = 0.f; }
-  }
+  const int g = threadIdx.x % G;
+  float w[8][NC], sc[8], sh[8], acc[8][NC], accb[NC];
+  float mu[BNR ? 8 : 1], rs[BNR ? 8 : 1], r1[BNR ? 8 : 1], r2[BNR ? 8 : 1];
   const bool tr = d.in_scale != nullptr;
 #pragma unroll
-  for (int c = 0; c < CIN; ++c) {
-    sc[c] = tr ? d.in_scale[c] : 1.f; sh[c] = tr ? d.in_shift[c] : 0.f;
+  for (int e = 0; e < 8; ++e) {
+    const int c = g * 8 + e;
+    sc[e] = tr ? d.in_scale[c] : 1.f; sh[e] = tr ? d.in_shift[c] : 0.f;
+    if constexpr (BNR) { mu[e] = d.bnr_mean[c]; rs[e] = d.bnr_rstd[c]; r1[e] = 0.f; r2[e] = 0.f; }
 #pragma unroll
-    for (int k = 0; k < NC; ++k) { w[c][k] = d.w[c * NC + k]; acc[c][k] = 0.f; }
+    for (int k = 0; k < NC; ++k) { w[e][k] = d.w[c * NC + k]; acc[e][k] = 0.f; }
   }
 #pragma unroll
   for (int k = 0; k < NC; ++k) accb[k] = 0.f;
   for (int i = threadIdx.x; i < CIN * NC + NC + 2 * CIN; i += blockDim.x) aw[i] = 0.f;
   __syncthreads();
   const T* x = (const T*)d.x; T* dx = (T*)d.dx;
-  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < d.npix; p += (long long)gridDim.x * blockDim.x) {
+  const long long total = d.npix * G;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+    const long long p = it / G;
     float dl[NC];
 #pragma unroll
-    for (int k = 0; k < NC; ++k) { dl[k] = d.dlogits[p * NC + k]; accb[k] += dl[k]; }
+    for (int k = 0; k < NC; ++k) { dl[k] = d.dlogits[p * NC + k]; if (g == 0) accb[k] += dl[k]; }
+    float v[8], o[8];
+    load8<T>(x + p * d.ldx + g * 8, v);
 #pragma unroll
-    for (int g = 0; g < CIN / 8; ++g) {
-      float v[8], o[8];
-      load8<T>(x + p * d.ldx + g * 8, v);
+    for (int e = 0; e < 8; ++e) {
+      const float a = tr ? fmaxf(v[e] * sc[e] + sh[e], 0.f) : v[e];
+      float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = g * 8 + e;
-        const float a = tr ? fmaxf(v[e] * sc[c] + sh[c], 0.f) : v[e];
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < NC; ++k) { s += dl[k] * w[c][k]; acc[c][k] += a * dl[k]; }
-        o[e] = s;
-        if constexpr (BNR) {      // first pass of the BN+ReLU backward of x, on the value as stored
-          const float gq = a > 0.f ? round_to<T>(s) : 0.f;
-          r1[c] += gq; r2[c] += gq * ((v[e] - mu[c]) * rs[c]);
-        }
+      for (int k = 0; k < NC; ++k) { s += dl[k] * w[e][k]; acc[e][k] += a * dl[k]; }
+      o[e] = s;
+      if constexpr (BNR) {      // first pass of the BN+ReLU backward of x, on the value as stored
+        const float gq = a > 0.f ? round_to<T>(s) : 0.f;
+        r1[e] += gq; r2[e] += gq * ((v[e] - mu[e]) * rs[e]);
       }
-      if (dx) store8<T>(dx + p * d.lddx + g * 8, o);
     }
+    if (dx) store8<T>(dx + p * d.lddx + g * 8, o);
   }
+  // lanes with equal (lane % G) hold the same channel group: butterfly over the lane bits above log2(G)
+  auto group_sum = [&](float val) {
+#pragma unroll
+    for (int o = 32; o >= G; o >>= 1) val += __shfl_xor(val, o, 64);
+    return val;
+  };
   const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int c = 0; c < CIN; ++c)
+  for (int e = 0; e < 8; ++e) {
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-      const float s = wave_sum(acc[c][k]);
-      if (lane == 0) atomicAdd(&aw[c * NC + k], s);
+      const float s = group_sum(acc[e][k]);
+      if (lane < G) atomicAdd(&aw[(lane * 8 + e) * NC + k], s);
     }
-#pragma unroll
-  for (int k = 0; k < NC; ++k) { const float s = wave_sum(accb[k]); if (lane == 0) atomicAdd(&aw[CIN * NC + k], s); }
-  if constexpr (BNR) {
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) {
-      const float s1 = wave_sum(r1[c]), s2 = wave_sum(r2[c]);
-      if (lane == 0) { atomicAdd(&aw[CIN * NC + NC + c], s1); atomicAdd(&aw[CIN * NC + NC + CIN + c], s2); }
+    if constexpr (BNR) {
+      const float s1 = group_sum(r1[e]), s2 = group_sum(r2[e]);
+      if (lane < G) { atomicAdd(&aw[CIN * NC + NC + lane * 8 + e], s1); atomicAdd(&aw[CIN * NC + NC + CIN + lane * 8 + e], s2); }
     }
   }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) { const float s = wave_sum(accb[k]); if (lane == 0) atomicAdd(&aw[CIN * NC + k], s); }
   __syncthreads();
   if (d.dw) for (int i = threadIdx.x; i < CIN * NC; i += blockDim.x) atomicAdd(d.dw + i, aw[i]);
   if (d.db) for (int i = threadIdx.x; i < NC; i += blockDim.x) atomicAdd(d.db + i, aw[CIN * NC + i]);
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(EW_BLOCK) void head_bwd_fast_kernel(const satcv_hea
 
 template <typename T, bool BWD>
 static bool head_fast_launch(const satcv_head_desc* d, hipStream_t st) {
-  const int grid = ew_grid(d->npix, 1024);
+  const int grid = BWD ? ew_grid(d->npix * (d->cin / 8), 2048) : ew_grid(d->npix, 1024);      // backward: one thread per 8-channel group
 #define HEAD_CASE(NC_, CIN_)                                                                                      \
   if (d->ncls == NC_ && d->cin == CIN_) {                                                                         \
     if constexpr (BWD) {                                                                                          \
