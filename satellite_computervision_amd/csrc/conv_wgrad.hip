@@ -404,7 +404,11 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   long long ptiles;
   if (d->h >= th) ptiles = (long long)d->n * cdiv(d->h, th) * tiles_x;
   else ptiles = (long long)cdiv(d->n, th / d->h) * tiles_x;
-  long long ns = cdiv(768, p.n_ci_blk * p.n_co_blk);       // ~3 workgroups per CU (2 resident + tail balance)
+  // two workgroups are resident per CU (144 accumulator registers): 512 fill the chip exactly once -- a third one per CU only
+  // started a second, half-empty round (thin layers: 257 -> 217 us, 450 -> 366 us).  Layers with many (ci, co) blocks keep 768:
+  // their per-block pixel share would get too coarse to balance.
+  const int nblk = p.n_ci_blk * p.n_co_blk;
+  long long ns = cdiv(nblk >= 128 ? 768 : 512, nblk);
   if (ns > ptiles) ns = ptiles;
   if (ns > 768) ns = 768;
   if (ns < 1) ns = 1;
