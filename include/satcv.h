@@ -26,6 +26,12 @@
 extern "C" {
 #endif
 
+/* Per-channel statistics rows (BatchNorm forward sum / sum-of-squares, backward sum g / sum g*xhat) are accumulated in DOUBLE:
+ * the replica rows are filled with atomics whose order varies from run to run, and fp32 rounding differences in the resulting
+ * scale/shift flip ReLU masks (a batch-64 U-Net's gradient moved by 2e-3 between two runs on the same batch).  In double the
+ * order only matters at 1e-16, so the fp32 quantities derived from the rows are reproducible. */
+typedef double satcv_stat_t;
+
 enum { SATCV_OK = 0, SATCV_ERR_INVALID = -1, SATCV_ERR_HIP = -2, SATCV_ERR_UNSUPPORTED = -3 };
 enum { SATCV_F32 = 0, SATCV_BF16 = 1,
        SATCV_FP8 = 2 /* OCP e4m3fn storage, inference only: ingest, pack_weights, conv2d_igemm (pipelined kernel), maxpool,
@@ -88,7 +94,7 @@ typedef struct satcv_conv_desc {
   const float* bias;       /* [cstat] or NULL                                         */
   void* y;                 /* output NHWC, channel stride ldy                         */
   int32_t ldy;
-  float* stats;            /* optional [SATCV_STAT_ROWS][2][stats_ld] sum / sum-of-squares
+  satcv_stat_t* stats;     /* optional [SATCV_STAT_ROWS][2][stats_ld] sum / sum-of-squares
                               of the stored outputs (atomically accumulated)          */
   int32_t stats_ld;
   int32_t n, h, w_;        /* GEMM pixel grid (= output grid, or input grid for mode_out=1) */
@@ -137,7 +143,7 @@ int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream);
  * Training: consume the [ROWS][2][ld] sum/sumsq rows (and zero them), produce per-channel
  * scale=gamma*rstd, shift=beta-mean*scale, mean, rstd, and update the moving statistics
  * `updates` times (2 reproduces the double cba1 call of conv_block.call, :238-239). */
-int satcv_bn_finalize_train(float* stats, int32_t stats_ld, int32_t c, float count,
+int satcv_bn_finalize_train(satcv_stat_t* stats, int32_t stats_ld, int32_t c, float count,
                             const float* gamma, const float* beta, float eps, float momentum,
                             int32_t updates, int32_t bessel, float* moving_mean, float* moving_var,
                             float* scale, float* shift, float* mean, float* rstd, void* stream);
@@ -150,7 +156,7 @@ int satcv_bn_affine_infer(const float* gamma, const float* beta, const float* mo
  * optional sum/sumsq rows of `act` (feeds the decoder's concat BatchNormalization).
  * Replaces Activation('relu') + MaxPooling2D (utils/model_tools.py:180,281). */
 int satcv_bn_relu_pool(const void* yraw, const float* scale, const float* shift, void* act, int32_t act_ld,
-                       void* pooled, float* stats, int32_t stats_ld, int32_t n, int32_t h,
+                       void* pooled, satcv_stat_t* stats, int32_t stats_ld, int32_t n, int32_t h,
                        int32_t w_, int32_t c, int32_t f, int32_t dtype, void* stream);
 
 /* Backward of  a = relu(scale*y+shift)  (training-mode BN):
@@ -164,7 +170,7 @@ typedef struct satcv_bnbwd_desc {
   int32_t f;
   const void* yraw; int32_t ldy;
   const float* scale; const float* shift; const float* mean; const float* rstd;
-  float* sums; int32_t sums_ld;        /* [ROWS][2][sums_ld]                                */
+  satcv_stat_t* sums; int32_t sums_ld; /* [ROWS][2][sums_ld]                                */
   const float* coef;                   /* [2][c] from finalize (apply only)                 */
   void* dy; int32_t lddy_out;          /* apply output                                      */
   float* dbias;                        /* optional [c], atomically accumulated (apply)      */
@@ -172,7 +178,7 @@ typedef struct satcv_bnbwd_desc {
   int32_t dtype;
 } satcv_bnbwd_desc;
 int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream);
-int satcv_bn_bwd_finalize(float* sums, int32_t sums_ld, int32_t c, float count, float* dgamma,
+int satcv_bn_bwd_finalize(satcv_stat_t* sums, int32_t sums_ld, int32_t c, float count, float* dgamma,
                           float* dbeta, float* coef, int32_t accumulate, void* stream);
 int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream);
 
@@ -229,7 +235,7 @@ typedef struct satcv_head_desc {
   /* bwd, optional: fused first pass of the BatchNorm+ReLU backward of x: with g = dx*(a>0), xhat = (x-mean)*rstd the kernel
    * accumulates per channel sum(g), sum(g*xhat) into bnr_sums ([SATCV_STAT_ROWS][2][bnr_sums_ld]) -- replaces
    * satcv_bn_bwd_reduce for that tensor (register-resident head kernel only) */
-  const float* bnr_mean; const float* bnr_rstd; float* bnr_sums; int32_t bnr_sums_ld;
+  const float* bnr_mean; const float* bnr_rstd; satcv_stat_t* bnr_sums; int32_t bnr_sums_ld;
   int64_t npix;
   int32_t dtype;
 } satcv_head_desc;

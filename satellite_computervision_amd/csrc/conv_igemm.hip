@@ -216,9 +216,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       if (hh == 0 && cvalid) {
-        float* row = a.stats + (size_t)((blockIdx.x + wave) % SATCV_STAT_ROWS) * 2 * a.stats_ld;
-        atomicAdd(row + cch, s1);
-        atomicAdd(row + a.stats_ld + cch, s2);
+        satcv_stat_t* row = a.stats + (size_t)((blockIdx.x + wave) % SATCV_STAT_ROWS) * 2 * a.stats_ld;
+        atomicAdd(row + cch, (satcv_stat_t)s1);
+        atomicAdd(row + a.stats_ld + cch, (satcv_stat_t)s2);
       }
     }
   }

@@ -200,19 +200,20 @@ extern "C" int satcv_pack_weights(const float* src, void* dst_fwd, void* dst_dgr
 }
 
 // -------------------------------------------------------------------- BN finalize
-__global__ void bn_finalize_train_kernel(float* stats, int ld, int c, float count, const float* gamma, const float* beta,
+__global__ void bn_finalize_train_kernel(satcv_stat_t* stats, int ld, int c, float count, const float* gamma, const float* beta,
                                          float eps, float momentum, int updates, int bessel, float* mm, float* mv,
                                          float* scale, float* shift, float* mean_o, float* rstd_o) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
-  float s1 = 0.f, s2 = 0.f;
+  double s1 = 0.0, s2 = 0.0;
   for (int r = 0; r < SATCV_STAT_ROWS; ++r) {
-    float* row = stats + (size_t)r * 2 * ld;
+    satcv_stat_t* row = stats + (size_t)r * 2 * ld;
     s1 += row[ch]; s2 += row[ld + ch];
-    row[ch] = 0.f; row[ld + ch] = 0.f;
+    row[ch] = 0.0; row[ld + ch] = 0.0;
   }
-  const float mean = s1 / count;
-  float var = s2 / count - mean * mean;
+  const double mean_d = s1 / (double)count;
+  const float mean = (float)mean_d;
+  float var = (float)(s2 / (double)count - mean_d * mean_d);      // E[x^2] - E[x]^2 without the fp32 cancellation
   var = fmaxf(var, 0.f);
   const float rstd = rsqrtf(var + eps);
   const float sc = gamma[ch] * rstd;
@@ -225,7 +226,7 @@ __global__ void bn_finalize_train_kernel(float* stats, int ld, int c, float coun
     mm[ch] = a; mv[ch] = b;
   }
 }
-extern "C" int satcv_bn_finalize_train(float* stats, int32_t stats_ld, int32_t c, float count, const float* gamma, const float* beta,
+extern "C" int satcv_bn_finalize_train(satcv_stat_t* stats, int32_t stats_ld, int32_t c, float count, const float* gamma, const float* beta,
                                        float eps, float momentum, int32_t updates, int32_t bessel, float* moving_mean, float* moving_var,
                                        float* scale, float* shift, float* mean, float* rstd, void* stream) {
   SATCV_CHECK(stats && gamma && beta && scale && shift && mean && rstd && c > 0 && stats_ld >= c && count > 0, "bn_finalize_train: bad args");
@@ -250,23 +251,31 @@ extern "C" int satcv_bn_affine_infer(const float* gamma, const float* beta, cons
 // Block-level per-channel accumulation into LDS then one global atomic per channel per block.
 // Threads iterate items = (window, group) with a stride that is a multiple of G so that a
 // thread's channel group never changes.
+// lds: EW_BLOCK * 16 floats.  Every thread parks its 16 partial sums; thread i then adds, in increasing thread order, the
+// partials of the threads that own channel i's group (thread t owns group (first_group + t) % G).  A fixed order, so the value a
+// workgroup contributes is reproducible; the replica rows are double (satcv_stat_t), where the arrival order of the workgroups
+// only matters at 1e-16.
 __device__ __forceinline__ void block_channel_reduce(float* lds, const float (&a)[8], const float (&b)[8], int g, bool active,
-                                                     int c, float* out, int out_ld) {
-  for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) lds[i] = 0.f;
-  __syncthreads();
-  if (active) {
+                                                     int c, satcv_stat_t* out, int out_ld) {
+  const int G = c / 8;
+  float* mine = lds + threadIdx.x * 16;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { atomicAdd(&lds[g * 8 + e], a[e]); atomicAdd(&lds[c + g * 8 + e], b[e]); }
-  }
+  for (int e = 0; e < 8; ++e) { mine[e] = active ? a[e] : 0.f; mine[8 + e] = active ? b[e] : 0.f; }
   __syncthreads();
-  float* row = out + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * out_ld;
-  for (int i = threadIdx.x; i < c; i += blockDim.x) { atomicAdd(row + i, lds[i]); atomicAdd(row + out_ld + i, lds[c + i]); }
+  const int g0 = (int)((blockIdx.x * (long long)blockDim.x) % G);          // group of thread 0
+  satcv_stat_t* row = out + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * out_ld;
+  for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
+    const int which = i / c, ch = i - which * c, gg = ch / 8, e = ch % 8;
+    float s = 0.f;
+    for (int t = (gg - g0 + G) % G; t < (int)blockDim.x; t += G) s += lds[t * 16 + which * 8 + e];
+    atomicAdd(row + which * out_ld + ch, (satcv_stat_t)s);
+  }
 }
 
 // ------------------------------------------------------------- BN + ReLU + maxpool
 template <typename T>
 __global__ void bn_relu_pool_kernel(const T* __restrict__ yraw, const float* __restrict__ scale, const float* __restrict__ shift,
-                                    T* __restrict__ act, T* __restrict__ pooled, float* stats, int stats_ld,
+                                    T* __restrict__ act, T* __restrict__ pooled, satcv_stat_t* stats, int stats_ld,
                                     int n, int h, int w, int c, int f, int act_ld) {
   extern __shared__ float lds[];
   const int G = c / 8;
@@ -312,12 +321,12 @@ __global__ void bn_relu_pool_kernel(const T* __restrict__ yraw, const float* __r
   }
   if (stats) block_channel_reduce(lds, s1, s2, g, active, c, stats, stats_ld);
 }
-extern "C" int satcv_bn_relu_pool(const void* yraw, const float* scale, const float* shift, void* act, int32_t act_ld, void* pooled, float* stats,
+extern "C" int satcv_bn_relu_pool(const void* yraw, const float* scale, const float* shift, void* act, int32_t act_ld, void* pooled, satcv_stat_t* stats,
                                   int32_t stats_ld, int32_t n, int32_t h, int32_t w_, int32_t c, int32_t f, int32_t dtype, void* stream) {
   if (act_ld <= 0) act_ld = c;
   SATCV_CHECK(yraw && scale && shift && n > 0 && h > 0 && w_ > 0 && c > 0 && c % 8 == 0 && c <= 2048 && f >= 1, "bn_relu_pool: bad args");
   const long long items = (long long)n * cdiv(h, f) * cdiv(w_, f) * (c / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_pool_kernel<T>, dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? 2 * c * sizeof(float) : 0, (hipStream_t)stream,
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_pool_kernel<T>, dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? EW_BLOCK * 16 * sizeof(float) : 0, (hipStream_t)stream,
                                        (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld));
   LAUNCH_OK("bn_relu_pool");
   return SATCV_OK;
@@ -475,9 +484,9 @@ extern "C" int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream) {
   const int f = d->dpool ? d->f : 1;
   const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
   if (!d->dpool && d->da && (long long)d->n * d->h * d->w_ < 0x7fffffffLL) {
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), 2 * d->c * sizeof(float), (hipStream_t)stream, *d));
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), EW_BLOCK * 16 * sizeof(float), (hipStream_t)stream, *d));
   } else {
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), 2 * d->c * sizeof(float), (hipStream_t)stream, *d));
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), EW_BLOCK * 16 * sizeof(float), (hipStream_t)stream, *d));
   }
   LAUNCH_OK("bn_bwd_reduce");
   return SATCV_OK;
@@ -494,20 +503,21 @@ extern "C" int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream) {
   LAUNCH_OK("bn_bwd_apply");
   return SATCV_OK;
 }
-__global__ void bn_bwd_finalize_kernel(float* sums, int ld, int c, float count, float* dgamma, float* dbeta, float* coef, int accumulate) {
+__global__ void bn_bwd_finalize_kernel(satcv_stat_t* sums, int ld, int c, float count, float* dgamma, float* dbeta, float* coef, int accumulate) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
-  float s1 = 0.f, s2 = 0.f;
+  double d1 = 0.0, d2 = 0.0;
   for (int r = 0; r < SATCV_STAT_ROWS; ++r) {
-    float* row = sums + (size_t)r * 2 * ld;
-    s1 += row[ch]; s2 += row[ld + ch];
-    row[ch] = 0.f; row[ld + ch] = 0.f;
+    satcv_stat_t* row = sums + (size_t)r * 2 * ld;
+    d1 += row[ch]; d2 += row[ld + ch];
+    row[ch] = 0.0; row[ld + ch] = 0.0;
   }
+  const float s1 = (float)d1, s2 = (float)d2;
   if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + s1 : s1;
   if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + s2 : s2;
   coef[ch] = s1 / count; coef[c + ch] = s2 / count;
 }
-extern "C" int satcv_bn_bwd_finalize(float* sums, int32_t sums_ld, int32_t c, float count, float* dgamma, float* dbeta, float* coef, int32_t accumulate,
+extern "C" int satcv_bn_bwd_finalize(satcv_stat_t* sums, int32_t sums_ld, int32_t c, float count, float* dgamma, float* dbeta, float* coef, int32_t accumulate,
                                      void* stream) {
   SATCV_CHECK(sums && coef && c > 0 && sums_ld >= c && count > 0, "bn_bwd_finalize: bad args");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 128)), dim3(128), 0, (hipStream_t)stream, sums, sums_ld, c, count, dgamma, dbeta, coef, accumulate);
@@ -639,7 +649,8 @@ __global__ __launch_bounds__(EW_BLOCK) void head_fwd_fast_kernel(const satcv_hea
 template <typename T, int NC, int CIN, bool BNR>
 __global__ __launch_bounds__(EW_BLOCK) void head_bwd_fast_kernel(const satcv_head_desc d) {
   constexpr int G = CIN / 8;                       // threads per pixel; EW_BLOCK * gridDim is a multiple of G, so a thread's group is fixed
-  __shared__ float aw[CIN * NC + NC + 2 * CIN];
+  constexpr int NW = EW_BLOCK / 64, AWN = CIN * NC + NC + 2 * CIN;
+  __shared__ float aw[NW][AWN];                    // one slot per wave: summed in wave order below (reproducible)
   const int g = threadIdx.x % G;
   float w[8][NC], sc[8], sh[8], acc[8][NC], accb[NC];
   float mu[BNR ? 8 : 1], rs[BNR ? 8 : 1], r1[BNR ? 8 : 1], r2[BNR ? 8 : 1];
@@ -654,8 +665,6 @@ __global__ __launch_bounds__(EW_BLOCK) void head_bwd_fast_kernel(const satcv_hea
   }
 #pragma unroll
   for (int k = 0; k < NC; ++k) accb[k] = 0.f;
-  for (int i = threadIdx.x; i < CIN * NC + NC + 2 * CIN; i += blockDim.x) aw[i] = 0.f;
-  __syncthreads();
   const T* x = (const T*)d.x; T* dx = (T*)d.dx;
   const long long total = d.npix * G;
   for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
@@ -685,29 +694,30 @@ __global__ __launch_bounds__(EW_BLOCK) void head_bwd_fast_kernel(const satcv_hea
     for (int o = 32; o >= G; o >>= 1) val += __shfl_xor(val, o, 64);
     return val;
   };
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
       const float s = group_sum(acc[e][k]);
-      if (lane < G) atomicAdd(&aw[(lane * 8 + e) * NC + k], s);
+      if (lane < G) aw[wave][(lane * 8 + e) * NC + k] = s;
     }
     if constexpr (BNR) {
       const float s1 = group_sum(r1[e]), s2 = group_sum(r2[e]);
-      if (lane < G) { atomicAdd(&aw[CIN * NC + NC + lane * 8 + e], s1); atomicAdd(&aw[CIN * NC + NC + CIN + lane * 8 + e], s2); }
+      if (lane < G) { aw[wave][CIN * NC + NC + lane * 8 + e] = s1; aw[wave][CIN * NC + NC + CIN + lane * 8 + e] = s2; }
     }
   }
 #pragma unroll
-  for (int k = 0; k < NC; ++k) { const float s = wave_sum(accb[k]); if (lane == 0) atomicAdd(&aw[CIN * NC + k], s); }
+  for (int k = 0; k < NC; ++k) { const float s = wave_sum(accb[k]); if (lane == 0) aw[wave][CIN * NC + k] = s; }
   __syncthreads();
-  if (d.dw) for (int i = threadIdx.x; i < CIN * NC; i += blockDim.x) atomicAdd(d.dw + i, aw[i]);
-  if (d.db) for (int i = threadIdx.x; i < NC; i += blockDim.x) atomicAdd(d.db + i, aw[CIN * NC + i]);
+  auto tot = [&](int i) { float t = 0.f; for (int w = 0; w < NW; ++w) t += aw[w][i]; return t; };
+  if (d.dw) for (int i = threadIdx.x; i < CIN * NC; i += blockDim.x) atomicAdd(d.dw + i, tot(i));
+  if (d.db) for (int i = threadIdx.x; i < NC; i += blockDim.x) atomicAdd(d.db + i, tot(CIN * NC + i));
   if constexpr (BNR) {
-    float* rowp = d.bnr_sums + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * d.bnr_sums_ld;
+    satcv_stat_t* rowp = d.bnr_sums + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * d.bnr_sums_ld;
     for (int i = threadIdx.x; i < CIN; i += blockDim.x) {
-      atomicAdd(rowp + i, aw[CIN * NC + NC + i]);
-      atomicAdd(rowp + d.bnr_sums_ld + i, aw[CIN * NC + NC + CIN + i]);
+      atomicAdd(rowp + i, (satcv_stat_t)tot(CIN * NC + NC + i));
+      atomicAdd(rowp + d.bnr_sums_ld + i, (satcv_stat_t)tot(CIN * NC + NC + CIN + i));
     }
   }
 }

@@ -8,7 +8,7 @@ struct IgemmArgs {
   const float* in_scale; const float* in_shift; int in_relu;
   const void* w; const float* bias; const float* out_scale;
   void* y; int ldy;
-  float* stats; int stats_ld;
+  satcv_stat_t* stats; int stats_ld;
   int n, h, w_;            // GEMM pixel grid
   int hs, ws;              // source spatial dims
   int cout, cout_pad;
@@ -159,9 +159,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
 #pragma unroll
       for (int w = 0; w < WM; ++w) { t1 += ldsS[(w * 2 + 0) * BN + tid]; t2 += ldsS[(w * 2 + 1) * BN + tid]; }
       const int cch = cn % a.cstat;
-      float* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
-      atomicAdd(rowp + cch, t1);
-      atomicAdd(rowp + a.stats_ld + cch, t2);
+      satcv_stat_t* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
+      atomicAdd(rowp + cch, (satcv_stat_t)t1);
+      atomicAdd(rowp + a.stats_ld + cch, (satcv_stat_t)t2);
     }
   }
   // coalesced 16-byte stores of whole channel rows

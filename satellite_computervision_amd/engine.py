@@ -94,8 +94,8 @@ class TRef:
 
 
 def _fp(t, off=0):
-    """device address of float32 tensor element `off` (or None)."""
-    return None if t is None else t.data_ptr() + 4 * off
+    """device address of element `off` of a float32 (parameters, affines) or float64 (statistics rows) tensor, or None."""
+    return None if t is None else t.data_ptr() + t.element_size() * off
 
 
 class Runtime:
@@ -326,7 +326,7 @@ class Plan:
             if node.op == 'concat_bn_relu':
                 a, b = node.inputs
                 ctot = a.channels + b.channels
-                st = self._z(STAT_ROWS, 2, ctot, dtype=torch.float32)
+                st = self._z(STAT_ROWS, 2, ctot, dtype=torch.float64)
                 cat_stats[id(node)] = st
                 sinks[a.id] = (st, 0, ctot)
                 sinks[b.id] = (st, a.channels, ctot)
@@ -354,7 +354,7 @@ class Plan:
                 ctot = sum(t.channels for t in node.inputs)
                 hh, ww = self._dims(node.inputs[0])
                 yshared = self._z(n, hh, ww, ctot)
-                stshared = self._z(STAT_ROWS, 2, ctot, dtype=torch.float32) if training else None
+                stshared = self._z(STAT_ROWS, 2, ctot, dtype=torch.float64) if training else None
                 aff = dict(scale=self._z(ctot, dtype=torch.float32), shift=self._z(ctot, dtype=torch.float32),
                            mean=self._z(ctot, dtype=torch.float32), rstd=self._z(ctot, dtype=torch.float32))
                 off = 0
@@ -397,7 +397,7 @@ class Plan:
                 sl = slots.get(tout.id)
                 if sl is None:
                     y = self._z(n, r.h, r.w, cout)
-                    stats = self._z(STAT_ROWS, 2, cout, dtype=torch.float32) if training else None
+                    stats = self._z(STAT_ROWS, 2, cout, dtype=torch.float64) if training else None
                     yoff, ldy, aoff, aff_in = 0, cout, 0, None
                 else:           # branch of a concatenation: write into the channel slice of the shared tensor
                     y, stats, yoff, ldy, aoff, aff_in = sl['y'], sl['stats'], sl['off'], sl['ctot'], sl['off'], sl['aff']
@@ -627,7 +627,7 @@ class Plan:
             if P.op != 'cba' or pc['yoff'] != 0 or pc['ldy'] != pc['cout']:
                 return None
             c, aff = pc['cout'], pc['aff']
-            sums = self._z(STAT_ROWS, 2, c, dtype=torch.float32)
+            sums = self._z(STAT_ROWS, 2, c, dtype=torch.float64)
             return dict(mean=_fp(aff['mean']), rstd=_fp(aff['rstd']), sums=_fp(sums), sums_ld=c), sums
 
         def dgrad_step(t, **kw):
@@ -717,7 +717,7 @@ class Plan:
                 yoff, ldy, aoff = cx['yoff'], cx['ldy'], cx['aoff']
                 hh, ww = r.h, r.w
                 pre = fused.get(tout.id)
-                sums = pre if pre is not None else self._z(STAT_ROWS, 2, cout, dtype=torch.float32)
+                sums = pre if pre is not None else self._z(STAT_ROWS, 2, cout, dtype=torch.float64)
                 dy = self._z(n, hh, ww, cout)
                 accum = 1 if lay.name in seen_layers else 0
                 seen_layers.add(lay.name)
@@ -779,7 +779,7 @@ class Plan:
                 ctot = ca + cb
                 hh, ww = ra.h, ra.w
                 pre = fused.get(tout.id)
-                sums = pre if pre is not None else self._z(STAT_ROWS, 2, ctot, dtype=torch.float32)
+                sums = pre if pre is not None else self._z(STAT_ROWS, 2, ctot, dtype=torch.float64)
                 dskip = self._z(n, hh, ww, ca)
                 du = self._z(n, hh, ww, cb)
                 bn = node.layer.name

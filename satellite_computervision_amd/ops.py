@@ -30,7 +30,7 @@ def ptr(t):
 
 
 def new_stats(c, device):
-    return torch.zeros(STAT_ROWS, 2, c, dtype=torch.float32, device=device)
+    return torch.zeros(STAT_ROWS, 2, c, dtype=torch.float64, device=device)      # satcv_stat_t rows
 
 
 # ------------------------------------------------------------------ data movement

@@ -600,7 +600,7 @@ def test_full_size_training_step_permutation_property(mt):
     l1 = m.train_on_batch(x, y)
     g1 = m.runtime.gflat.clone()
     m.train_on_batch(x, y)
-    rel_same = ((g1 - m.runtime.gflat).norm() / g1.norm()).item()        # run-to-run: float atomics in the BN statistics
+    rel_same = ((g1 - m.runtime.gflat).norm() / g1.norm()).item()        # run-to-run (was 2e-3 with fp32 statistics rows)
     perm = rng.permutation(64)
     l2 = m.train_on_batch(x[perm], y[perm])
     g2 = m.runtime.gflat.clone()
@@ -609,7 +609,7 @@ def test_full_size_training_step_permutation_property(mt):
     print(f'full-size gradient repeatability: same batch {rel_same:.2e}, permuted batch {rel:.2e}')
     # re-ordered fp32 sums flip isolated ReLU masks whose pre-activation is ~1e-7, which perturbs the gradients downstream of
     # them; a wrong tile mapping or a dropped slab would show up as O(1)
-    assert rel < 1e-2 and rel_same < 1e-2, (rel, rel_same)
+    assert rel < 1e-2 and rel_same < 2e-5, (rel, rel_same)         # same batch: reproducible to fp32 rounding (double statistics rows)
     assert torch.isfinite(g1).all() and g1.abs().max() > 0
 
 
