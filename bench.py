@@ -162,6 +162,7 @@ def main():
             dist.barrier(**BARRIER_KW)
         torch.cuda.synchronize()
 
+    model._head_plan(B, TILE, TILE, True)              # buffers and launch descriptors exist before any (warm-up or timed) step
     for i in range(args.warmup):
         xb, yb = pool[i % len(pool)]
         model.train_step_device(xb, yb, sync)
