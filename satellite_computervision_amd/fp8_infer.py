@@ -66,6 +66,12 @@ def calibrate(model, x):
     return q
 
 
+def _single(v):
+    if len(v) > 5:
+        raise NotImplementedError('folded inference: only a conv block may consume the (skip, up) pair')
+    return v
+
+
 class _Ones:
     """scale table of the unquantised (bf16) folded graph"""
 
@@ -163,7 +169,8 @@ class Fp8Plan:
                     vals[t.id] = (x8, cp, self.h, self.w, q[t.id])
             elif op == 'cba':
                 tin, tout = node.inputs[0], node.outputs[0]
-                x8, cin_s, hh, ww, qin = vals[tin.id]
+                x8, cin_s, hh, ww, qin = vals[tin.id][:5]
+                dual = vals[tin.id][5] if len(vals[tin.id]) > 5 else None
                 lay = node.layer
                 if node.attrs.get('stride', 1) != 1 or not node.attrs.get('relu', True):
                     raise NotImplementedError('fp8 inference: strided / linear conv blocks are not lowered')
@@ -196,12 +203,16 @@ class Fp8Plan:
                 obias = self._f32((s * rt.get_param(lay.name + '/bias') + t_) / qo)
                 y8 = self._z(n, hh, ww, cout)
                 k = node.attrs['k']
-                self._conv(x0=x8.data_ptr(), c0=cin_s, w=w8.data_ptr(), bias=obias.data_ptr(), out_scale=oscale.data_ptr(), y=y8.data_ptr(), ldy=cout,
-                           n=n, h=hh, w_=ww, cout=cout, cout_pad=_rup(cout, 32), kh=k, kw=k, dil=node.attrs['dil'], dtype=cdt)
+                src = dict(x0=x8.data_ptr(), c0=cin_s)
+                if dual is not None:
+                    src = dict(x0=x8.data_ptr(), c0=dual['c0'], x1=dual['x1'].data_ptr(), c1=dual['c1'], in_scale=dual['in_scale'].data_ptr(),
+                               in_shift=dual['in_shift'].data_ptr(), in_relu=1)
+                self._conv(w=w8.data_ptr(), bias=obias.data_ptr(), out_scale=oscale.data_ptr(), y=y8.data_ptr(), ldy=cout,
+                           n=n, h=hh, w_=ww, cout=cout, cout_pad=_rup(cout, 32), kh=k, kw=k, dil=node.attrs['dil'], dtype=cdt, **src)
                 vals[tout.id] = (y8, cout, hh, ww, qo)
             elif op == 'pool':
                 tin, tout = node.inputs[0], node.outputs[0]
-                x8, c, hh, ww, qin = vals[tin.id]
+                x8, c, hh, ww, qin = _single(vals[tin.id])
                 f = node.attrs['f']
                 if hh % f or ww % f:
                     raise ValueError(f'input {self.h}x{self.w} is not divisible by the model downsampling')
@@ -217,7 +228,7 @@ class Fp8Plan:
                 if len(cons) != 1 or cons[0].op != 'concat_bn_relu' or cons[0].inputs[1] is not tout:
                     raise NotImplementedError('fp8 inference: a transposed conv must feed concat([skip, up]) -> BN -> ReLU')
                 cat = cons[0]
-                x8, cin_s, hh, ww, qin = vals[tin.id]
+                x8, cin_s, hh, ww, qin = _single(vals[tin.id])
                 lay, f = node.layer, node.attrs['f']
                 ca, cb = cat.inputs[0].channels, tout.channels
                 if cb % 32 or ca % 16:
@@ -226,19 +237,31 @@ class Fp8Plan:
                 w8, wscale, cdt = self._pack(kernel, cin_s, True)
                 s0, t0 = self._bn(cat.layer.name)
                 qc = q[cat.outputs[0].id]
-                cat8 = self._z(n, hh * f, ww * f, ca + cb)
                 oscale = self._f32(qin * wscale * s0[ca:] / qc)
                 obias = self._f32((s0[ca:] * rt.get_param(lay.name + '/bias') + t0[ca:]) / qc)
+                if self.store == BF16:
+                    # unquantised graph: the concatenation is not materialised -- the up-sampled half goes to its own tensor and the
+                    # consumer conv reads (skip, up) as two sources, with the skip half's BN+ReLU applied in its loader
+                    cat8, ybase, ldy = None, self._z(n, hh * f, ww * f, cb), cb
+                    yptr = ybase.data_ptr()
+                else:
+                    cat8 = self._z(n, hh * f, ww * f, ca + cb)
+                    ybase, ldy, yptr = cat8, ca + cb, cat8.data_ptr() + ca * self.esz
                 self._conv(x0=x8.data_ptr(), c0=cin_s, w=w8.data_ptr(), bias=obias.data_ptr(), out_scale=oscale.data_ptr(),
-                           y=cat8.data_ptr() + ca * self.esz, ldy=ca + cb, n=n, h=hh, w_=ww, cout=f * f * cb, cout_pad=_rup(f * f * cb, 32),
+                           y=yptr, ldy=ldy, n=n, h=hh, w_=ww, cout=f * f * cb, cout_pad=_rup(f * f * cb, 32),
                            kh=1, kw=1, dil=1, mode_out=1, f=f, cstat=cb, dtype=cdt)
-                cats[id(cat)] = (cat8, ca, cb, qc, s0, t0, hh * f, ww * f)
+                cats[id(cat)] = (cat8 if cat8 is not None else ybase, ca, cb, qc, s0, t0, hh * f, ww * f)
             elif op == 'concat_bn_relu':
                 ta, tout = node.inputs[0], node.outputs[0]
                 cat8, ca, cb, qc, s0, t0, hh, ww = cats[id(node)]
-                a8, c, ha, wa, qa = vals[ta.id]
+                a8, c, ha, wa, qa = _single(vals[ta.id])
                 if c != ca or (ha, wa) != (hh, ww):
                     raise ValueError(f'concatenation of a {ha}x{wa}x{c} skip with a {hh}x{ww} up-sampled map')
+                if self.store == BF16:
+                    insc = self._f32(torch.cat([s0[:ca], torch.ones(cb, device=self.dev)]))
+                    insh = self._f32(torch.cat([t0[:ca], torch.zeros(cb, device=self.dev)]))      # identity on the (already activated) up half
+                    vals[tout.id] = (a8, ca + cb, hh, ww, 1.0, dict(x1=cat8, c0=ca, c1=cb, in_scale=insc, in_shift=insh))
+                    continue
                 rs = self._f32(s0[:ca] * qa / qc)
                 rsh = self._f32(t0[:ca] / qc)
                 npix = n * hh * ww
@@ -247,7 +270,7 @@ class Fp8Plan:
                 vals[tout.id] = (cat8, ca + cb, hh, ww, qc)
             elif op == 'head':
                 tin, tout = node.inputs[0], node.outputs[0]
-                x8, c, hh, ww, qin = vals[tin.id]
+                x8, c, hh, ww, qin = _single(vals[tin.id])
                 lay = node.layer
                 ncls = tout.channels
                 act = {'softmax': 0, 'sigmoid': 1, 'linear': 2}[node.attrs['activation']]
