@@ -114,8 +114,14 @@ typedef struct satcv_conv_desc {
   /* optional per-channel multiplier of the accumulator (indexed like bias): y = act(acc*out_scale + bias).  The folded
    * inference path puts BatchNorm and the fp8 quantisation scales here (q_in*w_scale*bn_scale/q_out). */
   const float* out_scale;
+  /* optional fused max-pool (window == stride == pool_f, 'valid') of the STORED outputs, written to pool_y with channel stride
+   * pool_ld: layers.MaxPooling2D (utils/model_tools.py:281) of an encoder block in the folded inference graph.  Pipelined kernel
+   * only (satcv_conv2d_igemm_pipelined), mode_out 0, h and w_ divisible by pool_f. */
+  void* pool_y; int32_t pool_ld, pool_f;
 } satcv_conv_desc;
 int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream);
+/* 1 if this descriptor runs on the pipelined kernel (required by out_scale / pool_y / the fp8 dtypes), else 0; no launch. */
+int satcv_conv2d_igemm_pipelined(const satcv_conv_desc* d);
 
 /* Weight gradient of the same convolutions: dW[tap][ci][co] = sum_p X[p+tap][ci]*dY[p][co],
  * written as Keras HWIO fp32.  X is staged with the same optional affine+ReLU as the

@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ('kh', c_i32), ('kw', c_i32), ('dil', c_i32),
                 ('mode_in', c_i32), ('mode_out', c_i32), ('f', c_i32),
                 ('cstat', c_i32), ('out_relu', c_i32), ('dtype', c_i32), ('accumulate', c_i32),
-                ('stride', c_i32), ('hin', c_i32), ('win', c_i32), ('out_scale', c_vp)]
+                ('stride', c_i32), ('hin', c_i32), ('win', c_i32), ('out_scale', c_vp), ('pool_y', c_vp), ('pool_ld', c_i32), ('pool_f', c_i32)]
 
 
 class PackJob(C.Structure):
@@ -85,6 +85,7 @@ _SIGS = {
     'satcv_pack_job_items': (c_i64, [C.POINTER(PackJob)]),
     'satcv_pack_weights_batched': (C.c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     'satcv_conv2d_igemm': (C.c_int, [C.POINTER(ConvDesc), c_vp]),
+    'satcv_conv2d_igemm_pipelined': (C.c_int, [C.POINTER(ConvDesc)]),
     'satcv_conv2d_wgrad_workspace': (c_i64, [C.POINTER(WgradDesc)]),
     'satcv_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), c_vp]),
     'satcv_bn_finalize_train': (C.c_int, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32,

@@ -310,6 +310,10 @@ static int igemm_fill_args(const satcv_conv_desc* d, IgemmArgs& a) {
   a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1;
   a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_relu = d->in_relu;
   a.w = d->w; a.bias = d->bias; a.out_scale = d->out_scale; a.y = d->y; a.ldy = d->ldy;
+  a.pool_y = d->pool_y; a.pool_ld = d->pool_ld; a.pool_f = d->pool_f;
+  SATCV_CHECK(!d->pool_y || (d->pool_f >= 2 && !d->mode_out && !d->accumulate && d->h % d->pool_f == 0 && d->w_ % d->pool_f == 0 && d->pool_ld >= d->cout &&
+                             d->cout % (d->dtype == SATCV_F32 ? 4 : (d->dtype == SATCV_BF16 ? 8 : 16)) == 0),
+              "igemm: fused max-pool needs pool_f >= 2 dividing h and w_, plain output mode, whole 16-byte channel vectors");
   a.stats = d->stats; a.stats_ld = d->stats_ld;
   a.n = d->n; a.h = d->h; a.w_ = d->w_;
   a.hs = d->mode_in ? d->h * d->f : d->h; a.ws = d->mode_in ? d->w_ * d->f : d->w_;
@@ -337,6 +341,13 @@ static bool igemm_force_generic() {
   return v;
 }
 
+extern "C" int satcv_conv2d_igemm_pipelined(const satcv_conv_desc* d) {
+  IgemmArgs a;
+  if (!d || igemm_fill_args(d, a) != SATCV_OK || igemm_force_generic()) return 0;
+  if (a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dil >= a.h && a.dil >= a.w_) { a.kh = a.kw = 1; a.dil = 1; }
+  return igemm_fast_launch(a, d->dtype, nullptr, true) == SATCV_OK ? 1 : 0;
+}
+
 extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   IgemmArgs a;
   int rc = igemm_fill_args(d, a);
@@ -354,7 +365,7 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   if (!igemm_force_generic()) rc = igemm_fast_launch(a, d->dtype, st);
   if (rc != SATCV_ERR_UNSUPPORTED) { /* launched (or failed hard) */ }
   else if (d->dtype == SATCV_FP8 || d->dtype == SATCV_FP8X) { satcv_set_error("igemm: this fp8 shape is outside the pipelined kernel's limits"); rc = SATCV_ERR_UNSUPPORTED; }
-  else if (d->out_scale) { satcv_set_error("igemm: out_scale needs the pipelined kernel"); rc = SATCV_ERR_UNSUPPORTED; }
+  else if (d->out_scale || d->pool_y) { satcv_set_error("igemm: out_scale / pool_y need the pipelined kernel"); rc = SATCV_ERR_UNSUPPORTED; }
   else if (d->dtype == SATCV_BF16) rc = launch_t<bf16>(a, st);
   else if (d->dtype == SATCV_F32) rc = launch_t<float>(a, st);
   else { satcv_set_error("igemm: bad dtype %d", d->dtype); rc = SATCV_ERR_INVALID; }

@@ -255,6 +255,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   a.nchunks = cin / KC;
   if (cin % KC != 0 || (a.x1 && a.c0 % KC != 0) || (a.mode_in == 1 && a.c0 % KC != 0)) return SATCV_ERR_UNSUPPORTED;
   if (a.mode_out == 1 && (a.cstat % BN != 0)) return SATCV_ERR_UNSUPPORTED;
+  if (a.pool_y && (TH % a.pool_f != 0 || TW % a.pool_f != 0 || a.rpi % a.pool_f != 0)) return SATCV_ERR_UNSUPPORTED;    // pooling windows inside one tile
   if (a.cout_pad < a.n_tiles * BN) return SATCV_ERR_UNSUPPORTED;
   {
     constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);

@@ -7,6 +7,7 @@ struct IgemmArgs {
   int c0, c1;
   const float* in_scale; const float* in_shift; int in_relu;
   const void* w; const float* bias; const float* out_scale;
+  void* pool_y; int pool_ld, pool_f;
   void* y; int ldy;
   satcv_stat_t* stats; int stats_ld;
   int n, h, w_;            // GEMM pixel grid
@@ -192,6 +193,33 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
       *reinterpret_cast<uint4*>(yp + off) = *reinterpret_cast<const uint4*>(sp);
     } else {
       for (int e = 0; e < ncols - vq * EPV; ++e) yp[off + e] = sp[e];
+    }
+  }
+  // fused max-pool of the tile just stored (inference encoder blocks): window == stride == pool_f, full windows only
+  if (a.pool_y) {
+    const int f = a.pool_f, pw = TW / f, ph = (BM / TW) / f;
+    const int hp = a.h / f, wp = a.w_ / f;
+    T* pp = reinterpret_cast<T*>(a.pool_y);
+    for (int it = tid; it < ph * pw * VPR; it += NTHREADS) {
+      const int vq = it % VPR, pq = it / VPR;
+      if (vq * EPV + EPV > ncols) continue;
+      const int t0 = (pq / pw) * f, c0 = (pq % pw) * f;
+      const int k = (a.imgs == 1) ? 0 : t0 / a.rpi;
+      const int nimg = n0 + k, y = y0 + (t0 - k * a.rpi), x = x0 + c0;
+      if (!((k < a.imgs) && (nimg < a.n) && (y + f <= a.h) && (x + f <= a.w_))) continue;
+      float mx[EPV];
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) mx[e] = -INFINITY;
+      for (int i = 0; i < f; ++i)
+        for (int j = 0; j < f; ++j) {
+          const T* sp = ldsO + ((t0 + i) * TW + c0 + j) * OPITCH + vq * EPV;
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) mx[e] = fmaxf(mx[e], (float)sp[e]);
+        }
+      T o[EPV];
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) o[e] = (T)mx[e];
+      *reinterpret_cast<uint4*>(pp + ((size_t)(nimg * hp + y / f) * wp + x / f) * a.pool_ld + cbase + vq * EPV) = *reinterpret_cast<const uint4*>(o);
     }
   }
 }

@@ -24,6 +24,7 @@ from ._lib import lib, check, FP8, FP8X, BF16
 
 # layers whose input channels are a multiple of 64 run on the block-scaled K=64 MFMA (2x the bf16 rate)
 USE_SCALED_MFMA = os.environ.get('SATCV_FP8_SCALED', '1') != '0'
+FUSE_POOL = os.environ.get('SATCV_FUSE_POOL', '1') != '0'
 
 E4M3_MAX = 448.0
 BN_EPS = 1e-3
@@ -145,6 +146,7 @@ class Fp8Plan:
             for t in node.inputs:
                 consumers.setdefault(t.id, []).append(node)
         vals = {}                                        # tensor id -> (uint8 tensor viewed as fp8, channels, h, w, q)
+        prepooled = {}                                   # conv output tensor id -> its max-pooled tensor written by the conv epilogue
         cats = {}                                        # concat_bn_relu node id -> (cat tensor, ca, cb, q_cat, bn scale, bn shift)
         for node in m.nodes:
             op = node.op
@@ -203,15 +205,31 @@ class Fp8Plan:
                 obias = self._f32((s * rt.get_param(lay.name + '/bias') + t_) / qo)
                 y8 = self._z(n, hh, ww, cout)
                 k = node.attrs['k']
+                # fuse the encoder block's MaxPooling2D into this conv's epilogue when the pipelined kernel takes the shape
+                pool_kw = {}
+                pnodes = [cn for cn in consumers.get(tout.id, []) if cn.op == 'pool']
+                if len(pnodes) == 1 and hh % pnodes[0].attrs['f'] == 0 and ww % pnodes[0].attrs['f'] == 0 and FUSE_POOL:
+                    fpool = pnodes[0].attrs['f']
+                    p8 = self._z(n, hh // fpool, ww // fpool, cout)
+                    pool_kw = dict(pool_y=p8.data_ptr(), pool_ld=cout, pool_f=fpool)
                 src = dict(x0=x8.data_ptr(), c0=cin_s)
                 if dual is not None:
                     src = dict(x0=x8.data_ptr(), c0=dual['c0'], x1=dual['x1'].data_ptr(), c1=dual['c1'], in_scale=dual['in_scale'].data_ptr(),
                                in_shift=dual['in_shift'].data_ptr(), in_relu=1)
-                self._conv(w=w8.data_ptr(), bias=obias.data_ptr(), out_scale=oscale.data_ptr(), y=y8.data_ptr(), ldy=cout,
-                           n=n, h=hh, w_=ww, cout=cout, cout_pad=_rup(cout, 32), kh=k, kw=k, dil=node.attrs['dil'], dtype=cdt, **src)
+                ckw = dict(w=w8.data_ptr(), bias=obias.data_ptr(), out_scale=oscale.data_ptr(), y=y8.data_ptr(), ldy=cout, n=n, h=hh, w_=ww, cout=cout,
+                           cout_pad=_rup(cout, 32), kh=k, kw=k, dil=node.attrs['dil'], dtype=cdt, **src)
+                if pool_kw:
+                    probe = ops.make_conv_desc(out_relu=1, **ckw, **pool_kw)
+                    if lib.satcv_conv2d_igemm_pipelined(C.byref(probe)):
+                        ckw.update(pool_kw)
+                        prepooled[tout.id] = (p8, cout, hh // fpool, ww // fpool, qo)
+                self._conv(**ckw)
                 vals[tout.id] = (y8, cout, hh, ww, qo)
             elif op == 'pool':
                 tin, tout = node.inputs[0], node.outputs[0]
+                if tin.id in prepooled:                  # already produced by the conv's epilogue
+                    vals[tout.id] = prepooled[tin.id]
+                    continue
                 x8, c, hh, ww, qin = _single(vals[tin.id])
                 f = node.attrs['f']
                 if hh % f or ww % f:

@@ -80,7 +80,7 @@ def pack_weights(kernel_f32, cin_pad, dtype, transposed=False, want_dgrad=True, 
 # --------------------------------------------------------------------------- conv
 def make_conv_desc(*, x0, c0, w, y, ldy, n, h, w_, cout, cout_pad, dtype, x1=None, c1=0, in_scale=None, in_shift=None,
                    in_relu=0, bias=None, stats=None, stats_ld=0, kh=3, kw=3, dil=1, mode_in=0, mode_out=0, f=1,
-                   cstat=None, out_relu=0, accumulate=0, stride=1, hin=0, win=0, out_scale=None):
+                   cstat=None, out_relu=0, accumulate=0, stride=1, hin=0, win=0, out_scale=None, pool_y=None, pool_ld=0, pool_f=0):
     d = ConvDesc()
     d.x0, d.x1, d.c0, d.c1 = x0, x1, c0, c1
     d.in_scale, d.in_shift, d.in_relu = in_scale, in_shift, int(in_relu)
@@ -93,6 +93,7 @@ def make_conv_desc(*, x0, c0, w, y, ldy, n, h, w_, cout, cout_pad, dtype, x1=Non
     d.cstat = cstat if cstat is not None else cout
     d.out_relu, d.dtype, d.accumulate = int(out_relu), dtype, int(accumulate)
     d.stride, d.hin, d.win, d.out_scale = stride, hin, win, out_scale
+    d.pool_y, d.pool_ld, d.pool_f = pool_y, pool_ld, pool_f
     return d
 
 

@@ -184,3 +184,33 @@ def test_folded_inference_tracks_weight_updates(env):
     m.set_weights_dict({k: np.zeros_like(v) if k == 'probs/kernel' else v for k, v in w.items()})
     p2, _ = m.predict(x)
     assert np.allclose(p2[..., 0], p2[0, 0, 0, 0], atol=1e-6)  # zero head kernel -> constant output: the load was seen
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp8'])
+@pytest.mark.parametrize('n,h,w,cin,cout', [(2, 16, 64, 32, 32), (3, 24, 40, 16, 64), (5, 8, 8, 64, 128), (2, 4, 12, 32, 32)])
+def test_fused_maxpool_epilogue_equals_separate_pool(env, dt, n, h, w, cin, cout):
+    """satcv_conv_desc.pool_y: the pooled tensor written by the conv epilogue equals max-pooling the stored output (partial tiles,
+    several images per workgroup), bit for bit."""
+    ops, lib, check = env['ops'], env['lib'], env['check']
+    from satellite_computervision_amd._lib import BF16, FP8
+    code, tdt = (BF16, torch.bfloat16) if dt == 'bf16' else (FP8, torch.uint8)
+    rng = np.random.default_rng(n * h + w)
+    if dt == 'bf16':
+        x = torch.tensor(rng.standard_normal((n, h, w, cin)), dtype=torch.float32).cuda().to(torch.bfloat16)
+        kern = torch.tensor(rng.standard_normal((3, 3, cin, cout)) * 0.1, dtype=torch.float32).cuda()
+    else:
+        x = _to_f8(torch.tensor(rng.integers(-3, 4, (n, h, w, cin)), dtype=torch.float32)).cuda().view(torch.uint8)
+        kern = torch.tensor(rng.integers(-2, 3, (3, 3, cin, cout)), dtype=torch.float32).cuda()
+    wp, _ = ops.pack_weights(kern, cin, code, want_dgrad=False)
+    osc = torch.full((cout,), 0.05, device='cuda'); b = torch.tensor(rng.standard_normal(cout), dtype=torch.float32).cuda()
+    y = torch.zeros(n, h, w, cout, dtype=tdt, device='cuda')
+    p = torch.zeros(n, h // 2, w // 2, cout, dtype=tdt, device='cuda')
+    d = ops.make_conv_desc(x0=x.data_ptr(), c0=cin, w=wp.data_ptr(), bias=b.data_ptr(), out_scale=osc.data_ptr(), y=y.data_ptr(), ldy=cout, n=n, h=h, w_=w,
+                           cout=cout, cout_pad=ops.rup(cout, 32), dtype=code, out_relu=1, pool_y=p.data_ptr(), pool_ld=cout, pool_f=2)
+    assert lib.satcv_conv2d_igemm_pipelined(C.byref(d)) == 1
+    check(lib.satcv_conv2d_igemm(C.byref(d), ops.stream_ptr()))
+    p2 = torch.zeros_like(p)
+    check(lib.satcv_maxpool(y.data_ptr(), p2.data_ptr(), n, h, w, cout, 2, 2, 0, code, ops.stream_ptr()))
+    torch.cuda.synchronize()
+    assert y.float().abs().sum() > 0 if dt == 'bf16' else y.any()
+    assert torch.equal(p, p2)
