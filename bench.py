@@ -222,6 +222,18 @@ def main():
         barrier()
         extra['infer_fp8_tiles_per_s'] = round(world * B * 10 / (time.perf_counter() - t1), 1)
         model.disable_fp8_inference()
+        # BASELINE configs[2]: DeepLab-v3 (ResNet-50 OS16 + the reference's ASPP block), NAIP-like 512x512x4 tiles, inference
+        dl = mt.get_deeplabv3_model(2, 4)
+        for bs in (1, 16):
+            xd = torch.from_numpy((np.random.default_rng(6).integers(0, 256, (bs, 512, 512, 4)) / 255.0).astype(np.float32)).cuda()
+            for _ in range(3):
+                dl.predict_on_device(xd)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                dl.predict_on_device(xd)
+            barrier()
+            extra[f'config3_deeplab_b{bs}_tiles_per_s'] = round(world * bs * 10 / (time.perf_counter() - t1), 1)
 
     if rank == 0:
         tiles = world * B * args.steps

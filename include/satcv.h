@@ -182,11 +182,19 @@ typedef struct satcv_bnbwd_desc {
   float* dbias;                        /* optional [c], atomically accumulated (apply)      */
   int32_t n, h, w_, c;
   int32_t dtype;
+  int32_t linear;                      /* 1: BatchNormalization without the ReLU (residual branch): g = da, no mask   */
 } satcv_bnbwd_desc;
 int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream);
 int satcv_bn_bwd_finalize(satcv_stat_t* sums, int32_t sums_ld, int32_t c, float count, float* dgamma,
                           float* dbeta, float* coef, int32_t accumulate, void* stream);
 int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream);
+
+/* Residual blocks of the atrous CNN family (utils/model_tools.py:922-979: ReLU(BN(conv) + shortcut), plain Conv2D layers):
+ * satcv_relu_bwd : g[i] = act[i] > 0 ? g[i] : 0 in place (gradient through the ReLU of a materialised activation; the masked
+ *                  gradient then serves BOTH addends of the sum).
+ * satcv_bias_grad: dbias[ch] += sum over pixels of dy[pix][ch] (a Conv2D that is not followed by BatchNormalization). */
+int satcv_relu_bwd(const void* act, void* g, int64_t count, int32_t dtype, void* stream);
+int satcv_bias_grad(const void* dy, int32_t lddy, int64_t npix, int32_t c, int32_t dtype, float* dbias, void* stream);
 
 /* ------------------------------------------ ResNet / DeepLab-v3 inference helpers
  * The reference has no DeepLab-v3/ResNet-50 code (README.md:8 only names it); these ops serve the build-defined

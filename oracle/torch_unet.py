@@ -167,3 +167,35 @@ def siamese_forward(p, xa_nhwc, xb_nhwc, filters, factors, training=False):
         h = cba(f'dec{j}.conv2', cba(f'dec{j}.conv1', a0))
     probs = torch.sigmoid(_conv(h, p['probs.kernel'], p['probs.bias'])).permute(0, 2, 3, 1)
     return probs
+
+
+def _cbn(p, conv, bn, t, training, d=1):
+    """Conv2D `conv` then BatchNormalization `bn` (Keras '<layer>/<variable>' parameter names)."""
+    return _bn(_conv(t, p[f'{conv}/kernel'], p[f'{conv}/bias'], d), {k.replace('/', '.'): v for k, v in p.items() if k.startswith(bn + '/')}, bn, training)
+
+
+def acnn_forward(p, x_nhwc, depth, training=False):
+    """build_acnn_layers (utils/model_tools.py:922-939) as coded: Conv2D_{l}_1 consumes the previous Conv2D's output (not its
+    BN/ReLU); only the last block's BN_{l}_2 / ReLU reaches the 'probabilities' head.  Parameter names are the Keras layer names."""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    feats = _conv(x, p['Conv2D_0_1/kernel'], p['Conv2D_0_1/bias'])
+    features_add = F.relu(_bn(feats, {k.replace('/', '.'): v for k, v in p.items()}, 'BN_0', training))
+    for layer in range(1, depth):
+        feats = _conv(feats, p[f'Conv2D_{layer}_1/kernel'], p[f'Conv2D_{layer}_1/bias'])
+        norm = _bn(feats, {k.replace('/', '.'): v for k, v in p.items()}, f'BN_{layer}_1', training)
+        features_add = F.relu(norm + features_add)
+        feats = _conv(features_add, p[f'Conv2D_{layer}_2/kernel'], p[f'Conv2D_{layer}_2/bias'], 3)
+    relu = F.relu(_bn(feats, {k.replace('/', '.'): v for k, v in p.items()}, f'BN_{depth - 1}_2', training))
+    return torch.softmax(_conv(relu, p['probabilities/kernel'], p['probabilities/bias']), dim=1).permute(0, 2, 3, 1)
+
+
+def acnn2_forward(p, x_nhwc, depth, training=False):
+    """get_acnn_model2 / build_acnn_layers2 (utils/model_tools.py:941-1014)."""
+    q = {k.replace('/', '.'): v for k, v in p.items()}
+    features = x_nhwc.permute(0, 3, 1, 2)
+    features_add = None
+    for layer in range(depth):
+        normed = _bn(_conv(features, p[f'Conv{layer}_1/kernel'], p[f'Conv{layer}_1/bias']), q, f'bn{layer}_1', training)
+        features_add = F.relu(normed if layer == 0 else normed + features_add)
+        features = F.relu(_bn(_conv(features_add, p[f'DilateConv{layer}_2/kernel'], p[f'DilateConv{layer}_2/bias'], 3), q, f'bn{layer}_2', training))
+    return torch.softmax(_conv(features, p['probs/kernel'], p['probs/bias']), dim=1).permute(0, 2, 3, 1)

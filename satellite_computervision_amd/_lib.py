@@ -60,7 +60,7 @@ class BnBwdDesc(C.Structure):
                 ('scale', c_vp), ('shift', c_vp), ('mean', c_vp), ('rstd', c_vp),
                 ('sums', c_vp), ('sums_ld', c_i32), ('coef', c_vp),
                 ('dy', c_vp), ('lddy_out', c_i32), ('dbias', c_vp),
-                ('n', c_i32), ('h', c_i32), ('w_', c_i32), ('c', c_i32), ('dtype', c_i32)]
+                ('n', c_i32), ('h', c_i32), ('w_', c_i32), ('c', c_i32), ('dtype', c_i32), ('linear', c_i32)]
 
 
 class HeadDesc(C.Structure):
@@ -98,6 +98,8 @@ _SIGS = {
     'satcv_maxpool': (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'satcv_affine_requant': (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp]),
     'satcv_add_act': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    'satcv_relu_bwd': (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    'satcv_bias_grad': (C.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp]),
     'satcv_upsample_head': (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
     'satcv_dropout_mask': (C.c_int, [C.c_uint64, C.c_uint64, c_f32, c_i64, c_vp, c_vp]),
     'satcv_dropout_apply': (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),

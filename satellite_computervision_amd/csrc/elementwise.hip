@@ -399,7 +399,7 @@ __global__ void bn_bwd_kernel(const satcv_bnbwd_desc d) {
             float gg = gr[e];
             if (full && am[e] == i * f + j) gg += gp[e];
             const float a = v[e] * sc[e] + sh[e];
-            gg = a > 0.f ? gg : 0.f;
+            gg = (a > 0.f || d.linear) ? gg : 0.f;
             const float xh = (v[e] - mu[e]) * rs[e];
             if (APPLY) { const float t = sc[e] * (gg - c1[e] - xh * c2[e]); o[e] = round_to<T>(t); s1[e] += o[e]; }
             else { s1[e] += gg; s2[e] += gg * xh; }
@@ -423,7 +423,7 @@ __global__ void bn_bwd_kernel(const satcv_bnbwd_desc d) {
 }
 // Dense variant (no pooled gradient): pure linear sweep, 32-bit incremental indexing.
 template <typename T, bool APPLY>
-__global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbwd_desc d) {
+__global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbwd_desc d, const int rev) {
   extern __shared__ float lds[];
   const int c = d.c, G = c / 8;
   const unsigned npix = (unsigned)d.n * d.h * d.w_;
@@ -443,14 +443,15 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbw
   }
   if (active) {
 #pragma unroll 2
-    for (unsigned p = gid / G; p < npix; p += per) {
+    for (unsigned p0 = gid / G; p0 < npix; p0 += per) {
+      const unsigned p = rev ? npix - 1 - p0 : p0;
       float v[8], gr[8], o[8];
       load8<T>(yr + (size_t)p * d.ldy, v);
       load8<T>(da + (size_t)p * d.ldda, gr);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float a = v[e] * sc[e] + sh[e];
-        const float gg = a > 0.f ? gr[e] : 0.f;
+        const float gg = (a > 0.f || d.linear) ? gr[e] : 0.f;
         const float xh = (v[e] - mu[e]) * rs[e];
         if (APPLY) { const float t = sc[e] * (gg - c1[e] - xh * c2[e]); o[e] = round_to<T>(t); s1[e] += o[e]; }
         else { s1[e] += gg; s2[e] += gg * xh; }
@@ -484,7 +485,7 @@ extern "C" int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream) {
   const int f = d->dpool ? d->f : 1;
   const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
   if (!d->dpool && d->da && (long long)d->n * d->h * d->w_ < 0x7fffffffLL) {
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), EW_BLOCK * 16 * sizeof(float), (hipStream_t)stream, *d));
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), EW_BLOCK * 16 * sizeof(float), (hipStream_t)stream, *d, 0));
   } else {
     DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), EW_BLOCK * 16 * sizeof(float), (hipStream_t)stream, *d));
   }
@@ -492,11 +493,12 @@ extern "C" int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream) {
   return SATCV_OK;
 }
 extern "C" int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream) {
+  static const int rev = getenv("SATCV_BN_REV") ? atoi(getenv("SATCV_BN_REV")) : 1;
   int rc = bnbwd_check(d, true); if (rc) return rc;
   const int f = d->dpool ? d->f : 1;
   const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
   if (!d->dpool && d->da && (long long)d->n * d->h * d->w_ < 0x7fffffffLL) {
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), d->c * sizeof(float), (hipStream_t)stream, *d));
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), d->c * sizeof(float), (hipStream_t)stream, *d, rev));
   } else {
     DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), d->c * sizeof(float), (hipStream_t)stream, *d));
   }
@@ -917,6 +919,58 @@ extern "C" int satcv_add_act(const void* y, const float* y_scale, const float* y
   DISPATCH_T(dtype, hipLaunchKernelGGL(add_act_kernel<T>, dim3(ew_grid(npix * (c / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)y, y_scale,
                                        y_shift, (const T*)res, res_scale, res_shift, relu, (T*)out, (long long)npix, c));
   LAUNCH_OK("add_act");
+  return SATCV_OK;
+}
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ act, T* __restrict__ g, long long nvec) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    float a[8], v[8];
+    load8<T>(act + i * 8, a); load8<T>(g + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = a[e] > 0.f ? v[e] : 0.f;
+    store8<T>(g + i * 8, v);
+  }
+}
+extern "C" int satcv_relu_bwd(const void* act, void* g, int64_t count, int32_t dtype, void* stream) {
+  SATCV_CHECK(act && g && count > 0 && count % 8 == 0, "relu_bwd: bad args");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(relu_bwd_kernel<T>, dim3(ew_grid(count / 8)), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)act, (T*)g,
+                                       (long long)(count / 8)));
+  LAUNCH_OK("relu_bwd");
+  return SATCV_OK;
+}
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void bias_grad_kernel(const T* __restrict__ dy, int lddy, long long npix, int c, float* __restrict__ dbias) {
+  extern __shared__ float lds[];
+  const int G = c / 8;
+  const long long nthreads = (long long)gridDim.x * blockDim.x, per = nthreads / G;
+  const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const bool active = gid < per * G;
+  const int g = (int)(gid % G);
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (active) {
+    for (long long p = gid / G; p < npix; p += per) {
+      float v[8];
+      load8<T>(dy + p * lddy + g * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += v[e];
+    }
+  }
+  for (int i = threadIdx.x; i < c; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&lds[g * 8 + e], s[e]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(dbias + i, lds[i]);
+}
+extern "C" int satcv_bias_grad(const void* dy, int32_t lddy, int64_t npix, int32_t c, int32_t dtype, float* dbias, void* stream) {
+  SATCV_CHECK(dy && dbias && npix > 0 && c > 0 && c % 8 == 0 && c <= 2048 && lddy >= c, "bias_grad: bad args");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bias_grad_kernel<T>, dim3(ew_grid(npix * (c / 8))), dim3(EW_BLOCK), c * sizeof(float), (hipStream_t)stream, (const T*)dy,
+                                       lddy, (long long)npix, c, dbias));
+  LAUNCH_OK("bias_grad");
   return SATCV_OK;
 }
 // bilinear upsampling (half-pixel centres, edge clamped -- tf.keras UpSampling2D(interpolation='bilinear')) of fp32 logits by an

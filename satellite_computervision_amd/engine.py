@@ -395,6 +395,16 @@ class Plan:
                         raise NotImplementedError('strided convolutions are inference-only (DeepLab backbone)')
                     r = TRef(r.srcs, r.n, (hin - 1) // stride + 1, (win - 1) // stride + 1, r.affine, r.relu)   # output grid
                 sl = slots.get(tout.id)
+                if not node.attrs.get('bn', True):
+                    # plain Conv2D + bias, no normalisation (atrous CNN family): consumers read the stored values as they are
+                    if sl is not None or stride > 1:
+                        raise NotImplementedError('a convolution without BatchNormalization as a concatenation branch / with a stride')
+                    y = self._z(n, r.h, r.w, cout)
+                    self.fwd.append(self._conv_step(w=pk['fwd'].data_ptr(), bias=rt.pptr(lay.name + '/bias'), y=y.data_ptr(), ldy=cout, n=n, h=r.h, w_=r.w,
+                                                    cout=cout, cout_pad=rup(cout, 32), kh=k, kw=k, dil=dil, dtype=dt, **self._src_args(r)))
+                    vals[tout.id] = TRef([(y, cout)], n, r.h, r.w)
+                    ctx[id(node)] = dict(r=r, y=y, yoff=0, ldy=cout, aff=None, aoff=0, cout=cout, k=k, dil=dil)
+                    continue
                 if sl is None:
                     y = self._z(n, r.h, r.w, cout)
                     stats = self._z(STAT_ROWS, 2, cout, dtype=torch.float64) if training else None
@@ -483,10 +493,20 @@ class Plan:
                 self.fwd.append(lambda st, src=src, out=out, hh=r.h, ww=r.w, c=c, kk=kk, ss=ss, pp=pp: check(lib.satcv_maxpool(
                     src.data_ptr(), out.data_ptr(), n, hh, ww, c, kk, ss, pp, dt, st)))
                 vals[tout.id] = TRef([(out, c)], n, ho, wo)
+            elif op == 'raw':
+                # the convolution output BEFORE its BatchNormalization (build_acnn_layers feeds it to the next Conv2D, utils/model_tools.py:930)
+                r = vals[node.inputs[0].id]
+                if len(r.srcs) != 1 or node.inputs[0].node.op != 'cba':
+                    raise NotImplementedError('raw view of a tensor that is not a single convolution output')
+                vals[node.outputs[0].id] = TRef(r.srcs, n, r.h, r.w)
             elif op == 'add_relu':
                 ty, tsc = node.inputs
                 tout = node.outputs[0]
                 ry, rs = vals[ty.id], vals[tsc.id]
+                if rs.affine and rs.relu and len(rs.srcs) == 1:       # shortcut = ReLU(BN(conv)) kept in raw form: activate it once
+                    if tsc.id not in acts:
+                        acts[tsc.id] = self._materialize(tsc, rs)
+                    rs = acts[tsc.id]
                 if len(ry.srcs) != 1 or len(rs.srcs) != 1 or ry.relu or (rs.affine and rs.relu):
                     raise NotImplementedError('residual join expects linear (BN without ReLU) branches')
                 (yb, c), (sb, c2) = ry.srcs[0], rs.srcs[0]
@@ -498,6 +518,7 @@ class Plan:
                     yb.data_ptr(), _fp(ya['scale']) if ya else None, _fp(ya['shift']) if ya else None, sb.data_ptr(),
                     _fp(sa['scale']) if sa else None, _fp(sa['shift']) if sa else None, 1, out.data_ptr(), npx, c, dt, st)))
                 vals[tout.id] = TRef([(out, c)], n, ry.h, ry.w)
+                ctx[id(node)] = dict(out=out, c=c, h=ry.h, w=ry.w)
             elif op == 'upsample_head':
                 tin, tout = node.inputs[0], node.outputs[0]
                 lg = self.outputs[tin.id]                         # fp32 logits written by the linear head
@@ -595,12 +616,12 @@ class Plan:
         self.loss_buf = self._z(1, dtype=torch.float32)
 
         def bn_bwd_steps(da, ldda, dp, lddp, f, yraw, ldy, aff, aoff, sums, sums_off, sums_ld, c, hh, ww, dy, lddy, dbias,
-                         dgamma, dbeta, accum=0):
+                         dgamma, dbeta, accum=0, linear=0):
             coef = self._z(2, c, dtype=torch.float32)
             d = ops.make_bnbwd_desc(yraw=yraw, ldy=ldy, scale=_fp(aff['scale'], aoff), shift=_fp(aff['shift'], aoff),
                                     mean=_fp(aff['mean'], aoff), rstd=_fp(aff['rstd'], aoff), n=n, h=hh, w_=ww, c=c, dtype=dt,
                                     da=da, ldda=ldda, dpool=dp, lddp=lddp, f=f, sums=_fp(sums, sums_off), sums_ld=sums_ld,
-                                    coef=_fp(coef), dy=dy, lddy_out=lddy, dbias=dbias)
+                                    coef=_fp(coef), dy=dy, lddy_out=lddy, dbias=dbias, linear=linear)
             self.keep.append(d)
             cnt = float(n * hh * ww)
             red = lambda st: check(lib.satcv_bn_bwd_reduce(C.byref(d), st))
@@ -708,10 +729,61 @@ class Plan:
                 self.keep.append(hd)
                 self.bwd.append(lambda st, hd=hd: check(lib.satcv_head_bwd(C.byref(hd), st)))
                 gact[node.inputs[0].id] = (dx, 0, c)
+            elif op == 'add_relu':
+                # out = ReLU(BN(conv) + shortcut): the masked gradient g * (out > 0) belongs to BOTH addends.  It is formed in place
+                # and handed to the branch's (linear) BN backward and to the shortcut; a tensor that already holds a gradient
+                # (several consumers) receives it by addition.
+                ty, tsc = node.inputs
+                g = gact.get(node.outputs[0].id)
+                if g is None or cx is None:
+                    continue
+                c, hh, ww, out = cx['c'], cx['h'], cx['w'], cx['out']
+                if g[1] != 0 or g[2] != c:
+                    raise NotImplementedError('residual-join gradient in a channel slice')
+                gb, cnt = g[0], n * hh * ww * c
+                self.bwd.append(lambda st, out=out, gb=gb, cnt=cnt: check(lib.satcv_relu_bwd(out.data_ptr(), gb.data_ptr(), cnt, dt, st)))
+                for t in (ty, tsc):
+                    prev = gact.get(t.id)
+                    if prev is None:
+                        gact[t.id] = (gb, 0, c)
+                    else:
+                        if prev[1] != 0 or prev[2] != c:
+                            raise NotImplementedError('gradient fan-in into a channel slice')
+                        self.bwd.append(lambda st, pb=prev[0], gb=gb, npx=n * hh * ww, c=c: check(lib.satcv_add_act(
+                            pb.data_ptr(), None, None, gb.data_ptr(), None, None, 0, pb.data_ptr(), npx, c, dt, st)))
+            elif op == 'cba' and not node.attrs.get('bn', True):
+                # plain Conv2D: the gradient of its stored output is the incoming one as it is
+                tin, tout = node.inputs[0], node.outputs[0]
+                da = gact.get(tout.id)
+                if da is None:
+                    continue
+                lay, r, cout = node.layer, cx['r'], cx['cout']
+                if da[1] != 0 or da[2] != cout:
+                    raise NotImplementedError('plain-convolution gradient in a channel slice')
+                hh, ww, dyb = r.h, r.w, da[0]
+                accum = 1 if lay.name in seen_layers else 0
+                seen_layers.add(lay.name)
+                self.bwd.append(lambda st, dyb=dyb, cout=cout, npx=n * hh * ww, db=rt.gptr(lay.name + '/bias'): check(lib.satcv_bias_grad(
+                    dyb.data_ptr(), cout, npx, cout, dt, db, st)))
+                pk = rt.packed[lay.name]
+                self.bwd.append(wgrad_step(r, dyb.data_ptr(), cout, lay, pk['cin'], cout, hh, ww, cx['k'], cx['dil'], accum=accum))
+                if tin.node.op != 'input':
+                    cinp = r.c
+                    prev = gact.get(tin.id)
+                    if prev is not None and (prev[1] != 0 or prev[2] != cinp):
+                        raise NotImplementedError('gradient fan-in into a channel slice')
+                    gin = prev[0] if prev is not None else self._z(n, hh, ww, cinp)
+                    self.bwd.append(dgrad_step(tin, x0=dyb.data_ptr(), c0=cout, w=pk['dgrad'].data_ptr(), y=gin.data_ptr(), ldy=cinp,
+                                               n=n, h=hh, w_=ww, cout=cinp, cout_pad=rup(cinp, 32), kh=cx['k'], kw=cx['k'],
+                                               dil=cx['dil'], dtype=dt, accumulate=1 if prev is not None else 0))
+                    gact[tin.id] = (gin, 0, cinp)
             elif op == 'cba':
                 tin, tout = node.inputs[0], node.outputs[0]
                 da, dp = gact.get(tout.id), gpool.get(tout.id)
+                graws = [gact[cn.outputs[0].id] for cn in consumers.get(tout.id, []) if cn.op == 'raw' and cn.outputs[0].id in gact]
                 if da is None and dp is None:
+                    if graws:
+                        raise NotImplementedError('a convolution consumed only through its un-normalised output')
                     continue
                 lay, r, y, aff, cout = node.layer, cx['r'], cx['y'], cx['aff'], cx['cout']
                 yoff, ldy, aoff = cx['yoff'], cx['ldy'], cx['aoff']
@@ -725,8 +797,15 @@ class Plan:
                 red, fin, app = bn_bwd_steps(da_ptr, da[2] if da is not None else 0, dp[0].data_ptr() if dp is not None else None,
                                              cout, gpool_f.get(tout.id, 1), y.data_ptr() + yoff * es, ldy, aff, aoff, sums, 0, cout, cout, hh, ww,
                                              dy.data_ptr(), cout, rt.gptr(lay.name + '/bias'),
-                                             rt.gptr(lay.bn_name + '/gamma'), rt.gptr(lay.bn_name + '/beta'), accum)
+                                             rt.gptr(lay.bn_name + '/gamma'), rt.gptr(lay.bn_name + '/beta'), accum,
+                                             linear=0 if node.attrs.get('relu', True) else 1)
                 self.bwd += [fin, app] if pre is not None else [red, fin, app]
+                for gr in graws:            # consumers of the un-normalised output add their gradient to dy (and to the bias gradient)
+                    if gr[1] != 0 or gr[2] != cout:
+                        raise NotImplementedError('raw-output gradient in a channel slice')
+                    self.bwd.append(lambda st, dy=dy, gb=gr[0], npx=n * hh * ww, cout=cout, db=rt.gptr(lay.name + '/bias'): (
+                        check(lib.satcv_bias_grad(gb.data_ptr(), cout, npx, cout, dt, db, st)),
+                        check(lib.satcv_add_act(dy.data_ptr(), None, None, gb.data_ptr(), None, None, 0, dy.data_ptr(), npx, cout, dt, st))))
                 self.dbg['dy:' + lay.name] = dy
                 self.dbg['_ctx:' + lay.name] = dict(da=da, dp=dp, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout)
                 pk = rt.packed[lay.name]

@@ -154,15 +154,17 @@ class conv_batch_act:
     Lowered to ONE node: implicit-GEMM conv kernel with BN statistics in its epilogue; the BN
     affine + ReLU is applied by the consumer's loader."""
 
-    def __init__(self, num_filters, kernel_size=(3, 3), dilation_rate=1, name='conv_batch_act', strides=1, activation='relu', **kwargs):
+    def __init__(self, num_filters, kernel_size=(3, 3), dilation_rate=1, name='conv_batch_act', strides=1, activation='relu',
+                 conv_name=None, bn_name=None, batch_norm=True, **kwargs):
         self.name = name
         ks = _pair(kernel_size)
         assert ks[0] == ks[1] and ks[0] % 2 == 1, 'kernel_size must be odd and square'
         self.strides = strides if isinstance(strides, int) else strides[0]      # extension (ResNet backbone): strided / linear variants
         self.activation = activation
-        self.conv_layer = _ConvParams(_unique('conv2d'), num_filters, ks)
-        self.bn_layer = _BNParams()
-        self.conv_layer.bn_name = self.bn_layer.name
+        # extensions for the atrous CNN family: explicitly named layers, and a Conv2D that is not followed by BatchNormalization
+        self.conv_layer = _ConvParams(conv_name or _unique('conv2d'), num_filters, ks, bias_initializer='zeros')
+        self.bn_layer = _BNParams(bn_name) if batch_norm else None
+        self.conv_layer.bn_name = self.bn_layer.name if batch_norm else None
         self.dilation_rate = dilation_rate if isinstance(dilation_rate, int) else dilation_rate[0]
         self.num_filters = num_filters
         self.bn_updates = 1
@@ -173,16 +175,20 @@ class conv_batch_act:
 
     @trainable.setter
     def trainable(self, v):
-        self.conv_layer.trainable = self.bn_layer.trainable = v
+        self.conv_layer.trainable = v
+        if self.bn_layer is not None:
+            self.bn_layer.trainable = v
 
     def _sublayers(self):
-        return [self.conv_layer, self.bn_layer]
+        return [l for l in (self.conv_layer, self.bn_layer) if l is not None]
 
     def __call__(self, inputs, bn_updates=None):
         self.conv_layer.build(inputs.channels)
-        self.bn_layer.build(self.num_filters)
+        if self.bn_layer is not None:
+            self.bn_layer.build(self.num_filters)
         node = E.Node('cba', [inputs], layer=self.conv_layer, k=self.conv_layer.kernel_size[0], dil=self.dilation_rate,
-                      bn_updates=bn_updates or self.bn_updates, owner=self, stride=self.strides, relu=self.activation == 'relu')
+                      bn_updates=bn_updates or self.bn_updates, owner=self, stride=self.strides, relu=self.activation == 'relu',
+                      bn=self.bn_layer is not None)
         return node.out(self.num_filters, inputs.down / self.strides)
 
     call = __call__
@@ -432,6 +438,64 @@ def get_deeplabv3_model(nclasses, nchannels=4, aspp_filters=256, blocks=(3, 4, 6
                           widths=list(widths), head_name=head_name)
     return model
 
+# --------------------------------------------------------------------------- atrous CNN family
+def _raw(t):
+    """The output of a conv_batch_act block BEFORE its BatchNormalization."""
+    node = E.Node('raw', [t])
+    return node.out(t.channels, t.down)
+
+
+def build_acnn_layers(input_tensor, depth, nfilters, nclasses):
+    """utils/model_tools.py:922-939, as coded: from the second block on, `Conv2D_{l}_1` is applied to `feats` -- the OUTPUT OF THE
+    PREVIOUS Conv2D, not of its BatchNormalization/ReLU -- and the `BN_{l}_2` / `relu_{l}_2` of every block but the last are dead
+    code (functional-API layers that reach no output own no weights in the Keras model).  `depth` = 1 fails like the reference
+    (`relu` is never bound)."""
+    c0 = conv_batch_act(nfilters, (3, 3), conv_name='Conv2D_0_1', bn_name='BN_0')
+    features_add = c0(input_tensor)
+    feats = _raw(features_add)
+    relu = None
+    for layer in range(1, depth):
+        norm = conv_batch_act(nfilters, (3, 3), activation=None, conv_name=f'Conv2D_{layer}_1', bn_name=f'BN_{layer}_1')(feats)
+        features_add = _add_relu(norm, features_add)
+        last = layer == depth - 1
+        c2 = conv_batch_act(nfilters, (3, 3), dilation_rate=3, conv_name=f'Conv2D_{layer}_2', bn_name=f'BN_{layer}_2', batch_norm=last)
+        relu = c2(features_add)
+        feats = relu if not last else None
+    if relu is None:
+        raise NameError("name 'relu' is not defined")            # utils/model_tools.py:938 with depth < 2
+    return _Head(nclasses, 'softmax', 'zeros', 'probabilities')(relu)
+
+
+def build_acnn_layers2(feature_in, n_blocks=16, kernel_size=3, feature_num=16):
+    """utils/model_tools.py:941-979: n_blocks x [Conv -> BN -> (+ previous sum) -> ReLU ; dilated(3) Conv -> BN -> ReLU]."""
+    features, features_add = feature_in, None
+    for layer in range(0, n_blocks):
+        c1 = conv_batch_act(feature_num, kernel_size, activation='relu' if layer == 0 else None, conv_name=f'Conv{layer}_1', bn_name=f'bn{layer}_1')
+        normed = c1(features)
+        features_add = normed if layer == 0 else _add_relu(normed, features_add)
+        features = conv_batch_act(feature_num, kernel_size, dilation_rate=3, conv_name=f'DilateConv{layer}_2', bn_name=f'bn{layer}_2')(features_add)
+    return features
+
+
+def get_acnn_model(nclasses, nfilters, nchannels, depth):
+    """utils/model_tools.py:981-990: Model(inputs, softmax probabilities) -- a single output, no class map."""
+    acnn_input = Input((None, None, nchannels))
+    logits = build_acnn_layers(acnn_input, depth=depth, nfilters=nfilters, nclasses=nclasses)
+    model = Model(inputs=acnn_input, outputs=logits)
+    model._builder = dict(fn='get_acnn_model', nclasses=nclasses, nfilters=nfilters, nchannels=nchannels, depth=depth)
+    return model
+
+
+def get_acnn_model2(nclasses, nchannels, nfilters=16, depth=16):
+    """utils/model_tools.py:992-1014."""
+    input = Input((None, None, nchannels))
+    features = build_acnn_layers2(feature_in=input, n_blocks=depth, kernel_size=3, feature_num=nfilters)
+    logits = _Head(nclasses, 'softmax', 'zeros', 'probs')(features)
+    m = Model(inputs=input, outputs=logits)
+    m._builder = dict(fn='get_acnn_model2', nclasses=nclasses, nchannels=nchannels, nfilters=nfilters, depth=depth)
+    return m
+
+
 # ---------------------------------------------------------------------------- losses
 class LossSpec:
     def __init__(self, kind, weights=None, eps=1e-6):
@@ -620,7 +684,7 @@ class Model:
             lay = node.layer
             subs = [lay] if lay is not None else []
             if node.op == 'cba':
-                subs = [lay, node.attrs['owner'].bn_layer]
+                subs = [l for l in (lay, node.attrs['owner'].bn_layer) if l is not None]
             for l in subs:
                 if id(l) not in seen:
                     seen.add(id(l))
@@ -1007,11 +1071,12 @@ def load_model(path, custom_objects=None, compile=False):
     p = path if os.path.exists(path) else path + '.npz'
     with np.load(p, allow_pickle=False) as z:
         cfg = json.loads(str(z['__builder__']))
-        if cfg.get('fn') != 'get_unet_model':
-            raise ValueError('file does not describe a get_unet_model() network')
-        cfg.pop('fn')
+        builders = {f.__name__: f for f in (get_unet_model, get_deeplabv3_model, get_acnn_model, get_acnn_model2)}
+        if cfg.get('fn') not in builders:
+            raise ValueError(f'file does not describe a network of {sorted(builders)}')
+        fn = builders[cfg.pop('fn')]
         reset_uids()
-        m = get_unet_model(**cfg)
+        m = fn(**cfg)
         m.set_weights_dict({k: z[k] for k in z.files if not k.startswith('__')})
         if '__adam_m__' in z.files:
             rt = m.runtime

@@ -220,8 +220,9 @@ def bn_relu_pool(yraw, scale, shift, f, want_act=True, want_pool=True, stats=Non
 
 
 def make_bnbwd_desc(*, yraw, ldy, scale, shift, mean, rstd, n, h, w_, c, dtype, da=None, ldda=0, dpool=None, lddp=0, f=1,
-                    sums=None, sums_ld=0, coef=None, dy=None, lddy_out=0, dbias=None):
+                    sums=None, sums_ld=0, coef=None, dy=None, lddy_out=0, dbias=None, linear=0):
     d = BnBwdDesc()
+    d.linear = linear
     d.da, d.ldda, d.dpool, d.lddp, d.f = da, ldda, dpool, lddp, f
     d.yraw, d.ldy = yraw, ldy
     d.scale, d.shift, d.mean, d.rstd = scale, shift, mean, rstd

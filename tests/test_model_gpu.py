@@ -185,7 +185,7 @@ def test_trained_model_bf16_iou_within_1e3(mt):
     o = UNetOracle(2, 4, filters, factors, dtype=np.float64)
     for k in o.params:
         o.params[k] = w[names[k]].astype(np.float64)
-    _, c_ref = o.forward(xt, training=False)
+    p_ref, c_ref = o.forward(xt, training=False)
     iou_ref = iou(c_ref, labt)
     assert iou_ref > 0.85, iou_ref                    # the model has actually learned the task
     mt.reset_uids()
@@ -194,7 +194,11 @@ def test_trained_model_bf16_iou_within_1e3(mt):
     mb.set_weights_dict({names[k]: w[names[k]] for k in o.params})
     _, c_bf = mb.predict(xt)
     _, c_f32 = m.predict(xt)
-    assert abs(iou(c_f32, labt) - iou_ref) < 1e-4
+    # fp32 mode: the mask is the oracle's except possibly on pixels whose two probabilities tie to 1e-4 (the trained weights differ
+    # from run to run -- float atomics in the bias / head gradients -- so such a pixel turns up in some runs; one pixel is 1e-4 of IoU)
+    sure = np.abs(p_ref[..., 0] - p_ref[..., 1]) > 1e-4
+    assert np.array_equal(c_f32[sure], c_ref[sure]) and (c_f32 != c_ref).sum() <= 3
+    assert abs(iou(c_f32, labt) - iou_ref) < 4e-4
     assert abs(iou(c_bf, labt) - iou_ref) < 1e-3, (iou(c_bf, labt), iou_ref)
 
 
@@ -711,3 +715,71 @@ def test_training_trajectory_matches_oracle_over_steps(mt):
                                                        # in test_tiny_unet_predict_and_train_step)
         upd = np.linalg.norm(ref - p_start[k])
         assert np.linalg.norm(got - ref) < 0.5 * max(upd, 1e-9), f'{k}: {np.linalg.norm(got - ref):.3e} vs update {upd:.3e}'
+
+
+@pytest.mark.parametrize('variant', ['acnn', 'acnn2'])
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_atrous_cnn_family_forward_backward(mt, variant, dtype):
+    """get_acnn_model / get_acnn_model2 (utils/model_tools.py:922-1014): residual sums ReLU(BN(conv) + shortcut), dilation-3
+    convolutions, a single softmax output, Keras layer names as coded -- including build_acnn_layers feeding each block's first
+    Conv2D with the previous Conv2D's un-normalised output.  Predictions, loss and every gradient against the PyTorch-CPU
+    restatement (autograd, float64)."""
+    from oracle import torch_unet as TU
+    depth, nf, ncls = 3, 16, 3
+    mt.reset_uids(); mt.set_seed(9)
+    if variant == 'acnn':
+        m = mt.get_acnn_model(ncls, nf, 4, depth)
+        fwd = lambda p, x, training=False: TU.acnn_forward(p, x, depth, training)
+        assert m.output_names == ['probabilities']
+        names = {ps.name for ps in m.param_specs}
+        assert 'BN_1_2/gamma' not in names and 'BN_2_2/gamma' in names and 'Conv2D_1_2/kernel' in names     # dead BN layers own no weights
+        with pytest.raises(NameError):
+            mt.get_acnn_model(ncls, nf, 4, 1)
+    else:
+        m = mt.get_acnn_model2(ncls, 4, nfilters=nf, depth=depth)
+        fwd = lambda p, x, training=False: TU.acnn2_forward(p, x, depth, training)
+        assert m.output_names == ['probs'] and m.count_params() == (9 * 4 * nf + nf + 4 * nf) + 5 * (9 * nf * nf + nf + 4 * nf) + nf * ncls + ncls
+    m.compute_dtype = dtype
+    rng = np.random.default_rng(23)
+    w = {}
+    for ps in m.param_specs:
+        if ps.kind == 'kernel':
+            w[ps.name] = (rng.standard_normal(ps.shape) * np.sqrt(2.0 / np.prod(ps.shape[:3]))).astype(np.float32)
+        elif ps.kind == 'moving_var':
+            w[ps.name] = (0.5 + rng.random(ps.shape)).astype(np.float32)
+        elif ps.kind == 'gamma':
+            w[ps.name] = (1 + 0.2 * rng.standard_normal(ps.shape)).astype(np.float32)
+        else:
+            w[ps.name] = (0.2 * rng.standard_normal(ps.shape)).astype(np.float32)
+    m.set_weights_dict(w)
+    tp = TU.params_to_torch(w, torch.float64)
+    x = rng.random((2, 40, 36, 4)).astype(np.float32)
+    lab = rng.integers(0, ncls, (2, 40, 36))
+    t = np.eye(ncls, dtype=np.float32)[lab]
+    f32 = dtype == 'float32'
+    with torch.no_grad():
+        p_ref = fwd(tp, torch.tensor(x, dtype=torch.float64)).numpy()
+    probs = m.predict(x)
+    assert isinstance(probs, np.ndarray) and probs.shape == (2, 40, 36, ncls)
+    np.testing.assert_allclose(probs, p_ref, atol=3e-5 if f32 else 6e-2)
+    wts = [1.0, 2.0, 3.0]
+    m.compile(optimizer=mt.Adam(1e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, wts))
+    pr = fwd(tp, torch.tensor(x, dtype=torch.float64), training=True)
+    lt = TU.weighted_cce_mean(torch.tensor(t, dtype=torch.float64), pr, wts); lt.backward()
+    loss = m.train_on_batch(x, t)
+    np.testing.assert_allclose(loss, lt.item(), rtol=3e-5 if f32 else 3e-2)
+    rt = m.runtime
+    bad = []
+    for k in w:
+        if 'moving' in k:
+            continue
+        r = tp[k].grad.numpy()
+        g = rt.get_grad(k).cpu().numpy().astype(np.float64)
+        if np.linalg.norm(r) < 1e-9:                      # bias of a Conv2D followed by BatchNormalization: zero in exact arithmetic
+            assert np.linalg.norm(g) < (1e-4 if f32 else 5e-2), k
+            continue
+        cos = (g * r).sum() / (np.linalg.norm(g) * np.linalg.norm(r))
+        l2 = np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30)
+        if (f32 and (l2 > 2e-2 or cos < 0.9999)) or (not f32 and cos < 0.9):
+            bad.append(f'{k}: relL2 {l2:.2e} cos {cos:.5f}')
+    assert not bad, '\n'.join(bad)
