@@ -1133,6 +1133,9 @@ __global__ void loss_kernel(int kind, const float* __restrict__ probs, const flo
       for (int k = 0; k < HEAD_NCMAX; ++k) dot += gp[k] * pr[k];
 #pragma unroll
       for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) dlogits[p * nc + k] = grad_scale * pr[k] * (gp[k] - dot);
+    } else if (activation == 2) {   // linear head (regression): the outputs are the logits
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) dlogits[p * nc + k] = grad_scale * gp[k];
     } else {
 #pragma unroll
       for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) dlogits[p * nc + k] = grad_scale * gp[k] * pr[k] * (1.f - pr[k]);
@@ -1229,6 +1232,9 @@ __global__ void loss_global_grad_kernel(int kind, const float* __restrict__ prob
       for (int k = 0; k < HEAD_NCMAX; ++k) dot += gp[k] * pr[k];
 #pragma unroll
       for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) dlogits[p * nc + k] = grad_scale * pr[k] * (gp[k] - dot);
+    } else if (activation == 2) {   // linear head (regression): the outputs are the logits
+#pragma unroll
+      for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) dlogits[p * nc + k] = grad_scale * gp[k];
     } else {
 #pragma unroll
       for (int k = 0; k < HEAD_NCMAX; ++k) if (k < nc) dlogits[p * nc + k] = grad_scale * gp[k] * pr[k] * (1.f - pr[k]);

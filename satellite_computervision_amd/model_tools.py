@@ -438,6 +438,19 @@ def get_deeplabv3_model(nclasses, nchannels=4, aspp_filters=256, blocks=(3, 4, 6
                           widths=list(widths), head_name=head_name)
     return model
 
+def get_autoencoder(depth, optim=None, loss=None, mets=None, filters=[32, 64, 128, 256, 512], factors=[2, 2, 2, 2, 2]):
+    """utils/model_tools.py:496-531: the five-level U-Net with a LINEAR 1x1 output 'continuous' (regression; the notebooks pair it
+    with mse_4d).  The reference body calls `encoder_block(inputs, 32)` as if the layer class were a function and cannot run as
+    coded; this is the network its comments describe, built from the same blocks as get_unet_model.  Compiled when `optim` is given."""
+    inputs = Input(shape=[None, None, depth])
+    decoder0 = build_unet_layers(inputs, filters, factors)
+    preds = _Head(1, 'linear', 'zeros', 'continuous')(decoder0)
+    model = Model(inputs=[inputs], outputs=[preds])
+    if optim is not None:
+        model.compile(optimizer=optim, loss={'continuous': loss} if loss is not None else None, metrics=mets)
+    return model
+
+
 # --------------------------------------------------------------------------- atrous CNN family
 def _raw(t):
     """The output of a conv_batch_act block BEFORE its BatchNormalization."""
@@ -767,6 +780,13 @@ class Model:
     # ---- compile
     def compile(self, optimizer='adam', loss=None, metrics=None, **kw):
         self.optimizer = Adam() if isinstance(optimizer, str) else optimizer
+        if isinstance(loss, dict):           # Keras per-output form, e.g. loss={'logits': fn} (utils/model_tools.py:487, 526): one loss-bearing output
+            unknown = [k for k in loss if k not in self.output_names]
+            if unknown or len(loss) != 1:
+                raise ValueError(f'loss dictionary must name exactly one of the outputs {self.output_names} (got {list(loss)})')
+            loss = next(iter(loss.values()))
+        if isinstance(metrics, dict):        # {'output name': [metrics]} -> flat list
+            metrics = [mm for v in metrics.values() for mm in (v if isinstance(v, (list, tuple)) else [v])]
         if callable(loss):
             spec = loss(_LossArg('y_true'), _LossArg('y_pred'))
         elif isinstance(loss, LossSpec):

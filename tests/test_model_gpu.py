@@ -783,3 +783,58 @@ def test_atrous_cnn_family_forward_backward(mt, variant, dtype):
         if (f32 and (l2 > 2e-2 or cos < 0.9999)) or (not f32 and cos < 0.9):
             bad.append(f'{k}: relL2 {l2:.2e} cos {cos:.5f}')
     assert not bad, '\n'.join(bad)
+
+
+def test_autoencoder_linear_head_mse_training(mt):
+    """get_autoencoder (utils/model_tools.py:496-531): U-Net with a linear 1x1 'continuous' output trained with mse_4d (mean over the
+    finite elements, :142-166).  Loss and gradients against autograd of the PyTorch-CPU U-Net restatement with the head left linear."""
+    from oracle import torch_unet as TU
+    import torch.nn.functional as F
+    filters, factors = [32, 64], [2, 2]
+    mt.reset_uids(); mt.set_seed(12)
+    m = mt.get_autoencoder(4, optim=mt.Adam(1e-3), loss=mt.mse_4d, filters=filters, factors=factors)
+    m.compute_dtype = 'float32'
+    assert m.output_names == ['continuous']
+    names = mt.structural_names(m)
+    w = m.get_weights_dict()
+    rng = np.random.default_rng(3)
+    for k in w:
+        if k.endswith('/bias') or k.endswith('/beta'):
+            w[k] = (0.1 * rng.standard_normal(w[k].shape)).astype(np.float32)
+    m.set_weights_dict(w)
+    x = rng.random((2, 32, 32, 4)).astype(np.float32)
+    t = rng.standard_normal((2, 32, 32, 1)).astype(np.float32)
+    t[0, 3, 4, 0] = np.nan                                   # ignored element (mse_4d averages over the finite ones)
+    tp = TU.params_to_torch({rn: w[kn] for rn, kn in names.items()}, torch.float64)
+
+    def fwd(training):
+        # unet_forward ends in softmax; recompute its last feature map and apply the linear head
+        xx = torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2)
+        skips, h = [], xx
+        for i in range(2):
+            a = F.relu(TU._bn(TU._conv(h, tp[f'enc{i}.conv.kernel'], tp[f'enc{i}.conv.bias']), tp, f'enc{i}.bn', training))
+            skips.append(a); h = F.max_pool2d(a, 2, 2)
+        h = F.relu(TU._bn(TU._conv(h, tp['center.conv.kernel'], tp['center.conv.bias']), tp, 'center.bn', training))
+        for j in (1, 0):
+            up = F.conv_transpose2d(h, tp[f'dec{j}.up.kernel'].permute(3, 2, 0, 1), tp[f'dec{j}.up.bias'], stride=2)
+            a0 = F.relu(TU._bn(torch.cat([skips[j], up], dim=1), tp, f'dec{j}.bn0', training))
+            a1 = F.relu(TU._bn(TU._conv(a0, tp[f'dec{j}.conv1.kernel'], tp[f'dec{j}.conv1.bias']), tp, f'dec{j}.bn1', training))
+            h = F.relu(TU._bn(TU._conv(a1, tp[f'dec{j}.conv2.kernel'], tp[f'dec{j}.conv2.bias']), tp, f'dec{j}.bn2', training))
+        return TU._conv(h, tp['probs.kernel'], tp['probs.bias']).permute(0, 2, 3, 1)
+    with torch.no_grad():
+        p_ref = fwd(False).numpy()
+    pred = m.predict(x)
+    if isinstance(pred, list):
+        pred = pred[0]
+    np.testing.assert_allclose(pred, p_ref, atol=3e-5)
+    out = fwd(True)
+    tt = torch.tensor(t, dtype=torch.float64)
+    fin = torch.isfinite(tt)
+    lt = ((out - torch.nan_to_num(tt)) ** 2)[fin].mean(); lt.backward()
+    loss = m.train_on_batch(x, t)
+    np.testing.assert_allclose(loss, lt.item(), rtol=3e-5)
+    rt = m.runtime
+    for rn in ('probs.kernel', 'probs.bias', 'dec0.conv2.kernel', 'enc0.conv.kernel', 'center.bn.gamma'):
+        g = rt.get_grad(names[rn]).cpu().numpy().astype(np.float64)
+        r = tp[rn].grad.numpy()
+        assert np.linalg.norm(g - r) / np.linalg.norm(r) < 2e-3, rn
