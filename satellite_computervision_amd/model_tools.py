@@ -1128,6 +1128,60 @@ def retrain_model(model_file, checkpoint, eval_data, metric, weights_file=None, 
     return m
 
 
+# --------------------------------------------------------------------------- chunk prediction (Dask map_overlap callers)
+_BLOB_MODELS = {}        # (absolute path, mtime[, weights path, mtime]) -> Model; the reference downloads and rebuilds the model PER CHUNK
+
+
+def _blob_path(url):
+    """Local path of a model / weights file.  The Azure download (BlobClient, utils/model_tools.py:1225-1236) is storage plumbing
+    outside this build: fetch the blob first and pass the path (or a file:// URL)."""
+    if url.startswith('file://'):
+        url = url[len('file://'):]
+    elif '://' in url:
+        raise RuntimeError(f'{url.split("://")[0]} URLs are not fetched by this build: download the blob and pass the local path')
+    return url if os.path.exists(url) or not os.path.exists(url + '.npz') else url + '.npz'
+
+
+def get_blob_model(h5_url=None, hdf5_url=None, custom_objects=None):
+    """utils/model_tools.py:1204-1269 for files written by Model.save; the loaded model is cached per (path, mtime)."""
+    url = h5_url or hdf5_url
+    if not url:
+        print('must provide a url to either an .h5 or .hdf5 file')
+        return None
+    p = _blob_path(url)
+    key = (os.path.abspath(p), os.path.getmtime(p))
+    if key not in _BLOB_MODELS:
+        _BLOB_MODELS[key] = load_model(p, custom_objects=custom_objects, compile=False)
+    return _BLOB_MODELS[key]
+
+
+def get_blob_weights(m, hdf5_url=None, by_name=False, skip_mismatch=False):
+    """utils/model_tools.py:1178-1202: load a separate weights file into an existing model."""
+    m.load_weights(_blob_path(hdf5_url), by_name=by_name, skip_mismatch=skip_mismatch)
+    return m
+
+
+def predict_chunk(data, model_blob_url, weights_blob_url=None, custom_objects=None):
+    """utils/model_tools.py:1271-1304: predictions for ONE (C, H, W) chunk of a Dask / xarray mosaic -> np.squeeze(pred[0]).
+    (The reference passes `model_blob_url=` / `weights_blob_url=` to get_blob_model, whose parameters are `h5_url` / `hdf5_url`:
+    a TypeError as coded.  Here the model file is `model_blob_url`, optionally overlaid with the weights of `weights_blob_url`;
+    both stay cached between chunks instead of being fetched and rebuilt for each one.)"""
+    print('input shape', data.shape)
+    m = get_blob_model(h5_url=model_blob_url, custom_objects=custom_objects)
+    if weights_blob_url:
+        wp = _blob_path(weights_blob_url)
+        wkey = (os.path.abspath(wp), os.path.getmtime(wp))
+        if getattr(m, '_blob_weights_key', None) != wkey:
+            get_blob_weights(m, wp)
+            m._blob_weights_key = wkey
+    hwc = np.moveaxis(data, 0, -1)
+    nhwc = np.expand_dims(hwc, axis=0)          # the model expects 4-D data
+    pred = m.predict(nhwc)
+    logits = np.squeeze(pred[0])
+    print('logits shape', logits.shape)
+    return logits
+
+
 def structural_names(model):
     """Map structural weight names (enc{i}.conv.kernel, enc{i}.bn.gamma, center.*, dec{j}.up.*,
     dec{j}.bn0.*, dec{j}.conv1/2.*, dec{j}.bn1/2.*, probs.*) to this model's parameter names, for a

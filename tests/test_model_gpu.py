@@ -838,3 +838,29 @@ def test_autoencoder_linear_head_mse_training(mt):
         g = rt.get_grad(names[rn]).cpu().numpy().astype(np.float64)
         r = tp[rn].grad.numpy()
         assert np.linalg.norm(g - r) / np.linalg.norm(r) < 2e-3, rn
+
+
+def test_predict_chunk_cached_model_files(mt, tmp_path, capsys):
+    """predict_chunk (utils/model_tools.py:1271-1304): (C, H, W) chunk -> squeezed probabilities of the saved model, optional weights
+    overlay, model cached between chunks; remote URLs are refused loudly."""
+    mt.reset_uids(); mt.set_seed(3)
+    m = mt.get_unet_model(2, 4, filters=[32, 64], factors=[2, 2])
+    path = str(tmp_path / 'model.h5')
+    m.save(path)
+    rng = np.random.default_rng(1)
+    chunk = rng.random((4, 64, 48)).astype(np.float32)
+    want = m.predict(np.moveaxis(chunk, 0, -1)[None])[0][0]
+    got = mt.predict_chunk(chunk, path)
+    assert got.shape == (64, 48, 2) and np.array_equal(got, want)
+    assert 'input shape (4, 64, 48)' in capsys.readouterr().out
+    assert mt.get_blob_model(h5_url='file://' + path) is mt.get_blob_model(hdf5_url=path)           # cached, not rebuilt per chunk
+    w = m.get_weights_dict()
+    w['probs/bias'] = w['probs/bias'] + np.array([2.0, -2.0], np.float32)
+    m.set_weights_dict(w)
+    wpath = str(tmp_path / 'weights.hdf5')
+    m.save_weights(wpath)
+    got2 = mt.predict_chunk(chunk, path, weights_blob_url=wpath)
+    assert np.array_equal(got2, m.predict(np.moveaxis(chunk, 0, -1)[None])[0][0]) and not np.array_equal(got2, got)
+    with pytest.raises(RuntimeError):
+        mt.predict_chunk(chunk, 'https://account.blob.core.windows.net/models/model.h5?sig=x')
+    assert mt.get_blob_model() is None
