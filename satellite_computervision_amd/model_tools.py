@@ -1128,6 +1128,12 @@ def retrain_model(model_file, checkpoint, eval_data, metric, weights_file=None, 
     return m
 
 
+def normalize_confusion_matrix(arr):
+    """utils/model_tools.py:1111-1126: rows (label categories) scaled to sum to one, rounded to 4 decimals."""
+    arr = np.asarray(arr)
+    return np.around(arr / arr.sum(axis=1)[:, np.newaxis], decimals=4)
+
+
 # --------------------------------------------------------------------------- chunk prediction (Dask map_overlap callers)
 _BLOB_MODELS = {}        # (absolute path, mtime[, weights path, mtime]) -> Model; the reference downloads and rebuilds the model PER CHUNK
 

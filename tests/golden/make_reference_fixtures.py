@@ -92,6 +92,11 @@ def main():
         out[f'mosaic_{tag}_cfg'] = np.array([kernel[0], kernel[1], buff[0], buff[1], cols, n])
         out[f'mosaic_{tag}_out'] = mosaic
         os.unlink(f.name)
+    # normalize_confusion_matrix (utils/model_tools.py:1111-1126) is NumPy only: run the real body
+    ncm = extract_functions(f'{REF}/utils/model_tools.py', {'normalize_confusion_matrix'})
+    cm = np.random.default_rng(11).integers(1, 5000, (5, 5)).astype(np.int64)
+    out['ncm_in'] = cm
+    out['ncm_out'] = ncm['normalize_confusion_matrix'](cm)
     np.savez_compressed(f'{OUT}/tiling_reference.npz', **out)
     sys.path.insert(0, f'{REF}/utils')
     import array_tools as at

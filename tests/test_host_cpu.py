@@ -80,6 +80,28 @@ def test_chip_helpers_match_reference_fixtures():
     assert np.array_equal(np.stack(pt.extract_chips(z['ec_arr'], 16, 32)), z['ec_chips'])
 
 
+def test_graph_builders_of_the_atrous_family_and_helpers():
+    """Graph construction is pure Python (no GPU): node lists, Keras layer names and parameter counts of get_acnn_model /
+    get_acnn_model2 / get_autoencoder; normalize_confusion_matrix against the reference-generated fixture."""
+    from satellite_computervision_amd import model_tools as mt
+    mt.reset_uids()
+    m = mt.get_acnn_model(3, 16, 4, 3)
+    assert [n.op for n in m.nodes] == ['input', 'cba', 'raw', 'cba', 'add_relu', 'cba', 'cba', 'add_relu', 'cba', 'head']
+    names = [ps.name for ps in m.param_specs]
+    assert names[:2] == ['Conv2D_0_1/kernel', 'Conv2D_0_1/bias'] and 'BN_1_2/gamma' not in names and 'BN_2_2/gamma' in names
+    assert m.output_names == ['probabilities']
+    m2 = mt.get_acnn_model2(2, 4, 16, 2)
+    assert m2.count_params() == 7842 and m2.output_names == ['probs']
+    ae = mt.get_autoencoder(6, filters=[32, 64], factors=[2, 2])
+    assert ae.output_names == ['continuous'] and [n.op for n in ae.nodes][-1] == 'head'
+    with pytest.raises(NameError):
+        mt.get_acnn_model(3, 16, 4, 1)
+    z = np.load(os.path.join(GOLD, 'tiling_reference.npz'))
+    assert np.array_equal(mt.normalize_confusion_matrix(z['ncm_in']), z['ncm_out'])
+    with pytest.raises(RuntimeError):
+        mt.predict_chunk(np.zeros((4, 8, 8), np.float32), 'https://account.blob.core.windows.net/c/model.h5')
+
+
 def test_loss_spec_resolution():
     from satellite_computervision_amd import model_tools as mt
     m = mt.get_unet_model(2, 4, filters=[32], factors=[2])
