@@ -156,3 +156,30 @@ def test_data_parallel_logic_gloo_world2(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert 'OK' in o
+
+
+def test_descriptor_layouts_match_the_header(tmp_path):
+    """Every descriptor struct of include/satcv.h has the same size and field offsets as its ctypes mirror in _lib.py (compiled
+    with the host C compiler), and the binding stub printed in INTEGRATION.md lists the same fields."""
+    import subprocess
+    from satellite_computervision_amd import _lib
+    pairs = {'satcv_conv_desc': _lib.ConvDesc, 'satcv_pack_job': _lib.PackJob, 'satcv_tile_desc': _lib.TileDesc, 'satcv_wgrad_desc': _lib.WgradDesc,
+             'satcv_bnbwd_desc': _lib.BnBwdDesc, 'satcv_head_desc': _lib.HeadDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "satcv.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f'{cname}.{fname}']) == getattr(cls, fname).offset, f'{cname}.{fname}'
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blk = doc[doc.index('class ConvDesc'):doc.index('lib.satcv_conv2d_igemm.argtypes')]
+    assert re.findall(r"\('(\w+)',", blk) == [f[0] for f in _lib.ConvDesc._fields_]
