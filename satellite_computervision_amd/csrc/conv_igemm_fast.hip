@@ -254,7 +254,8 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   const int cin = a.c0 + a.c1;
   a.nchunks = cin / KC;
   if (cin % KC != 0 || (a.x1 && a.c0 % KC != 0) || (a.mode_in == 1 && a.c0 % KC != 0)) return SATCV_ERR_UNSUPPORTED;
-  if (a.mode_out == 1 && (a.cstat % BN != 0)) return SATCV_ERR_UNSUPPORTED;
+  // depth-to-space tiles: whole sub-pixel positions per tile, or whole tiles per sub-pixel position
+  if (a.mode_out == 1 && !(a.cstat % BN == 0 || (BN % a.cstat == 0 && a.cstat % (16 / (int)sizeof(T)) == 0))) return SATCV_ERR_UNSUPPORTED;
   if (a.pool_y && (TH % a.pool_f != 0 || TW % a.pool_f != 0 || a.rpi % a.pool_f != 0)) return SATCV_ERR_UNSUPPORTED;    // pooling windows inside one tile
   if (a.cout_pad < a.n_tiles * BN) return SATCV_ERR_UNSUPPORTED;
   {
@@ -292,7 +293,10 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
 template <typename T, int TW, int TAPS>
 static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   const int cin = a.c0 + a.c1;
-  const int nspace = a.mode_out ? a.cstat : a.cout;
+  // transposed conv: N = f*f sub-pixel positions x cstat channels.  Tiles spanning several positions read the input tile once
+  // instead of once per position and write whole lines (SATCV_CONVT_WIDE=0: one position per tile, the earlier behaviour)
+  static const bool convt_wide = !(getenv("SATCV_CONVT_WIDE") && atoi(getenv("SATCV_CONVT_WIDE")) == 0);
+  const int nspace = (a.mode_out && !convt_wide) ? a.cstat : a.cout;
   // 32-channel chunks only for 1x1 taps (the 9-tap weight slab of a 32-channel chunk would not leave
   // room for 2-3 workgroups per CU)
   if constexpr (KTraits<T>::SUB == 2) {

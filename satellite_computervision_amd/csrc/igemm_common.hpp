@@ -172,8 +172,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
   const int ho = a.mode_out ? a.h * a.f : a.h;
   const int wo = a.mode_out ? a.w_ * a.f : a.w_;
   const int ncols = min(BN, a.cout - nbase);      // valid columns of this tile
-  int ij = 0, cbase = nbase;
-  if (a.mode_out == 1) { ij = nbase / a.cstat; cbase = nbase - ij * a.cstat; }
+  int cbase = nbase;
+  // depth-to-space (transposed conv): a tile may span several (i, j) sub-pixel positions of cstat channels each -- with all f*f of
+  // them in one workgroup the (j, channel) runs of an output row are written as whole contiguous lines.  NTHREADS is a multiple
+  // of VPR, so the 16-byte column group of a thread (and with it its sub-pixel position) is fixed.
+  static_assert(NTHREADS % VPR == 0, "column group of a thread must be loop-invariant");
+  int ij = 0, cvec = (tid % VPR) * EPV;       // channel offset of this thread's vectors inside (ij, cbase)
+  if (a.mode_out == 1) {
+    const int cn0 = nbase + cvec;
+    ij = cn0 / a.cstat;
+    cbase = cn0 - ij * a.cstat; cvec = 0;
+  }
   for (int it = tid; it < BM * VPR; it += NTHREADS) {
     const int q = it / VPR, vq = it % VPR;
     if (vq * EPV >= ncols) continue;
@@ -182,7 +191,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     const int nimg = n0 + k, y = y0 + (t - k * a.rpi), x = x0 + cx;
     if (!((k < a.imgs) && (nimg < a.n) && (y < a.h) && (x < a.w_))) continue;
     size_t off;
-    if (a.mode_out == 1) off = ((size_t)(nimg * ho + y * a.f + ij / a.f) * wo + x * a.f + ij % a.f) * a.ldy + cbase + vq * EPV;
+    if (a.mode_out == 1) off = ((size_t)(nimg * ho + y * a.f + ij / a.f) * wo + x * a.f + ij % a.f) * a.ldy + cbase + cvec;
     else off = ((size_t)(nimg * ho + y) * wo + x) * a.ldy + cbase + vq * EPV;
     const T* sp = ldsO + q * OPITCH + vq * EPV;
     if (SKIP_STORES) continue;
