@@ -25,7 +25,10 @@
 #define SATCV_ABLATE 0
 #endif
 #define ABL(bit) ((SATCV_ABLATE & (bit)) != 0)
-template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool DYN>
+// TL (tap loop, TAPS == 1 geometry): a 3x3 conv whose dilation makes the halo tile many times larger than the tile itself (ASPP: 3 / 6 /
+// 12 against 4 x 32 pixels) runs as 9 x Cin/32 K-chunks instead -- per tap the tile is gathered at its shifted position (no halo, zero
+// outside the image) and multiplied with that tap's weight slab.
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool DYN, bool TL = false>
 // thin configurations (<= 32 accumulator registers) request 4 waves/SIMD; the scaled-fp8 fragments are 8 registers each, so
 // that path asks for 2
 __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 ? 2 : 4) : 1)) void igemm_fast_kernel(const IgemmArgs a) {
@@ -120,15 +123,17 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
     const int ty = mt % a.tiles_y;
     n0 = (mt / a.tiles_y) * a.imgs; y0 = ty * TH; x0 = tx * TW;
   };
-  auto gather_pixels = [&](int n0, int y0, int x0) {      // source pixel of every staged item of the tile at (n0, y0, x0)
+  auto gather_pixels = [&](int n0, int y0, int x0, int oy = 0, int ox = 0) {      // source pixel of every staged item of the tile at (n0, y0, x0)
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
       const int k = a_pk[j] >> 24, yy = ((a_pk[j] >> 12) & 0xfff) - a.halh, c = (a_pk[j] & 0xfff) - a.halw;
-      const int n = n0 + k, y = y0 + yy, x = x0 + c;
+      const int n = n0 + k, y = y0 + yy + oy, x = x0 + c + ox;
       a_p[j] = ((a_l[j] >= 0) && (n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_)) ? (n * a.hs + y * fs) * a.ws + x * fs : -1;
     }
   };
-  auto load_regs = [&](int chunk) {
+  auto load_regs = [&](int chunk_) {
+    const int tap = TL ? chunk_ / a.cpt : 0;
+    const int chunk = TL ? chunk_ - tap * a.cpt : chunk_;
     const int cg0 = chunk * KC;
     const T* src; int cs, coff, sadd = 0;
     if (a.mode_in == 1) {
@@ -145,14 +150,15 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
       if (a_p[j] >= 0 && !ABL(4)) ra[j] = gload8<T>(src + (size_t)(a_p[j] + sadd) * cs + coff + slot_t * EL);
       else ra[j] = zero8<T>();
     }
-    const size_t cadd = (size_t)chunk * SLOTS * a.cout_pad;
+    const size_t cadd = ((size_t)chunk * SLOTS + (TL ? (size_t)tap * (cin / EL) : 0)) * a.cout_pad;
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
       if (tid + j * NTHREADS < b_items && !ABL(8)) rb[j] = gload8<T>(wp + ((size_t)b_g[j] + cadd) * EL);
       else rb[j] = zero8<T>();
     }
   };
-  auto store_lds = [&](int chunk) {
+  auto store_lds = [&](int chunk_) {
+    const int chunk = TL ? chunk_ % a.cpt : chunk_;
     const int cg0 = chunk * KC + slot_t * EL;
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
@@ -171,7 +177,8 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
 
   int n0, y0, x0;
   tile_origin(bid, n0, y0, x0);
-  gather_pixels(n0, y0, x0);
+  if constexpr (TL) gather_pixels(n0, y0, x0, -a.dil, -a.dil);
+  else gather_pixels(n0, y0, x0);
   load_regs(0);
   store_lds(0);
   __syncthreads();
@@ -186,6 +193,12 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
       const bool more = chunk + 1 < a.nchunks;
       if (more) {
+        if constexpr (TL) {
+          if ((chunk + 1) % a.cpt == 0) {             // next chunk starts a new tap: its tile sits at another offset
+            const int tap = (chunk + 1) / a.cpt;
+            gather_pixels(n0, y0, x0, (tap / 3 - 1) * a.dil, (tap % 3 - 1) * a.dil);
+          }
+        }
         load_regs(chunk + 1);
       }
       // software-pipelined fragment reads: the LDS reads of step s+1 are issued before the MFMAs of step s (the compiler
@@ -235,12 +248,12 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
 }
 
 // ------------------------------------------------------------------ host side
-template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS>
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool TL = false>
 static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   constexpr int EL = KTraits<T>::EL, SUB = KTraits<T>::SUB;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, KC = KS * 2 * SUB * EL, NTHREADS = WM * WN * 64;
-  a.halh = a.dil * (a.kh - 1) / 2;
-  a.halw = a.dil * (a.kw - 1) / 2;
+  a.halh = TL ? 0 : a.dil * (a.kh - 1) / 2;
+  a.halw = TL ? 0 : a.dil * (a.kw - 1) / 2;
   a.tiles_x = cdiv(a.w_, TW);
   if (a.h >= TH) { a.rpi = TH; a.imgs = 1; a.tiles_y = cdiv(a.h, TH); a.ngroups = a.n; }
   else { a.rpi = a.h; a.imgs = TH / a.h; a.tiles_y = 1; a.ngroups = cdiv(a.n, a.imgs); }
@@ -252,7 +265,9 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   else a.pitch = (a.cl <= 8) ? 8 : (cdiv(a.cl - 8, 16) * 16 + 8);
   a.n_tiles = cdiv(a.cout, BN);
   const int cin = a.c0 + a.c1;
-  a.nchunks = cin / KC;
+  a.cpt = cin / KC;
+  a.nchunks = TL ? 9 * a.cpt : a.cpt;
+  if (TL && (a.mode_in != 0 || a.kh != 3 || a.kw != 3 || a.cpt < 1)) return SATCV_ERR_UNSUPPORTED;
   if (cin % KC != 0 || (a.x1 && a.c0 % KC != 0) || (a.mode_in == 1 && a.c0 % KC != 0)) return SATCV_ERR_UNSUPPORTED;
   // depth-to-space tiles: whole sub-pixel positions per tile, or whole tiles per sub-pixel position
   if (a.mode_out == 1 && !(a.cstat % BN == 0 || (BN % a.cstat == 0 && a.cstat % (16 / (int)sizeof(T)) == 0))) return SATCV_ERR_UNSUPPORTED;
@@ -276,7 +291,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
     constexpr int PITCHc = TW == 32 ? CLc : (TW == 16 ? ((CLc + 15) / 16) * 16 : (CLc <= 8 ? 8 : ((CLc - 8 + 15) / 16) * 16 + 8));
     if (a.cl != CLc || a.pitch != PITCHc) { satcv_set_error("igemm_fast: internal pitch mismatch (%d/%d vs %d/%d)", a.cl, a.pitch, CLc, PITCHc); return SATCV_ERR_INVALID; }
   }
-  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, false>;
+  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, false, TL>;
   if constexpr (TAPS == 9) { if (dyn) kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, true>; }
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -307,6 +322,12 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   }
   if constexpr (TAPS == 1 && KTraits<T>::SUB == 1) {
     const bool ks2 = (cin % 32 == 0) && (!a.x1 || a.c0 % 32 == 0) && (a.mode_in != 1 || a.c0 % 32 == 0);
+    if (a.taploop) {
+      if (!ks2) return SATCV_ERR_UNSUPPORTED;
+      if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS, true>(a, st, dry);
+      if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 2, TAPS, true>(a, st, dry);
+      return fast_cfg<T, TW, 4, 1, 2, 1, 2, TAPS, true>(a, st, dry);
+    }
     if (ks2) {
       if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS>(a, st, dry);
       if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 2, TAPS>(a, st, dry);
@@ -339,6 +360,20 @@ static int fast_t(IgemmArgs& a, hipStream_t st, bool dry) {
 int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   const int taps = a.kh * a.kw;
   if (!(taps == 1 || (a.kh == 3 && a.kw == 3)) || a.stride != 1) return SATCV_ERR_UNSUPPORTED;
+  a.taploop = 0;
+  if (taps == 9 && a.dil > 1 && dtype != SATCV_FP8X) {
+    // dilated 3x3: the halo-tile form when its staged tile fits the register budget (small dilation on narrow tiles), else the tap loop
+    int rc = SATCV_ERR_UNSUPPORTED;
+    if (dtype == SATCV_BF16) rc = fast_t<bf16, 9>(a, st, true);
+    else if (dtype == SATCV_F32) rc = fast_t<float, 9>(a, st, true);
+    else if (dtype == SATCV_FP8) rc = fast_t<fp8, 9>(a, st, true);
+    if (rc != SATCV_OK) {
+      a.taploop = 1;
+      if (dtype == SATCV_BF16) return fast_t<bf16, 1>(a, st, dry);
+      if (dtype == SATCV_F32) return fast_t<float, 1>(a, st, dry);
+      return fast_t<fp8, 1>(a, st, dry);
+    }
+  }
   if (dtype == SATCV_BF16) return taps == 1 ? fast_t<bf16, 1>(a, st, dry) : fast_t<bf16, 9>(a, st, dry);
   if (dtype == SATCV_F32) return taps == 1 ? fast_t<float, 1>(a, st, dry) : fast_t<float, 9>(a, st, dry);
   if (dtype == SATCV_FP8) return taps == 1 ? fast_t<fp8, 1>(a, st, dry) : fast_t<fp8, 9>(a, st, dry);

@@ -892,21 +892,32 @@ extern "C" int satcv_affine_requant(const void* x, int32_t ldx, const float* sca
 }
 // out = relu?( affine?(y) + affine?(res) ): the residual join of a bottleneck block
 template <typename T>
-__global__ void add_act_kernel(const T* __restrict__ y, const float* __restrict__ ysc, const float* __restrict__ ysh, const T* __restrict__ res,
-                               const float* __restrict__ rsc, const float* __restrict__ rsh, int relu, T* __restrict__ out, long long npix, int c) {
+__global__ __launch_bounds__(EW_BLOCK) void add_act_kernel(const T* __restrict__ y, const float* __restrict__ ysc, const float* __restrict__ ysh,
+                                                           const T* __restrict__ res, const float* __restrict__ rsc, const float* __restrict__ rsh, int relu,
+                                                           T* __restrict__ out, long long npix, int c) {
+  // a thread keeps one 8-channel group for all its pixels: the four per-channel coefficients live in registers
   const int G = c / 8;
-  const long long total = npix * G;
-  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
-    const int g = (int)(it % G);
-    const long long p = it / G;
+  const long long nthreads = (long long)gridDim.x * blockDim.x, per = nthreads / G;
+  const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (gid >= per * G) return;
+  const int g = (int)(gid % G);
+  float s0[8], h0[8], s1[8], h1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = g * 8 + e;
+    s0[e] = ysc ? ysc[ch] : 1.f; h0[e] = ysc ? ysh[ch] : 0.f;
+    s1[e] = rsc ? rsc[ch] : 1.f; h1[e] = rsc ? rsh[ch] : 0.f;
+  }
+  const bool ya = ysc != nullptr, ra = rsc != nullptr;
+#pragma unroll 2
+  for (long long p = gid / G; p < npix; p += per) {
     float a[8], b[8];
     load8<T>(y + p * c + g * 8, a);
     load8<T>(res + p * c + g * 8, b);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int ch = g * 8 + e;
-      float u = ysc ? a[e] * ysc[ch] + ysh[ch] : a[e];
-      const float r = rsc ? b[e] * rsc[ch] + rsh[ch] : b[e];
+      float u = ya ? a[e] * s0[e] + h0[e] : a[e];
+      const float r = ra ? b[e] * s1[e] + h1[e] : b[e];
       u += r;
       a[e] = relu ? fmaxf(u, 0.f) : u;
     }
@@ -915,7 +926,7 @@ __global__ void add_act_kernel(const T* __restrict__ y, const float* __restrict_
 }
 extern "C" int satcv_add_act(const void* y, const float* y_scale, const float* y_shift, const void* res, const float* res_scale, const float* res_shift,
                              int32_t relu, void* out, int64_t npix, int32_t c, int32_t dtype, void* stream) {
-  SATCV_CHECK(y && res && out && npix > 0 && c > 0 && c % 8 == 0, "add_act: bad args");
+  SATCV_CHECK(y && res && out && npix > 0 && c > 0 && c % 8 == 0 && c <= 2048, "add_act: bad args");
   DISPATCH_T(dtype, hipLaunchKernelGGL(add_act_kernel<T>, dim3(ew_grid(npix * (c / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)y, y_scale,
                                        y_shift, (const T*)res, res_scale, res_shift, relu, (T*)out, (long long)npix, c));
   LAUNCH_OK("add_act");

@@ -84,6 +84,8 @@ CONV_CASES = [
     (1, 12, 12, 32, 32, 3, 1),     # 384-chip bottleneck size
     (1, 40, 40, 32, 32, 3, 3),     # dilated (ASPP rate 3)
     (1, 32, 32, 32, 64, 3, 6),     # dilated (ASPP rate 6)
+    (3, 8, 8, 32, 128, 3, 3),      # dilated, several images per tile (tap-loop form of the pipelined kernel)
+    (2, 20, 24, 64, 32, 3, 2),     # dilated, ragged tile grid
     (2, 16, 16, 64, 32, 1, 1),     # 1x1
     (1, 32, 32, 48, 96, 3, 1),     # channel counts that are not powers of two
     (1, 256, 256, 16, 32, 3, 1),   # full-resolution tile
@@ -383,3 +385,15 @@ def test_aspp_shapes_backward_and_accumulate(ops, td, case):
     close(back(acc, cin), dx_ref + base, td, f'dgrad accumulate {case}', k=2.0)
     dk = ops.conv2d_wgrad(to_dev(x, td), to_dev(dy, td), cin, cout, kh=k, kw=k, dil=dil)
     close(back(dk), dk_ref, td, f'wgrad {case}', k=(5.0 if td == torch.float32 else 0.5))
+
+
+def test_dilated_convs_run_on_the_pipelined_kernel(ops):
+    """ASPP rates on a 32x32 map: the pipelined kernel takes them (tap-loop form) instead of the generic fallback."""
+    import ctypes as C
+    from satellite_computervision_amd._lib import lib, BF16
+    x = torch.zeros(2, 32, 32, 128, dtype=torch.bfloat16, device='cuda'); y = torch.zeros(2, 32, 32, 256, dtype=torch.bfloat16, device='cuda')
+    w = torch.zeros(9 * 128 * 256, dtype=torch.bfloat16, device='cuda')
+    for dil in (2, 3, 6, 12):
+        d = ops.make_conv_desc(x0=x.data_ptr(), c0=128, w=w.data_ptr(), y=y.data_ptr(), ldy=256, n=2, h=32, w_=32, cout=256, cout_pad=256, kh=3, kw=3,
+                               dil=dil, dtype=BF16)
+        assert lib.satcv_conv2d_igemm_pipelined(C.byref(d)) == 1, dil
