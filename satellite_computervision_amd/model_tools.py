@@ -649,16 +649,31 @@ class ModelCheckpoint:
 
 
 class TensorBoard:
-    """tf.keras.callbacks.TensorBoard stand-in: appends epoch scalars as JSON lines under log_dir."""
+    """tf.keras.callbacks.TensorBoard(log_dir): epoch scalars as real TensorBoard event files -- `<log_dir>/train` and
+    `<log_dir>/validation`, tags `epoch_<name>` like Keras (notebooks/UNET_G4G_2019_solar.ipynb:1255) -- written without
+    TensorFlow (tfrecord_io.EventFileWriter), plus one JSON line per epoch in `<log_dir>/scalars.jsonl`."""
 
     def __init__(self, log_dir='logs', **kw):
         self.log_dir = log_dir
         self.model = None
+        self._writers = {}
+
+    def _writer(self, which):
+        from . import tfrecord_io
+        if which not in self._writers:
+            self._writers[which] = tfrecord_io.EventFileWriter(os.path.join(self.log_dir, which))
+        return self._writers[which]
 
     def on_epoch_end(self, epoch, logs):
         os.makedirs(self.log_dir, exist_ok=True)
         with open(os.path.join(self.log_dir, 'scalars.jsonl'), 'a') as f:
             f.write(json.dumps(dict(epoch=epoch, **{k: float(v) for k, v in logs.items()})) + '\n')
+        train = {f'epoch_{k}': float(v) for k, v in logs.items() if not k.startswith('val_')}
+        val = {f'epoch_{k[4:]}': float(v) for k, v in logs.items() if k.startswith('val_')}
+        if train:
+            self._writer('train').scalars(epoch, train)
+        if val:
+            self._writer('validation').scalars(epoch, val)
 
 
 # ----------------------------------------------------------------------------- Model

@@ -13,6 +13,7 @@ runs in libsatcv (`satcv_crc32c`).  Mirrors of the reference's callers:
   write_tfrecord_predictions   utils/prediction_tools.py:375-445   (b1..bC float lists of the cropped patch)
 """
 import gzip
+import os
 import json
 import struct
 from os.path import join
@@ -126,6 +127,73 @@ def encode_example(features):
                 feat = _ld(3, _ld(1, b''.join(_varint(int(x)) for x in a.reshape(-1))))
         entries += _ld(1, _ld(1, key.encode()) + _ld(2, feat))
     return _ld(1, entries)
+
+
+# ------------------------------------------------------------------ TensorBoard event files (tensorflow.Event wire format)
+def encode_event(wall_time, step=0, scalars=None, file_version=None):
+    """Serialized tensorflow.Event: wall_time (1, double), step (2, int64), file_version (3) or summary (5) holding one
+    Summary.Value {tag (1), simple_value (2, float)} per scalar -- what tf.summary.scalar / the Keras TensorBoard callback write."""
+    ev = struct.pack('<Bd', (1 << 3) | 1, float(wall_time)) + _varint((2 << 3) | 0) + _varint(int(step))
+    if file_version is not None:
+        ev += _ld(3, file_version.encode())
+    if scalars:
+        vals = b''.join(_ld(1, _ld(1, tag.encode()) + struct.pack('<Bf', (2 << 3) | 5, float(v))) for tag, v in scalars.items())
+        ev += _ld(5, vals)
+    return ev
+
+
+def decode_event(buf):
+    """Inverse of encode_event -> dict(wall_time, step, file_version, scalars)."""
+    out = dict(wall_time=None, step=0, file_version=None, scalars={})
+    pos = 0
+    while pos < len(buf):
+        tag, pos = _read_varint(buf, pos)
+        f, wt = tag >> 3, tag & 7
+        if wt == 1:
+            (v,) = struct.unpack('<d', buf[pos:pos + 8]); pos += 8
+            if f == 1:
+                out['wall_time'] = v
+        elif wt == 0:
+            v, pos = _read_varint(buf, pos)
+            if f == 2:
+                out['step'] = v
+        elif wt == 2:
+            n, pos = _read_varint(buf, pos)
+            body = buf[pos:pos + n]; pos += n
+            if f == 3:
+                out['file_version'] = bytes(body).decode()
+            elif f == 5:
+                for f1, _, val in _fields(body):
+                    if f1 == 1:
+                        tg, sv = None, None
+                        for f2, wt2, x in _fields(val):
+                            if f2 == 1:
+                                tg = bytes(x).decode()
+                            elif f2 == 2 and wt2 == 5:
+                                (sv,) = struct.unpack('<f', x)
+                        out['scalars'][tg] = sv
+        elif wt == 5:
+            pos += 4
+    return out
+
+
+class EventFileWriter:
+    """events.out.tfevents.<time>.<host> under `logdir`: TFRecord framing, first record = file_version 'brain.Event:2'."""
+
+    def __init__(self, logdir):
+        import socket, time
+        os.makedirs(logdir, exist_ok=True)
+        self.path = os.path.join(logdir, f'events.out.tfevents.{int(time.time())}.{socket.gethostname()}.{os.getpid()}.v2')
+        self._w = TFRecordWriter(self.path)
+        self._time = time.time
+        self._w.write(encode_event(self._time(), 0, file_version='brain.Event:2'))
+
+    def scalars(self, step, values):
+        self._w.write(encode_event(self._time(), step, scalars=values))
+        self._w._f.flush()
+
+    def close(self):
+        self._w.close()
 
 
 def _fields(buf):
