@@ -275,6 +275,150 @@ def rescale_tensor(img, axes=[2], epsilon=1e-8, moments=None, splits=None):
     return rescale(img)
 
 
+# ---- training / evaluation datasets over Earth-Engine TFRecords (utils/processing.py:129-183, 335-454), NumPy on the host.  The
+# random draws (tf.random.uniform, tf.image.random_flip_*) cannot be reproduced bit for bit without TensorFlow: the same
+# distributions are drawn from a seedable NumPy generator (set_seed).
+_RNG = np.random.default_rng()
+
+
+def set_seed(seed):
+    global _RNG
+    _RNG = np.random.default_rng(seed)
+
+
+class FixedLenFeature:
+    """tf.io.FixedLenFeature(shape, dtype) as used for the `ftDict` argument (one [H, W] float list per band)."""
+
+    def __init__(self, shape, dtype='float32', default_value=None):
+        self.shape, self.dtype = tuple(shape), dtype
+
+
+def aug_tensor_color(img):
+    """utils/processing.py:129-152: per-channel contrast about the channel mean and brightness of the mean, both U(0.95, 1.05)."""
+    n_ch = img.shape[-1]
+    ch_mean = img.mean(axis=(0, 1), keepdims=True)
+    contra_mul = _RNG.uniform(0.95, 1.05, (1, 1, n_ch)).astype(np.float32)
+    bright_mul = _RNG.uniform(0.95, 1.05, (1, 1, n_ch)).astype(np.float32)
+    return (img - ch_mean) * contra_mul + ch_mean * bright_mul
+
+
+def aug_tensor_morph(img):
+    """utils/processing.py:169-183: random left-right flip, random up-down flip, rot90 by a random k in 0..3 (counter-clockwise)."""
+    x = img[:, ::-1] if _RNG.random() < 0.5 else img
+    x = x[::-1] if _RNG.random() < 0.5 else x
+    return np.squeeze(np.rot90(x, int(_RNG.integers(0, 4)), axes=(0, 1)))
+
+
+def to_tuple(inputs, features, response, axes=[2], splits=None, one_hot=None, moments=None, **kwargs):
+    """utils/processing.py:335-392: dict of [H, W] arrays -> (features HWC, labels HWC).  Continuous bands are colour-augmented and
+    rescaled, one-hot features and the response are appended, the stack is flipped / rotated as one, labels above 1 become 1."""
+    for fxn in kwargs.values():              # custom preprocessing functions receive and return the dictionary
+        inputs = fxn(inputs)
+    if type(response) == dict:
+        key, depth = list(response.keys())[0], list(response.values())[0]
+        res = np.squeeze((inputs.get(key).astype(np.uint8)[..., None] == np.arange(depth)).astype(np.float32))
+    else:
+        res = np.expand_dims(inputs.get(response), axis=2).astype(np.float32)
+    if one_hot:
+        featList = [inputs.get(key) for key in features if key not in one_hot.keys()]
+        hotList = [(inputs.get(key).astype(np.uint8)[..., None] == np.arange(val)).astype(np.float32) for key, val in one_hot.items() if key in features]
+    else:
+        featList = [inputs.get(key) for key in features]
+    bands = np.transpose(np.stack(featList, axis=0), [1, 2, 0]).astype(np.float32)
+    bands = aug_tensor_color(bands)
+    bands = rescale_tensor(bands, axes=axes, moments=moments, splits=splits)
+    stacked = np.concatenate([bands] + (hotList if one_hot else []) + [res], axis=2)
+    stacked = aug_tensor_morph(stacked)
+    nres = res.shape[2]
+    feats, labels = stacked[:, :, :-nres], stacked[:, :, -nres:]
+    labels = np.where(labels > 1.0, 1.0, labels)
+    return np.ascontiguousarray(feats, dtype=np.float32), np.ascontiguousarray(labels, dtype=np.float32)
+
+
+class Dataset:
+    """The tf.data chain the reference builds -- map / shuffle(buffer) / batch / repeat -- as a re-iterable Python object that
+    Model.fit / evaluate / predict accept (an iterable of (features, labels) batches)."""
+
+    def __init__(self, source):
+        self._source = source                 # callable -> iterator of elements
+
+    def __iter__(self):
+        return self._source()
+
+    def map(self, fn, num_parallel_calls=None):
+        return Dataset(lambda: (fn(*e) if isinstance(e, tuple) else fn(e) for e in self._source()))
+
+    def shuffle(self, buffer_size):
+        """tf.data shuffle semantics: a buffer of `buffer_size` elements, one drawn at random as each new element arrives."""
+        def gen():
+            buf = []
+            for e in self._source():
+                buf.append(e)
+                if len(buf) > buffer_size:
+                    yield buf.pop(int(_RNG.integers(0, len(buf))))
+            while buf:
+                yield buf.pop(int(_RNG.integers(0, len(buf))))
+        return Dataset(gen)
+
+    def batch(self, n, drop_remainder=False):
+        def gen():
+            cur = []
+            for e in self._source():
+                cur.append(e)
+                if len(cur) == n:
+                    yield tuple(np.stack(c) for c in zip(*cur)) if isinstance(cur[0], tuple) else np.stack(cur)
+                    cur = []
+            if cur and not drop_remainder:
+                yield tuple(np.stack(c) for c in zip(*cur)) if isinstance(cur[0], tuple) else np.stack(cur)
+        return Dataset(gen)
+
+    def repeat(self, count=None):
+        def gen():
+            i = 0
+            while count is None or i < count:
+                empty = True
+                for e in self._source():
+                    empty = False
+                    yield e
+                if empty:
+                    return
+                i += 1
+        return Dataset(gen)
+
+    def take(self, n):
+        import itertools
+        return Dataset(lambda: itertools.islice(self._source(), n))
+
+
+def get_dataset(files, ftDict, features, response, axes=[2], splits=None, one_hot=None, moments=None, **kwargs):
+    """utils/processing.py:394-419: GZIP TFRecords -> parse_single_example(ftDict) -> to_tuple."""
+    files = [files] if isinstance(files, str) else list(files)
+
+    def records():
+        for path in files:
+            for payload in read_records(path):
+                ex = decode_example(payload)
+                dic = {}
+                for k, spec in ftDict.items():
+                    if k not in ex:
+                        raise KeyError(f'{path}: feature {k} not in the record')
+                    shape = tuple(getattr(spec, 'shape', spec))
+                    dic[k] = np.asarray(ex[k], dtype=np.float32).reshape(shape)
+                yield to_tuple(dic, features, response, axes, splits, one_hot, moments, **kwargs)
+    return Dataset(records)
+
+
+def get_training_dataset(files, ftDict, features, response, buff, batch=16, repeat=True, axes=[2], splits=None, one_hot=None, moments=None, **kwargs):
+    """utils/processing.py:421-441: shuffle(buff).batch(batch)[.repeat()]."""
+    dataset = get_dataset(files, ftDict, features, response, axes, splits, one_hot, moments, **kwargs)
+    return dataset.shuffle(buff).batch(batch).repeat() if repeat else dataset.shuffle(buff).batch(batch)
+
+
+def get_eval_dataset(files, ftDict, features, response, axes=[2], splits=None, one_hot=None, moments=None, **kwargs):
+    """utils/processing.py:443-454: batch(1)."""
+    return get_dataset(files, ftDict, features, response, axes, splits, one_hot, moments, **kwargs).batch(1)
+
+
 def make_pred_dataset(file_list, features, kernel_shape=[256, 256], kernel_buffer=[128, 128], axes=[2], splits=None, moments=None,
                       one_hot=None, **kwargs):
     """utils/prediction_tools.py:159-226: generator of (1, H+buf, W+buf, C) float32 batches, files in sorted order."""

@@ -866,3 +866,33 @@ def test_predict_chunk_cached_model_files(mt, tmp_path, capsys):
     with pytest.raises(RuntimeError):
         mt.predict_chunk(chunk, 'https://account.blob.core.windows.net/models/model.h5?sig=x')
     assert mt.get_blob_model() is None
+
+
+def test_fit_and_evaluate_from_tfrecord_datasets(mt, tmp_path):
+    """The notebook's training path (notebooks/UNET_G4G_2019_solar.ipynb:1189-1277): get_training_dataset / get_eval_dataset over
+    GZIP TFRecords -> Model.fit(x=training, steps_per_epoch, validation_data, validation_steps, callbacks=[TensorBoard])."""
+    import glob
+    from satellite_computervision_amd import tfrecord_io as tio
+    rng = np.random.default_rng(5)
+    H, bands = 32, ['B2', 'B3', 'B4', 'B8']
+    path = str(tmp_path / 'train.tfrecord.gz')
+    with tio.TFRecordWriter(path, compression='GZIP') as w:
+        for i in range(12):
+            d = {b: (rng.random((H, H)) * 3000).astype(np.float32) for b in bands}
+            d['landcover'] = (d['B8'] > 1500).astype(np.float32)
+            w.write(tio.encode_example({k: v.reshape(-1) for k, v in d.items()}))
+    ft = {k: tio.FixedLenFeature([H, H]) for k in bands + ['landcover']}
+    tio.set_seed(0)
+    training = tio.get_training_dataset([path], ft, bands, {'landcover': 2}, buff=8, batch=4, moments=[(0, 3000)] * 4)
+    evaluation = tio.get_eval_dataset([path], ft, bands, {'landcover': 2}, moments=[(0, 3000)] * 4)
+    mt.reset_uids(); mt.set_seed(2)
+    m = mt.get_unet_model(2, 4, filters=[32, 64], factors=[2, 2])
+    m.compile(optimizer=mt.Adam(2e-3), loss=lambda t, p: mt.weighted_categorical_crossentropy(t, p, [1.0, 1.0]), metrics=[mt.MeanIoU(2)])
+    tb = mt.TensorBoard(log_dir=str(tmp_path / 'logs'))
+    h = m.fit(x=training, epochs=3, steps_per_epoch=6, validation_data=evaluation, validation_steps=12, callbacks=[tb], verbose=0)
+    assert len(h.history['loss']) == 3 and h.history['loss'][-1] < h.history['loss'][0]
+    assert 'val_loss' in h.history and 'val_mean_io_u' in h.history
+    ev = [tio.decode_event(r) for r in tio.read_records(glob.glob(str(tmp_path / 'logs' / 'train' / 'events.out.tfevents.*'))[0])]
+    assert [e['step'] for e in ev[1:]] == [0, 1, 2] and abs(ev[-1]['scalars']['epoch_loss'] - h.history['loss'][-1]) < 1e-6
+    res = m.evaluate(evaluation, steps=12, verbose=0)
+    assert len(res) == len(m.metrics_names) == 2
