@@ -77,7 +77,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
   }
   const int nbase = (bid % a.n_tiles) * BN;
   const int cin = a.c0 + a.c1;
-  const int fs = a.mode_in == 1 ? a.f : 1;
+  const int fs = a.mode_in == 1 ? a.f : a.stride;      // source pixels per output pixel (space-to-depth gather / strided conv)
   const int slot_t = tid % SLOTS;                  // NTHREADS % SLOTS == 0: a thread's slot is fixed
 
   // ---- tile-independent gather tables (registers): LDS offset and halo coordinates of every staged 16-byte item
@@ -127,8 +127,10 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
       const int k = a_pk[j] >> 24, yy = ((a_pk[j] >> 12) & 0xfff) - a.halh, c = (a_pk[j] & 0xfff) - a.halw;
-      const int n = n0 + k, y = y0 + yy + oy, x = x0 + c + ox;
-      a_p[j] = ((a_l[j] >= 0) && (n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_)) ? (n * a.hs + y * fs) * a.ws + x * fs : -1;
+      const int n = n0 + k, y = y0 + yy, x = x0 + c;            // output-grid coordinates (halo rows / columns may fall outside)
+      const int sy = y * fs + oy, sx = x * fs + ox;             // source coordinates; (oy, ox) = tap offset of the tap-loop form
+      a_p[j] = ((a_l[j] >= 0) && (n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_) && (sy >= 0) && (sy < a.hs) && (sx >= 0) && (sx < a.ws))
+                   ? (n * a.hs + sy) * a.ws + sx : -1;
     }
   };
   auto load_regs = [&](int chunk_) {
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
 
   int n0, y0, x0;
   tile_origin(bid, n0, y0, x0);
-  if constexpr (TL) gather_pixels(n0, y0, x0, -a.dil, -a.dil);
+  if constexpr (TL) gather_pixels(n0, y0, x0, -a.halh_tl, -a.halw_tl);
   else gather_pixels(n0, y0, x0);
   load_regs(0);
   store_lds(0);
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
         if constexpr (TL) {
           if ((chunk + 1) % a.cpt == 0) {             // next chunk starts a new tap: its tile sits at another offset
             const int tap = (chunk + 1) / a.cpt;
-            gather_pixels(n0, y0, x0, (tap / 3 - 1) * a.dil, (tap % 3 - 1) * a.dil);
+            gather_pixels(n0, y0, x0, (tap / a.kw) * a.dil - a.halh_tl, (tap % a.kw) * a.dil - a.halw_tl);
           }
         }
         load_regs(chunk + 1);
@@ -266,8 +268,10 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   a.n_tiles = cdiv(a.cout, BN);
   const int cin = a.c0 + a.c1;
   a.cpt = cin / KC;
-  a.nchunks = TL ? 9 * a.cpt : a.cpt;
-  if (TL && (a.mode_in != 0 || a.kh != 3 || a.kw != 3 || a.cpt < 1)) return SATCV_ERR_UNSUPPORTED;
+  a.nchunks = TL ? a.kh * a.kw * a.cpt : a.cpt;
+  a.halh_tl = a.dil * (a.kh - 1) / 2; a.halw_tl = a.dil * (a.kw - 1) / 2;
+  if (TL && (a.mode_in != 0 || a.cpt < 1)) return SATCV_ERR_UNSUPPORTED;
+  if (a.stride != 1 && (a.mode_in != 0 || a.mode_out != 0 || !(TL || TAPS == 1))) return SATCV_ERR_UNSUPPORTED;
   if (cin % KC != 0 || (a.x1 && a.c0 % KC != 0) || (a.mode_in == 1 && a.c0 % KC != 0)) return SATCV_ERR_UNSUPPORTED;
   // depth-to-space tiles: whole sub-pixel positions per tile, or whole tiles per sub-pixel position
   if (a.mode_out == 1 && !(a.cstat % BN == 0 || (BN % a.cstat == 0 && a.cstat % (16 / (int)sizeof(T)) == 0))) return SATCV_ERR_UNSUPPORTED;
@@ -323,7 +327,10 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   if constexpr (TAPS == 1 && KTraits<T>::SUB == 1) {
     const bool ks2 = (cin % 32 == 0) && (!a.x1 || a.c0 % 32 == 0) && (a.mode_in != 1 || a.c0 % 32 == 0);
     if (a.taploop) {
-      if (!ks2) return SATCV_ERR_UNSUPPORTED;
+      if (!ks2) {            // 16-channel chunks (the 7x7 stem on a 4-band tile stored as 16 channels)
+        if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 1, TAPS, true>(a, st, dry);
+        return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS, true>(a, st, dry);
+      }
       if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS, true>(a, st, dry);
       if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 2, TAPS, true>(a, st, dry);
       return fast_cfg<T, TW, 4, 1, 2, 1, 2, TAPS, true>(a, st, dry);
@@ -359,14 +366,19 @@ static int fast_t(IgemmArgs& a, hipStream_t st, bool dry) {
 
 int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   const int taps = a.kh * a.kw;
-  if (!(taps == 1 || (a.kh == 3 && a.kw == 3)) || a.stride != 1) return SATCV_ERR_UNSUPPORTED;
+  const bool k3 = a.kh == 3 && a.kw == 3;
+  const bool odd_sq = a.kh == a.kw && (a.kh & 1) && a.kh <= 7;
   a.taploop = 0;
-  if (taps == 9 && a.dil > 1 && dtype != SATCV_FP8X) {
-    // dilated 3x3: the halo-tile form when its staged tile fits the register budget (small dilation on narrow tiles), else the tap loop
+  if (a.stride < 1) a.stride = 1;
+  if (taps > 1 && odd_sq && (a.dil > 1 || a.stride > 1 || !k3) && dtype != SATCV_FP8X) {
+    // dilated 3x3: the halo-tile form when its staged tile fits the register budget (small dilation on narrow tiles), else the tap loop;
+    // strided and larger odd kernels (ResNet stem / stage transitions): always the tap loop
     int rc = SATCV_ERR_UNSUPPORTED;
-    if (dtype == SATCV_BF16) rc = fast_t<bf16, 9>(a, st, true);
-    else if (dtype == SATCV_F32) rc = fast_t<float, 9>(a, st, true);
-    else if (dtype == SATCV_FP8) rc = fast_t<fp8, 9>(a, st, true);
+    if (k3 && a.stride == 1) {
+      if (dtype == SATCV_BF16) rc = fast_t<bf16, 9>(a, st, true);
+      else if (dtype == SATCV_F32) rc = fast_t<float, 9>(a, st, true);
+      else if (dtype == SATCV_FP8) rc = fast_t<fp8, 9>(a, st, true);
+    }
     if (rc != SATCV_OK) {
       a.taploop = 1;
       if (dtype == SATCV_BF16) return fast_t<bf16, 1>(a, st, dry);
@@ -374,6 +386,7 @@ int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
       return fast_t<fp8, 1>(a, st, dry);
     }
   }
+  if (!(taps == 1 || k3) || (a.stride != 1 && taps != 1)) return SATCV_ERR_UNSUPPORTED;
   if (dtype == SATCV_BF16) return taps == 1 ? fast_t<bf16, 1>(a, st, dry) : fast_t<bf16, 9>(a, st, dry);
   if (dtype == SATCV_F32) return taps == 1 ? fast_t<float, 1>(a, st, dry) : fast_t<float, 9>(a, st, dry);
   if (dtype == SATCV_FP8) return taps == 1 ? fast_t<fp8, 1>(a, st, dry) : fast_t<fp8, 9>(a, st, dry);

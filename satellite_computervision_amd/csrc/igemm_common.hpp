@@ -21,6 +21,7 @@ struct IgemmArgs {
   int rpi, imgs, seg, rl, cl, pitch, halh, halw;
   int n_tiles;                     // N tiles
   int nchunks;
+  int halh_tl, halw_tl;            // tap-loop form: offset of tap (0, 0) in source pixels
   int taploop, cpt;                // tap-loop form of a dilated 3x3 conv: K = 9 taps x cpt channel chunks, one shifted tile per tap
   int dbg;                         // ablation bits (env SATCV_DBG): 1 skip stores, 2 skip MFMA, 4 skip A loads, 8 skip B loads
 };

@@ -102,10 +102,12 @@ def _p(t):
 
 
 def conv2d(x, w_packed, cout, *, kh=3, kw=3, dil=1, bias=None, x1=None, in_scale=None, in_shift=None, in_relu=False,
-           stats=None, out=None, out_relu=False):
+           stats=None, out=None, out_relu=False, stride=1):
     """layers.Conv2D(cout,(kh,kw),padding='same',dilation_rate=dil) (utils/model_tools.py:178) on
-    NHWC storage tensors; optional fused input BatchNorm-affine+ReLU and output sum/sumsq."""
-    n, h, w_, c0 = x.shape
+    NHWC storage tensors; optional fused input BatchNorm-affine+ReLU and output sum/sumsq.  stride > 1 (ResNet backbone of the
+    build-defined DeepLab): symmetric padding dil*(k-1)/2, output (h-1)//stride+1."""
+    n, hin, win, c0 = x.shape
+    h, w_ = ((hin - 1) // stride + 1, (win - 1) // stride + 1) if stride > 1 else (hin, win)
     dtype = DTYPE_CODE[x.dtype]
     c1 = x1.shape[-1] if x1 is not None else 0
     cpad = rup(cout, 32)
@@ -113,7 +115,7 @@ def conv2d(x, w_packed, cout, *, kh=3, kw=3, dil=1, bias=None, x1=None, in_scale
     d = make_conv_desc(x0=_p(x), c0=c0, x1=_p(x1), c1=c1, w=_p(w_packed), y=_p(y), ldy=y.shape[-1], n=n, h=h, w_=w_,
                        cout=cout, cout_pad=cpad, dtype=dtype, in_scale=_p(in_scale), in_shift=_p(in_shift),
                        in_relu=in_relu, bias=_p(bias), stats=_p(stats), stats_ld=stats.shape[-1] if stats is not None else 0,
-                       kh=kh, kw=kw, dil=dil, out_relu=out_relu)
+                       kh=kh, kw=kw, dil=dil, out_relu=out_relu, stride=stride, hin=hin if stride > 1 else 0, win=win if stride > 1 else 0)
     check(lib.satcv_conv2d_igemm(C.byref(d), stream_ptr()))
     return y
 

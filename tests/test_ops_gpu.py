@@ -397,3 +397,41 @@ def test_dilated_convs_run_on_the_pipelined_kernel(ops):
         d = ops.make_conv_desc(x0=x.data_ptr(), c0=128, w=w.data_ptr(), y=y.data_ptr(), ldy=256, n=2, h=32, w_=32, cout=256, cout_pad=256, kh=3, kw=3,
                                dil=dil, dtype=BF16)
         assert lib.satcv_conv2d_igemm_pipelined(C.byref(d)) == 1, dil
+
+
+@pytest.mark.parametrize('td', DT)
+@pytest.mark.parametrize('case', [(2, 64, 64, 4, 64, 7, 2, 1), (2, 33, 47, 64, 64, 3, 2, 1), (3, 32, 32, 64, 128, 1, 2, 1), (1, 31, 31, 32, 32, 3, 2, 2),
+                                  (2, 24, 40, 16, 32, 5, 1, 1)])
+def test_strided_and_large_kernel_convs(ops, td, case):
+    """ResNet-style convolutions of the build-defined DeepLab backbone: 7x7 / stride-2 stem, 3x3 and 1x1 stride-2 transitions, odd
+    input sizes (symmetric padding dil*(k-1)/2, output (h-1)//stride+1) -- the tap-loop form of the pipelined kernel -- against
+    torch.nn.functional.conv2d in float64, with the fused input affine + ReLU and the epilogue statistics."""
+    import ctypes as C
+    from satellite_computervision_amd._lib import lib
+    n, h, w, cin, cout, k, stride, dil = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (k, k, cin, cout), td, 0.2)
+    b = rng.standard_normal(cout)
+    sc, sh = 1 + 0.2 * rng.standard_normal(cin), 0.2 * rng.standard_normal(cin)
+    act = np.maximum(x * sc + sh, 0)
+    pad = dil * (k - 1) // 2
+    ref = torch.nn.functional.conv2d(torch.tensor(act).permute(0, 3, 1, 2), torch.tensor(kern).permute(3, 2, 0, 1), torch.tensor(b), stride=stride,
+                                     padding=pad, dilation=dil).permute(0, 2, 3, 1).numpy()
+    cpad = rup(cin, 16)
+    wf, _ = ops.pack_weights(f32dev(kern), cpad, ops.DTYPE_CODE[td], want_dgrad=False)
+    scp, shp = np.zeros(cpad), np.zeros(cpad)
+    scp[:cin], shp[:cin] = sc, sh
+    stats = ops.new_stats(rup(cout, 16), dev())
+    xd = to_dev(x, td, cpad)
+    y = ops.conv2d(xd, wf, cout, kh=k, kw=k, dil=dil, bias=f32dev(b), stats=stats, stride=stride, in_scale=f32dev(scp), in_shift=f32dev(shp), in_relu=True)
+    torch.cuda.synchronize()
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    assert tuple(y.shape[:3]) == (n, ho, wo) and ref.shape[1:3] == (ho, wo)
+    got = back(y, cout)
+    close(got, ref, td, f'strided conv {case}', k=2.0)
+    s = stats.sum(0).double().cpu().numpy()
+    np.testing.assert_allclose(s[0, :cout], got.sum((0, 1, 2)), rtol=2e-4, atol=2e-3 * np.sqrt(n * ho * wo))
+    d = ops.make_conv_desc(x0=xd.data_ptr(), c0=cpad, w=wf.data_ptr(), y=y.data_ptr(), ldy=y.shape[-1], n=n, h=ho, w_=wo, cout=cout, cout_pad=rup(cout, 32),
+                           kh=k, kw=k, dil=dil, dtype=ops.DTYPE_CODE[td], stride=stride, hin=h if stride > 1 else 0, win=w if stride > 1 else 0)
+    assert lib.satcv_conv2d_igemm_pipelined(C.byref(d)) == 1
