@@ -9,9 +9,11 @@ Random draws use Python's `random` in the reference's order (per colour-augmente
 vertical flip, horizontal flip, rot90 count), so `random.seed(k)` reproduces the reference's augmentation choices; the
 N(0,1) replacement values of masked pixels come from a counter-based device generator (the reference's np.random.randn
 stream cannot be reproduced on the device)."""
+import copy
 import ctypes as C
 import os
 import random
+from pathlib import Path
 
 import numpy as np
 import torch
@@ -21,6 +23,35 @@ from ._lib import lib, check, TileDesc
 
 _KIND = {np.dtype('uint8'): 0, np.dtype('uint16'): 1, np.dtype('float32'): 2, np.dtype('int16'): 3, np.dtype('float64'): 4,
          np.dtype('int32'): 5, np.dtype('int64'): 6}
+
+
+# ---- file-list helpers that feed the generators (utils/processing.py:26-114); pinned by tests/golden/file_helpers_reference.json
+def get_file_id(f, delim='_', parts=slice(3, 5), flag=False):
+    """Identifier of a tile file: the `parts` slice of its stem split on `delim`, as a tuple (utils/processing.py:26-45)."""
+    return tuple(Path(f).stem.split(delim)[parts])
+
+
+def match_files(urls, vars, delim='_', parts=slice(3, 5), subset=None, flatdirectory=False):
+    """utils/processing.py:47-89: per variable of `vars` (skipping those whose 'files' is None) the sorted files whose identifier
+    occurs for EVERY variable (and in `subset`, when given).  A file belongs to variable k if its path contains '/k/' -- or
+    '_k_' with flatdirectory.  Returns a deep copy of `vars` with the 'files' lists filled in."""
+    out = copy.deepcopy(vars)
+    mark = '_{}_' if flatdirectory else '/{}/'
+    per_var = {k: [u for u in urls if mark.format(k) in u] for k, v in out.items() if v['files'] is not None}
+    common = set.intersection(*[{get_file_id(f, delim, parts) for f in fl} for fl in per_var.values()])
+    if subset:
+        common &= set(subset)
+    for k, fl in per_var.items():
+        out[k].update({'files': sorted(f for f in fl if get_file_id(f, delim, parts) in common)})
+    return out
+
+
+def split_files(files, labels=['label', 'lu', 'naip', 'lidar', 's2'], delim='_', parts=slice(3, 5)):
+    """utils/processing.py:91-114: one list per label (a path COMPONENT here, not a substring) of the files whose identifier is
+    present for every label, in the order of `files`."""
+    of = [[f for f in files if lab in Path(f).parts] for lab in labels]
+    common = set.intersection(*[{get_file_id(f, delim, parts) for f in fl} for fl in of])
+    return [[f for f in fl if get_file_id(f, delim, parts) in common] for fl in of]
 
 
 def merge_lut(trans, device):

@@ -127,6 +127,29 @@ def main():
     a['merge_lc_default'] = at.merge_classes(lab, [(12, 3), (11, 3), (10, 3), (9, 8), (255, 0)], lab)
     a['merge_dup_rule'] = at.merge_classes(lab, [(5, 1), (1, 7), (5, 2)], lab)          # rules test the ORIGINAL values; later wins
     np.savez_compressed(f'{OUT}/array_tools_reference.npz', **a)
+    # file-list helpers of utils/processing.py:26-114 are pure Python (the module itself needs tensorflow): run the real bodies
+    import copy, json
+    from pathlib import Path
+    fh = extract_functions(f'{REF}/utils/processing.py', {'get_file_id', 'match_files', 'split_files'})
+    fh.update(Path=Path, copy=copy)
+    rngf = np.random.default_rng(21)
+    urls = []
+    for var in ('naip', 's2', 'label', 'lidar'):
+        for t in range(12):
+            if rngf.random() < 0.8:
+                urls.append(f'/data/train/{var}/md_2019_{var}_{t // 4:03d}_{t % 4:03d}.npy')
+    flat = [f'/blob/train/aoi_2019_{var}_{t:03d}_{(t * 7) % 5:03d}.npy' for var in ('naip', 's2', 'label') for t in range(9) if (t + len(var)) % 4]
+    rngf.shuffle(urls)
+    cases = {
+        'ids': [[u, list(fh['get_file_id'](u))] for u in urls[:6]] + [['a-b-c-d-e-f.npy', list(fh['get_file_id']('a-b-c-d-e-f.npy', '-', slice(1, 4)))]],
+        'match': fh['match_files'](urls, {'naip': {'files': []}, 's2': {'files': []}, 'label': {'files': []}, 'lidar': {'files': None}}),
+        'match_subset': fh['match_files'](urls, {'naip': {'files': [], 'bands': 4}, 'label': {'files': []}}, subset={('000', '001'), ('001', '002'), ('002', '003')}),
+        'match_flat': fh['match_files'](flat, {'naip': {'files': []}, 's2': {'files': []}, 'label': {'files': []}}, parts=slice(3, 5), flatdirectory=True),
+        'split': fh['split_files'](urls, labels=['label', 'naip', 's2']),
+        'urls': urls, 'flat': flat,
+    }
+    with open(f'{OUT}/file_helpers_reference.json', 'w') as f:
+        json.dump(cases, f, indent=1, sort_keys=True)
     print('wrote fixtures:', len(out), len(a))
 
 

@@ -183,3 +183,21 @@ def test_descriptor_layouts_match_the_header(tmp_path):
     doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     blk = doc[doc.index('class ConvDesc'):doc.index('lib.satcv_conv2d_igemm.argtypes')]
     assert re.findall(r"\('(\w+)',", blk) == [f[0] for f in _lib.ConvDesc._fields_]
+
+
+def test_file_list_helpers_match_reference_fixture():
+    """get_file_id / match_files / split_files (utils/processing.py:26-114) against outputs of the reference's own function bodies
+    (tests/golden/make_reference_fixtures.py)."""
+    import json
+    from satellite_computervision_amd import processing as P
+    z = json.load(open(os.path.join(GOLD, 'file_helpers_reference.json')))
+    for u, want in z['ids'][:-1]:
+        assert list(P.get_file_id(u)) == want
+    assert list(P.get_file_id('a-b-c-d-e-f.npy', '-', slice(1, 4))) == z['ids'][-1][1]
+    urls, flat = z['urls'], z['flat']
+    spec = {'naip': {'files': []}, 's2': {'files': []}, 'label': {'files': []}, 'lidar': {'files': None}}
+    assert P.match_files(urls, spec) == z['match'] and spec['naip']['files'] == []              # the argument is not modified
+    got = P.match_files(urls, {'naip': {'files': [], 'bands': 4}, 'label': {'files': []}}, subset={('000', '001'), ('001', '002'), ('002', '003')})
+    assert got == z['match_subset']
+    assert P.match_files(flat, {'naip': {'files': []}, 's2': {'files': []}, 'label': {'files': []}}, parts=slice(3, 5), flatdirectory=True) == z['match_flat']
+    assert P.split_files(urls, labels=['label', 'naip', 's2']) == z['split']
