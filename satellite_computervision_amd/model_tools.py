@@ -881,9 +881,23 @@ class Model:
             else:
                 dst.copy_(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)), non_blocking=True)
 
-    @staticmethod
-    def _shape_of(xb):
-        return (xb[0] if isinstance(xb, (list, tuple)) else xb).shape
+    def _shape_of(self, xb):
+        """(n, h, w, c) of a batch (of the first input for multi-input models); Keras-style ValueError for anything that is not a
+        non-empty NHWC batch with the channel counts the model was built for."""
+        xs = list(xb) if isinstance(xb, (list, tuple)) else [xb]
+        if len(xs) != len(self.inputs):
+            raise ValueError(f'model expects {len(self.inputs)} input array(s), got {len(xs)}')
+        for t, x in zip(self.inputs, xs):
+            shp = tuple(x.shape)
+            if len(shp) != 4:
+                raise ValueError(f'input {t.name}: expected a 4-D (batch, height, width, channels) array, got shape {shp}')
+            if shp[0] == 0:
+                raise ValueError('Expect x to be a non-empty array or dataset.')
+            if shp[3] != t.channels:
+                raise ValueError(f'input {t.name}: expected {t.channels} channels (shape (None, None, None, {t.channels})), got shape {shp}')
+            if shp != tuple(xs[0].shape[:3]) + (shp[3],):
+                raise ValueError(f'inputs disagree in batch / spatial size: {tuple(xs[0].shape)} vs {shp}')
+        return tuple(xs[0].shape)
 
     def predict_on_device(self, xb):
         """xb: (n,h,w,c) ndarray or device tensor -> list of device tensors [probs, classes] (no host sync)."""
@@ -896,8 +910,10 @@ class Model:
     def predict(self, x, batch_size=None, verbose=0, steps=None, **kw):
         """Model.predict semantics used by the reference (utils/prediction_tools.py:152, 251, 333, 515):
         inference-mode forward; ndarray or iterable of batches; list of arrays in output order."""
-        batches, nb = _as_batches(x, None, batch_size or 32)
         multi = len(self.inputs) > 1
+        if isinstance(x, (np.ndarray, torch.Tensor)) or (multi and isinstance(x, (list, tuple)) and all(isinstance(a_, (np.ndarray, torch.Tensor)) for a_ in x)):
+            self._shape_of(x)                    # whole-array input: reject empty / mis-shaped data before anything is staged
+        batches, nb = _as_batches(x, None, batch_size or 32)
         # results go D2H asynchronously into page-locked host arrays (one per output, grown as batches arrive): no per-batch
         # synchronisation and no final concatenation; the copy of batch i overlaps the staging and compute of batch i+1
         pinned, filled = None, 0
@@ -923,8 +939,10 @@ class Model:
                 p_[filled:filled + nb_i].copy_(r, non_blocking=p_.is_pinned())
             filled += nb_i
             # the plan's output buffers are rewritten by the next batch: that launch is stream-ordered after the copy above
+        if pinned is None:
+            raise ValueError('Expect x to be a non-empty array or dataset.')
         torch.cuda.current_stream().synchronize()
-        arrays = [p_[:filled].numpy() for p_ in (pinned or [])]
+        arrays = [p_[:filled].numpy() for p_ in pinned]
         return arrays[0] if self._single_output else arrays
 
     __call__ = predict_on_device
@@ -1056,6 +1074,10 @@ class Model:
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, validation_data=None, steps_per_epoch=None,
             validation_steps=None, initial_epoch=0, **kw):
         """Model.fit as the notebooks call it (notebooks/UNET_G4G_2019_solar.ipynb:1267-1275)."""
+        if isinstance(x, (np.ndarray, torch.Tensor)):
+            self._shape_of(x)
+            if y is not None and len(y) != len(x):
+                raise ValueError(f'x and y hold different numbers of samples: {len(x)} vs {len(y)}')
         self._apply_trainable()
         hist = History()
         callbacks = list(callbacks or [])

@@ -896,3 +896,27 @@ def test_fit_and_evaluate_from_tfrecord_datasets(mt, tmp_path):
     assert [e['step'] for e in ev[1:]] == [0, 1, 2] and abs(ev[-1]['scalars']['epoch_loss'] - h.history['loss'][-1]) < 1e-6
     res = m.evaluate(evaluation, steps=12, verbose=0)
     assert len(res) == len(m.metrics_names) == 2
+
+
+def test_input_validation_messages(mt):
+    """Keras-style ValueErrors instead of kernel-level failures: empty arrays, missing batch axis, wrong band count, sizes the pooling
+    pyramid does not divide, x / y length mismatch; an empty chip list leaves the template untouched."""
+    from satellite_computervision_amd import prediction_tools as pt
+    mt.reset_uids(); mt.set_seed(0)
+    m = mt.get_unet_model(2, 4, filters=[32, 64], factors=[2, 2])
+    m.compile(optimizer=mt.Adam(1e-3), loss=lambda t, p: mt.weighted_bce(t, p, 2.0))
+    for bad, msg in ((np.zeros((0, 64, 64, 4), np.float32), 'non-empty'), (np.zeros((64, 64, 4), np.float32), '4-D'),
+                     (np.zeros((1, 64, 64, 3), np.float32), '4 channels'), (np.zeros((1, 62, 64, 4), np.float32), 'divisible')):
+        with pytest.raises(ValueError, match=msg):
+            m.predict(bad)
+    with pytest.raises(ValueError, match='non-empty'):
+        m.predict(iter([]))
+    with pytest.raises(ValueError, match='non-empty'):
+        m.fit(np.zeros((0, 64, 64, 4), np.float32), np.zeros((0, 64, 64, 2), np.float32), epochs=1, verbose=0)
+    with pytest.raises(ValueError, match='different numbers'):
+        m.fit(np.zeros((4, 64, 64, 4), np.float32), np.zeros((3, 64, 64, 2), np.float32), epochs=1, verbose=0)
+    t = pt.predict_chips(np.zeros((100, 100, 4), np.float32), [], np.ones((100, 100)), m, 32, 16)
+    assert np.array_equal(t, np.ones((100, 100)))
+    s = mt.make_siamese_unet(4, [32, 64], [2, 2])
+    with pytest.raises(ValueError, match='2 input'):
+        s.predict(np.zeros((1, 64, 64, 4), np.float32))
