@@ -455,8 +455,8 @@ class Plan:
                 lay = node.layer
                 pk = rt.packed[lay.name]
                 cout, f = tout.channels, node.attrs['f']
-                if cout % 32:
-                    raise NotImplementedError(f'{lay.name}: transposed-conv filters must be a multiple of 32')
+                if cout % 16:
+                    raise NotImplementedError(f'{lay.name}: transposed-conv filters must be a multiple of 16')
                 u = self._z(n, r.h * f, r.w * f, cout)
                 sink = sinks.get(tout.id) if training else None
                 self.fwd.append(self._conv_step(w=pk['fwd'].data_ptr(), bias=rt.pptr(lay.name + '/bias'), y=u.data_ptr(), ldy=cout,
@@ -658,6 +658,9 @@ class Plan:
         def wgrad_step(r, dy, lddy, lay, cin_real, cout, hh, ww, k, dil, f=0, accum=0):
             nonlocal ws_need
             sa = self._src_args(r)
+            if sa['x1'] is not None and sa['c0'] % 32:
+                raise NotImplementedError(f'{lay.name}: training a convolution over a concatenation needs a first part of a multiple of 32 channels '
+                                          f'(got {sa["c0"]}); inference has no such limit')
             d = ops.make_wgrad_desc(dy=dy, lddy=lddy, dw=rt.gptr(lay.name + '/kernel'), cin=cin_real, cout=cout, n=n, h=hh, w_=ww,
                                     dtype=dt, kh=k, kw=k, dil=dil, mode_dy=1 if f else 0, f=f if f else 1, transposed=1 if f else 0, accumulate=accum, **sa)
             nb = lib.satcv_conv2d_wgrad_workspace(C.byref(d))

@@ -249,7 +249,7 @@ class Fp8Plan:
                 x8, cin_s, hh, ww, qin = _single(vals[tin.id])
                 lay, f = node.layer, node.attrs['f']
                 ca, cb = cat.inputs[0].channels, tout.channels
-                if cb % 32 or ca % 16:
+                if cb % 16 or ca % 16:
                     raise NotImplementedError(f'{lay.name}: unsupported channel counts for the fp8 path')
                 kernel = rt.get_param(lay.name + '/kernel')
                 w8, wscale, cdt = self._pack(kernel, cin_s, True)

@@ -779,9 +779,48 @@ class Model:
         np.savez(path if path.endswith('.npz') else path + '.npz', **self.get_weights_dict())
 
     def load_weights(self, path, by_name=False, skip_mismatch=False):
+        """Own .npz container, or a Keras HDF5 file (`save_weights('x.h5')`, `save('x.h5')`, ModelCheckpoint .hdf5) read without
+        h5py / TensorFlow (hdf5_io.py).  HDF5 semantics follow tf.keras (utils/model_tools.py:1162, 1196): by default the
+        weight-bearing layers of the file are matched to the model's IN ORDER (names are ignored, shapes must agree);
+        by_name=True matches variables by '<layer>/<variable>' name and ignores the rest, skip_mismatch then also skips
+        variables whose shape differs."""
+        from . import hdf5_io
         p = path if os.path.exists(path) else path + '.npz'
+        if hdf5_io.is_hdf5(p):
+            return self._load_keras_hdf5(hdf5_io.read_keras_weights(p), by_name, skip_mismatch)
         with np.load(p, allow_pickle=False) as z:
             self.set_weights_dict({k: z[k] for k in z.files if not k.startswith('__')}, skip_mismatch=skip_mismatch or by_name)
+
+    def _load_keras_hdf5(self, layers, by_name, skip_mismatch):
+        specs = {ps.name: ps for ps in self.param_specs}
+        out = {}
+        if by_name:
+            for lname, ws in layers:
+                for wn, arr in ws:
+                    parts = wn.split(':')[0].split('/')
+                    key = '/'.join(parts[-2:]) if len(parts) >= 2 else f'{lname}/{parts[-1]}'
+                    key = key[:-len('moving_variance')] + 'moving_var' if key.endswith('/moving_variance') else key
+                    if key not in specs:
+                        continue
+                    if tuple(arr.shape) != specs[key].shape:
+                        if skip_mismatch:
+                            continue
+                        raise ValueError(f'{key}: shape {tuple(arr.shape)} in the file, {specs[key].shape} in the model')
+                    out[key] = arr
+        else:
+            if skip_mismatch:
+                raise ValueError('When calling model.load_weights, skip_mismatch can only be set to True when by_name is True.')
+            arrays = [(lname, wn, arr) for lname, ws in layers for wn, arr in ws]
+            mine = list(self.param_specs)
+            if len(arrays) != len(mine):
+                raise ValueError(f'the file holds {len(arrays)} weight arrays in {sum(1 for _, w in layers if w)} layers, the model '
+                                 f'expects {len(mine)} in {len(self.layers)} layers')
+            for (lname, wn, arr), ps in zip(arrays, mine):
+                if tuple(arr.shape) != ps.shape:
+                    raise ValueError(f'{lname}/{wn}: shape {tuple(arr.shape)} does not match {ps.name} {ps.shape} '
+                                     '(weights are matched in layer order; use by_name=True for partial loads)')
+                out[ps.name] = arr
+        self.set_weights_dict({k: np.ascontiguousarray(v, dtype=np.float32) for k, v in out.items()})
 
     def save(self, path):
         d = self.get_weights_dict()
@@ -1123,9 +1162,33 @@ class Model:
             print(f'  {l.name:40s} ' + ', '.join(f'{p.name.split("/")[-1]}{p.shape}' for p in l.specs))
 
 
+def unet_config_from_keras_weights(layers):
+    """Arguments of get_unet_model recovered from the weight shapes of a Keras file of that network (the model_config JSON of a
+    `.h5` names custom layers that only the reference's own module can rebuild): filters = output widths of the encoder blocks,
+    factors = kernel sizes of the transposed convolutions (up_size == pool size, utils/model_tools.py:350-372), nclasses /
+    nchannels from the head and the first kernel."""
+    kernels = [(ln, wn, a.shape) for ln, ws in layers for wn, a in ws if a.ndim == 4]
+    ups = [sh for ln, wn, sh in kernels if 'transpose' in wn or 'transpose' in ln]
+    L = len(ups)
+    if L == 0 or len(kernels) != 3 * L + 2 + L or kernels[-1][2][:2] != (1, 1):
+        raise ValueError('the weight file does not have the layer structure of get_unet_model (encoder blocks, centre, transposed '
+                         'convolution + two conv blocks per level, 1x1 head)')
+    filters = [kernels[i][2][3] for i in range(L)]
+    factors = [ups[L - 1 - i][0] for i in range(L)]
+    return dict(nclasses=kernels[-1][2][3], nchannels=kernels[0][2][2], filters=filters, factors=factors)
+
+
 def load_model(path, custom_objects=None, compile=False):
-    """models.load_model for files written by Model.save (own .npz container)."""
+    """models.load_model for files written by Model.save (own .npz container) and for Keras HDF5 files of a get_unet_model network
+    (architecture recovered from the weight shapes, weights loaded in layer order)."""
+    from . import hdf5_io
     p = path if os.path.exists(path) else path + '.npz'
+    if hdf5_io.is_hdf5(p):
+        layers = hdf5_io.read_keras_weights(p)
+        reset_uids()
+        m = get_unet_model(**unet_config_from_keras_weights(layers))
+        m._load_keras_hdf5(layers, False, False)
+        return m
     with np.load(p, allow_pickle=False) as z:
         cfg = json.loads(str(z['__builder__']))
         builders = {f.__name__: f for f in (get_unet_model, get_deeplabv3_model, get_acnn_model, get_acnn_model2)}

@@ -1,0 +1,74 @@
+"""hdf5_io (pure-Python HDF5 reader for Keras weight files) against files written by the REAL HDF5 library
+(tests/golden/make_h5_fixtures.py, run with the side interpreter that has h5py)."""
+import os
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_keras_weight_files_read_back_exactly():
+    from satellite_computervision_amd import hdf5_io as H
+    z = np.load(os.path.join(GOLD, 'keras_unet_weights.npz'))
+    keys = sorted(z.files)
+    for fname in ('keras_unet_weights.h5', 'keras_unet_model.h5'):
+        path = os.path.join(GOLD, fname)
+        assert H.is_hdf5(path) and not H.is_hdf5(os.path.join(GOLD, 'keras_unet_weights.npz'))
+        layers = H.read_keras_weights(path)
+        assert [l for l, _ in layers][:3] == ['input_1', 'encoder_block', 'encoder_block_1'] and len(layers) == 26
+        flat = [(ln, wn, a) for ln, ws in layers for wn, a in ws]
+        assert len(flat) == len(keys) == 56
+        for k, (ln, wn, a) in zip(keys, flat):
+            _, kl, kw = k.split('|')
+            assert (kl, kw) == (ln, wn) and a.dtype == np.float32 and np.array_equal(a, z[k])
+    with H.File(os.path.join(GOLD, 'keras_unet_model.h5')) as f:
+        assert f.keys() == ['extras', 'model_weights', 'optimizer_weights']
+        assert f.attrs['backend'] == 'tensorflow' and f.attrs['keras_version'] == '2.6.0'              # variable-length strings (global heap)
+        assert '"class_name": "Functional"' in f.attrs['model_config']
+        assert f['optimizer_weights/Adam/iter:0'].read() == 1234 and f['optimizer_weights/Adam/iter:0'].dtype == np.int64   # scalar dataset
+        assert np.array_equal(f['extras/chunked'].read(), np.arange(6000, dtype=np.float32).reshape(60, 100))              # chunked + gzip
+        assert np.allclose(f['extras/f64'].read(), np.linspace(0, 1, 7)) and f['extras'].attrs['note'] == 'variable-length utf-8 é'
+        assert 'model_weights/probs/probs/kernel:0' in f and 'model_weights/nope' not in f
+        with pytest.raises(KeyError):
+            f['model_weights/probs/missing']
+
+
+def test_structures_of_larger_files():
+    """300 links in one group (multi-level B-tree), header continuation blocks, chunked attributes, other numeric types, a file
+    written with libver='latest'."""
+    from satellite_computervision_amd import hdf5_io as H
+    z = np.load(os.path.join(GOLD, 'h5_stress_expected.npz'))
+    with H.File(os.path.join(GOLD, 'h5_stress.h5')) as f:
+        assert f.keys() == sorted([f'layer_{i:03d}' for i in range(300)] + ['many_attrs', 'types'])
+        for k in z.files:
+            path = k.replace('|', '/')
+            if path.startswith('latest/'):
+                continue
+            a = f[path].read()
+            assert a.shape == z[k].shape and np.array_equal(a, z[k]), path
+        at = f['many_attrs'].attrs
+        assert all(np.array_equal(at[f'attr_{i:02d}'], np.arange(i + 1) * 3) for i in range(40))
+        assert at['fixed'] == b'fixed-length' and at['f64'] == 2.5
+    layers = H.read_keras_weights(os.path.join(GOLD, 'h5_stress.h5'))             # layer_names0 + layer_names1
+    assert [l for l, _ in layers] == [f'layer_{i:03d}' for i in range(300)]
+    assert [l for l, ws in layers if ws] == [f'layer_{i:03d}' for i in range(0, 300, 50)]
+    latest = H.read_keras_weights(os.path.join(GOLD, 'h5_latest.h5'))
+    assert [(l, [w for w, _ in ws]) for l, ws in latest] == [('dense', ['dense/kernel:0', 'dense/bias:0']), ('act', [])]
+    assert np.array_equal(latest[0][1][0][1], z['latest|dense|dense|kernel:0']) and np.array_equal(latest[0][1][1][1], z['latest|dense|dense|bias:0'])
+    with pytest.raises(ValueError):
+        H.File(os.path.join(GOLD, 'h5_stress_expected.npz'))
+
+
+def test_unet_arguments_recovered_from_a_keras_file():
+    from satellite_computervision_amd import hdf5_io as H
+    from satellite_computervision_amd import model_tools as mt
+    layers = H.read_keras_weights(os.path.join(GOLD, 'keras_unet_model.h5'))
+    assert mt.unet_config_from_keras_weights(layers) == dict(nclasses=2, nchannels=4, filters=[16, 32], factors=[2, 2])
+    # the graph built from them has the same variables, in the same order and shapes, as the file
+    mt.reset_uids()
+    m = mt.get_unet_model(2, 4, filters=[16, 32], factors=[2, 2])
+    flat = [(wn, a.shape) for _, ws in layers for wn, a in ws]
+    assert [tuple(ps.shape) for ps in m.param_specs] == [tuple(sh) for _, sh in flat]
+    for ps, (wn, _) in zip(m.param_specs, flat):                  # innermost '<layer>/<variable>' scopes are Keras' automatic names
+        want = '/'.join(wn.split(':')[0].split('/')[-2:]).replace('moving_variance', 'moving_var')
+        assert ps.name == want, (ps.name, wn)

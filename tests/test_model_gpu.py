@@ -920,3 +920,81 @@ def test_input_validation_messages(mt):
     s = mt.make_siamese_unet(4, [32, 64], [2, 2])
     with pytest.raises(ValueError, match='2 input'):
         s.predict(np.zeros((1, 64, 64, 4), np.float32))
+
+
+def test_keras_hdf5_weight_files_load_into_the_model(mt, tmp_path):
+    """load_weights / load_model / predict_chunk on REAL HDF5 files in the Keras layout (written by h5py, tests/golden/make_h5_fixtures.py):
+    positional (Keras default) and by_name loading give the same model as setting the arrays directly; shape / count mismatches are
+    reported like Keras does."""
+    import os
+    from oracle.unet import UNetOracle
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    z = np.load(os.path.join(gold, 'keras_unet_weights.npz'))
+    arrays = [z[k] for k in sorted(z.files)]
+    mt.reset_uids(); mt.set_seed(1)
+    ref = mt.get_unet_model(2, 4, filters=[16, 32], factors=[2, 2])
+    ref.compute_dtype = 'float32'
+    ref.set_weights_dict({ps.name: a for ps, a in zip(ref.param_specs, arrays)})
+    x = np.random.default_rng(0).random((2, 32, 32, 4)).astype(np.float32)
+    want = ref.predict(x)
+    # independent check of the loaded numbers: the float64 oracle with the same arrays
+    names = mt.structural_names(ref)
+    o = UNetOracle(2, 4, [16, 32], [2, 2], dtype=np.float64)
+    w = ref.get_weights_dict()
+    for k in o.params:
+        o.params[k] = w[names[k]].astype(np.float64)
+    p_ref, _ = o.forward(x, training=False)
+    np.testing.assert_allclose(want[0], p_ref, atol=3e-5)
+    for kw in (dict(), dict(by_name=True), dict(by_name=True, skip_mismatch=True)):
+        for fname in ('keras_unet_weights.h5', 'keras_unet_model.h5'):
+            mt.reset_uids(); mt.set_seed(7)
+            m = mt.get_unet_model(2, 4, filters=[16, 32], factors=[2, 2])
+            m.compute_dtype = 'float32'
+            m.load_weights(os.path.join(gold, fname), **kw)
+            got = m.predict(x)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    chunk = np.moveaxis(x[0], -1, 0)
+    mt.set_compute_dtype('float32')              # load_model builds the runtime: the precision is the module default at that moment
+    try:
+        lm = mt.load_model(os.path.join(gold, 'keras_unet_model.h5'), custom_objects={'weighted_bce': None})
+        assert lm._builder['filters'] == [16, 32] and lm._builder['factors'] == [2, 2] and np.array_equal(lm.predict(x)[0], want[0])
+        assert np.array_equal(mt.predict_chunk(chunk, os.path.join(gold, 'keras_unet_model.h5')), want[0][0])
+    finally:
+        mt.set_compute_dtype('bfloat16')
+    mt.reset_uids()
+    other = mt.get_unet_model(3, 4, filters=[16, 32], factors=[2, 2])
+    with pytest.raises(ValueError, match='does not match'):
+        other.load_weights(os.path.join(gold, 'keras_unet_weights.h5'))
+    other.load_weights(os.path.join(gold, 'keras_unet_weights.h5'), by_name=True, skip_mismatch=True)       # head skipped, the rest loaded
+    assert np.array_equal(other.get_weights_dict()['conv2d/kernel'], arrays[0])
+    with pytest.raises(ValueError, match='skip_mismatch'):
+        other.load_weights(os.path.join(gold, 'keras_unet_weights.h5'), skip_mismatch=True)
+    mt.reset_uids()
+    deeper = mt.get_unet_model(2, 4, filters=[16, 32, 64], factors=[2, 2, 2])
+    with pytest.raises(ValueError, match='weight arrays'):
+        deeper.load_weights(os.path.join(gold, 'keras_unet_weights.h5'))
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_sixteen_filter_unet_inference(mt, dtype):
+    """filters=[16, 32]: 16-channel transposed convolutions (a depth-to-space tile then spans several sub-pixel positions) against the
+    NumPy oracle; training such a network is refused with a clear message (the weight-gradient kernel reads a concatenation in
+    32-channel blocks)."""
+    from oracle.unet import UNetOracle
+    filters, factors = [16, 32], [2, 2]
+    mt.reset_uids(); mt.set_seed(11)
+    m = mt.get_unet_model(2, 4, filters=filters, factors=factors)
+    m.compute_dtype = dtype
+    names = mt.structural_names(m)
+    o = UNetOracle(2, 4, filters, factors, dtype=np.float64)
+    w = m.get_weights_dict()
+    for k in o.params:
+        o.params[k] = w[names[k]].astype(np.float64)
+    rng = np.random.default_rng(4)
+    x = rng.random((3, 32, 48, 4)).astype(np.float32)
+    t = np.eye(2, dtype=np.float32)[(rng.random((3, 32, 48)) < 0.3).astype(int)]
+    p_ref, _ = o.forward(x, training=False)
+    np.testing.assert_allclose(m.predict(x)[0], p_ref, atol=3e-5 if dtype == 'float32' else 6e-2)
+    m.compile(optimizer=mt.Adam(1e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 3.0]))
+    with pytest.raises(NotImplementedError, match='multiple of 32'):
+        m.train_on_batch(x, t)
