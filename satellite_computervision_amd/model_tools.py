@@ -1207,25 +1207,35 @@ def load_model(path, custom_objects=None, compile=False):
     return m
 
 
-def retrain_model(model_file, checkpoint, eval_data, metric, weights_file=None, custom_objects=None, lr=None, freeze=None):
-    """utils/model_tools.py:1128-1176: load a saved model, evaluate it, seed checkpoint.best with the
-    current value of `metric`, optionally set the learning rate and freeze all but the last layer."""
-    m = load_model(model_file, custom_objects=custom_objects)
-    if weights_file is not None:
-        m.load_weights(weights_file, by_name=True, skip_mismatch=True)
+def retrain_model(model_file, checkpoint, eval_data, metric, weights_file=None, by_name=False, skip_mismatch=False, custom_objects=None,
+                  lr=None, freeze=None):
+    """utils/model_tools.py:1128-1176: load a saved model (a path -- own container or Keras .h5 -- or a Model object), optionally a
+    separate weights file (`by_name` / `skip_mismatch` as in Model.load_weights), evaluate it on `eval_data`, seed
+    `checkpoint.best` with the current value of `metric`, set the learning rate and optionally freeze all but the last layer.
+    Returns (model, checkpoint) like the reference.  A model restored from a file carries no loss: pass
+    custom_objects={'compile': dict(optimizer=..., loss=..., metrics=[...])} to compile it here (tf.keras restores that from the
+    file's training_config, which names Python functions this build cannot import)."""
+    m = load_model(model_file, custom_objects=custom_objects) if isinstance(model_file, (str, os.PathLike)) else model_file
+    if weights_file:
+        if str(weights_file).startswith('https'):
+            m = get_blob_weights(m=m, hdf5_url=weights_file, by_name=by_name, skip_mismatch=skip_mismatch)
+        else:
+            m.load_weights(weights_file, by_name=by_name, skip_mismatch=skip_mismatch)
     if custom_objects and 'compile' in custom_objects:
         m.compile(**custom_objects['compile'])
-    if m._loss is not None:
-        evalMetrics = m.evaluate(x=eval_data, verbose=1)
-        evalMetrics = evalMetrics if isinstance(evalMetrics, list) else [evalMetrics]
-        index = m.metrics_names.index(metric)
-        checkpoint.best = evalMetrics[index]
-    if lr and m.optimizer is not None:
+    if m._loss is None:
+        raise RuntimeError("retrain_model: the model has no loss; pass custom_objects={'compile': {...}} or compile() it first")
+    evalMetrics = m.evaluate(x=eval_data, verbose=1)
+    evalMetrics = evalMetrics if isinstance(evalMetrics, list) else [evalMetrics]
+    metrics = m.metrics_names
+    print(metrics)
+    checkpoint.best = evalMetrics[metrics.index(metric)]
+    if lr:
         m.optimizer.learning_rate = lr
     if freeze:
         for layer in m.layers[:-1]:
             layer.trainable = False
-    return m
+    return m, checkpoint
 
 
 def normalize_confusion_matrix(arr):

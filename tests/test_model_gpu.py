@@ -998,3 +998,24 @@ def test_sixteen_filter_unet_inference(mt, dtype):
     m.compile(optimizer=mt.Adam(1e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 3.0]))
     with pytest.raises(NotImplementedError, match='multiple of 32'):
         m.train_on_batch(x, t)
+
+
+def test_retrain_model_from_keras_h5(mt, tmp_path):
+    """retrain_model (utils/model_tools.py:1128-1176) on a Keras .h5 model file plus a separate weights file: evaluates, seeds the
+    checkpoint's best value, sets the learning rate, freezes all but the head, returns (model, checkpoint)."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    rng = np.random.default_rng(9)
+    x = rng.random((4, 32, 32, 4)).astype(np.float32)
+    y = np.eye(2, dtype=np.float32)[(x[..., 0] > 0.5).astype(int)]
+    ck = mt.ModelCheckpoint(str(tmp_path / 'best.npz'), monitor='val_mean_io_u', save_best_only=True, mode='max')
+    comp = dict(optimizer=mt.Adam(1e-3), loss=lambda t, p: mt.weighted_bce(t, p, 2.0), metrics=[mt.MeanIoU(2)])
+    m, ck2 = mt.retrain_model(os.path.join(gold, 'keras_unet_model.h5'), ck, [(x, y)], 'mean_io_u', weights_file=os.path.join(gold, 'keras_unet_weights.h5'),
+                              by_name=True, skip_mismatch=True, custom_objects={'compile': comp}, lr=5e-4, freeze=True)
+    assert ck2 is ck and 0.0 <= ck.best <= 1.0 and abs(float(m.optimizer.learning_rate.numpy()) - 5e-4) < 1e-9
+    assert [l.trainable for l in m.layers][-1] and not any(l.trainable for l in m.layers[:-1])
+    m2, _ = mt.retrain_model(m, ck, [(x, y)], 'loss')                      # a Model object is accepted as well
+    assert m2 is m and ck.best > 0
+    mt.reset_uids()
+    with pytest.raises(RuntimeError, match='no loss'):
+        mt.retrain_model(os.path.join(gold, 'keras_unet_model.h5'), ck, [(x, y)], 'loss')
