@@ -487,3 +487,190 @@ def read_keras_weights(path):
             ws = [(wn, np.asarray(lg[wn].read())) for wn in (_chunked_attr(lg.attrs, 'weight_names') if len(lg.attrs.get('weight_names', [])) or 'weight_names0' in lg.attrs else [])]
             out.append((lname, ws))
         return out
+
+
+# ------------------------------------------------------------------ writer (Keras weight files)
+class _Node:
+    """In-memory group: attrs {name: bytes | ndarray | float}, children {name: _Node | ndarray}."""
+
+    def __init__(self):
+        self.attrs, self.children = {}, {}
+
+    def group(self, path):
+        node = self
+        for part in [p for p in path.split('/') if p]:
+            node = node.children.setdefault(part, _Node())
+        return node
+
+    def dataset(self, path, array):
+        parts = [p for p in path.split('/') if p]
+        self.group('/'.join(parts[:-1])).children[parts[-1]] = np.asarray(array)
+
+
+_LEAF_K, _FLOAT32 = 4, bytes.fromhex('11201f000400000000002000170800177f000000')
+_DTYPES = {np.dtype('<f4'): _FLOAT32,
+           np.dtype('<f8'): bytes.fromhex('11203f000800000000004000340b0034ff030000'),
+           np.dtype('<i8'): bytes.fromhex('1008000008000000' + '00004000'), np.dtype('<i4'): bytes.fromhex('1008000004000000' + '00002000')}
+
+
+def _pad8(b):
+    return b + b'\x00' * (-len(b) % 8)
+
+
+def _space_msg(shape):
+    return struct.pack('<BBBB4x', 1, len(shape), 0, 0) + b''.join(struct.pack('<Q', int(s)) for s in shape)
+
+
+def _type_msg(dt):
+    dt = np.dtype(dt)
+    if dt.kind == 'S':
+        return struct.pack('<BBBBI', 0x13, 0x01, 0, 0, dt.itemsize)          # fixed-length string, null-padded, ASCII
+    le = dt.newbyteorder('<') if dt.itemsize > 1 else dt
+    if le not in _DTYPES:
+        raise NotImplementedError(f'writing dtype {dt}')
+    return _DTYPES[le]
+
+
+class _Writer:
+    def __init__(self):
+        self.buf = bytearray(96)                           # superblock v0 + root symbol table entry, filled in at the end
+        self.max_snods = 1
+
+    def alloc(self, data):
+        self.buf += b'\x00' * (-len(self.buf) % 8)
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    def _messages(self, msgs):
+        """version-1 object header; continuation blocks are not needed (every message < 64 KiB, total size is a 32-bit field)."""
+        body = b''
+        for mtype, flags, data in msgs:
+            data = _pad8(data)
+            if len(data) > 0xFFF8:
+                raise ValueError('object header message above 64 KiB (Keras splits such attributes: see write_keras_weights)')
+            body += struct.pack('<HHB3x', mtype, len(data), flags) + data
+        return struct.pack('<BBHII4x', 1, 0, len(msgs), 1, len(body)) + body
+
+    @staticmethod
+    def _attr_msg(name, value):
+        if isinstance(value, (bytes, str)):
+            raw = value.encode('utf8') if isinstance(value, str) else value
+            arr = np.array(raw if raw else b'\x00', dtype=f'S{max(len(raw), 1)}')
+        else:
+            arr = np.asarray(value)
+            if arr.dtype.kind == 'U':
+                arr = np.char.encode(arr, 'utf8')
+            if arr.dtype.kind == 'S' and arr.dtype.itemsize == 0:
+                arr = arr.astype('S1')
+            if arr.dtype.kind == 'f' and arr.dtype != np.float32:
+                arr = arr.astype('<f8')
+        nm = name.encode('utf8') + b'\x00'
+        t, s = _type_msg(arr.dtype), _space_msg(arr.shape)
+        raw = arr.astype(arr.dtype.newbyteorder('<') if arr.dtype.kind in 'iuf' else arr.dtype).tobytes(order='C')
+        return (0x0C, 0, struct.pack('<BBHHH', 1, 0, len(nm), len(t), len(s)) + _pad8(nm) + _pad8(t) + _pad8(s) + raw)
+
+    def dataset(self, arr):
+        arr = np.asarray(arr)
+        if arr.dtype.kind == 'f' and arr.dtype.itemsize not in (4, 8):
+            arr = arr.astype(np.float32)
+        arr = arr.astype(arr.dtype.newbyteorder('<'))
+        raw = arr.tobytes(order='C')
+        daddr = self.alloc(raw) if raw else UNDEF
+        msgs = [(0x01, 0, _space_msg(arr.shape)), (0x03, 1, _type_msg(arr.dtype)), (0x05, 1, bytes.fromhex('0202020100000000')),
+                (0x08, 0, struct.pack('<BBQQ', 3, 1, daddr, len(raw)))]
+        return self.alloc(self._messages(msgs))
+
+    def group(self, node, internal_k):
+        """-> (object header address, B-tree address, heap address)."""
+        names = sorted(node.children, key=lambda s: s.encode('utf8'))
+        addrs = {}
+        for n in names:
+            c = node.children[n]
+            addrs[n] = self.group(c, internal_k)[0] if isinstance(c, _Node) else self.dataset(c)
+        # local heap: offset 0 = empty string, then the names, then one free block
+        heap, offs = bytearray(8), {}
+        for n in names:
+            offs[n] = len(heap)
+            heap += _pad8(n.encode('utf8') + b'\x00')
+        free_at = len(heap)
+        heap += struct.pack('<QQ', 1, 32) + b'\x00' * 16          # free block: next = H5HL_FREE_NULL (1), size 32
+        haddr_data = self.alloc(bytes(heap))
+        haddr = self.alloc(b'HEAP' + struct.pack('<B3xQQQ', 0, len(heap), free_at, haddr_data))
+        # symbol table nodes of <= 2 * leaf K entries, one B-tree node above them
+        per = 2 * _LEAF_K
+        chunks = [names[i:i + per] for i in range(0, len(names), per)]
+        self.max_snods = max(self.max_snods, len(chunks))
+        keys, kids = [0], []
+        for ch in chunks:
+            ent = b''.join(struct.pack('<QQII16x', offs[n], addrs[n], 0, 0) for n in ch)
+            ent += b'\x00' * (40 * (per - len(ch)))
+            kids.append(self.alloc(b'SNOD' + struct.pack('<BBH', 1, 0, len(ch)) + ent))
+            keys.append(offs[ch[-1]])
+        body = b''
+        for i in range(2 * internal_k):
+            body += struct.pack('<Q', keys[i] if i < len(keys) else 0)
+            body += struct.pack('<Q', kids[i] if i < len(kids) else 0)
+        body += struct.pack('<Q', keys[2 * internal_k] if 2 * internal_k < len(keys) else 0)
+        baddr = self.alloc(b'TREE' + struct.pack('<BBHQQ', 0, 0, len(kids), UNDEF, UNDEF) + body)
+        msgs = [(0x11, 0, struct.pack('<QQ', baddr, haddr))] + [self._attr_msg(k, v) for k, v in node.attrs.items()]
+        return self.alloc(self._messages(msgs)), baddr, haddr
+
+
+def _count_snods(node):
+    n = (len(node.children) + 2 * _LEAF_K - 1) // (2 * _LEAF_K)
+    return max([n] + [_count_snods(c) for c in node.children.values() if isinstance(c, _Node)])
+
+
+def write_file(path, root):
+    """Serialize a _Node tree as an HDF5 file in the structures h5py writes by default (superblock v0, version-1 object headers,
+    symbol-table groups, contiguous datasets, fixed-length string attributes)."""
+    internal_k = max(16, (_count_snods(root) + 1) // 2)
+    w = _Writer()
+    oaddr, baddr, haddr = w.group(root, internal_k)
+    w.buf += b'\x00' * (-len(w.buf) % 8)
+    sb = SIGNATURE + struct.pack('<BBBBBBBBHHI', 0, 0, 0, 0, 0, 8, 8, 0, _LEAF_K, internal_k, 0)
+    sb += struct.pack('<QQQQ', 0, UNDEF, len(w.buf), UNDEF)
+    sb += struct.pack('<QQII', 0, oaddr, 1, 0) + struct.pack('<QQ', baddr, haddr)
+    w.buf[:96] = sb
+    with open(path, 'wb') as f:
+        f.write(bytes(w.buf))
+
+
+_ATTR_LIMIT = 64512            # Keras' HDF5_OBJECT_HEADER_LIMIT: larger string-array attributes are split into name0, name1, ...
+
+
+def _names_attr(node, name, values):
+    arr = np.array([v.encode('utf8') for v in values]) if values else np.array([], dtype='S1')
+    if arr.nbytes <= _ATTR_LIMIT:
+        node.attrs[name] = arr
+        return
+    nchunks = 1
+    while any(c.nbytes > _ATTR_LIMIT for c in np.array_split(arr, nchunks)):
+        nchunks += 1
+    for i, c in enumerate(np.array_split(arr, nchunks)):
+        node.attrs[f'{name}{i}'] = c
+
+
+def write_keras_weights(path, layers, root_attrs=None, model_weights_group=False, extra_groups=None):
+    """The layout of tf.keras `save_weights('x.h5')` (or, with model_weights_group, of `save('x.h5')`): `layers` =
+    [(layer name, [(weight name, array)])] in model order; root_attrs are bytes / str / arrays; extra_groups = {group path:
+    [(dataset path, array)]} (e.g. optimizer_weights)."""
+    root = _Node()
+    for k, v in (root_attrs or {}).items():
+        root.attrs[k] = v
+    g = root.group('model_weights') if model_weights_group else root
+    _names_attr(g, 'layer_names', [ln for ln, _ in layers])
+    g.attrs['backend'] = b'tensorflow'
+    g.attrs.setdefault('keras_version', b'2.6.0')
+    for ln, ws in layers:
+        lg = g.group(ln)
+        _names_attr(lg, 'weight_names', [wn for wn, _ in ws])
+        for wn, arr in ws:
+            lg.dataset(wn, arr)
+    for gp, items in (extra_groups or {}).items():
+        eg = root.group(gp)
+        _names_attr(eg, 'weight_names', [wn for wn, _ in items])
+        for wn, arr in items:
+            eg.dataset(wn, arr)
+    write_file(path, root)

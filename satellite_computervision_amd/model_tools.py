@@ -773,9 +773,44 @@ class Model:
             self._fp8_plans = {}                             # fp8 weight images are re-quantised when the plans are rebuilt
         self._weights_version = getattr(self, '_weights_version', 0) + 1      # folded inference plans re-derive their arrays
 
-    # ---- persistence: own .npz container keyed '<layer>/<variable>' with Keras' auto-generated layer names; a real
-    # tf.keras model converts to/from it with tools/keras_to_npz.py on a TensorFlow host (HDF5 itself is not read here)
+    # ---- persistence.  Paths ending in .h5 / .hdf5 are Keras HDF5 files (hdf5_io.py: written and read without h5py / TensorFlow, in the
+    # layer grouping tf.keras uses for this network so that the reference's own model can load them in layer order); anything else
+    # is the own .npz container keyed '<layer>/<variable>' with Keras' auto-generated layer names.
+    def _keras_layers(self):
+        """[(top-level Keras layer name, [(variable name, array)])] in model order.  For get_unet_model graphs the encoder blocks
+        and the centre block are the reference's custom layers (`encoder_{i}` / `conv_block`, utils/model_tools.py:348, 359) owning
+        the six variables of their conv + BatchNormalization under nested scopes; every other layer is a plain Keras layer."""
+        w = self.get_weights_dict()
+        owner = {}
+        try:
+            sn = structural_names(self)
+            for rn, pn in sn.items():
+                blk = rn.split('.')[0]
+                if blk.startswith('enc'):
+                    owner[pn] = (f'encoder_{blk[3:]}', f'encoder_{blk[3:]}/conv_block/conv_batch_act/')
+                elif blk == 'center':
+                    owner[pn] = ('conv_block', 'conv_block/conv_batch_act/')
+        except Exception:
+            owner = {}
+        groups, index = [], {}
+        for lay in self.layers:
+            for ps in lay.specs:
+                top, prefix = owner.get(ps.name, (lay.name, ''))
+                if top not in index:
+                    index[top] = len(groups)
+                    groups.append((top, []))
+                var = ps.name.replace('/moving_var', '/moving_variance')
+                groups[index[top]][1].append((f'{prefix}{var}:0', w[ps.name]))
+        return groups
+
+    @staticmethod
+    def _is_h5_path(path):
+        return str(path).endswith(('.h5', '.hdf5'))
+
     def save_weights(self, path):
+        if self._is_h5_path(path):
+            from . import hdf5_io
+            return hdf5_io.write_keras_weights(path, self._keras_layers())
         np.savez(path if path.endswith('.npz') else path + '.npz', **self.get_weights_dict())
 
     def load_weights(self, path, by_name=False, skip_mismatch=False):
@@ -823,9 +858,19 @@ class Model:
         self.set_weights_dict({k: np.ascontiguousarray(v, dtype=np.float32) for k, v in out.items()})
 
     def save(self, path):
+        rt = self.runtime
+        if self._is_h5_path(path):
+            from . import hdf5_io
+            layers = self._keras_layers()
+            cfg = {'class_name': 'Functional', 'config': {'name': self.name, 'layers': [{'name': n} for n, _ in layers]}}
+            attrs = {'model_config': json.dumps(cfg), 'satcv_builder': json.dumps(self._builder or {}), 'keras_version': b'2.6.0', 'backend': b'tensorflow'}
+            extra = None
+            if rt.adam_m is not None:
+                extra = {'optimizer_weights': [('satcv_adam/m:0', rt.adam_m.cpu().numpy()), ('satcv_adam/v:0', rt.adam_v.cpu().numpy()),
+                                               ('satcv_adam/state:0', rt.adam_state.cpu().numpy())]}
+            return hdf5_io.write_keras_weights(path, layers, root_attrs=attrs, model_weights_group=True, extra_groups=extra)
         d = self.get_weights_dict()
         d['__builder__'] = np.asarray(json.dumps(self._builder or {}))
-        rt = self.runtime
         if rt.adam_m is not None:
             d['__adam_m__'], d['__adam_v__'] = rt.adam_m.cpu().numpy(), rt.adam_v.cpu().numpy()
             d['__adam_state__'] = rt.adam_state.cpu().numpy()
@@ -1185,9 +1230,20 @@ def load_model(path, custom_objects=None, compile=False):
     p = path if os.path.exists(path) else path + '.npz'
     if hdf5_io.is_hdf5(p):
         layers = hdf5_io.read_keras_weights(p)
+        with hdf5_io.File(p) as f:
+            cfg = json.loads(f.attrs['satcv_builder']) if 'satcv_builder' in f.attrs else {}
+            opt = {k: f['optimizer_weights/satcv_adam/' + k + ':0'].read() for k in ('m', 'v', 'state')} if 'optimizer_weights/satcv_adam/m:0' in f else None
+        builders = {fn.__name__: fn for fn in (get_unet_model, get_deeplabv3_model, get_acnn_model, get_acnn_model2)}
         reset_uids()
-        m = get_unet_model(**unet_config_from_keras_weights(layers))
+        if cfg.get('fn') in builders:            # written by Model.save of this build: any of its network families
+            m = builders[cfg.pop('fn')](**cfg)
+        else:                                    # a tf.keras file of the reference's get_unet_model
+            m = get_unet_model(**unet_config_from_keras_weights(layers))
         m._load_keras_hdf5(layers, False, False)
+        if opt is not None:
+            rt = m.runtime
+            rt.ensure_adam()
+            rt.adam_m.copy_(torch.from_numpy(opt['m'])); rt.adam_v.copy_(torch.from_numpy(opt['v'])); rt.adam_state.copy_(torch.from_numpy(opt['state']))
         return m
     with np.load(p, allow_pickle=False) as z:
         cfg = json.loads(str(z['__builder__']))

@@ -8,7 +8,7 @@ of `Model.save('x.h5')`: the same tree under /model_weights plus model_config / 
 /optimizer_weights group) and keras_unet_weights.npz (the same arrays, flat, in file order) to compare against.
 
 The layer / variable names follow what tf.keras generates for the reference's get_unet_model(2, 4, filters=[16, 32],
-factors=[2, 2]) (utils/model_tools.py:394-415): custom layers (encoder_block > conv_block > conv_batch_act) own nested variable
+factors=[2, 2]) (utils/model_tools.py:394-415): custom layers (encoder_{i} > conv_block > conv_batch_act) own nested variable
 scopes, the layers of decoder_block (Conv2DTranspose, Concatenate, BatchNormalization, Activation, Conv2D) are top-level functional layers,
 weightless layers are listed with an empty weight_names attribute.  Values are seeded random numbers: the files pin the CONTAINER
 format, not a trained model.
@@ -30,9 +30,10 @@ def cba(prefix, cin, cout, conv, bn, k=3):
 
 def layers():
     L = [('input_1', [])]
-    L.append(('encoder_block', cba('encoder_block/conv_block/conv_batch_act', 4, 16, 'conv2d', 'batch_normalization')))
-    L.append(('encoder_block_1', cba('encoder_block_1/conv_block_1/conv_batch_act_2', 16, 32, 'conv2d_2', 'batch_normalization_2')))
-    L.append(('conv_block_2', cba('conv_block_2/conv_batch_act_4', 32, 64, 'conv2d_4', 'batch_normalization_4')))
+    # explicit names of the reference: encoder_block(..., name=f'encoder_{i}') (:348), conv_block / conv_batch_act defaults (:213, :176)
+    L.append(('encoder_0', cba('encoder_0/conv_block/conv_batch_act', 4, 16, 'conv2d', 'batch_normalization')))
+    L.append(('encoder_1', cba('encoder_1/conv_block/conv_batch_act', 16, 32, 'conv2d_2', 'batch_normalization_2')))
+    L.append(('conv_block', cba('conv_block/conv_batch_act', 32, 64, 'conv2d_4', 'batch_normalization_4')))
     n_bn, n_conv, n_act = 6, 6, 0
     bnw = lambda bn, c: (bn, [(f'{bn}/{v}:0', (c,)) for v in ('gamma', 'beta', 'moving_mean', 'moving_variance')])
     act = lambda i: ('activation' + ('' if i == 0 else f'_{i}'), [])

@@ -1019,3 +1019,38 @@ def test_retrain_model_from_keras_h5(mt, tmp_path):
     mt.reset_uids()
     with pytest.raises(RuntimeError, match='no loss'):
         mt.retrain_model(os.path.join(gold, 'keras_unet_model.h5'), ck, [(x, y)], 'loss')
+
+
+def test_models_save_and_load_as_keras_hdf5(mt, tmp_path):
+    """Model.save / save_weights / ModelCheckpoint with .h5 / .hdf5 paths write Keras-layout HDF5 (encoder / centre blocks grouped
+    as the reference's custom layers) and load back bit-identically, optimizer state included; other families round-trip through
+    the stored builder arguments."""
+    from satellite_computervision_amd import hdf5_io as H
+    rng = np.random.default_rng(3)
+    x = rng.random((4, 32, 32, 4)).astype(np.float32)
+    y = np.eye(2, dtype=np.float32)[(x[..., 0] > 0.5).astype(int)]
+    mt.reset_uids(); mt.set_seed(6)
+    m = mt.get_unet_model(2, 4, filters=[32, 64], factors=[2, 2])
+    m.compile(optimizer=mt.Adam(1e-3), loss=lambda t, p: mt.weighted_bce(t, p, 2.0), metrics=[mt.MeanIoU(2)])
+    ck = mt.ModelCheckpoint(str(tmp_path / 'best.hdf5'), monitor='loss', save_best_only=True, mode='min')
+    m.fit(x, y, batch_size=4, epochs=2, verbose=0, callbacks=[ck])
+    assert H.is_hdf5(str(tmp_path / 'best.hdf5'))
+    path = str(tmp_path / 'model.h5')
+    m.save(path)
+    layers = H.read_keras_weights(path)
+    assert [l for l, _ in layers][:3] == ['encoder_0', 'encoder_1', 'conv_block'] and [len(w) for _, w in layers][:5] == [6, 6, 6, 2, 4]
+    assert layers[0][1][0][0] == 'encoder_0/conv_block/conv_batch_act/conv2d/kernel:0' and layers[0][1][5][0].endswith('batch_normalization/moving_variance:0')
+    m2 = mt.load_model(path)
+    a, b = m.predict(x), m2.predict(x)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(m2.runtime.adam_m.cpu().numpy(), m.runtime.adam_m.cpu().numpy())
+    m.save_weights(str(tmp_path / 'w.h5'))
+    mt.reset_uids(); mt.set_seed(99)
+    m3 = mt.get_unet_model(2, 4, filters=[32, 64], factors=[2, 2])
+    m3.load_weights(str(tmp_path / 'w.h5'))
+    assert np.array_equal(m3.predict(x)[0], a[0])
+    mt.reset_uids(); mt.set_seed(2)
+    ac = mt.get_acnn_model2(3, 4, nfilters=16, depth=2)
+    ac.save(str(tmp_path / 'acnn.h5'))
+    ac2 = mt.load_model(str(tmp_path / 'acnn.h5'))
+    assert [l for l, _ in H.read_keras_weights(str(tmp_path / 'acnn.h5'))][:2] == ['Conv0_1', 'bn0_1'] and np.array_equal(ac.predict(x), ac2.predict(x))
