@@ -24,10 +24,11 @@ def run(n, h, w, cin, cout, reps=20):
     print(f'  n{n} {h}x{w} {cin}->{cout}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s  {by/t/1e12:5.2f} TB/s(alg)', flush=True)
 
 
-SH = [(64, 256, 256, 16, 32), (64, 256, 256, 32, 32), (64, 256, 256, 64, 32), (64, 128, 128, 32, 64), (64, 128, 128, 64, 64), (64, 128, 128, 128, 64),
-            (64, 64, 64, 64, 128), (64, 64, 64, 128, 128), (64, 64, 64, 384, 128), (64, 32, 32, 256, 256), (64, 32, 32, 768, 256), (64, 16, 16, 512, 512),
-            (64, 16, 16, 1536, 512), (64, 8, 8, 512, 1024)]
+# every 3x3 weight gradient of get_unet_model(2, 4) at batch 64: encoder / centre Cin->Cout, decoder conv1 (2f->f) and conv2 (f->f)
+SH = [(64, 256, 256, 16, 32), (64, 256, 256, 64, 32), (64, 256, 256, 32, 32), (64, 128, 128, 32, 64), (64, 128, 128, 128, 64), (64, 128, 128, 64, 64),
+      (64, 64, 64, 64, 128), (64, 64, 64, 256, 128), (64, 64, 64, 128, 128), (64, 32, 32, 128, 256), (64, 32, 32, 512, 256), (64, 32, 32, 256, 256),
+      (64, 16, 16, 256, 512), (64, 16, 16, 1024, 512), (64, 16, 16, 512, 512), (64, 8, 8, 512, 1024)]
 if os.environ.get('PROBE_DEEP'):
-    SH = [(64, 64, 64, 128, 128), (64, 32, 32, 256, 256), (64, 32, 32, 768, 256), (64, 16, 16, 512, 512)]
+    SH = [(64, 64, 64, 128, 128), (64, 32, 32, 256, 256), (64, 32, 32, 512, 256), (64, 16, 16, 512, 512)]
 for shp in SH:
     run(*shp)
