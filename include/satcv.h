@@ -266,6 +266,9 @@ uint32_t satcv_crc32c(const void* data, uint64_t nbytes, uint32_t crc_in);
  *   x / rescale (float64; 0 = none)                                     -- :551-552, 601, 613 (255 / 10000 / 100 / 2000)
  *   nan_mask: append the mask channel; with replace (to_fit) values that are NaN or < -5000 -- in this channel or an
  *   EARLIER one of the image, as coded -- become N(0,1) draws (counter RNG on seed) and the mask is 1     -- :553-583
+ *   nan_mask == 2 (SiameseDataGenerator._get_unet_data, :797-805): mask channel = 1 where NO band of the pixel is NaN or
+ *   below -1 after the rescale; NaN elements (only) become U[0,1) draws; the colour augmentation that follows takes its mean
+ *   over the replaced values, as the reference does
  *   centre trim to (h, w_)                                                                                 -- :586-590
  *   ch_mean != NULL: (x - mean)*contra_mul + mean*bright_mul, mean = nanmean over (h, w_) per image and channel from
  *   satcv_tile_channel_mean                                             -- utils/array_tools.py:159-186

@@ -52,6 +52,10 @@ __device__ __forceinline__ double normal_draw(uint64_t seed, uint64_t idx) {
   return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
 }
 
+__device__ __forceinline__ double uniform_draw(uint64_t seed, uint64_t idx) {
+  return (double)(splitmix64(seed ^ (idx * 0xD1342543DE82EF95ull)) >> 11) * (1.0 / 9007199254740992.0);      // [0, 1)
+}
+
 // nanmean over the trimmed window of x / rescale, one workgroup per (image, channel)
 __global__ void tile_mean_kernel(const satcv_tile_desc d, double* __restrict__ out) {
   const int b = blockIdx.x / d.c, ch = blockIdx.x % d.c;
@@ -62,6 +66,8 @@ __global__ void tile_mean_kernel(const satcv_tile_desc d, double* __restrict__ o
     const int y = i / d.w_, x = i % d.w_;
     double v = load_src(d.src, d.src_kind, plane + (size_t)(y + ty) * d.win + x + tx);
     if (d.rescale != 0.0) v = d.src_kind == 2 ? (double)((float)v / (float)d.rescale) : v / d.rescale;
+    // mask mode 2 (SiameseDataGenerator): NaNs were already replaced by U[0,1) draws when the colour augmentation takes its mean
+    if (d.nan_mask == 2 && v != v) v = uniform_draw(d.seed, plane + (size_t)(y + ty) * d.win + x + tx);
     if (v == v) { s += v; ++cnt; }
   }
   __shared__ double ss[256]; __shared__ long long sc[256];
@@ -95,7 +101,13 @@ __global__ void tile_ingest_kernel(const satcv_tile_desc d) {
       const size_t plane = ((size_t)b * d.c + ch) * d.hin * d.win;
       double v = load_src(d.src, d.src_kind, plane + pix);
       if (d.rescale != 0.0) v = f32 ? (double)((float)v / (float)d.rescale) : v / d.rescale;
-      if (d.nan_mask) {
+      if (d.nan_mask == 2) {
+        // SiameseDataGenerator._get_unet_data (utils/processing.py:797-805): a pixel is valid when no band is NaN or below -1 (after the
+        // rescale); only the NaN elements themselves are replaced, by U[0,1) draws
+        const bool isn = v != v;
+        flagged = flagged || isn || (v < -1.0);
+        if (isn) v = uniform_draw(d.seed, plane + pix);
+      } else if (d.nan_mask) {
         // the reference's mask ACCUMULATES over the channel order (utils/processing.py:561-566)
         flagged = flagged || (v != v) || (v < -5000.0);
         if (flagged && d.replace) v = normal_draw(d.seed, plane + pix);
@@ -112,7 +124,8 @@ __global__ void tile_ingest_kernel(const satcv_tile_desc d) {
       }
       o[ch] = (float)v;
     }
-    if (d.nan_mask) o[d.c] = (flagged && d.replace) ? 1.f : 0.f;
+    if (d.nan_mask == 2) o[d.c] = flagged ? 0.f : 1.f;                 // 1 = every band valid
+    else if (d.nan_mask) o[d.c] = (flagged && d.replace) ? 1.f : 0.f;
   }
 }
 
@@ -172,7 +185,8 @@ extern "C" int satcv_tile_ingest(const satcv_tile_desc* d, void* stream) {
   int rc = check_desc(d, "tile_ingest");
   if (rc) return rc;
   SATCV_CHECK(d->dst && d->ldc >= d->coff + d->c + (d->nan_mask ? 1 : 0), "tile_ingest: destination channel range");
-  SATCV_CHECK(!(d->nan_mask && d->ch_mean), "tile_ingest: the reference applies the colour augmentation only to unmasked sources");
+  SATCV_CHECK(!(d->nan_mask == 1 && d->ch_mean), "tile_ingest: UNETDataGenerator applies the colour augmentation only to unmasked sources");
+  SATCV_CHECK(d->nan_mask >= 0 && d->nan_mask <= 2, "tile_ingest: nan_mask must be 0, 1 (UNETDataGenerator) or 2 (SiameseDataGenerator)");
   hipLaunchKernelGGL(tile_ingest_kernel, dim3(grid_for((long long)d->n * d->h * d->w_)), dim3(256), 0, (hipStream_t)stream, *d);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("tile_ingest launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }

@@ -995,7 +995,8 @@ class Model:
         """Model.predict semantics used by the reference (utils/prediction_tools.py:152, 251, 333, 515):
         inference-mode forward; ndarray or iterable of batches; list of arrays in output order."""
         multi = len(self.inputs) > 1
-        if isinstance(x, (np.ndarray, torch.Tensor)) or (multi and isinstance(x, (list, tuple)) and all(isinstance(a_, (np.ndarray, torch.Tensor)) for a_ in x)):
+        whole = isinstance(x, (np.ndarray, torch.Tensor)) or (multi and isinstance(x, (list, tuple)) and all(isinstance(a_, (np.ndarray, torch.Tensor)) for a_ in x))
+        if whole:
             self._shape_of(x)                    # whole-array input: reject empty / mis-shaped data before anything is staged
         batches, nb = _as_batches(x, None, batch_size or 32)
         # results go D2H asynchronously into page-locked host arrays (one per output, grown as batches arrive): no per-batch
@@ -1009,7 +1010,7 @@ class Model:
             res = self.predict_on_device(xb)
             nb_i = res[0].shape[0]
             if pinned is None:
-                total = (self._shape_of(x)[0] if isinstance(x, (np.ndarray, torch.Tensor)) or multi else (steps or nb or 1) * nb_i)
+                total = self._shape_of(x)[0] if whole else (steps or nb or 1) * nb_i
                 rows = max(total, nb_i)
                 big = sum(rows * r[0].numel() * r.element_size() for r in res) >= (16 << 20)      # page-locking small buffers costs more than it saves
                 pinned = [torch.empty((rows,) + tuple(r.shape[1:]), dtype=r.dtype, pin_memory=big) for r in res]

@@ -85,7 +85,7 @@ def device_source(batch_chw, unet_dim, dst, coff, *, rescale_val=0.0, add_nan_ma
     src = torch.from_numpy(batch_chw).to(dst.device, non_blocking=True)
     n, c, hin, win = batch_chw.shape
     d = TileDesc(src=src.data_ptr(), src_kind=_KIND[batch_chw.dtype], n=n, c=c, hin=hin, win=win, h=unet_dim[0], w_=unet_dim[1],
-                 rescale=float(rescale_val or 0.0), nan_mask=int(bool(add_nan_mask)), replace=int(bool(to_fit)), seed=int(seed),
+                 rescale=float(rescale_val or 0.0), nan_mask=int(add_nan_mask) if add_nan_mask in (0, 1, 2) else 1, replace=int(bool(to_fit)), seed=int(seed),
                  flip_v=int(bool(morph[0])), flip_h=int(bool(morph[1])), rot=int(morph[2]) % 4,
                  dst=dst.data_ptr(), ldc=dst.shape[-1], coff=coff)
     st = ops.stream_ptr()
@@ -129,7 +129,7 @@ class UNETDataGenerator:
         self.splits, self.moments = splits, moments
         self.lc_trans, self.lu_trans = lc_transitions, lu_transitions
         self.device = device or torch.device('cuda', torch.cuda.current_device())
-        first = labelfiles if labelfiles is not None else next(getattr(self, a) for a, *_ in self._SOURCES if getattr(self, a))
+        first = labelfiles if labelfiles is not None else next((getattr(self, a) for a, *_ in self._SOURCES if getattr(self, a)), [])
         self.indexes = np.arange(len(first))
         self.mask = bool(to_fit)                                   # :498-500
         self.on_epoch_end()
@@ -189,3 +189,59 @@ class UNETDataGenerator:
         keep += device_labels(lc, self.unet_dim, self.n_classes, y, 0, self._lut if self.lc_trans else None, lu, self._lu_lut, morph)
         torch.cuda.current_stream().synchronize()                  # the staged host batches may be released
         return x[..., :self.n_channels], y
+
+
+class SiameseDataGenerator(UNETDataGenerator):
+    """utils/processing.py:757-893: two dates of the same tiles for make_siamese_unet -- `[features_before, features_after], labels`.
+    Both dates: x / 10000, centre trim, optional validity mask (1 where no band of the pixel is NaN or below -1; NaN elements
+    become U[0,1) draws -- the reference's np.random stream is not reproduced), colour augmentation per date when fitting; labels
+    are binary (values above 1 become 1; class ids 0..255) and multiplied by the mask of BOTH dates; one flip / rot90 draw for the
+    whole stack.  Random draws in the reference's order: colour (before), colour (after), flips + rotation."""
+
+    def __init__(self, beforefiles, afterfiles, add_nan_mask: bool, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.beforefiles, self.afterfiles = beforefiles, afterfiles
+        self.mask = add_nan_mask
+        if self.labelfiles is None:
+            self.indexes = np.arange(len(beforefiles))
+        if self.shuffle:
+            np.random.shuffle(self.indexes)
+        lut = np.full(256, -1, np.int32)
+        lut[2:] = 1
+        self._binary_lut = torch.from_numpy(lut).to(self.device)
+
+    def _date(self, files, idx, color, morph, seed):
+        batch = _stack_chw([files[k] for k in idx])
+        c = batch.shape[1]
+        h, w = self.unet_dim
+        ho, wo = (w, h) if morph[2] % 2 else (h, w)
+        t = torch.empty(len(idx), ho, wo, c + (1 if self.mask else 0), dtype=torch.float32, device=self.device)
+        keep = device_source(batch, self.unet_dim, t, 0, rescale_val=10000.0, add_nan_mask=2 if self.mask else 0, to_fit=True, color=color, morph=morph, seed=seed)
+        return t, c, keep
+
+    def __getitem__(self, index):
+        idx = self.indexes[index * self.batch_size:(index + 1) * self.batch_size]
+        cb = ca = None
+        if self.to_fit:
+            cb = (random.uniform(1 - 0.05, 1 + 0.05), random.uniform(1 - 0.05, 1 + 0.05))
+            ca = (random.uniform(1 - 0.05, 1 + 0.05), random.uniform(1 - 0.05, 1 + 0.05))
+        morph = (0, 0, 0)
+        if self.to_fit:
+            morph = (random.uniform(0, 1) < 0.5, random.uniform(0, 1) < 0.5, random.randint(0, 3))
+        self._batch_counter += 1
+        tb, c, k1 = self._date(self.beforefiles, idx, cb, morph, (self._batch_counter << 21) + 1)
+        ta, _, k2 = self._date(self.afterfiles, idx, ca, morph, (self._batch_counter << 21) + (1 << 20))
+        if not self.to_fit:
+            torch.cuda.current_stream().synchronize()
+            return [tb[..., :c].contiguous(), ta[..., :c].contiguous()]
+        lc = np.stack([np.squeeze(_load(self.labelfiles[k])) for k in idx], axis=0)[:, None]       # (B, 1, H, W)
+        assert lc.ndim == 4, 'labels must be 2-D (or (1, H, W)) arrays'
+        if lc.dtype not in _KIND:
+            lc = lc.astype(np.int64)
+        y2 = torch.empty(tb.shape[0], tb.shape[1], tb.shape[2], 2, dtype=torch.float32, device=self.device)
+        k3 = device_labels(lc, self.unet_dim, 2, y2, 0, self._binary_lut, morph=morph)
+        labels = y2[..., 1:2]
+        if self.mask:
+            labels = labels * torch.minimum(tb[..., c:c + 1], ta[..., c:c + 1])
+        torch.cuda.current_stream().synchronize()
+        return [tb[..., :self.n_channels].contiguous(), ta[..., :self.n_channels].contiguous()], labels.contiguous()
