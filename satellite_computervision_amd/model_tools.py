@@ -754,6 +754,18 @@ class Model:
         torch.cuda.synchronize()
         return {p.name: rt.get_param(p.name).detach().cpu().numpy().copy() for p in self.param_specs}
 
+    def get_weights(self):
+        """Keras list form: the variables in layer order (per layer: kernel, bias / gamma, beta, moving_mean, moving_variance)."""
+        w = self.get_weights_dict()
+        return [w[ps.name] for ps in self.param_specs]
+
+    def set_weights(self, weights):
+        weights = list(weights)
+        if len(weights) != len(self.param_specs):
+            raise ValueError(f'You called `set_weights(weights)` with a weight list of length {len(weights)}, but the model was expecting '
+                             f'{len(self.param_specs)} weights.')
+        self.set_weights_dict({ps.name: np.asarray(v) for ps, v in zip(self.param_specs, weights)})
+
     def set_weights_dict(self, d, skip_mismatch=False):
         rt = self.runtime
         for k, v in d.items():

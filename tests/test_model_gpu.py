@@ -1049,6 +1049,12 @@ def test_models_save_and_load_as_keras_hdf5(mt, tmp_path):
     m3 = mt.get_unet_model(2, 4, filters=[32, 64], factors=[2, 2])
     m3.load_weights(str(tmp_path / 'w.h5'))
     assert np.array_equal(m3.predict(x)[0], a[0])
+    mt.reset_uids(); mt.set_seed(98)
+    m4 = mt.get_unet_model(2, 4, filters=[32, 64], factors=[2, 2])
+    m4.set_weights(m.get_weights())                                      # Keras list form
+    assert np.array_equal(m4.predict(x)[0], a[0]) and len(m.get_weights()) == len(m.param_specs)
+    with pytest.raises(ValueError, match='weight list of length'):
+        m4.set_weights(m.get_weights()[:-1])
     mt.reset_uids(); mt.set_seed(2)
     ac = mt.get_acnn_model2(3, 4, nfilters=16, depth=2)
     ac.save(str(tmp_path / 'acnn.h5'))
