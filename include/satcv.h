@@ -252,9 +252,15 @@ typedef struct satcv_head_desc {
   const float* bnr_mean; const float* bnr_rstd; satcv_stat_t* bnr_sums; int32_t bnr_sums_ld;
   int64_t npix;
   int32_t dtype;
+  /* bwd, optional: [satcv_head_bwd_workspace(d) bytes] -- every workgroup writes its dW / db partial sums here instead of adding
+   * them to dw / db with float atomics; satcv_head_bwd_finalize then adds the rows in fixed order (bit-reproducible gradients) */
+  float* partials;
 } satcv_head_desc;
 int satcv_head_fwd(const satcv_head_desc* d, void* stream);
 int satcv_head_bwd(const satcv_head_desc* d, void* stream);
+/* bytes of `partials` for this descriptor (0: shape outside the register-resident kernel, which then uses atomics) */
+int64_t satcv_head_bwd_workspace(const satcv_head_desc* d);
+int satcv_head_bwd_finalize(const satcv_head_desc* d, void* stream);
 
 /* CRC-32C (Castagnoli) of a HOST buffer, continuing from crc_in (0 to start): the checksum of the TFRecord framing that
  * tf.io.TFRecordWriter / tf.data.TFRecordDataset use (utils/prediction_tools.py:221, 404; utils/processing.py:416). */

@@ -70,7 +70,7 @@ class HeadDesc(C.Structure):
                 ('probs', c_vp), ('classes', c_vp), ('dlogits', c_vp),
                 ('dx', c_vp), ('lddx', c_i32), ('dw', c_vp), ('db', c_vp),
                 ('bnr_mean', c_vp), ('bnr_rstd', c_vp), ('bnr_sums', c_vp), ('bnr_sums_ld', c_i32),
-                ('npix', c_i64), ('dtype', c_i32)]
+                ('npix', c_i64), ('dtype', c_i32), ('partials', c_vp)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/satcv.h
@@ -109,6 +109,8 @@ _SIGS = {
     'satcv_crc32c': (C.c_uint32, [c_vp, C.c_uint64, C.c_uint32]),
     'satcv_head_fwd': (C.c_int, [C.POINTER(HeadDesc), c_vp]),
     'satcv_head_bwd': (C.c_int, [C.POINTER(HeadDesc), c_vp]),
+    'satcv_head_bwd_workspace': (c_i64, [C.POINTER(HeadDesc)]),
+    'satcv_head_bwd_finalize': (C.c_int, [C.POINTER(HeadDesc), c_vp]),
     'satcv_loss_fwd_bwd': (C.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_f32, c_vp, c_vp, c_vp]),
     'satcv_loss_global_fwd_bwd': (C.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     'satcv_confusion': (C.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),

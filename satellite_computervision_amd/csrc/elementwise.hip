@@ -713,8 +713,12 @@ __global__ __launch_bounds__(EW_BLOCK) void head_bwd_fast_kernel(const satcv_hea
   for (int k = 0; k < NC; ++k) { const float s = wave_sum(accb[k]); if (lane == 0) aw[wave][CIN * NC + k] = s; }
   __syncthreads();
   auto tot = [&](int i) { float t = 0.f; for (int w = 0; w < NW; ++w) t += aw[w][i]; return t; };
-  if (d.dw) for (int i = threadIdx.x; i < CIN * NC; i += blockDim.x) atomicAdd(d.dw + i, tot(i));
-  if (d.db) for (int i = threadIdx.x; i < NC; i += blockDim.x) atomicAdd(d.db + i, tot(CIN * NC + i));
+  if (d.partials) {            // one row per workgroup, added in row order by satcv_head_bwd_finalize
+    for (int i = threadIdx.x; i < CIN * NC + NC; i += blockDim.x) d.partials[(size_t)blockIdx.x * (CIN * NC + NC) + i] = tot(i);
+  } else {
+    if (d.dw) for (int i = threadIdx.x; i < CIN * NC; i += blockDim.x) atomicAdd(d.dw + i, tot(i));
+    if (d.db) for (int i = threadIdx.x; i < NC; i += blockDim.x) atomicAdd(d.db + i, tot(CIN * NC + i));
+  }
   if constexpr (BNR) {
     satcv_stat_t* rowp = d.bnr_sums + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * d.bnr_sums_ld;
     for (int i = threadIdx.x; i < CIN; i += blockDim.x) {
@@ -812,11 +816,41 @@ extern "C" int satcv_head_bwd(const satcv_head_desc* d, void* stream) {
   SATCV_CHECK(d && d->x && d->w && d->dlogits, "head_bwd: null pointer");
   SATCV_CHECK(!d->bnr_sums || (d->bnr_mean && d->bnr_rstd && d->in_scale && d->dx && d->bnr_sums_ld >= d->cin), "head_bwd: incomplete bnr_* fields");
   SATCV_CHECK(d->cin > 0 && d->cin % 8 == 0 && d->ncls >= 1 && d->ncls <= HEAD_NCMAX && d->npix > 0, "head_bwd: bad dims");
+  SATCV_CHECK(!d->partials || satcv_head_bwd_workspace(d) > 0, "head_bwd: partial rows only with the register-resident kernel");
   const size_t lds = (size_t)(2 * d->cin * d->ncls + d->ncls + 2 * d->cin) * sizeof(float);
   DISPATCH_T(d->dtype, { if (!head_fast_launch<T, true>(d, (hipStream_t)stream))
       { if (d->bnr_sums) { satcv_set_error("head_bwd: bnr fusion only on the register-resident kernel (cin in 16/32/64, small ncls)"); return SATCV_ERR_UNSUPPORTED; }
         hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(ew_grid(d->npix, 1024)), dim3(EW_BLOCK), lds, (hipStream_t)stream, *d); } });
   LAUNCH_OK("head_bwd");
+  return SATCV_OK;
+}
+
+static bool head_fast_shape(const satcv_head_desc* d) {
+  static const int shapes[][2] = {{1, 16}, {2, 16}, {1, 32}, {2, 32}, {3, 32}, {4, 32}, {1, 64}, {2, 64}};
+  for (auto& s : shapes) if (d->ncls == s[0] && d->cin == s[1]) return true;
+  return false;
+}
+extern "C" int64_t satcv_head_bwd_workspace(const satcv_head_desc* d) {
+  if (!d || d->npix <= 0 || d->cin <= 0 || d->cin % 8 || !head_fast_shape(d)) return 0;
+  return (int64_t)ew_grid(d->npix * (d->cin / 8)) * (d->cin * d->ncls + d->ncls) * (int64_t)sizeof(float);
+}
+// dw[i] / db[i] += sum over the workgroup rows of `partials`: one wave per output element, lane l adds rows l, l+64, ... in order and
+// the 64 lane sums are combined by the fixed butterfly of wave_sum -- the same association every run
+__global__ __launch_bounds__(64) void head_bwd_finalize_kernel(const float* __restrict__ partials, int rows, int nw, int nb, float* dw, float* db) {
+  const int i = blockIdx.x;
+  float s = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 64) s += partials[(size_t)r * (nw + nb) + i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
+    if (i < nw) { if (dw) dw[i] += s; }
+    else if (db) db[i - nw] += s;
+  }
+}
+extern "C" int satcv_head_bwd_finalize(const satcv_head_desc* d, void* stream) {
+  SATCV_CHECK(d && d->partials && satcv_head_bwd_workspace(d) > 0, "head_bwd_finalize: no partial rows for this descriptor");
+  const int nw = d->cin * d->ncls, nb = d->ncls, rows = ew_grid(d->npix * (d->cin / 8));
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(nw + nb), dim3(64), 0, (hipStream_t)stream, d->partials, rows, nw, nb, d->dw, d->db);
+  LAUNCH_OK("head_bwd_finalize");
   return SATCV_OK;
 }
 

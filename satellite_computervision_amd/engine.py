@@ -13,6 +13,7 @@ Fusion contract (what the HIP kernels expect):
 There is no CPU path: everything here requires the HIP library and a ROCm device.
 """
 import ctypes as C
+import os
 import itertools
 from collections import defaultdict
 from fractions import Fraction
@@ -59,6 +60,14 @@ class ParamSpec:
     @property
     def size(self):
         return int(np.prod(self.shape))
+
+
+# The bias of a convolution that feeds a training-mode BatchNormalization has an identically zero gradient: with
+# dy = scale*rstd*(g - mean(g) - xhat*mean(g*xhat)) the sum over the batch vanishes because sum(xhat) = 0.  TensorFlow computes
+# reduce_sum(dy) anyway and gets rounding noise (~1e-9), which Adam's normalisation turns into +-lr steps of a parameter that has
+# no effect on any output.  Here the gradient is the exact 0 (the bias stays at its value) unless SATCV_BN_BIAS_NOISE=1 asks for
+# the summed-noise form; the atomics it needs are also the one remaining source of run-to-run differences in a training step.
+BIAS_NOISE = os.environ.get('SATCV_BN_BIAS_NOISE', '0') == '1'
 
 
 def rup(a, b):
@@ -731,6 +740,11 @@ class Plan:
                                         dw=rt.gptr(lay.name + '/kernel'), db=rt.gptr(lay.name + '/bias'), bnr=hb)
                 self.keep.append(hd)
                 self.bwd.append(lambda st, hd=hd: check(lib.satcv_head_bwd(C.byref(hd), st)))
+                nb = lib.satcv_head_bwd_workspace(C.byref(hd))
+                if nb > 0:            # per-workgroup partial rows + an ordered sum instead of float atomics: reproducible dW / db
+                    part = self._z(nb // 4, dtype=torch.float32)
+                    hd.partials = part.data_ptr()
+                    self.bwd.append(lambda st, hd=hd: check(lib.satcv_head_bwd_finalize(C.byref(hd), st)))
                 gact[node.inputs[0].id] = (dx, 0, c)
             elif op == 'add_relu':
                 # out = ReLU(BN(conv) + shortcut): the masked gradient g * (out > 0) belongs to BOTH addends.  It is formed in place
@@ -799,7 +813,7 @@ class Plan:
                 da_ptr = da[0].data_ptr() + da[1] * es if da is not None else None
                 red, fin, app = bn_bwd_steps(da_ptr, da[2] if da is not None else 0, dp[0].data_ptr() if dp is not None else None,
                                              cout, gpool_f.get(tout.id, 1), y.data_ptr() + yoff * es, ldy, aff, aoff, sums, 0, cout, cout, hh, ww,
-                                             dy.data_ptr(), cout, rt.gptr(lay.name + '/bias'),
+                                             dy.data_ptr(), cout, rt.gptr(lay.name + '/bias') if BIAS_NOISE else None,
                                              rt.gptr(lay.bn_name + '/gamma'), rt.gptr(lay.bn_name + '/beta'), accum,
                                              linear=0 if node.attrs.get('relu', True) else 1)
                 self.bwd += [fin, app] if pre is not None else [red, fin, app]
@@ -872,7 +886,7 @@ class Plan:
                 ra_, fa_, aa_ = bn_bwd_steps(gptr_, ctot, None, 0, 1, ra.srcs[0][0].data_ptr(), ca, aff, 0, sums, 0, ctot, ca, hh, ww,
                                              dskip.data_ptr(), ca, None, rt.gptr(bn + '/gamma'), rt.gptr(bn + '/beta'))
                 rb_, fb_, ab_ = bn_bwd_steps(gptr_ + ca * es, ctot, None, 0, 1, rb.srcs[0][0].data_ptr(), cb, aff, ca, sums, ca, ctot, cb,
-                                             hh, ww, du.data_ptr(), cb, rt.gptr(upl.name + '/bias') if tb.node.op == 'convT' else None,
+                                             hh, ww, du.data_ptr(), cb, rt.gptr(upl.name + '/bias') if (tb.node.op == 'convT' and BIAS_NOISE) else None,
                                              rt.gptr(bn + '/gamma') + 4 * ca, rt.gptr(bn + '/beta') + 4 * ca)
                 self.bwd += [fa_, fb_, aa_, ab_] if pre is not None else [ra_, rb_, fa_, fb_, aa_, ab_]
                 # the skip is the activated output of an encoder conv_batch_act block

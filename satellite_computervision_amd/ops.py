@@ -257,8 +257,9 @@ def bn_relu_bwd(yraw, scale, shift, mean, rstd, da=None, dpool=None, f=1, want_d
 
 # ------------------------------------------------------------------------------ head
 def make_head_desc(*, x, ldx, cin, w, b, ncls, activation, npix, dtype, in_scale=None, in_shift=None, thresh=0.5,
-                   probs=None, classes=None, dlogits=None, dx=None, lddx=0, dw=None, db=None, bnr=None):
+                   probs=None, classes=None, dlogits=None, dx=None, lddx=0, dw=None, db=None, bnr=None, partials=None):
     d = HeadDesc()
+    d.partials = partials
     d.x, d.ldx, d.cin = x, ldx, cin
     d.in_scale, d.in_shift, d.w, d.b = in_scale, in_shift, w, b
     d.ncls, d.activation, d.thresh = ncls, activation, thresh

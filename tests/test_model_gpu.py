@@ -1060,3 +1060,27 @@ def test_models_save_and_load_as_keras_hdf5(mt, tmp_path):
     ac.save(str(tmp_path / 'acnn.h5'))
     ac2 = mt.load_model(str(tmp_path / 'acnn.h5'))
     assert [l for l, _ in H.read_keras_weights(str(tmp_path / 'acnn.h5'))][:2] == ['Conv0_1', 'bn0_1'] and np.array_equal(ac.predict(x), ac2.predict(x))
+
+
+def test_training_is_bit_reproducible(mt):
+    """Two runs of the same training steps from the same weights and batches end in BIT-IDENTICAL parameters, Adam slots and moving
+    statistics: weight-gradient slabs and head dW / db rows are added in fixed order, BN statistics go through double-precision
+    rows, the bias of a convolution under BatchNormalization has an exactly zero gradient."""
+    rng = np.random.default_rng(12)
+    xs = [rng.random((8, 64, 64, 4)).astype(np.float32) for _ in range(3)]
+    ys = [np.eye(2, dtype=np.float32)[(x[..., 0] + x[..., 3] > 1.0).astype(int)] for x in xs]
+    runs = []
+    for rep in range(2):
+        mt.reset_uids(); mt.set_seed(5)
+        m = mt.get_unet_model(2, 4, filters=[32, 64, 128], factors=[2, 2, 2])
+        m.compile(optimizer=mt.Adam(2e-3), loss=lambda t, p: mt.weighted_categorical_crossentropy(t, p, [1.0, 3.0]))
+        for step in range(6):
+            m.train_on_batch(xs[step % 3], ys[step % 3])
+        rt = m.runtime
+        torch.cuda.synchronize()
+        runs.append((m.get_weights_dict(), rt.adam_m.cpu().numpy().copy(), rt.adam_v.cpu().numpy().copy()))
+    (w0, m0, v0), (w1, m1, v1) = runs
+    diff = [k for k in w0 if not np.array_equal(w0[k], w1[k])]
+    assert not diff, diff
+    assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
+    assert all(np.all(w0[k] == 0) for k in w0 if k.endswith('/bias') and not k.startswith('probs'))      # exact zero gradient: never moved
