@@ -192,9 +192,12 @@ int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream);
 /* Residual blocks of the atrous CNN family (utils/model_tools.py:922-979: ReLU(BN(conv) + shortcut), plain Conv2D layers):
  * satcv_relu_bwd : g[i] = act[i] > 0 ? g[i] : 0 in place (gradient through the ReLU of a materialised activation; the masked
  *                  gradient then serves BOTH addends of the sum).
- * satcv_bias_grad: dbias[ch] += sum over pixels of dy[pix][ch] (a Conv2D that is not followed by BatchNormalization). */
+ * satcv_bias_grad: dbias[ch] += sum over pixels of dy[pix][ch] (a Conv2D that is not followed by BatchNormalization).  With
+ *                  `partials` (satcv_bias_grad_workspace bytes) the workgroups write rows that a second launch adds in fixed order
+ *                  (bit-reproducible); NULL: float atomics. */
 int satcv_relu_bwd(const void* act, void* g, int64_t count, int32_t dtype, void* stream);
-int satcv_bias_grad(const void* dy, int32_t lddy, int64_t npix, int32_t c, int32_t dtype, float* dbias, void* stream);
+int64_t satcv_bias_grad_workspace(int64_t npix, int32_t c);
+int satcv_bias_grad(const void* dy, int32_t lddy, int64_t npix, int32_t c, int32_t dtype, float* dbias, float* partials, void* stream);
 
 /* ------------------------------------------ ResNet / DeepLab-v3 inference helpers
  * The reference has no DeepLab-v3/ResNet-50 code (README.md:8 only names it); these ops serve the build-defined

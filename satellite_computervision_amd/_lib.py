@@ -99,7 +99,8 @@ _SIGS = {
     'satcv_affine_requant': (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp]),
     'satcv_add_act': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp]),
     'satcv_relu_bwd': (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp]),
-    'satcv_bias_grad': (C.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    'satcv_bias_grad_workspace': (c_i64, [c_i64, c_i32]),
+    'satcv_bias_grad': (C.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     'satcv_upsample_head': (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
     'satcv_dropout_mask': (C.c_int, [C.c_uint64, C.c_uint64, c_f32, c_i64, c_vp, c_vp]),
     'satcv_dropout_apply': (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),

@@ -984,7 +984,8 @@ extern "C" int satcv_relu_bwd(const void* act, void* g, int64_t count, int32_t d
   return SATCV_OK;
 }
 template <typename T>
-__global__ __launch_bounds__(EW_BLOCK) void bias_grad_kernel(const T* __restrict__ dy, int lddy, long long npix, int c, float* __restrict__ dbias) {
+__global__ __launch_bounds__(EW_BLOCK) void bias_grad_kernel(const T* __restrict__ dy, int lddy, long long npix, int c, float* __restrict__ dbias,
+                                                             float* __restrict__ partials) {
   extern __shared__ float lds[];
   const int G = c / 8;
   const long long nthreads = (long long)gridDim.x * blockDim.x, per = nthreads / G;
@@ -1002,6 +1003,22 @@ __global__ __launch_bounds__(EW_BLOCK) void bias_grad_kernel(const T* __restrict
       for (int e = 0; e < 8; ++e) s[e] += v[e];
     }
   }
+  if (partials) {
+    // reproducible form: the threads of a channel group park their sums and are added in thread order; one row per workgroup
+    float* park = lds + c;                                   // [EW_BLOCK][8]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) park[threadIdx.x * 8 + e] = active ? s[e] : 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += blockDim.x) {
+      const int gg = i / 8, e = i % 8;
+      // threads with (global id % G) == gg: local ids t with (blockIdx.x * blockDim.x + t) % G == gg
+      const int first = (int)(((long long)gg - (long long)blockIdx.x * blockDim.x % G + G) % G);
+      float t = 0.f;
+      for (int th = first; th < (int)blockDim.x; th += G) t += park[th * 8 + e];
+      partials[(size_t)blockIdx.x * c + i] = t;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < c; i += blockDim.x) lds[i] = 0.f;
   __syncthreads();
   if (active) {
@@ -1011,11 +1028,29 @@ __global__ __launch_bounds__(EW_BLOCK) void bias_grad_kernel(const T* __restrict
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(dbias + i, lds[i]);
 }
-extern "C" int satcv_bias_grad(const void* dy, int32_t lddy, int64_t npix, int32_t c, int32_t dtype, float* dbias, void* stream) {
+// dbias[i] += sum of the rows: one wave per channel, fixed association (see head_bwd_finalize_kernel)
+__global__ __launch_bounds__(64) void bias_grad_finalize_kernel(const float* __restrict__ partials, int rows, int c, float* dbias) {
+  const int i = blockIdx.x;
+  float s = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 64) s += partials[(size_t)r * c + i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) dbias[i] += s;
+}
+extern "C" int64_t satcv_bias_grad_workspace(int64_t npix, int32_t c) {
+  if (npix <= 0 || c <= 0 || c % 8) return 0;
+  return (int64_t)ew_grid(npix * (c / 8)) * c * (int64_t)sizeof(float);
+}
+extern "C" int satcv_bias_grad(const void* dy, int32_t lddy, int64_t npix, int32_t c, int32_t dtype, float* dbias, float* partials, void* stream) {
   SATCV_CHECK(dy && dbias && npix > 0 && c > 0 && c % 8 == 0 && c <= 2048 && lddy >= c, "bias_grad: bad args");
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bias_grad_kernel<T>, dim3(ew_grid(npix * (c / 8))), dim3(EW_BLOCK), c * sizeof(float), (hipStream_t)stream, (const T*)dy,
-                                       lddy, (long long)npix, c, dbias));
+  const int grid = ew_grid(npix * (c / 8));
+  const size_t lds = (size_t)c * sizeof(float) + (partials ? (size_t)EW_BLOCK * 8 * sizeof(float) : 0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bias_grad_kernel<T>, dim3(grid), dim3(EW_BLOCK), lds, (hipStream_t)stream, (const T*)dy,
+                                       lddy, (long long)npix, c, dbias, partials));
   LAUNCH_OK("bias_grad");
+  if (partials) {
+    hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, partials, grid, c, dbias);
+    LAUNCH_OK("bias_grad_finalize");
+  }
   return SATCV_OK;
 }
 // bilinear upsampling (half-pixel centres, edge clamped -- tf.keras UpSampling2D(interpolation='bilinear')) of fp32 logits by an

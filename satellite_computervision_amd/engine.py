@@ -780,8 +780,9 @@ class Plan:
                 hh, ww, dyb = r.h, r.w, da[0]
                 accum = 1 if lay.name in seen_layers else 0
                 seen_layers.add(lay.name)
-                self.bwd.append(lambda st, dyb=dyb, cout=cout, npx=n * hh * ww, db=rt.gptr(lay.name + '/bias'): check(lib.satcv_bias_grad(
-                    dyb.data_ptr(), cout, npx, cout, dt, db, st)))
+                bpart = self._z(max(lib.satcv_bias_grad_workspace(n * hh * ww, cout) // 4, 1), dtype=torch.float32)
+                self.bwd.append(lambda st, dyb=dyb, cout=cout, npx=n * hh * ww, db=rt.gptr(lay.name + '/bias'), bpart=bpart: check(lib.satcv_bias_grad(
+                    dyb.data_ptr(), cout, npx, cout, dt, db, bpart.data_ptr(), st)))
                 pk = rt.packed[lay.name]
                 self.bwd.append(wgrad_step(r, dyb.data_ptr(), cout, lay, pk['cin'], cout, hh, ww, cx['k'], cx['dil'], accum=accum))
                 if tin.node.op != 'input':
@@ -820,8 +821,9 @@ class Plan:
                 for gr in graws:            # consumers of the un-normalised output add their gradient to dy (and to the bias gradient)
                     if gr[1] != 0 or gr[2] != cout:
                         raise NotImplementedError('raw-output gradient in a channel slice')
-                    self.bwd.append(lambda st, dy=dy, gb=gr[0], npx=n * hh * ww, cout=cout, db=rt.gptr(lay.name + '/bias'): (
-                        check(lib.satcv_bias_grad(gb.data_ptr(), cout, npx, cout, dt, db, st)),
+                    bpart = self._z(max(lib.satcv_bias_grad_workspace(n * hh * ww, cout) // 4, 1), dtype=torch.float32)
+                    self.bwd.append(lambda st, dy=dy, gb=gr[0], npx=n * hh * ww, cout=cout, db=rt.gptr(lay.name + '/bias'), bpart=bpart: (
+                        check(lib.satcv_bias_grad(gb.data_ptr(), cout, npx, cout, dt, db, bpart.data_ptr(), st)),
                         check(lib.satcv_add_act(dy.data_ptr(), None, None, gb.data_ptr(), None, None, 0, dy.data_ptr(), npx, cout, dt, st))))
                 self.dbg['dy:' + lay.name] = dy
                 self.dbg['_ctx:' + lay.name] = dict(da=da, dp=dp, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout)

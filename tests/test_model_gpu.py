@@ -1070,6 +1070,16 @@ def test_training_is_bit_reproducible(mt):
     xs = [rng.random((8, 64, 64, 4)).astype(np.float32) for _ in range(3)]
     ys = [np.eye(2, dtype=np.float32)[(x[..., 0] + x[..., 3] > 1.0).astype(int)] for x in xs]
     runs = []
+    for rep in range(2):                      # the atrous family too (plain Conv2D bias gradients, residual joins)
+        mt.reset_uids(); mt.set_seed(5)
+        ac = mt.get_acnn_model(2, 16, 4, 3)
+        ac.compile(optimizer=mt.Adam(2e-3), loss=lambda t, p: mt.weighted_categorical_crossentropy(t, p, [1.0, 3.0]))
+        for step in range(4):
+            ac.train_on_batch(xs[step % 3], ys[step % 3])
+        runs.append(ac.get_weights_dict())
+    assert not [k for k in runs[0] if not np.array_equal(runs[0][k], runs[1][k])]
+    assert np.abs(runs[0]['Conv2D_1_2/bias']).max() > 0                  # a Conv2D without BatchNormalization: its bias does train
+    runs = []
     for rep in range(2):
         mt.reset_uids(); mt.set_seed(5)
         m = mt.get_unet_model(2, 4, filters=[32, 64, 128], factors=[2, 2, 2])
