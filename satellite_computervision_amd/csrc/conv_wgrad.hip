@@ -366,6 +366,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// float4 form for the plain (HWIO) layout: 4 consecutive output channels per lane, the same slab order and the same association of
+// the partial sums as above (bit-identical results), a quarter of the load instructions and four times the bytes in flight
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab, int taps, int kpad,
+                                                            int npad, int cin, int nvalid, int accumulate) {
+  __shared__ float4 part[4][64];
+  const int nv4 = nvalid / 4;
+  const long long total = (long long)taps * cin * nv4;
+  const size_t slab = (size_t)taps * kpad * npad;
+  const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+    const long long it = base + ol;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int co = 0, ci = 0, tap = 0;
+    if (it < total) {
+      co = (int)(it % nv4) * 4;
+      ci = (int)((it / nv4) % cin);
+      tap = (int)(it / ((long long)nv4 * cin));
+      const float* p = ws + ((size_t)tap * kpad + ci) * npad + co;
+      float4 s0 = s, s1 = s;
+      int sp = sl;
+      for (; sp + 4 < nslab; sp += 8) {
+        const float4 a = *reinterpret_cast<const float4*>(p + (size_t)sp * slab), b = *reinterpret_cast<const float4*>(p + (size_t)(sp + 4) * slab);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+      }
+      if (sp < nslab) { const float4 a = *reinterpret_cast<const float4*>(p + (size_t)sp * slab); s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; }
+      s = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    }
+    part[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && it < total) {
+      const float4 a = part[0][ol], b = part[1][ol], c = part[2][ol], e = part[3][ol];
+      float4 r = make_float4((a.x + b.x) + (c.x + e.x), (a.y + b.y) + (c.y + e.y), (a.z + b.z) + (c.z + e.z), (a.w + b.w) + (c.w + e.w));
+      float4* dst = reinterpret_cast<float4*>(dw + ((size_t)tap * cin + ci) * nvalid + co);
+      if (accumulate) { const float4 o = *dst; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+      *dst = r;
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ host side
 struct WgradPlan { int tw, nci, nco, nks, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk, pix; size_t ws_bytes; };
 
@@ -498,6 +539,14 @@ static int wgrad_any(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t 
 }
 static int wgrad_reduce_launch(const satcv_wgrad_desc* d, const WgradPlan& p, float* dw, int nvalid, hipStream_t st) {
   const long long total = (long long)p.ntaps * d->cin * nvalid;
+  if (!d->transposed && nvalid % 4 == 0 && p.npad % 4 == 0 && ((uintptr_t)dw % 16) == 0 && ((uintptr_t)d->workspace % 16) == 0) {
+    int grid4 = (int)((total / 4 + 63) / 64); if (grid4 > 8192) grid4 = 8192;
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(grid4), dim3(256), 0, st, (const float*)d->workspace, dw, p.nsplit, p.ntaps, p.kpad, p.npad, d->cin, nvalid,
+                       d->accumulate);
+    hipError_t e4 = hipGetLastError();
+    if (e4 != hipSuccess) { satcv_set_error("wgrad reduce launch: %s", hipGetErrorString(e4)); return SATCV_ERR_HIP; }
+    return SATCV_OK;
+  }
   int grid = (int)((total + 63) / 64); if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, d->workspace, dw, p.nsplit, p.ntaps, p.kpad, p.npad, d->cin, nvalid,
                      d->transposed, d->accumulate);
