@@ -203,14 +203,19 @@ extern "C" int satcv_pack_weights(const float* src, void* dst_fwd, void* dst_dgr
 __global__ void bn_finalize_train_kernel(satcv_stat_t* stats, int ld, int c, float count, const float* gamma, const float* beta,
                                          float eps, float momentum, int updates, int bessel, float* mm, float* mv,
                                          float* scale, float* shift, float* mean_o, float* rstd_o) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+  // 32 lanes per channel, one replica row each (one load round trip instead of 32 dependent ones: the launch sits on the critical
+  // path of every layer); the rows are combined by a fixed xor butterfly, i.e. in the same association every run
+  static_assert(SATCV_STAT_ROWS == 32, "one lane per replica row");
+  const int ch = blockIdx.x * (blockDim.x / 32) + threadIdx.x / 32, r = threadIdx.x & 31;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < SATCV_STAT_ROWS; ++r) {
+  if (ch < c) {
     satcv_stat_t* row = stats + (size_t)r * 2 * ld;
-    s1 += row[ch]; s2 += row[ld + ch];
+    s1 = row[ch]; s2 = row[ld + ch];
     row[ch] = 0.0; row[ld + ch] = 0.0;
   }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if (ch >= c || r != 0) return;
   const double mean_d = s1 / (double)count;
   const float mean = (float)mean_d;
   float var = (float)(s2 / (double)count - mean_d * mean_d);      // E[x^2] - E[x]^2 without the fp32 cancellation
@@ -230,7 +235,7 @@ extern "C" int satcv_bn_finalize_train(satcv_stat_t* stats, int32_t stats_ld, in
                                        float eps, float momentum, int32_t updates, int32_t bessel, float* moving_mean, float* moving_var,
                                        float* scale, float* shift, float* mean, float* rstd, void* stream) {
   SATCV_CHECK(stats && gamma && beta && scale && shift && mean && rstd && c > 0 && stats_ld >= c && count > 0, "bn_finalize_train: bad args");
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(cdiv(c, 128)), dim3(128), 0, (hipStream_t)stream, stats, stats_ld, c, count, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(cdiv(c, 8)), dim3(256), 0, (hipStream_t)stream, stats, stats_ld, c, count, gamma, beta,
                      eps, momentum, updates, bessel, moving_mean, moving_var, scale, shift, mean, rstd);
   LAUNCH_OK("bn_finalize_train");
   return SATCV_OK;
@@ -506,14 +511,16 @@ extern "C" int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream) {
   return SATCV_OK;
 }
 __global__ void bn_bwd_finalize_kernel(satcv_stat_t* sums, int ld, int c, float count, float* dgamma, float* dbeta, float* coef, int accumulate) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+  const int ch = blockIdx.x * (blockDim.x / 32) + threadIdx.x / 32, r = threadIdx.x & 31;      // see bn_finalize_train_kernel
   double d1 = 0.0, d2 = 0.0;
-  for (int r = 0; r < SATCV_STAT_ROWS; ++r) {
+  if (ch < c) {
     satcv_stat_t* row = sums + (size_t)r * 2 * ld;
-    d1 += row[ch]; d2 += row[ld + ch];
+    d1 = row[ch]; d2 = row[ld + ch];
     row[ch] = 0.0; row[ld + ch] = 0.0;
   }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o, 64); d2 += __shfl_xor(d2, o, 64); }
+  if (ch >= c || r != 0) return;
   const float s1 = (float)d1, s2 = (float)d2;
   if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + s1 : s1;
   if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + s2 : s2;
@@ -522,7 +529,7 @@ __global__ void bn_bwd_finalize_kernel(satcv_stat_t* sums, int ld, int c, float 
 extern "C" int satcv_bn_bwd_finalize(satcv_stat_t* sums, int32_t sums_ld, int32_t c, float count, float* dgamma, float* dbeta, float* coef, int32_t accumulate,
                                      void* stream) {
   SATCV_CHECK(sums && coef && c > 0 && sums_ld >= c && count > 0, "bn_bwd_finalize: bad args");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 128)), dim3(128), 0, (hipStream_t)stream, sums, sums_ld, c, count, dgamma, dbeta, coef, accumulate);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 8)), dim3(256), 0, (hipStream_t)stream, sums, sums_ld, c, count, dgamma, dbeta, coef, accumulate);
   LAUNCH_OK("bn_bwd_finalize");
   return SATCV_OK;
 }
