@@ -231,17 +231,21 @@ class Runtime:
             self.adam_v = torch.zeros_like(self.pflat)
 
     def plan(self, n, h, w, training):
-        key = (n, h, w, bool(training))
+        # tf.keras runs a BatchNormalization whose `trainable` is False in INFERENCE mode even inside fit() (moving statistics, no
+        # update): the set of frozen layers is part of a training plan's identity (retrain_model(freeze=True), utils/model_tools.py:1174)
+        frozen = tuple(sorted(l.name for l in self.model.layers if not l.trainable)) if training else ()
+        key = (n, h, w, bool(training), frozen)
         if key not in self.plans:
-            self.plans[key] = Plan(self, n, h, w, training)
+            self.plans[key] = Plan(self, n, h, w, training, frozen)
         return self.plans[key]
 
 
 class Plan:
     """Static launch sequence for one input shape."""
 
-    def __init__(self, rt, n, h, w, training):
+    def __init__(self, rt, n, h, w, training, frozen=()):
         self.rt, self.n, self.h, self.w, self.training = rt, n, h, w, training
+        self.frozen = set(frozen)
         self.fwd, self.bwd = [], []
         self.keep = []                        # ctypes descriptors / tensors kept alive
         self.dropouts = []                    # dropout masks (regenerated every training step)
@@ -290,6 +294,15 @@ class Plan:
             bessel = 1 if rt.model.bn_bessel else 0
             if self.sync_bn:            # SyncBN: [Σx, Σx²] averaged over replicas before the finalize
                 self.fwd.append(lambda st: parallel.allreduce_mean_(stats))
+            if bnname in self.frozen:
+                # frozen BatchNormalization: the batch statistics are consumed (rows cleared, batch mean / rstd kept for the backward
+                # kernels' addressing) but the layer normalises with its MOVING statistics and does not update them
+                ts, tt = self._z(c, dtype=torch.float32), self._z(c, dtype=torch.float32)
+                self.fwd.append(lambda st: check(lib.satcv_bn_finalize_train(
+                    _fp(stats, off), ld, c, float(count), g, b, BN_EPS, BN_MOMENTUM, updates, bessel, None, None,
+                    _fp(ts), _fp(tt), _fp(a['mean'], aoff), _fp(a['rstd'], aoff), st)))
+                self.fwd.append(lambda st: check(lib.satcv_bn_affine_infer(g, b, mm, mv, BN_EPS, c, _fp(a['scale'], aoff), _fp(a['shift'], aoff), st)))
+                return a
             self.fwd.append(lambda st: check(lib.satcv_bn_finalize_train(
                 _fp(stats, off), ld, c, float(count), g, b, BN_EPS, BN_MOMENTUM, updates, bessel, mm, mv,
                 _fp(a['scale'], aoff), _fp(a['shift'], aoff), _fp(a['mean'], aoff), _fp(a['rstd'], aoff), st)))
@@ -625,7 +638,7 @@ class Plan:
         self.loss_buf = self._z(1, dtype=torch.float32)
 
         def bn_bwd_steps(da, ldda, dp, lddp, f, yraw, ldy, aff, aoff, sums, sums_off, sums_ld, c, hh, ww, dy, lddy, dbias,
-                         dgamma, dbeta, accum=0, linear=0):
+                         dgamma, dbeta, accum=0, linear=0, frozen=False):
             coef = self._z(2, c, dtype=torch.float32)
             d = ops.make_bnbwd_desc(yraw=yraw, ldy=ldy, scale=_fp(aff['scale'], aoff), shift=_fp(aff['shift'], aoff),
                                     mean=_fp(aff['mean'], aoff), rstd=_fp(aff['rstd'], aoff), n=n, h=hh, w_=ww, c=c, dtype=dt,
@@ -642,6 +655,12 @@ class Plan:
             else:
                 fin = fin0
             app = lambda st: check(lib.satcv_bn_bwd_apply(C.byref(d), st))
+            if frozen:
+                # inference-mode BatchNormalization: dy = scale * g * mask, no batch-statistics terms (coef stays 0), no dgamma / dbeta
+                def fin_frozen(st):
+                    sums.zero_()
+                    coef.zero_()
+                return None, fin_frozen, app
             return red, fin, app
 
         seen_layers = set()     # layers applied more than once (shared weights): later visits accumulate their gradients
@@ -816,8 +835,8 @@ class Plan:
                                              cout, gpool_f.get(tout.id, 1), y.data_ptr() + yoff * es, ldy, aff, aoff, sums, 0, cout, cout, hh, ww,
                                              dy.data_ptr(), cout, rt.gptr(lay.name + '/bias') if BIAS_NOISE else None,
                                              rt.gptr(lay.bn_name + '/gamma'), rt.gptr(lay.bn_name + '/beta'), accum,
-                                             linear=0 if node.attrs.get('relu', True) else 1)
-                self.bwd += [fin, app] if pre is not None else [red, fin, app]
+                                             linear=0 if node.attrs.get('relu', True) else 1, frozen=lay.bn_name in self.frozen)
+                self.bwd += [fin, app] if (pre is not None or red is None) else [red, fin, app]
                 for gr in graws:            # consumers of the un-normalised output add their gradient to dy (and to the bias gradient)
                     if gr[1] != 0 or gr[2] != cout:
                         raise NotImplementedError('raw-output gradient in a channel slice')
@@ -886,11 +905,11 @@ class Plan:
                     raise NotImplementedError('decoder concat gradient in a channel slice')
                 gptr_ = g[0].data_ptr() + g[1] * es
                 ra_, fa_, aa_ = bn_bwd_steps(gptr_, ctot, None, 0, 1, ra.srcs[0][0].data_ptr(), ca, aff, 0, sums, 0, ctot, ca, hh, ww,
-                                             dskip.data_ptr(), ca, None, rt.gptr(bn + '/gamma'), rt.gptr(bn + '/beta'))
+                                             dskip.data_ptr(), ca, None, rt.gptr(bn + '/gamma'), rt.gptr(bn + '/beta'), frozen=bn in self.frozen)
                 rb_, fb_, ab_ = bn_bwd_steps(gptr_ + ca * es, ctot, None, 0, 1, rb.srcs[0][0].data_ptr(), cb, aff, ca, sums, ca, ctot, cb,
                                              hh, ww, du.data_ptr(), cb, rt.gptr(upl.name + '/bias') if (tb.node.op == 'convT' and BIAS_NOISE) else None,
-                                             rt.gptr(bn + '/gamma') + 4 * ca, rt.gptr(bn + '/beta') + 4 * ca)
-                self.bwd += [fa_, fb_, aa_, ab_] if pre is not None else [ra_, rb_, fa_, fb_, aa_, ab_]
+                                             rt.gptr(bn + '/gamma') + 4 * ca, rt.gptr(bn + '/beta') + 4 * ca, frozen=bn in self.frozen)
+                self.bwd += [fa_, fb_, aa_, ab_] if (pre is not None or ra_ is None) else [ra_, rb_, fa_, fb_, aa_, ab_]
                 # the skip is the activated output of an encoder conv_batch_act block
                 gact[ta.id] = (dskip, 0, ca)
                 self.dbg['dskip:' + bn] = dskip

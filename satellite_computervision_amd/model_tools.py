@@ -1097,6 +1097,9 @@ class Model:
         rt.ensure_adam()
         n, h, w, _ = self._shape_of(xb)
         plan = self._head_plan(n, h, w, True)
+        if getattr(self, '_frozen_applied', None) != plan.frozen:        # `layer.trainable` changed since the update masks were built
+            self._apply_trainable()
+            self._frozen_applied = plan.frozen
         self._stage_x(plan, xb)
         self._stage_y(plan, yb)
         st = ops.stream_ptr()

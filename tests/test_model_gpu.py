@@ -1094,3 +1094,51 @@ def test_training_is_bit_reproducible(mt):
     assert not diff, diff
     assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
     assert all(np.all(w0[k] == 0) for k in w0 if k.endswith('/bias') and not k.startswith('probs'))      # exact zero gradient: never moved
+
+
+def test_frozen_layers_run_batchnorm_in_inference_mode(mt):
+    """tf.keras semantics of `layer.trainable = False` (retrain_model(freeze=True), utils/model_tools.py:1174-1175): a frozen
+    BatchNormalization normalises with its MOVING statistics inside fit() and does not update them; only the head trains.  Loss and
+    head gradients against autograd of the PyTorch-CPU restatement run with inference-mode BatchNorm."""
+    from oracle import torch_unet as TU
+    filters, factors = [32, 64], [2, 2]
+    mt.reset_uids(); mt.set_seed(21)
+    m = mt.get_unet_model(2, 4, filters=filters, factors=factors)
+    m.compute_dtype = 'float32'
+    rng = np.random.default_rng(6)
+    w = m.get_weights_dict()
+    for k in w:                                       # moving statistics that differ clearly from any batch statistics
+        if k.endswith('moving_mean'):
+            w[k] = (0.3 * rng.standard_normal(w[k].shape)).astype(np.float32)
+        elif k.endswith('moving_var'):
+            w[k] = (0.5 + rng.random(w[k].shape)).astype(np.float32)
+    m.set_weights_dict(w)
+    names = mt.structural_names(m)
+    tp = TU.params_to_torch({rn: w[kn] for rn, kn in names.items()}, torch.float64)
+    x = rng.random((4, 32, 32, 4)).astype(np.float32)
+    t = np.eye(2, dtype=np.float32)[(x[..., 1] > 0.5).astype(int)]
+    m.compile(optimizer=mt.Adam(1e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 2.0]))
+    for layer in m.layers[:-1]:
+        layer.trainable = False
+    pr, _ = TU.unet_forward(tp, torch.tensor(x, dtype=torch.float64), filters, factors, training=False)
+    lt = TU.weighted_cce_mean(torch.tensor(t, dtype=torch.float64), pr, [1.0, 2.0]); lt.backward()
+    loss = m.train_on_batch(x, t)
+    np.testing.assert_allclose(loss, lt.item(), rtol=3e-5)
+    rt = m.runtime
+    for rn in ('probs.kernel', 'probs.bias'):
+        g = rt.get_grad(names[rn]).cpu().numpy().astype(np.float64)
+        r = tp[rn].grad.numpy()
+        assert np.linalg.norm(g - r) / np.linalg.norm(r) < 1e-4, rn
+    w1 = m.get_weights_dict()
+    changed = [k for k in w if not np.array_equal(w[k], w1[k])]
+    assert changed and all(k.startswith('probs/') for k in changed), changed          # moving statistics untouched as well
+    # un-freezing restores batch-statistics training (a different plan)
+    for layer in m.layers:
+        layer.trainable = True
+    pr2, _ = TU.unet_forward(tp, torch.tensor(x, dtype=torch.float64), filters, factors, training=True)
+    w2 = m.get_weights_dict()
+    tp2 = TU.params_to_torch({rn: w2[kn] for rn, kn in names.items()}, torch.float64)
+    pr2, _ = TU.unet_forward(tp2, torch.tensor(x, dtype=torch.float64), filters, factors, training=True)
+    l2 = TU.weighted_cce_mean(torch.tensor(t, dtype=torch.float64), pr2, [1.0, 2.0]).item()
+    np.testing.assert_allclose(m.train_on_batch(x, t), l2, rtol=3e-5)
+    assert any(not np.array_equal(w2[k], v) for k, v in m.get_weights_dict().items() if k.endswith('moving_mean'))
