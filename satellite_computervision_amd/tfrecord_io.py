@@ -275,6 +275,31 @@ def rescale_tensor(img, axes=[2], epsilon=1e-8, moments=None, splits=None):
     return rescale(img)
 
 
+def normalize_tensor(x, axes=[2], epsilon=1e-8, moments=None, splits=None):
+    """utils/processing.py:225-279: (x - mean) / sqrt(variance + epsilon) with moments over `axes` (tf.nn.moments: population
+    variance) or from a list of (mean, variance) tuples; with `splits` the first sum(splits) channels are standardised group by
+    group and the remaining channels pass through."""
+    def normalize(t):
+        if moments:
+            mean = np.array([tpl[0] for tpl in moments], dtype='float32')
+            variance = np.array([tpl[1] for tpl in moments], dtype='float32')
+        else:
+            mean = t.mean(axis=tuple(axes), keepdims=True)
+            variance = t.var(axis=tuple(axes), keepdims=True)
+        return (t - mean) / np.sqrt(variance + epsilon)
+    if splits:
+        n = sum(splits)
+        parts = np.split(x[:, :, 0:n], np.cumsum(splits)[:-1], axis=2)
+        return np.concatenate([normalize(p) for p in parts] + [x[:, :, n:]], axis=2)
+    return normalize(x)
+
+
+def calc_ndvi(input):
+    """utils/processing.py:116-127: (B8 - B4) / (1e-8 + B8 + B4) from a dictionary of band arrays."""
+    nir, red = input.get('B8'), input.get('B4')
+    return (nir - red) / (1e-8 + (nir + red))
+
+
 # ---- training / evaluation datasets over Earth-Engine TFRecords (utils/processing.py:129-183, 335-454), NumPy on the host.  The
 # random draws (tf.random.uniform, tf.image.random_flip_*) cannot be reproduced bit for bit without TensorFlow: the same
 # distributions are drawn from a seedable NumPy generator (set_seed).
