@@ -447,7 +447,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbw
     s1[e] = 0.f; s2[e] = 0.f;
   }
   if (active) {
-#pragma unroll 2
+#pragma unroll 4
     for (unsigned p0 = gid / G; p0 < npix; p0 += per) {
       const unsigned p = rev ? npix - 1 - p0 : p0;
       float v[8], gr[8], o[8];
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(EW_BLOCK) void add_act_kernel(const T* __restrict__
     s1[e] = rsc ? rsc[ch] : 1.f; h1[e] = rsc ? rsh[ch] : 0.f;
   }
   const bool ya = ysc != nullptr, ra = rsc != nullptr;
-#pragma unroll 2
+#pragma unroll 4
   for (long long p = gid / G; p < npix; p += per) {
     float a[8], b[8];
     load8<T>(y + p * c + g * 8, a);
