@@ -333,7 +333,8 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
       }
       if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS, true>(a, st, dry);
       if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 2, TAPS, true>(a, st, dry);
-      return fast_cfg<T, TW, 4, 1, 2, 1, 2, TAPS, true>(a, st, dry);
+      // (the 256x32 tile with 32-channel chunks needs 64-92 bytes of scratch in its tap-loop form: the 16-channel form does not)
+      return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS, true>(a, st, dry);
     }
     if (ks2) {
       if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS>(a, st, dry);
