@@ -53,7 +53,7 @@ __device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
 // NCI x NCO waves own distinct (ci, co) 32x32 tiles; NKS waves share a tile and split the
 // k-steps (pixels) of every staged tile, each writing its own partial slab.
 template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS, int PIX>
-__global__ __launch_bounds__(NCI* NCO* NKS * 64, 2) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(NCI* NCO* NKS * 64, (TW == 8 ? 1 : 2)) void wgrad_kernel(const WgradArgs a) {
   using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
   constexpr int NTHREADS = NCI * NCO * NKS * 64;
   constexpr int BMPIX = PIX;               // pixels per staged tile: 128, or 256 for the thin layers (more bytes in flight)
@@ -439,7 +439,9 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   // thin layers (a handful of (ci, co) blocks at full resolution) are bound by bytes in flight: stage 256 pixels per step
   // (only with 32-channel X blocks: the 256-pixel halo tile of a 64-channel block is 65 KB and leaves ONE workgroup per CU --
   //  measured 842 us on dec0.conv1 (64->32), the slowest kernel of the step)
-  p.pix = (p.ntaps == 9 && p.tw == 32 && p.nci == 1 && p.n_ci_blk * p.n_co_blk <= 3 && d->h >= 8 && d->w_ >= 256 && d->dil == 1 && wgrad_pix256()) ? 256 : 128;
+  // (and only the 1 x 1 block form in bf16: every other 256-pixel instantiation spills into scratch, which is ruinous)
+  p.pix = (p.ntaps == 9 && p.tw == 32 && p.nci == 1 && p.nco == 1 && d->dtype == SATCV_BF16 && p.n_ci_blk * p.n_co_blk <= 3 && d->h >= 8 && d->w_ >= 256 &&
+           d->dil == 1 && wgrad_pix256()) ? 256 : 128;
   const int th = p.pix / p.tw;
   const int tiles_x = cdiv(d->w_, p.tw);
   long long ptiles;
@@ -512,11 +514,8 @@ static int wgrad_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t 
   if (p.nci == 1 && p.nco == 4) return wgrad_launch<T, TW, 1, 4, 1, 9>(d, p, st);
   if (p.nci == 2 && p.nco == 2) return wgrad_launch<T, TW, 2, 2, 1, 9>(d, p, st);
   if constexpr (TW == 32) {
-    if (p.pix == 256) {
-      if (p.nci == 2 && p.nco == 2) return wgrad_launch<T, TW, 2, 2, 1, 9, 256>(d, p, st);
-      if (p.nci == 1 && p.nco == 2) return wgrad_launch<T, TW, 1, 2, 2, 9, 256>(d, p, st);
-      if (p.nci == 2 && p.nco == 1) return wgrad_launch<T, TW, 2, 1, 2, 9, 256>(d, p, st);
-      if (p.nci == 1 && p.nco == 1) return wgrad_launch<T, TW, 1, 1, 4, 9, 256>(d, p, st);
+    if constexpr (std::is_same<T, bf16>::value) {
+      if (p.pix == 256 && p.nci == 1 && p.nco == 1) return wgrad_launch<T, TW, 1, 1, 4, 9, 256>(d, p, st);
     }
   }
   if (p.nci == 1 && p.nco == 2) return wgrad_launch<T, TW, 1, 2, 2, 9>(d, p, st);
