@@ -30,24 +30,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TILE, CH, NCLS, BATCH = 256, 4, 2, 64
-FWD_GFLOP_PER_TILE = 22.641          # SURVEY.md §8(d)
+FWD_GFLOP_PER_TILE = 22.641          # SURVEY.md section 8(d)
 TRAIN_GFLOP_PER_TILE = 67.77
 PEAK_BF16_TFLOPS = 2500.0
-# algorithmic HBM bytes of the 3x3 conv launches of one training step at batch 64 (each launch reads its input once and
-# writes its output once, bf16, weights once): forward 11 layers + data gradient 10 layers, see DESIGN.md section 3
-def _alg_3x3_bytes(batch, esize=2, tile=TILE, filters=(32, 64, 128, 256, 512), cin0=16):
+PEAK_HBM_TBPS = 8.0
+
+
+def unet_layers(batch, tile=TILE, cin0=CH, filters=(32, 64, 128, 256, 512), ncls=NCLS):
+    """(kind, pixels of the GEMM grid, Cin, Cout, taps) of every convolution of get_unet_model(2, 4) as coded
+    (utils/model_tools.py:321-415): 6 encoder / centre convs, per decoder level one transposed conv (k = s = 2: per INPUT
+    pixel Cin x 4*Cout) and two 3x3 convs (the first reads concat([skip, up])), the 1x1 head.  Cin is the ALGORITHMIC one
+    (4 for the first layer, although 16 channels are stored)."""
     L, cin = [], cin0
     for i, c in enumerate(filters):
-        L.append((batch * (tile >> i) ** 2, cin, c)); cin = c
-    L.append((batch * (tile >> len(filters)) ** 2, filters[-1], 2 * filters[-1]))
+        L.append(('conv3', batch * (tile >> i) ** 2, cin, c, 9)); cin = c
+    L.append(('conv3', batch * (tile >> len(filters)) ** 2, filters[-1], 2 * filters[-1], 9))
+    cin = 2 * filters[-1]
     for j in range(len(filters) - 1, -1, -1):
+        L.append(('convT', batch * (tile >> (j + 1)) ** 2, cin, 4 * filters[j], 1))
         px = batch * (tile >> j) ** 2
-        L += [(px, 2 * filters[j], filters[j]), (px, filters[j], filters[j])]       # conv1 reads concat([skip f, up f])
-    one = lambda px, ci, co: px * (ci + co) * esize + 9 * ci * co * esize
-    return sum(one(*l) for l in L) + sum(one(*l) for l in L[1:])        # forward + data gradient (none for the first layer)
+        L += [('conv3', px, 2 * filters[j], filters[j], 9), ('conv3', px, filters[j], filters[j], 9)]
+        cin = filters[j]
+    L.append(('head', batch * tile * tile, filters[0], ncls, 1))
+    return L
 
 
-ALG_3X3_BYTES_PER_STEP = _alg_3x3_bytes(BATCH)                          # 6.45 GB at batch 64: 16 forward + 15 dgrad launches
+def alg_work(batch, esize=2):
+    """algorithmic FLOPs / unfused HBM bytes (input once, output once, weights once) of the launches of one training step,
+    per class, and the per-layer roofline time sum(max(flops / MFMA peak, bytes / HBM peak))."""
+    out = {'conv3_fwd_dgrad': [0.0, 0.0, 0.0, 0], 'all': [0.0, 0.0, 0.0, 0]}
+
+    def add(key, fl, by):
+        t = max(fl / (PEAK_BF16_TFLOPS * 1e12), by / (PEAK_HBM_TBPS * 1e12))
+        for k in (key, 'all'):
+            if k in out:
+                out[k][0] += fl; out[k][1] += by; out[k][2] += t; out[k][3] += 1
+    first = True
+    for kind, px, ci, co, taps in unet_layers(batch):
+        fl = 2.0 * px * ci * co * taps
+        by = px * (ci + co) * esize + taps * ci * co * esize
+        key = 'conv3_fwd_dgrad' if kind == 'conv3' else 'other'
+        add(key, fl, by)                                  # forward
+        if not first:
+            add(key, fl, by)                              # data gradient (none for the first layer)
+        add('wgrad', fl, px * (ci + co) * esize + taps * ci * co * 4)          # weight gradient: X and dY once, fp32 dW
+        first = False
+    return {k: dict(flops=v[0], bytes=v[1], roof_s=v[2], launches=v[3]) for k, v in out.items()}
 
 
 def synth_batch(rng, n):
@@ -64,19 +92,83 @@ def synth_batch(rng, n):
 
 
 def pmc_traffic_per_launch():
-    """HBM bytes per 3x3 implicit-GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this same
-    command (profiles/r01_pmc_traffic.json, produced by tools/pmc_summary.py with the gfx950 FETCH_SIZE x2 correction).
-    PMC counters cannot be collected from inside the timed run; None when the summary is absent."""
+    """HBM bytes per 3x3 implicit-GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command (profiles/rNN_pmc_traffic.json, produced by tools/pmc_summary.py with the gfx950 FETCH_SIZE x2 correction).  PMC
+    counters cannot be collected from inside the timed run, so the line carries the newest committed summary and names the
+    file and the commit it was measured at; (None, None) when there is no summary."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+        try:
+            d = json.load(open(path))
+            c = d['classes'].get('igemm_3x3') or d['classes'].get('igemm_3x3_1x1_convT')
+            src = f"{os.path.basename(path)} @ {d.get('commit', 'round-1 tree 138affc')}"
+            return round(c['hbm_bytes_per_launch'] / 1e6, 1), src
+        except Exception:
+            continue
+    return None, None
+
+
+def _cpu_model():
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['classes']
-        c = d.get('igemm_3x3') or d.get('igemm_3x3_1x1_convT')
-        return round(c['hbm_bytes_per_launch'] / 1e6, 1)
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
     except Exception:
-        return None
+        pass
+    return 'unknown'
+
+
+def _tf_cpu_baseline(seconds_budget):
+    """when TensorFlow is importable, time the Keras graph of the reference's builder semantics on the
+    host cores (GPUs hidden).  The graph is rebuilt here from tf.keras layers following utils/model_tools.py:174-415 as
+    coded (one conv per block) -- none of the reference's files travel to the GPU box."""
+    os.environ.setdefault('CUDA_VISIBLE_DEVICES', '')
+    import tensorflow as tf                                   # noqa: F401  (absent in this image: the caller falls back)
+    L = tf.keras.layers
+
+    def cba(x, f):
+        return L.Activation('relu')(L.BatchNormalization()(L.Conv2D(f, 3, padding='same')(x)))
+    inp = L.Input([TILE, TILE, CH])
+    x, skips = inp, []
+    for f in (32, 64, 128, 256, 512):
+        e = cba(x, f); skips.append(e); x = L.MaxPooling2D(2)(e)
+    x = cba(x, 1024)
+    for f, sk in zip((512, 256, 128, 64, 32), skips[::-1]):
+        x = L.Conv2DTranspose(f, 2, strides=2, padding='same')(x)
+        x = L.Activation('relu')(L.BatchNormalization()(L.concatenate([sk, x])))
+        x = cba(cba(x, f), f)
+    probs = L.Conv2D(NCLS, 1, activation='softmax')(x)
+    m = tf.keras.Model(inp, probs)
+    m.compile(optimizer=tf.keras.optimizers.Adam(9e-4), loss='categorical_crossentropy')
+    rng = np.random.default_rng(0)
+    res = {}
+    for bs in (1, 16):
+        xb, _ = synth_batch(rng, bs)
+        m.predict(xb, verbose=0)
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < seconds_budget / 4 or n < 1:
+            m.predict(xb, batch_size=bs, verbose=0); n += 1
+        res[f'predict_b{bs}_tiles_per_s'] = round(bs * n / (time.perf_counter() - t0), 3)
+    xb, yb = synth_batch(rng, 1)
+    m.train_on_batch(xb, yb)
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds_budget / 2 or n < 1:
+        m.train_on_batch(xb, yb); n += 1
+    return dict(value=round(n / (time.perf_counter() - t0), 3), unit='tiles/s', cores=os.cpu_count(), kind='reference',
+                sample=f'{n} tf.keras train_on_batch steps of batch 1 (256x256x4, fp32, TensorFlow {tf.__version__} CPU)', **res)
 
 
 def cpu_baseline(seconds_budget=20.0):
-    """torch-CPU port of the identical training step (fp32), batch 2, all host cores."""
+    """The reference's CPU path timed on this host (rank 0, N = 1 only, bounded sample): TensorFlow's Keras graph when
+    TensorFlow can be imported (kind "reference"), else the PyTorch-CPU (oneDNN) restatement of the identical graph
+    (oracle/torch_unet.py, kind "port"): one training step of batch 1 plus inference at batch 1 and 16
+    (utils/prediction_tools.py:152 predicts chip by chip at batch 1)."""
+    try:
+        out = _tf_cpu_baseline(seconds_budget)
+        out['cpu_model'] = _cpu_model()
+        return out
+    except ImportError:
+        pass
     from oracle.unet import UNetOracle
     from oracle import torch_unet as TU
     cores = min(os.cpu_count() or 1, 64)       # more oneDNN threads than this only slows the 256^2 convs
@@ -102,12 +194,24 @@ def cpu_baseline(seconds_budget=20.0):
     step(1)                                  # warm-up (oneDNN primitive creation)
     t0 = time.perf_counter()
     nsteps = 0
-    while (time.perf_counter() - t0 < seconds_budget and nsteps < 50) or nsteps < 1:
+    while (time.perf_counter() - t0 < seconds_budget * 0.6 and nsteps < 50) or nsteps < 1:
         step(nsteps + 2)
         nsteps += 1
     dt = time.perf_counter() - t0
-    return dict(value=round(bs * nsteps / dt, 3), unit='tiles/s', cores=cores, kind='port',
-                sample=f'{nsteps} training steps of batch {bs} (256x256x4, fp32, torch-CPU/oneDNN stand-in: TensorFlow absent)')
+    res = {}
+    with torch.no_grad():
+        for b in (1, 16):
+            xb = torch.from_numpy(synth_batch(rng, b)[0])
+            TU.unet_forward(p, xb, filters, factors, training=False)
+            t1, n = time.perf_counter(), 0
+            while (time.perf_counter() - t1 < seconds_budget * 0.2 and n < 50) or n < 1:
+                TU.unet_forward(p, xb, filters, factors, training=False)
+                n += 1
+            res[f'predict_b{b}_tiles_per_s'] = round(b * n / (time.perf_counter() - t1), 3)
+    return dict(value=round(bs * nsteps / dt, 3), unit='tiles/s', cores=cores, kind='port', cpu_model=_cpu_model(),
+                threads=f'torch.set_num_threads({cores}); os.cpu_count()={os.cpu_count()}',
+                sample=f'{nsteps} training steps of batch {bs} (256x256x4, fp32, torch-CPU/oneDNN stand-in: TensorFlow absent), '
+                       f'predict at batch 1 and 16 beside it', **res)
 
 
 def main():
@@ -118,7 +222,9 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--dtype', default='bfloat16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--infer', action='store_true', help='also time inference (reported under "extra")')
+    ap.add_argument('--infer', action='store_true', help='(default) also time bf16 / fp8 inference and the config-5 chip rate, reported under "extra"')
+    ap.add_argument('--no-infer', action='store_true', help='skip the inference timings')
+    ap.add_argument('--full-infer', action='store_true', help='also DeepLab-v3 (config 3) inference timings')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -189,7 +295,7 @@ def main():
 
     extra = {'loss_last': loss, 'kernel_ms_per_step': {k: round(v['ms'] / args.steps, 3) for k, v in prof.items()},
              'kernel_tflops': {k: round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 1) for k, v in prof.items()}}
-    if args.infer:
+    if not args.no_infer:
         xb, _ = pool[0]
         for _ in range(3):
             model.predict_on_device(xb)
@@ -223,8 +329,8 @@ def main():
         extra['infer_fp8_tiles_per_s'] = round(world * B * 10 / (time.perf_counter() - t1), 1)
         model.disable_fp8_inference()
         # BASELINE configs[2]: DeepLab-v3 (ResNet-50 OS16 + the reference's ASPP block), NAIP-like 512x512x4 tiles, inference
-        dl = mt.get_deeplabv3_model(2, 4)
-        for bs in (1, 16):
+        dl = mt.get_deeplabv3_model(2, 4) if args.full_infer else None
+        for bs in ((1, 16) if args.full_infer else ()):
             xd = torch.from_numpy((np.random.default_rng(6).integers(0, 256, (bs, 512, 512, 4)) / 255.0).astype(np.float32)).cuda()
             for _ in range(3):
                 dl.predict_on_device(xd)
@@ -239,7 +345,14 @@ def main():
         tiles = world * B * args.steps
         value = tiles / dt
         d = prof['conv3x3_igemm_fwd_dgrad']
-        ach = d['flops'] / max(d['ms'], 1e-9) / 1e9
+        peak = PEAK_BF16_TFLOPS if args.dtype == 'bfloat16' else 157.3
+        aw = alg_work(B, 2 if args.dtype == 'bfloat16' else 4)
+        a3 = aw['conv3_fwd_dgrad']
+        # achieved = ALGORITHMIC FLOPs of the 3x3 forward + data-gradient launches of the timed steps (true Cin: 4 for the first
+        # layer although 16 channels are stored) / their summed HIP-event durations on the launch stream
+        ach = a3['flops'] * args.steps / max(d['ms'], 1e-9) / 1e9
+        launches_per_step = max(d['launches'] / args.steps, 1)
+        traffic, traffic_src = pmc_traffic_per_launch()
         out = {
             'metric': 'tiles/sec (train) 256x256x4 U-Net', 'value': round(value, 2), 'unit': 'tiles/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -248,12 +361,18 @@ def main():
             'config': {'workload': f'U-Net 256x256x4 {args.dtype} training, batch {B} per GPU (BASELINE configs[1])',
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'loss': 'weighted_categorical_crossentropy',
                        'optimizer': 'adam(9e-4)'},
-            'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS if args.dtype == 'bfloat16' else 157.3,
-                         'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_BF16_TFLOPS if args.dtype == 'bfloat16' else 157.3), 4),
-                         'traffic': pmc_traffic_per_launch(), 'traffic_unit': 'MB per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)',
-                         'algorithmic_bytes_per_launch_MB': round(ALG_3X3_BYTES_PER_STEP / max(d['launches'] / args.steps, 1) / 1e6, 1),
-                         'kernel': 'igemm_fast_kernel (3x3 conv fwd + dgrad)',
-                         'avg_launch_us': round(1000 * d['ms'] / max(d['launches'], 1), 2)},
+            'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                         'traffic': traffic, 'traffic_unit': 'MB per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src,
+                         'algorithmic_bytes_per_launch_MB': round(a3['bytes'] / a3['launches'] / 1e6, 1),
+                         'algorithmic_gflop_per_step': round(a3['flops'] / 1e9, 1),
+                         'kernel': '3x3 implicit-GEMM conv (forward + data gradient)', 'launches_per_step': launches_per_step,
+                         'avg_launch_us': round(1000 * d['ms'] / max(d['launches'], 1), 2),
+                         # whole step against the per-layer rooflines: sum over every conv-like layer and pass (forward, data
+                         # gradient, weight gradient) of max(flops / MFMA peak, unfused bytes / 8 TB/s), / measured step time
+                         'step_roofline_ms': round(1000 * aw['all']['roof_s'], 3),
+                         'step_frac': round(1000 * aw['all']['roof_s'] / (1000 * dt / args.steps), 4),
+                         'stack_roofline_ms': round(1000 * a3['roof_s'], 3),
+                         'stack_roofline_frac': round(1000 * a3['roof_s'] / max(d['ms'] / args.steps, 1e-9), 4)},
             'model_tflops': round(value * TRAIN_GFLOP_PER_TILE / 1000, 2),
             'extra': extra,
         }

@@ -28,10 +28,16 @@
 // TL (tap loop, TAPS == 1 geometry): a 3x3 conv whose dilation makes the halo tile many times larger than the tile itself (ASPP: 3 / 6 /
 // 12 against 4 x 32 pixels) runs as 9 x Cin/32 K-chunks instead -- per tap the tile is gathered at its shifted position (no halo, zero
 // outside the image) and multiplied with that tap's weight slab.
-template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool DYN, bool TL = false>
+// DB (double buffer): two LDS stages and ONE barrier per K-chunk.  The registers hold chunk c+1 while chunk c is multiplied; at the top
+// of iteration c they are written into the stage that chunk c-1 used (every wave is past the barrier that ended c-1) and re-issued
+// for chunk c+2 at once, so a chunk's loads are in flight for a whole iteration (write-after-barrier / re-issue-immediately,
+// cdna_hip_programming.md T14).  Used with the 256-pixel x 128-channel, 8-wave tile for the deep layers: per MFMA the 9-tap weight
+// slab (77 % of the staged bytes, re-fetched from L2 by every workgroup) is amortised over twice the pixels of the 128 x 128 tile
+// (20.7 instead of 37.7 staged bytes per MFMA-cycle and CU at full rate), which is what bounded that tile at ~0.9 PFLOP/s.
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool DYN, bool TL = false, bool DB = false, int WPS = 0>
 // thin configurations (<= 32 accumulator registers) request 4 waves/SIMD; the scaled-fp8 fragments are 8 registers each, so
-// that path asks for 2
-__global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 ? 2 : 4) : 1)) void igemm_fast_kernel(const IgemmArgs a) {
+// that path asks for 2.  WPS overrides (tile-at-once configurations stage a whole tile through registers)
+__global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<T>::SUB == 2 ? 2 : 4) : 1))) void igemm_fast_kernel(const IgemmArgs a) {
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int BM = WM * MT * 32;
   constexpr int BN = WN * NT * 32;
@@ -59,6 +65,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
   const int spad = SLOTS > 2 ? ((32 - (plane * (int)sizeof(T)) % 128 + 128) % 128) / (int)sizeof(T) : 0;
   const int slot_stride = plane + spad;
   T* ldsB = ldsA + SLOTS * slot_stride;
+  const int stage_elems = SLOTS * slot_stride + TAPS * SLOTS * BN * EL;      // one LDS stage (A planes + weight slab); DB: two of them
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
       else rb[j] = zero8<T>();
     }
   };
-  auto store_lds = [&](int chunk_) {
+  auto store_lds = [&](int chunk_, int boff = 0) {
     const int chunk = TL ? chunk_ % a.cpt : chunk_;
     const int cg0 = chunk * KC + slot_t * EL;
 #pragma unroll
@@ -167,13 +174,13 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
       if (a_l[j] >= 0) {
         Raw8<T> v = ra[j];
         if (a.in_scale && a_p[j] >= 0) v = affine8<T>(v, a.in_scale + cg0, a.in_shift + cg0, a.in_relu);
-        lstore8<T>(ldsA + a_l[j], v);
+        lstore8<T>(ldsA + boff + a_l[j], v);
       }
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
       const int it = tid + j * NTHREADS;
-      if (it < b_items) lstore8<T>(ldsB + (size_t)it * EL, rb[j]);
+      if (it < b_items) lstore8<T>(ldsB + boff + (size_t)it * EL, rb[j]);
     }
   };
 
@@ -183,6 +190,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
   else gather_pixels(n0, y0, x0);
   load_regs(0);
   store_lds(0);
+  if constexpr (DB) { if (a.nchunks > 1) load_regs(1); }
   __syncthreads();
   {
     f32x16 acc[MT][NT];
@@ -192,6 +200,51 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    // one K-chunk: software-pipelined fragment reads -- the LDS reads of step s+1 are issued before the MFMAs of step s (the
+    // compiler otherwise waits for every read right before its MFMAs and the matrix pipe idles for the LDS latency)
+    auto compute_chunk = [&](int boff) {
+      constexpr int STEPS = TAPS * KS;
+      FragT<T> af[2][MT], bf[2][NT];
+      auto read_step = [&](int st, int buf) {
+        const int tap = st / KS, ks = st % KS;
+        const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap % 3;
+        const int tap_off = (ky * dil * pitch + kx * dil) * EL;
+        const int slot = (ks * 2 + hh) * SUB;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[buf][m] = lds_frag<T>(ldsA + boff + (ABL(16) ? 0 : slot * slot_stride + a_off[m] + tap_off), slot_stride);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[buf][n] = lds_frag<T>(ldsB + boff + ((tap * SLOTS + slot) * BN + (wn * NT + n) * 32 + r) * EL, BN * EL);
+      };
+      read_step(0, 0);
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        asm volatile("" ::: "memory");              // IR-level fence: later steps' LDS reads must not be hoisted up here
+        if (st + 1 < STEPS) read_step(st + 1, (st + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this step's MFMAs
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) { if (!ABL(2)) mma32<T>(acc[m][n], af[st & 1][m], bf[st & 1][n]); }
+      }
+      // pin this chunk's MFMAs before the barrier: nothing else orders them, and the compiler otherwise sinks all of them below
+      // the LDS restaging of the next chunk, which keeps every fragment of the chunk live (seen with the scaled-fp8 form: spills)
+      if constexpr (SUB == 2 || DB) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(acc[m][n]));
+      }
+    };
+    if constexpr (DB) {
+      for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const int cur = (chunk & 1) * stage_elems;
+        if (chunk + 1 < a.nchunks) store_lds(chunk + 1, stage_elems - cur);      // the stage chunk-1 used: every wave is past the barrier that ended it
+        if (chunk + 2 < a.nchunks) load_regs(chunk + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_chunk(cur);
+        __syncthreads();
+      }
+    } else {
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
       const bool more = chunk + 1 < a.nchunks;
       if (more) {
@@ -203,46 +256,13 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
         }
         load_regs(chunk + 1);
       }
-      // software-pipelined fragment reads: the LDS reads of step s+1 are issued before the MFMAs of step s (the compiler
-      // otherwise waits for every read right before its MFMAs and the matrix pipe idles for the LDS latency)
-      {
-        constexpr int STEPS = TAPS * KS;
-        FragT<T> af[2][MT], bf[2][NT];
-        auto read_step = [&](int st, int buf) {
-          const int tap = st / KS, ks = st % KS;
-          const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap % 3;
-          const int tap_off = (ky * dil * pitch + kx * dil) * EL;
-          const int slot = (ks * 2 + hh) * SUB;
-#pragma unroll
-          for (int m = 0; m < MT; ++m) af[buf][m] = lds_frag<T>(ldsA + (ABL(16) ? 0 : slot * slot_stride + a_off[m] + tap_off), slot_stride);
-#pragma unroll
-          for (int n = 0; n < NT; ++n) bf[buf][n] = lds_frag<T>(ldsB + ((tap * SLOTS + slot) * BN + (wn * NT + n) * 32 + r) * EL, BN * EL);
-        };
-        read_step(0, 0);
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-          asm volatile("" ::: "memory");              // IR-level fence: later steps' LDS reads must not be hoisted up here
-          if (st + 1 < STEPS) read_step(st + 1, (st + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this step's MFMAs
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) { if (!ABL(2)) mma32<T>(acc[m][n], af[st & 1][m], bf[st & 1][n]); }
-        }
-        // pin this chunk's MFMAs before the barrier: nothing else orders them, and the compiler otherwise sinks all of them below
-        // the LDS restaging of the next chunk, which keeps every fragment of the chunk live (seen with the scaled-fp8 form: spills)
-        if constexpr (SUB == 2) {
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(acc[m][n]));
-        }
-      }
+      compute_chunk(0);
       __syncthreads();
       if (more) {
         store_lds(chunk + 1);
         __syncthreads();
       }
+    }
     }
 
     igemm_epilogue<T, TW, WM, WN, MT, NT, ABL(1)>(a, acc, n0, y0, x0, nbase, smem_raw);
@@ -250,7 +270,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MT * NT <= 2 ? (KTraits<T>::SUB == 2 
 }
 
 // ------------------------------------------------------------------ host side
-template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool TL = false>
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool TL = false, bool DB = false, int WPS = 0>
 static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   constexpr int EL = KTraits<T>::EL, SUB = KTraits<T>::SUB;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, KC = KS * 2 * SUB * EL, NTHREADS = WM * WN * 64;
@@ -284,7 +304,8 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   }
   if (a.ldy % (16 / (int)sizeof(T)) != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;
   if (a.mode_out == 0 && a.cout % (16 / (int)sizeof(T)) != 0 && a.cout < a.ldy) { /* tail handled by scalar stores */ }
-  const size_t lds_stage = ((size_t)KC * a.rl * a.pitch + (size_t)TAPS * KC * BN) * sizeof(T) + (size_t)(KC / EL) * 128;      // + slot padding (< 128 B per plane)
+  const size_t lds_stage = (((size_t)KC * a.rl * a.pitch + (size_t)TAPS * KC * BN) * sizeof(T) + (size_t)(KC / EL) * 128) * (DB ? 2 : 1);      // + slot padding (< 128 B per plane)
+  if (DB && (TL || a.mode_in != 0)) return SATCV_ERR_UNSUPPORTED;
   const size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
   const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
@@ -295,11 +316,18 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
     constexpr int PITCHc = TW == 32 ? CLc : (TW == 16 ? ((CLc + 15) / 16) * 16 : (CLc <= 8 ? 8 : ((CLc - 8 + 15) / 16) * 16 + 8));
     if (a.cl != CLc || a.pitch != PITCHc) { satcv_set_error("igemm_fast: internal pitch mismatch (%d/%d vs %d/%d)", a.cl, a.pitch, CLc, PITCHc); return SATCV_ERR_INVALID; }
   }
-  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, false, TL>;
-  if constexpr (TAPS == 9) { if (dyn) kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, true>; }
+  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, false, TL, DB, WPS>;
+  if constexpr (TAPS == 9 && !DB && WPS == 0) { if (dyn) kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, true>; }
+  if ((DB || WPS) && dyn) return SATCV_ERR_UNSUPPORTED;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+    // once per instantiation and LDS high-water mark (a driver call on the launch path of every layer otherwise)
+    static size_t lds_set[2] = {0, 0};
+    size_t& have = lds_set[dyn ? 1 : 0];
+    if (lds > have) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+      have = lds;
+    }
   }
   const long long blocks = (long long)a.ngroups * a.tiles_y * a.tiles_x * a.n_tiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return SATCV_ERR_UNSUPPORTED;
@@ -316,6 +344,17 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   // instead of once per position and write whole lines (SATCV_CONVT_WIDE=0: one position per tile, the earlier behaviour)
   static const bool convt_wide = !(getenv("SATCV_CONVT_WIDE") && atoi(getenv("SATCV_CONVT_WIDE")) == 0);
   const int nspace = (a.mode_out && !convt_wide) ? a.cstat : a.cout;
+  if constexpr (TAPS == 9 && std::is_same<T, bf16>::value) {
+    // deep 3x3 layers: 256-pixel x 128-channel tile, 8 waves, double-buffered stages (SATCV_DB=0 keeps the 128 x 128 tile)
+    static const int db_mode = getenv("SATCV_DB") ? atoi(getenv("SATCV_DB")) : 1;
+    if (db_mode && a.dil == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && nspace % 128 == 0 && cin >= 64) {
+      const long long tiles256 = (long long)cdiv(a.n * a.h * a.w_, 256) * (nspace / 128);
+      if (db_mode >= 2 || tiles256 >= 192) {
+        const int rc = fast_cfg<T, TW, 4, 2, 2, 2, 1, TAPS, false, true>(a, st, dry);
+        if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+      }
+    }
+  }
   // 32-channel chunks only for 1x1 taps (the 9-tap weight slab of a 32-channel chunk would not leave
   // room for 2-3 workgroups per CU)
   if constexpr (KTraits<T>::SUB == 2) {

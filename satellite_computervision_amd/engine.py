@@ -254,7 +254,7 @@ class Plan:
         self.side = torch.cuda.Stream() if (training and rt.model.wgrad_side_stream) else None
         self.step_count = 0
         self.outputs = {}
-        self.sync_bn = bool(training and getattr(rt.model, 'sync_bn', False) and parallel.world_size() > 1)
+        self.sync_bn = bool(training and getattr(rt.model, 'sync_bn', False) and parallel.active())
         self._build()
 
     # -- helpers
@@ -269,10 +269,17 @@ class Plan:
             raise ValueError(f'input {self.h}x{self.w} is not divisible by the model downsampling ({1 / t.down})')
         return int(hh), int(ww)
 
-    def _conv_step(self, **kw):
+    def _conv_step(self, role='fwd', **kw):
         d = ops.make_conv_desc(**kw)
         self.keep.append(d)
-        return lambda st, d=d: check(lib.satcv_conv2d_igemm(C.byref(d), st))
+        fn = lambda st, d=d: check(lib.satcv_conv2d_igemm(C.byref(d), st))
+        # label + algorithmic work of the launch (tools/step_probe.py, bench.py's per-layer roofline)
+        k, cin, cout = kw.get('kh', 1) * kw.get('kw', 1), kw.get('c0', 0) + (kw.get('c1', 0) or 0), kw['cout']
+        px = kw['n'] * kw['h'] * kw['w_']
+        fn.label = (f"conv_{role} k{kw.get('kh', 1)} d{kw.get('dil', 1)} n{kw['n']} {kw['h']}x{kw['w_']} {kw.get('c0', 0)}+{kw.get('c1', 0) or 0}->{cout}"
+                    f"{' d2s' if kw.get('mode_out') else ''}{' s2d' if kw.get('mode_in') else ''}")
+        fn.work = dict(kind='conv', role=role, taps=k, px=px, cin=cin, cout=cout, esize=self.rt.esize)
+        return fn
 
     def _src_args(self, r):
         (x0, c0) = r.srcs[0]
@@ -647,6 +654,8 @@ class Plan:
             self.keep.append(d)
             cnt = float(n * hh * ww)
             red = lambda st: check(lib.satcv_bn_bwd_reduce(C.byref(d), st))
+            red.label = f"bn_bwd_reduce n{n} {hh}x{ww} c{c} f{f}"
+            red.work = dict(kind='bn_bwd_reduce', px=n * hh * ww, c=c, esize=es)
             fin0 = lambda st: check(lib.satcv_bn_bwd_finalize(_fp(sums, sums_off), sums_ld, c, cnt, dgamma, dbeta, _fp(coef), accum, st))
             if self.sync_bn:
                 def fin(st):            # SyncBN: Σdy, Σdy·x̂ averaged over replicas (linear + idempotent, so the whole buffer is reduced)
@@ -655,6 +664,8 @@ class Plan:
             else:
                 fin = fin0
             app = lambda st: check(lib.satcv_bn_bwd_apply(C.byref(d), st))
+            app.label = f"bn_bwd_apply n{n} {hh}x{ww} c{c} f{f}"
+            app.work = dict(kind='bn_bwd_apply', px=n * hh * ww, c=c, esize=es)
             if frozen:
                 # inference-mode BatchNormalization: dy = scale * g * mask, no batch-statistics terms (coef stays 0), no dgamma / dbeta
                 def fin_frozen(st):
@@ -681,7 +692,7 @@ class Plan:
 
         def dgrad_step(t, **kw):
             """data-gradient launch writing the activation gradient of tensor t"""
-            return self._conv_step(**kw)
+            return self._conv_step(role='dgrad', **kw)
 
         def wgrad_step(r, dy, lddy, lay, cin_real, cout, hh, ww, k, dil, f=0, accum=0):
             nonlocal ws_need
@@ -697,8 +708,12 @@ class Plan:
             ws_need = max(ws_need, nb)
             wdescs.append(d)
             self.keep.append(d)
+            label = f"wgrad k{k} d{dil} n{n} {hh}x{ww} {sa['c0']}+{sa['c1']}->{cout}{' convT f%d' % f if f else ''}"
+            work = dict(kind='wgrad', taps=(f * f if f else k * k), px=n * hh * ww, cin=cin_real, cout=cout, esize=es)
             if self.side is None:
-                return lambda st: check(lib.satcv_conv2d_wgrad(C.byref(d), st))
+                fn = lambda st: check(lib.satcv_conv2d_wgrad(C.byref(d), st))
+                fn.label, fn.work = label, work
+                return fn
             # weight gradient and data gradient of a layer only share their INPUT (dy): run the weight gradients on a
             # second HIP stream so that their load/MFMA/store phases interleave with the main stream's kernels
             ev = torch.cuda.Event()
@@ -708,6 +723,7 @@ class Plan:
                 ev.record(torch.cuda.current_stream())
                 side.wait_event(ev)
                 check(lib.satcv_conv2d_wgrad(C.byref(d), sptr))
+            run.label, run.work = label, work
             return run
 
         # data-parallel overlap: after every parameter-bearing node tell the gradient exchange which tail of the flat
@@ -718,6 +734,15 @@ class Plan:
                 pending[node.layer.name] = pending.get(node.layer.name, 0) + 1
         layer_hi = {l.name: max(rt.offsets[ps.name] + ps.size for ps in l.specs if ps.name in rt.offsets)
                     for l in m.layers if l.name in pending}
+        # a conv_batch_act node also writes the gamma / beta gradients of ITS BatchNormalization (a layer of its own, directly
+        # above the convolution in the flat buffer): until the node has run, nothing below the end of that layer is final
+        by_name = {l.name: l for l in m.layers}
+        for node in m.nodes:
+            bn = getattr(node.layer, 'bn_name', None) if node.op == 'cba' else None
+            if bn in by_name and node.layer.name in layer_hi:
+                his = [rt.offsets[ps.name] + ps.size for ps in by_name[bn].specs if ps.name in rt.offsets]
+                if his:
+                    layer_hi[node.layer.name] = max(layer_hi[node.layer.name], max(his))
 
         def grads_ready(node):
             lay = node.layer

@@ -33,13 +33,24 @@ def init_from_env(backend=None):
     return dist.get_rank(), dist.get_world_size()
 
 
+# test switch: run every collective at world size 1 as well (RCCL accepts a one-rank communicator), so that the nccl code
+# path -- communicator init, ReduceOp.AVG, the async bucketed all-reduce on the side stream, the stream waits -- can execute on
+# a single-GPU box (tests/test_dp_gpu.py::test_rccl_single_rank_path)
+FORCE = os.environ.get('SATCV_FORCE_COLLECTIVES', '0') == '1'
+
+
 def world_size(group=None):
     return dist.get_world_size(group) if dist.is_initialized() else 1
 
 
+def active(group=None):
+    """True when the collectives have to run: an initialised process group of more than one rank (or the test switch)."""
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE)
+
+
 def allreduce_mean_(t, group=None):
     """In-place mean over ranks (RCCL has a native AVG; gloo sums then scales)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not active(group):
         return t
     if dist.get_backend(group) == 'nccl':
         dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
@@ -73,7 +84,7 @@ class GradSync:
         self._works = []
 
     def _active(self):
-        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return active(self.group)
 
     def ready_above(self, flat, lo, stream=None):
         """every gradient element at offset >= lo is final once the work queued so far on the current stream and on `stream`
@@ -107,7 +118,7 @@ class GradSync:
 
 
 def broadcast_state(tensors, src=0, group=None):
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         for t in tensors:
             dist.broadcast(t, src, group=group)
 
@@ -135,6 +146,6 @@ def shard_list(items, rank, world):
 
 def reduce_templates(template, group=None):
     """Sum the per-rank stitched outputs (disjoint writes elsewhere zero) on every rank."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         dist.all_reduce(template, op=dist.ReduceOp.SUM, group=group)
     return template

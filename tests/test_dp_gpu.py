@@ -143,3 +143,146 @@ def test_sharded_chip_inference_equals_single_process(tmp_path):
         assert p.returncode == 0, o[-3000:]
     err, mag, nchips = [float(v) for v in [l for l in outs[0].splitlines() if l.startswith('RESULT')][0].split()[1:]]
     assert err == 0.0 and mag > 0 and nchips >= 4          # inference is bit-identical across batch splits
+
+
+BUCKET_WORKER = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ["REPO"])
+import torch.distributed as dist
+from satellite_computervision_amd import model_tools as mt, parallel
+rank, world = parallel.init_from_env("gloo")
+torch.cuda.set_device(0)
+rng = np.random.default_rng(5)
+B = 8
+x = rng.random((B, 32, 32, 4)).astype(np.float32)
+y = np.eye(2, dtype=np.float32)[(rng.random((B, 32, 32)) < 0.3).astype(np.int64)]
+
+
+def run(overlap, per=None):
+    mt.reset_uids(); mt.set_seed(11)
+    m = mt.get_unet_model(2, 4, filters=[32, 64], factors=[2, 2])
+    m.compute_dtype = "float32"
+    m.compile(optimizer=mt.Adam(1e-2), loss=lambda t, p: mt.weighted_categorical_crossentropy(t, p, [1.0, 3.0]))
+    rt = m.runtime
+    if per is None:
+        # bucket boundaries sit at numel - k * per: put every one of the first few INSIDE the gamma / beta range of a
+        # BatchNormalization that belongs to a conv_batch_act node (the ranges the overlap bookkeeping used to miss)
+        hits = []
+        for l in m.layers:
+            for ps in l.specs:
+                if ps.kind in ("gamma", "beta") and ps.name in rt.offsets:
+                    hits.append((rt.offsets[ps.name], ps.size, ps.name))
+        hits.sort(reverse=True)
+        numel = rt.gflat.numel()
+        off, size, name = hits[2]
+        per = numel - (off + size // 2)
+        assert 0 < per < numel
+    sync = parallel.make_grad_sync(m, bucket_bytes=4 * per, overlap=overlap)
+    inside = [a for a, b in sync.bounds if any(o < a < o + s for o, s, _ in [(rt.offsets[ps.name], ps.size, 0) for l in m.layers for ps in l.specs if ps.kind in ("gamma", "beta") and ps.name in rt.offsets])]
+    for _ in range(3):
+        m.train_on_batch(x[rank::world], y[rank::world])
+    torch.cuda.synchronize()
+    return rt.pflat.clone(), per, len(inside)
+
+
+w_ov, per, n_inside = run(True)
+w_no, _, _ = run(False, per)
+assert n_inside >= 1, "no bucket boundary inside a BatchNorm gamma/beta range"
+same = bool(torch.equal(w_ov, w_no))
+g = [torch.empty_like(w_ov) for _ in range(world)]
+dist.all_gather(g, w_ov)
+if rank == 0:
+    print("RESULT", int(same), int(torch.equal(g[0], g[1])), n_inside)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_overlapped_buckets_cut_inside_batchnorm_ranges(tmp_path):
+    """a bucket boundary inside the gamma / beta range of a conv_batch_act's BatchNormalization: the overlapped exchange may
+    only start a bucket once that node has written dgamma / dbeta -- the parameters after three steps must be bit-identical
+    to the run with a single exchange after the backward pass (a + b is order-free for two ranks), and equal on both ranks."""
+    script = tmp_path / 'bucket_worker.py'
+    script.write_text(BUCKET_WORKER)
+    env = dict(os.environ, REPO=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT='29683', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK='0'),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    same, lockstep, n_inside = [int(v) for v in [l for l in outs[0].splitlines() if l.startswith('RESULT')][0].split()[1:]]
+    assert same == 1 and lockstep == 1 and n_inside >= 1
+
+
+RCCL_WORKER = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ["REPO"])
+import torch.distributed as dist
+from satellite_computervision_amd import model_tools as mt, parallel
+assert parallel.FORCE
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+rng = np.random.default_rng(5)
+B = 8
+x = rng.random((B, 64, 64, 4)).astype(np.float32)
+y = np.eye(2, dtype=np.float32)[(rng.random((B, 64, 64)) < 0.3).astype(np.int64)]
+
+
+def run(sync_on, sync_bn=False, overlap=True):
+    mt.reset_uids(); mt.set_seed(11)
+    m = mt.get_unet_model(2, 4, filters=[32, 64, 128], factors=[2, 2, 2])
+    m.compute_dtype = "bfloat16"
+    m.sync_bn = sync_bn
+    m.compile(optimizer=mt.Adam(1e-3), loss=lambda t, p: mt.weighted_categorical_crossentropy(t, p, [1.0, 3.0]))
+    sync = parallel.make_grad_sync(m, bucket_bytes=256 << 10, overlap=overlap) if sync_on else None
+    if sync_on:
+        assert sync._active() and len(sync.bounds) > 3
+    for _ in range(3):
+        m.train_step_device(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), sync)
+    torch.cuda.synchronize()
+    dist.barrier(device_ids=[0])
+    return m.runtime.pflat.clone(), m.runtime.sflat.clone()
+
+
+w0, s0 = run(False)
+w1, s1 = run(True)                      # overlapped buckets on the weight-gradient stream, ReduceOp.SUM over one rank
+w2, s2 = run(True, sync_bn=True)        # + ReduceOp.AVG of the BatchNorm statistics buffers
+w3, s3 = run(True, overlap=False)
+t = torch.arange(8, dtype=torch.float64, device="cuda")
+parallel.allreduce_mean_(t)
+print("RESULT", int(torch.equal(w0, w1)), int(torch.equal(s0, s1)), int(torch.equal(w0, w2)), int(torch.equal(s0, s2)), int(torch.equal(w0, w3)),
+      int(torch.equal(t.cpu(), torch.arange(8, dtype=torch.float64))))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_path(tmp_path):
+    """the RCCL code path on the one GPU a test box has: backend "nccl" with a one-rank communicator and
+    SATCV_FORCE_COLLECTIVES=1, so the bucketed async all-reduce on the weight-gradient stream, the stream waits, ReduceOp.AVG
+    (SyncBN buffers) and barrier(device_ids=...) all execute.  A one-rank sum / mean is the identity: parameters and moving
+    statistics after three steps must be BIT-IDENTICAL to the run without any exchange."""
+    script = tmp_path / 'rccl_worker.py'
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, REPO=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT='29691', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0',
+               SATCV_FORCE_COLLECTIVES='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    flags = [int(v) for v in [l for l in r.stdout.splitlines() if l.startswith('RESULT')][0].split()[1:]]
+    assert flags == [1, 1, 1, 1, 1, 1], flags
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_under_torchrun_over_rccl(tmp_path):
+    """bench.py launched the way the driver launches it (torch.distributed.run, RANK / WORLD_SIZE from the environment) with
+    one rank on the one GPU, backend nccl, collectives forced: init, barriers with device_ids, the overlapped exchange,
+    max-over-ranks timing and teardown all run over RCCL.  A fresh subprocess: nothing that has touched the GPU is exec'd."""
+    import json
+    env = dict(os.environ, SATCV_FORCE_COLLECTIVES='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('SATCV_BENCH_BACKEND', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29657',
+           os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '2', '--batch', '8', '--no-cpu-baseline', '--no-infer']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert out['n_gpus'] == 1 and out['value'] > 0 and np.isfinite(out['extra']['loss_last'])

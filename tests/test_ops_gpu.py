@@ -89,6 +89,17 @@ CONV_CASES = [
     (2, 16, 16, 64, 32, 1, 1),     # 1x1
     (1, 32, 32, 48, 96, 3, 1),     # channel counts that are not powers of two
     (1, 256, 256, 16, 32, 3, 1),   # full-resolution tile
+    # the deep shapes of get_unet_model(2, 4) at 256x256 -- the instantiations bench.py times (K up to 9 * 1024)
+    (2, 16, 16, 1024, 512, 3, 1),  # dec4.conv1 (consumes concat([skip, up]))
+    (2, 16, 16, 512, 512, 3, 1),   # dec4.conv2
+    (2, 8, 8, 512, 1024, 3, 1),    # centre block
+    (2, 32, 32, 512, 256, 3, 1),   # dec3.conv1
+    (2, 32, 32, 128, 256, 3, 1),   # enc3
+    (1, 64, 64, 256, 128, 3, 1),   # dec2.conv1
+    (1, 128, 128, 128, 64, 3, 1),  # dec1.conv1
+    (1, 128, 128, 64, 64, 3, 1),   # dec1.conv2
+    (1, 256, 256, 64, 32, 3, 1),   # dec0.conv1
+    (1, 256, 256, 32, 32, 3, 1),   # dec0.conv2
 ]
 
 
@@ -144,6 +155,16 @@ BWD_CASES = [
     (2, 32, 32, 64, 64),     # (2,2) at TW=32
     (2, 24, 24, 64, 64),     # ragged rows, TW=8
     (2, 48, 48, 32, 32),     # 3 column tiles of 16
+    # deep shapes of the benchmarked model (data gradient: Cout -> Cin; weight gradient tiles of 128 channels and more)
+    (2, 16, 16, 512, 512),   # dec4.conv2
+    (2, 16, 16, 1024, 512),  # dec4.conv1
+    (2, 8, 8, 512, 1024),    # centre block
+    (2, 32, 32, 512, 256),   # dec3.conv1
+    (2, 16, 16, 256, 512),   # enc4
+    (1, 64, 64, 256, 128),   # dec2.conv1
+    (1, 64, 64, 128, 128),   # dec2.conv2
+    (1, 128, 128, 128, 64),  # dec1.conv1
+    (1, 256, 256, 64, 32),   # dec0.conv1
 ]
 
 
@@ -186,7 +207,8 @@ def test_wgrad_padded_input_and_affine(ops, td):
 # ------------------------------------------------------------------ transposed conv
 @pytest.mark.parametrize('td', DT)
 @pytest.mark.parametrize('case', [(2, 8, 8, 64, 32, 2), (1, 16, 16, 128, 64, 2), (2, 4, 4, 256, 128, 2), (1, 6, 6, 32, 32, 3),
-                                  (2, 32, 32, 64, 32, 2), (2, 24, 24, 64, 32, 2), (1, 64, 64, 64, 32, 2), (2, 32, 32, 128, 64, 2)])
+                                  (2, 32, 32, 64, 32, 2), (2, 24, 24, 64, 32, 2), (1, 64, 64, 64, 32, 2), (2, 32, 32, 128, 64, 2),
+                                  (2, 8, 8, 1024, 512, 2), (2, 16, 16, 512, 256, 2)])
 def test_conv2d_transpose(ops, td, case):
     n, h, w, cin, cout, f = case
     rng = np.random.default_rng(hash(case) % 2**31)
