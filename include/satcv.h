@@ -341,6 +341,14 @@ int satcv_graph_destroy(void* graph_exec);
 /* event pairs recorded around every igemm launch while enabled; total ms + count returned */
 int satcv_prof_enable(int32_t kind_mask);
 int satcv_prof_collect(int32_t kind, double* total_ms, int64_t* launches, double* flops);
+/* kernel-selection knobs (tests force a tile configuration on small shapes; probes A/B variants in one process).  Keys:
+ * "igemm_db"  0 = 128x128 single-buffered tile only, 1 = automatic (default), 2 = the double-buffered 256x128 tile wherever
+ *             its shape limits allow;
+ * "igemm_thin" 0 (default) = general kernel, 1 = the persistent weights-stationary kernel for thin 3x3 layers with >= 2048 tiles, 2 = wherever its shape limits allow.
+ * "wgrad_db"  1 (default) = double-buffered weight-gradient kernel where its limits allow, 0 = the single-buffered one.
+ * Returns SATCV_ERR_INVALID for an unknown key.  Not thread-safe against concurrent launches. */
+int satcv_set_option(const char* key, int32_t value);
+int satcv_get_option(const char* key, int32_t* value);
 
 #ifdef __cplusplus
 }

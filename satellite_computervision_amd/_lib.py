@@ -122,6 +122,8 @@ _SIGS = {
     'satcv_graph_destroy': (C.c_int, [c_vp]),
     'satcv_prof_enable': (C.c_int, [c_i32]),
     'satcv_prof_collect': (C.c_int, [c_i32, C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)]),
+    'satcv_set_option': (C.c_int, [C.c_char_p, c_i32]),
+    'satcv_get_option': (C.c_int, [C.c_char_p, C.POINTER(c_i32)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -104,6 +105,32 @@ extern "C" int satcv_prof_collect(int32_t kind, double* total_ms, int64_t* launc
   }
   *total_ms = ms; *launches = (int64_t)g_prof[kind].size(); *flops = fl;
   g_prof[kind].clear();
+  return SATCV_OK;
+}
+
+// ------------------------------------------------------------------ kernel-selection knobs
+// (environment defaults SATCV_DB / SATCV_THIN; satcv_set_option overrides them at run time)
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+int g_opt_igemm_db = env_int("SATCV_DB", 1);
+int g_opt_wgrad_db = env_int("SATCV_WGRAD_DB", 1);
+int g_opt_igemm_thin = env_int("SATCV_THIN", 0);      // measured equal to the general kernel (round 2): opt-in
+static int* opt_slot(const char* key) {
+  if (!key) return nullptr;
+  if (!strcmp(key, "igemm_db")) return &g_opt_igemm_db;
+  if (!strcmp(key, "igemm_thin")) return &g_opt_igemm_thin;
+  if (!strcmp(key, "wgrad_db")) return &g_opt_wgrad_db;
+  return nullptr;
+}
+extern "C" int satcv_set_option(const char* key, int32_t value) {
+  int* p = opt_slot(key);
+  SATCV_CHECK(p, "set_option: unknown key '%s'", key ? key : "(null)");
+  *p = value;
+  return SATCV_OK;
+}
+extern "C" int satcv_get_option(const char* key, int32_t* value) {
+  int* p = opt_slot(key);
+  SATCV_CHECK(p && value, "get_option: unknown key '%s'", key ? key : "(null)");
+  *value = *p;
   return SATCV_OK;
 }
 

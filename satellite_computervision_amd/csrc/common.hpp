@@ -181,6 +181,63 @@ __device__ __forceinline__ Raw8<T> affine8(const Raw8<T>& r, const float* sc, co
   return o;
 }
 
+// the same with the 8 scale + 8 shift values already in registers (rs[0..1] scale, rs[2..3] shift): bf16 / f32 / 8-element fp8 items
+template <typename T>
+__device__ __forceinline__ Raw8<T> affine8r(const Raw8<T>& r, const float4 (&rs)[4], int relu) {
+  const float sc[8] = {rs[0].x, rs[0].y, rs[0].z, rs[0].w, rs[1].x, rs[1].y, rs[1].z, rs[1].w};
+  const float sh[8] = {rs[2].x, rs[2].y, rs[2].z, rs[2].w, rs[3].x, rs[3].y, rs[3].z, rs[3].w};
+  Raw8<T> o;
+  if constexpr (std::is_same<T, bf16>::value) {
+    bf16x8 v = __builtin_bit_cast(bf16x8, r.q[0]);
+    bf16x8 w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (float)v[e] * sc[e] + sh[e];
+      t = relu ? fmaxf(t, 0.f) : t;
+      w[e] = (bf16)t;
+    }
+    o.q[0] = __builtin_bit_cast(uint4, w);
+  } else if constexpr (std::is_same<T, fp8>::value) {
+    const fp8* f = reinterpret_cast<const fp8*>(&r.q);
+    fp8* g = reinterpret_cast<fp8*>(&o.q);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (float)f[e] * sc[e] + sh[e];
+      g[e] = (fp8)(relu ? fmaxf(t, 0.f) : t);
+    }
+  } else {
+    const float* f = reinterpret_cast<const float*>(&r.q[0]);
+    float* g = reinterpret_cast<float*>(&o.q[0]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = f[e] * sc[e] + sh[e];
+      g[e] = relu ? fmaxf(t, 0.f) : t;
+    }
+  }
+  return o;
+}
+// ablation builds: keep a loaded item alive without storing it
+template <typename T>
+__device__ __forceinline__ void keep8(const Raw8<T>& r) {
+  if constexpr (std::is_same<T, fp8>::value) { asm volatile("" :: "v"(r.q.x), "v"(r.q.y)); }
+  else {
+#pragma unroll
+    for (int i = 0; i < Raw8<T>::NQ; ++i) asm volatile("" :: "v"(r.q[i].x), "v"(r.q[i].y), "v"(r.q[i].z), "v"(r.q[i].w));
+  }
+}
+// keep ? r : 0 without a branch
+template <typename T>
+__device__ __forceinline__ Raw8<T> select8(bool keep, const Raw8<T>& r) {
+  Raw8<T> o;
+  if constexpr (std::is_same<T, fp8>::value) {
+    o.q = make_uint2(keep ? r.q.x : 0u, keep ? r.q.y : 0u);
+  } else {
+#pragma unroll
+    for (int i = 0; i < Raw8<T>::NQ; ++i) o.q[i] = make_uint4(keep ? r.q[i].x : 0u, keep ? r.q[i].y : 0u, keep ? r.q[i].z : 0u, keep ? r.q[i].w : 0u);
+  }
+  return o;
+}
+
 // value as it will read back from storage (bf16 rounding, identity for f32)
 template <typename T>
 __device__ __forceinline__ float round_to(float x) {

@@ -362,7 +362,10 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   }
   satcv_prof_begin(d->kh * d->kw > 1 ? 0 : 1, flops, st);
   rc = SATCV_ERR_UNSUPPORTED;
-  if (!igemm_force_generic()) rc = igemm_fast_launch(a, d->dtype, st);
+  if (!igemm_force_generic()) {
+    rc = igemm_ws_launch(a, d->dtype, st, false);            // thin 3x3 layers: persistent weights-stationary kernel
+    if (rc == SATCV_ERR_UNSUPPORTED) rc = igemm_fast_launch(a, d->dtype, st);
+  }
   if (rc != SATCV_ERR_UNSUPPORTED) { /* launched (or failed hard) */ }
   else if (d->dtype == SATCV_FP8 || d->dtype == SATCV_FP8X) { satcv_set_error("igemm: this fp8 shape is outside the pipelined kernel's limits"); rc = SATCV_ERR_UNSUPPORTED; }
   else if (d->out_scale || d->pool_y) { satcv_set_error("igemm: out_scale / pool_y need the pipelined kernel"); rc = SATCV_ERR_UNSUPPORTED; }

@@ -18,13 +18,23 @@
 //     halos run on the same XCD (private L2).
 #include "igemm_common.hpp"
 #include <cstdlib>
+extern int g_opt_igemm_db, g_opt_igemm_thin;      // api.hip: satcv_set_option
 
 // compile-time ablation switches for profiling builds (-DSATCV_ABLATE=bits): 1 skip global stores, 2 skip MFMA,
-// 4 skip activation loads, 8 skip weight loads, 16 skip the LDS fragment reads, 32 skip the whole epilogue
+// 4 skip activation loads, 8 skip weight loads, 16 skip the LDS fragment reads, 32 skip the whole epilogue, 64 skip the LDS stores
 #ifndef SATCV_ABLATE
 #define SATCV_ABLATE 0
 #endif
 #define ABL(bit) ((SATCV_ABLATE & (bit)) != 0)
+// diagnostic build only (-DSATCV_STAMP): per-wave cycle sums of the phases of the double-buffered K loop (s_memtime), for the first
+// workgroups; read back with satcv_debug_read_stamps (not part of the product ABI, absent from normal builds)
+#ifdef SATCV_STAMP
+__device__ unsigned long long g_stamp[8][8][8];
+#define STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int satcv_debug_read_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(g_stamp)) == hipSuccess ? 0 : -1;
+}
+#endif
 // TL (tap loop, TAPS == 1 geometry): a 3x3 conv whose dilation makes the halo tile many times larger than the tile itself (ASPP: 3 / 6 /
 // 12 against 4 x 32 pixels) runs as 9 x Cin/32 K-chunks instead -- per tap the tile is gathered at its shifted position (no halo, zero
 // outside the image) and multiplied with that tap's weight slab.
@@ -72,6 +82,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, hh = lane >> 5;
+#ifdef SATCV_STAMP
+  unsigned long long k0, k1, k2, k3;
+  STAMP(k0);
+#endif
 
   // ---- XCD-aware tile id: blocks b and b+8 share an XCD (private L2); give each XCD a contiguous tile range so that the
   //      workgroups running side by side read neighbouring halos
@@ -106,7 +120,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
   int b_g[BI];
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
-    const int it = tid + j * NTHREADS;
+    const int it = min(tid + j * NTHREADS, b_items - 1);      // surplus items of the last round: a valid address, never stored
     const int co = it % BN, run = it / BN;
     b_g[j] = ((run / SLOTS) * (cin / EL) + (run % SLOTS)) * a.cout_pad + nbase + co;
   }
@@ -140,47 +154,134 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
                    ? (n * a.hs + sy) * a.ws + sx : -1;
     }
   };
-  auto load_regs = [&](int chunk_) {
+  // No vector-memory instruction of the K loop sits inside a lane-dependent branch: hipcc's s_waitcnt bookkeeping turns conservative at
+  // the joins of such branches and put an `s_waitcnt vmcnt(0)` between the activation loads and the weight loads of a chunk (the
+  // activation latency was exposed once per chunk, measured: 1.1 us x 64 chunks on 1024 -> 512 channels at 16 x 16).  Items outside
+  // the image load pixel 0 and are zeroed by a select when they are written to LDS (after the affine: padding is zero in the
+  // ACTIVATED tensor); the surplus weight items of the last round re-load the last valid item.
+  float4 rs[4];                                    // this thread's 8 scale + 8 shift values of the chunk in flight (fused input BatchNorm)
+  // staging is cut into UNITS -- activation items, the scale / shift values, weight items -- so that the double-buffered loop can
+  // spread them over the tap steps of the chunk being multiplied (one LDS store + one global load between two groups of MFMAs):
+  // issued back to back, the 11 loads of a chunk kept every wave in its issue phase for 1,400-3,000 cycles per chunk while the
+  // vector-memory pipe took them in, with the matrix pipe idle (s_memtime stamps: tools/stamp_probe.py)
+  struct ChunkSrc { const T* src; int cs, coff, sadd; size_t cadd; const float* scp; const float* shp; };
+  auto chunk_src = [&](int chunk_) {
+    ChunkSrc c;
     const int tap = TL ? chunk_ / a.cpt : 0;
     const int chunk = TL ? chunk_ - tap * a.cpt : chunk_;
     const int cg0 = chunk * KC;
-    const T* src; int cs, coff, sadd = 0;
+    c.sadd = 0;
     if (a.mode_in == 1) {
       const int ij = cg0 / a.c0;
-      sadd = (ij / a.f) * a.ws + (ij % a.f);
-      src = reinterpret_cast<const T*>(a.x0); cs = a.c0; coff = cg0 - ij * a.c0;
+      c.sadd = (ij / a.f) * a.ws + (ij % a.f);
+      c.src = reinterpret_cast<const T*>(a.x0); c.cs = a.c0; c.coff = cg0 - ij * a.c0;
     } else if (cg0 < a.c0) {
-      src = reinterpret_cast<const T*>(a.x0); cs = a.c0; coff = cg0;
+      c.src = reinterpret_cast<const T*>(a.x0); c.cs = a.c0; c.coff = cg0;
     } else {
-      src = reinterpret_cast<const T*>(a.x1); cs = a.c1; coff = cg0 - a.c0;
+      c.src = reinterpret_cast<const T*>(a.x1); c.cs = a.c1; c.coff = cg0 - a.c0;
     }
-#pragma unroll
-    for (int j = 0; j < AI; ++j) {
-      if (a_p[j] >= 0 && !ABL(4)) ra[j] = gload8<T>(src + (size_t)(a_p[j] + sadd) * cs + coff + slot_t * EL);
-      else ra[j] = zero8<T>();
+    c.cadd = ((size_t)chunk * SLOTS + (TL ? (size_t)tap * (cin / EL) : 0)) * a.cout_pad;
+    // (a pointer select, not a branch: without an input transform the values are loaded from the weight image and never used)
+    c.scp = a.in_scale ? a.in_scale + cg0 + slot_t * EL : reinterpret_cast<const float*>(a.w);
+    c.shp = a.in_scale ? a.in_shift + cg0 + slot_t * EL : reinterpret_cast<const float*>(a.w);
+    return c;
+  };
+  auto load_a = [&](const ChunkSrc& c, int j) {
+    const int p = a_p[j] < 0 ? 0 : a_p[j];
+    if (!ABL(4)) ra[j] = gload8<T>(c.src + (size_t)(p + c.sadd) * c.cs + c.coff + slot_t * EL);
+    else ra[j] = zero8<T>();
+  };
+  auto load_b = [&](const ChunkSrc& c, int j) {
+    if (!ABL(8)) rb[j] = gload8<T>(wp + ((size_t)b_g[j] + c.cadd) * EL);
+    else rb[j] = zero8<T>();
+  };
+  auto load_p = [&](const ChunkSrc& c) {
+    if constexpr (KTraits<T>::EL == 8) {
+      rs[0] = reinterpret_cast<const float4*>(c.scp)[0]; rs[1] = reinterpret_cast<const float4*>(c.scp)[1];
+      rs[2] = reinterpret_cast<const float4*>(c.shp)[0]; rs[3] = reinterpret_cast<const float4*>(c.shp)[1];
     }
-    const size_t cadd = ((size_t)chunk * SLOTS + (TL ? (size_t)tap * (cin / EL) : 0)) * a.cout_pad;
+  };
+  auto store_a = [&](int chunk_, int boff, int j) {
+    Raw8<T> v = ra[j];
+    if (a.in_scale) {
+      if constexpr (KTraits<T>::EL == 8) v = affine8r<T>(v, rs, a.in_relu);
+      else {
+        const int cg0 = (TL ? chunk_ % a.cpt : chunk_) * KC + slot_t * EL;
+        v = affine8<T>(v, a.in_scale + cg0, a.in_shift + cg0, a.in_relu);
+      }
+    }
+    v = select8<T>(a_p[j] >= 0, v);
+    if (ABL(64)) { keep8<T>(v); return; }
+    if (a_l[j] >= 0) lstore8<T>(ldsA + boff + a_l[j], v);
+  };
+  auto store_b = [&](int boff, int j) {
+    const int it = tid + j * NTHREADS;
+    if (ABL(64)) { keep8<T>(rb[j]); return; }
+    if (it < b_items) lstore8<T>(ldsB + boff + (size_t)it * EL, rb[j]);
+  };
+  // single-buffered instantiations keep the loader they were tuned with (lane-predicated loads, scale / shift read where an item is
+  // written: the thin configurations sit exactly at the 128-register cap of four waves per SIMD, 16 more live registers spill)
+  auto load_regs = [&](int chunk_) {
+    if constexpr (DB) {
+      const ChunkSrc c = chunk_src(chunk_);
+      // (same issue order as the units of the double-buffered loop -- activations, scale / shift, weights -- so that the counted
+      //  s_waitcnt of the first iteration and of the steady state agree)
 #pragma unroll
-    for (int j = 0; j < BI; ++j) {
-      if (tid + j * NTHREADS < b_items && !ABL(8)) rb[j] = gload8<T>(wp + ((size_t)b_g[j] + cadd) * EL);
-      else rb[j] = zero8<T>();
+      for (int j = 0; j < AI; ++j) load_a(c, j);
+      load_p(c);
+#pragma unroll
+      for (int j = 0; j < BI; ++j) load_b(c, j);
+    } else {
+      const int tap = TL ? chunk_ / a.cpt : 0;
+      const int chunk = TL ? chunk_ - tap * a.cpt : chunk_;
+      const int cg0 = chunk * KC;
+      const T* src; int cs, coff, sadd = 0;
+      if (a.mode_in == 1) {
+        const int ij = cg0 / a.c0;
+        sadd = (ij / a.f) * a.ws + (ij % a.f);
+        src = reinterpret_cast<const T*>(a.x0); cs = a.c0; coff = cg0 - ij * a.c0;
+      } else if (cg0 < a.c0) {
+        src = reinterpret_cast<const T*>(a.x0); cs = a.c0; coff = cg0;
+      } else {
+        src = reinterpret_cast<const T*>(a.x1); cs = a.c1; coff = cg0 - a.c0;
+      }
+#pragma unroll
+      for (int j = 0; j < AI; ++j) {
+        if (a_p[j] >= 0 && !ABL(4)) ra[j] = gload8<T>(src + (size_t)(a_p[j] + sadd) * cs + coff + slot_t * EL);
+        else ra[j] = zero8<T>();
+      }
+      const size_t cadd = ((size_t)chunk * SLOTS + (TL ? (size_t)tap * (cin / EL) : 0)) * a.cout_pad;
+#pragma unroll
+      for (int j = 0; j < BI; ++j) {
+        if (tid + j * NTHREADS < b_items && !ABL(8)) rb[j] = gload8<T>(wp + ((size_t)b_g[j] + cadd) * EL);
+        else rb[j] = zero8<T>();
+      }
     }
   };
   auto store_lds = [&](int chunk_, int boff = 0) {
-    const int chunk = TL ? chunk_ % a.cpt : chunk_;
-    const int cg0 = chunk * KC + slot_t * EL;
+    if constexpr (DB) {
 #pragma unroll
-    for (int j = 0; j < AI; ++j) {
-      if (a_l[j] >= 0) {
-        Raw8<T> v = ra[j];
-        if (a.in_scale && a_p[j] >= 0) v = affine8<T>(v, a.in_scale + cg0, a.in_shift + cg0, a.in_relu);
-        lstore8<T>(ldsA + boff + a_l[j], v);
+      for (int j = 0; j < AI; ++j) store_a(chunk_, boff, j);
+#pragma unroll
+      for (int j = 0; j < BI; ++j) store_b(boff, j);
+    } else {
+      const int chunk = TL ? chunk_ % a.cpt : chunk_;
+      const int cg0 = chunk * KC + slot_t * EL;
+#pragma unroll
+      for (int j = 0; j < AI; ++j) {
+        if (a_l[j] >= 0) {
+          Raw8<T> v = ra[j];
+          if (a.in_scale && a_p[j] >= 0) v = affine8<T>(v, a.in_scale + cg0, a.in_shift + cg0, a.in_relu);
+          if (ABL(64)) { keep8<T>(v); continue; }
+          lstore8<T>(ldsA + boff + a_l[j], v);
+        }
       }
-    }
 #pragma unroll
-    for (int j = 0; j < BI; ++j) {
-      const int it = tid + j * NTHREADS;
-      if (it < b_items) lstore8<T>(ldsB + boff + (size_t)it * EL, rb[j]);
+      for (int j = 0; j < BI; ++j) {
+        const int it = tid + j * NTHREADS;
+        if (ABL(64)) { keep8<T>(rb[j]); continue; }
+        if (it < b_items) lstore8<T>(ldsB + boff + (size_t)it * EL, rb[j]);
+      }
     }
   };
 
@@ -188,10 +289,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
   tile_origin(bid, n0, y0, x0);
   if constexpr (TL) gather_pixels(n0, y0, x0, -a.halh_tl, -a.halw_tl);
   else gather_pixels(n0, y0, x0);
+#ifdef SATCV_STAMP
+  STAMP(k1);
+#endif
   load_regs(0);
   store_lds(0);
   if constexpr (DB) { if (a.nchunks > 1) load_regs(1); }
   __syncthreads();
+#ifdef SATCV_STAMP
+  STAMP(k2);
+#endif
   {
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -202,7 +309,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
         for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
     // one K-chunk: software-pipelined fragment reads -- the LDS reads of step s+1 are issued before the MFMAs of step s (the
     // compiler otherwise waits for every read right before its MFMAs and the matrix pipe idles for the LDS latency)
-    auto compute_chunk = [&](int boff) {
+    auto compute_chunk = [&](int boff, auto&& side) {
       constexpr int STEPS = TAPS * KS;
       FragT<T> af[2][MT], bf[2][NT];
       auto read_step = [&](int st, int buf) {
@@ -220,6 +327,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
       for (int st = 0; st < STEPS; ++st) {
         asm volatile("" ::: "memory");              // IR-level fence: later steps' LDS reads must not be hoisted up here
         if (st + 1 < STEPS) read_step(st + 1, (st + 1) & 1);
+        side(st);                                   // (double-buffered loop) this step's share of the staging of the next chunks
         __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this step's MFMAs
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -236,17 +344,55 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
       }
     };
     if constexpr (DB) {
+#ifdef SATCV_STAMP
+      unsigned long long t0, t1, t2, t3, t4, s_wait = 0, s_store = 0, s_comp = 0, s_bar = 0;
+#endif
+      // units of one chunk's staging in program order: A items (store c+1, then re-issue for c+2), the scale / shift values (needed by
+      // the A stores above, so re-issued after them), weight items; unit u runs in tap step u (the surplus in the last step)
+      constexpr int NUNITS = AI + 1 + BI, STEPS_ = TAPS * KS;
       for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        const int cur = (chunk & 1) * stage_elems;
-        if (chunk + 1 < a.nchunks) store_lds(chunk + 1, stage_elems - cur);      // the stage chunk-1 used: every wave is past the barrier that ended it
-        if (chunk + 2 < a.nchunks) load_regs(chunk + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_chunk(cur);
+        const int cur = (chunk & 1) * stage_elems, oth = stage_elems - cur;
+        const bool do_store = chunk + 1 < a.nchunks, do_load = chunk + 2 < a.nchunks;
+        // (wave-uniform flags; the loads of the last two iterations re-read the last chunk instead of branching around vector-memory
+        //  instructions inside the loop: see the note at the loaders)
+        const ChunkSrc cs_ = chunk_src(do_load ? chunk + 2 : a.nchunks - 1);
+#ifdef SATCV_STAMP
+        STAMP(t0);
+        STAMP(t1);
+        STAMP(t2);
+#endif
+        compute_chunk(cur, [&](int st) {
+#pragma unroll
+          for (int u = 0; u < NUNITS; ++u) {
+            if ((u < STEPS_ ? u : STEPS_ - 1) != st) continue;
+            if (u < AI) { if (do_store) store_a(chunk + 1, oth, u); load_a(cs_, u); }
+            else if (u == AI) load_p(cs_);
+            else { if (do_store) store_b(oth, u - AI - 1); load_b(cs_, u - AI - 1); }
+          }
+        });
+#ifdef SATCV_STAMP
+        STAMP(t3);
+#endif
         __syncthreads();
+#ifdef SATCV_STAMP
+        STAMP(t4);
+        s_wait += t1 - t0; s_store += t2 - t1; s_comp += t3 - t2; s_bar += t4 - t3;
+#endif
       }
+#ifdef SATCV_STAMP
+      if (blockIdx.x < 8 && lane == 0) {
+        g_stamp[blockIdx.x][wave][0] = s_wait; g_stamp[blockIdx.x][wave][1] = s_store; g_stamp[blockIdx.x][wave][2] = s_comp; g_stamp[blockIdx.x][wave][3] = s_bar;
+      }
+#endif
     } else {
+#ifdef SATCV_STAMP
+    unsigned long long t0, t1, t2, t3, t4, t5, s_issue = 0, s_comp = 0, s_bar1 = 0, s_store = 0, s_bar2 = 0;
+#endif
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
       const bool more = chunk + 1 < a.nchunks;
+#ifdef SATCV_STAMP
+      STAMP(t0);
+#endif
       if (more) {
         if constexpr (TL) {
           if ((chunk + 1) % a.cpt == 0) {             // next chunk starts a new tap: its tile sits at another offset
@@ -256,16 +402,51 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
         }
         load_regs(chunk + 1);
       }
-      compute_chunk(0);
+#ifdef SATCV_STAMP
+      STAMP(t1);
+#endif
+      compute_chunk(0, [](int) {});
+#ifdef SATCV_STAMP
+      STAMP(t2);
+#endif
       __syncthreads();
+#ifdef SATCV_STAMP
+      STAMP(t3);
+#endif
       if (more) {
         store_lds(chunk + 1);
+#ifdef SATCV_STAMP
+        STAMP(t4);
+#endif
         __syncthreads();
       }
+#ifdef SATCV_STAMP
+      else { STAMP(t4); }
+      STAMP(t5);
+      s_issue += t1 - t0; s_comp += t2 - t1; s_bar1 += t3 - t2; s_store += t4 - t3; s_bar2 += t5 - t4;
+#endif
     }
+#ifdef SATCV_STAMP
+    if (blockIdx.x < 8 && lane == 0) {
+      g_stamp[blockIdx.x][wave][0] = s_issue; g_stamp[blockIdx.x][wave][1] = s_comp; g_stamp[blockIdx.x][wave][2] = s_bar1;
+      g_stamp[blockIdx.x][wave][3] = s_store; g_stamp[blockIdx.x][wave][7] = s_bar2;
     }
+#endif
+    }
+#ifdef SATCV_STAMP
+    STAMP(k3);
+#endif
 
     igemm_epilogue<T, TW, WM, WN, MT, NT, ABL(1)>(a, acc, n0, y0, x0, nbase, smem_raw);
+#ifdef SATCV_STAMP
+    {
+      unsigned long long k4;
+      STAMP(k4);
+      if (blockIdx.x < 8 && lane == 0) {
+        g_stamp[blockIdx.x][wave][4] = k1 - k0; g_stamp[blockIdx.x][wave][5] = k2 - k1; g_stamp[blockIdx.x][wave][6] = k4 - k3;
+      }
+    }
+#endif
   }
 }
 
@@ -346,7 +527,7 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   const int nspace = (a.mode_out && !convt_wide) ? a.cstat : a.cout;
   if constexpr (TAPS == 9 && std::is_same<T, bf16>::value) {
     // deep 3x3 layers: 256-pixel x 128-channel tile, 8 waves, double-buffered stages (SATCV_DB=0 keeps the 128 x 128 tile)
-    static const int db_mode = getenv("SATCV_DB") ? atoi(getenv("SATCV_DB")) : 1;
+    const int db_mode = g_opt_igemm_db;
     if (db_mode && a.dil == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && nspace % 128 == 0 && cin >= 64) {
       const long long tiles256 = (long long)cdiv(a.n * a.h * a.w_, 256) * (nspace / 128);
       if (db_mode >= 2 || tiles256 >= 192) {

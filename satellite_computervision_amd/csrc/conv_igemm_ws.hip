@@ -1,0 +1,285 @@
+// Weights-stationary 3x3 convolution for the THIN full- and half-resolution layers of the U-Net (Cin <= 64 stored channels,
+// Cout 32 or 64; Conv2D of utils/model_tools.py:178, 312, 315 at decoder / encoder levels 0 and 1, forward and data gradient).
+//
+// Why a kernel of its own (s_memtime stamps of the general kernel on 64 -> 32 channels at 256 x 256, tools/stamp_probe.py): of the
+// ~24,500 cycles a workgroup spent per 256-pixel tile only 3,500 were the MFMA phase; 4,300 went into the gather-table setup, 5,500 into
+// issuing 11 loads per thread and 16-channel chunk, 2,300 into LDS stores, 4,700 into the epilogue, with two barriers per chunk.  Here:
+//   * PERSISTENT workgroups (grid = resident workgroups): the setup runs once, the loop walks the tiles;
+//   * the whole 9-tap weight tensor (<= 37 KB) is staged in LDS ONCE per workgroup instead of per tile and chunk (it was 46 % of the
+//     bytes that went through the load path);
+//   * the activation halo tile is staged for ALL input channels at once (one barrier pair per tile, no chunk loop); a thread always
+//     handles the same 8 channels, so its BatchNorm scale / shift values live in registers for the whole launch;
+//   * the next tile's loads are issued before the current tile is multiplied and stay in flight through its MFMA phase and epilogue;
+//     2-4 workgroups per CU overlap one another's load, MFMA and store phases.
+// LDS images and MFMA fragment addressing are those of conv_igemm_fast.hip ([slot][row][pitch][8] activations, [tap][slot][cout][8]
+// weights, v_mfma_f32_32x32x16_bf16), the epilogue is the shared igemm_epilogue (bias, BN statistics, LDS-staged 16-byte stores).
+#include "igemm_common.hpp"
+#include <cstdlib>
+extern int g_opt_igemm_thin;      // api.hip: satcv_set_option("igemm_thin", ...)
+
+#ifndef SATCV_ABLATE
+#define SATCV_ABLATE 0
+#endif
+#define WABL(bit) ((SATCV_ABLATE & (bit)) != 0)
+#ifdef SATCV_STAMP
+__device__ unsigned long long g_stamp_ws[8][8][8];        // diagnostic build only
+extern "C" int satcv_debug_read_stamps_ws(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp_ws), sizeof(g_stamp_ws)) == hipSuccess ? 0 : -1; }
+#define STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_V(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
+
+template <int CIN, int NT, int WPS>
+__global__ __launch_bounds__(256, WPS) void igemm_ws_kernel(const IgemmArgs a, const int total_tiles) {
+  typedef bf16 T;
+  constexpr int TW = 32, TH = 8, WM = 4, WN = 1, MT = 2, BM = 256, BN = NT * 32, NTHREADS = 256, EL = 8;
+  constexpr int SLOTS = CIN / EL, CL = TW + 2, PITCH = CL, RL = TH + 2;
+  constexpr int PLANE = RL * PITCH * EL;                                   // elements of one slot plane
+  // 8 consecutive lanes store 8 / SLOTS pixels x SLOTS slots with one ds_write_b128 (serviced in groups of 8 lanes over 32 banks):
+  // the plane stride must be 128 / SLOTS bytes modulo 128 for the eight 16-byte stores to fall on distinct banks
+  constexpr int WANT = (SLOTS >= 8 ? 16 : 128 / SLOTS) / (int)sizeof(T);
+  constexpr int SPAD = ((WANT - PLANE % 64) % 64 + 64) % 64;
+  constexpr int SLOT_STRIDE = PLANE + SPAD;
+  constexpr int A_ITEMS = RL * CL * SLOTS, AI = (A_ITEMS + NTHREADS - 1) / NTHREADS;
+  constexpr int W_ITEMS = 9 * SLOTS * BN;
+  constexpr int OPITCH = BN + 8;
+  constexpr size_t A_BYTES = (size_t)SLOTS * SLOT_STRIDE * sizeof(T);
+  constexpr size_t O_BYTES = (size_t)BM * OPITCH * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
+  constexpr size_t R0_BYTES = ((A_BYTES > O_BYTES ? A_BYTES : O_BYTES) + 127) / 128 * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* ldsA = reinterpret_cast<T*>(smem_raw);                                 // activation tile; re-used as the output staging tile
+  T* ldsW = reinterpret_cast<T*>(smem_raw + R0_BYTES);                      // [tap][slot][BN][8], resident for the whole launch
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int slot_t = tid % SLOTS;                                           // NTHREADS % SLOTS == 0: a thread's channel slot is fixed
+  const T* wp = reinterpret_cast<const T*>(a.w);
+
+  // ---- once per workgroup: weights -> LDS, this thread's source / scale / shift, the gather table
+  for (int it = tid; it < W_ITEMS; it += NTHREADS) {
+    const int co = it % BN, run = it / BN;                                  // run = tap * SLOTS + slot
+    const Raw8<T> v = gload8<T>(wp + ((size_t)run * a.cout_pad + co) * EL); // (cout_pad == BN: one N tile)
+    lstore8<T>(ldsW + (size_t)it * EL, v);
+  }
+  const int ch0 = slot_t * EL;
+  const bool second = ch0 >= a.c0;                                          // concat([skip, up]): which source holds this thread's channels
+  const T* src = second ? reinterpret_cast<const T*>(a.x1) + (ch0 - a.c0) : reinterpret_cast<const T*>(a.x0) + ch0;
+  const int cs = second ? a.c1 : a.c0;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = a.in_scale ? a.in_scale[ch0 + e] : 1.f; sh[e] = a.in_scale ? a.in_shift[ch0 + e] : 0.f; }
+  const bool aff = a.in_scale != nullptr;
+  const bool relu = a.in_relu != 0;
+
+  int a_l[AI], a_yx[AI];
+#pragma unroll
+  for (int j = 0; j < AI; ++j) {
+    const int it = tid + j * NTHREADS;
+    const int pix = it / SLOTS, c = pix % CL, L = pix / CL;
+    a_l[j] = it < A_ITEMS ? slot_t * SLOT_STRIDE + (L * PITCH + c) * EL : -1;
+    a_yx[j] = ((L - 1) << 16) | ((c - 1) & 0xffff);                         // halo coordinates relative to the tile origin
+  }
+  int a_off[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int q = (wave * MT + m) * 32 + r;
+    a_off[m] = ((q / TW) * PITCH + (q % TW)) * EL;
+  }
+
+  auto tile_origin = [&](int v, int& n0, int& y0, int& x0) {
+    const int tx = v % a.tiles_x; v /= a.tiles_x;
+    const int ty = v % a.tiles_y;
+    n0 = v / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
+  };
+  Raw8<T> ra[AI];
+  unsigned valid = 0;                                                       // bit j: item j lies inside the image (else zero padding)
+  auto issue_loads = [&](int n0, int y0, int x0) -> unsigned {
+    unsigned vm = 0;
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      const int y = y0 + (a_yx[j] >> 16), x = x0 + (int)(short)(a_yx[j] & 0xffff);
+      const bool ok = a_l[j] >= 0 && y >= 0 && y < a.h && x >= 0 && x < a.w_;
+      const int p = ok ? (n0 * a.h + y) * a.w_ + x : 0;                     // (items outside load pixel 0 and are zeroed below: no branch
+      vm |= (ok ? 1u : 0u) << j;                                            //  around a vector-memory instruction in the loop)
+      if (!WABL(4)) ra[j] = gload8<T>(src + (size_t)p * cs);
+      else ra[j] = zero8<T>();
+    }
+    return vm;
+  };
+
+  // ---- XCD-aware tile order: blocks b and b + 8 share an XCD; each XCD walks a contiguous range of tiles (neighbouring halos in its L2)
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, nx = G >> 3, remx = G & 7;
+  const int bid = (xcd < remx ? xcd * (nx + 1) : remx * (nx + 1) + (xcd - remx) * nx) + (blockIdx.x >> 3);
+  // tiles of this workgroup: [t_lo, t_hi) -- contiguous, so consecutive tiles of one workgroup share halo rows / columns too
+  const int per = total_tiles / G, extra = total_tiles % G;
+  const int t_lo = bid * per + (bid < extra ? bid : extra), t_hi = t_lo + per + (bid < extra ? 1 : 0);
+
+  // BN statistics of all tiles of this workgroup are summed in registers (thread c < BN owns channel c) and reach the replica rows
+  // with ONE pair of atomics per channel at the end: per-tile atomics stay on the wave's vmcnt queue for thousands of cycles under
+  // load and the next tile's loads could not be waited for without them
+  double carry[2] = {0.0, 0.0};
+  int n0, y0, x0;
+  if (t_lo < t_hi) { tile_origin(t_lo, n0, y0, x0); valid = issue_loads(n0, y0, x0); }
+  __syncthreads();                                                          // weights are in LDS
+#ifdef SATCV_STAMP
+  unsigned long long q0, q1, q2, q3, q4, q5, q6, q7, q8, z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  for (int t = t_lo; t < t_hi; ++t) {
+#ifdef SATCV_STAMP
+    STAMP(q0);
+    STAMP_V(q1);                               // wait for this tile's loads
+#endif
+    // ---- registers -> LDS (BatchNorm affine + ReLU of the producing layer, zero padding AFTER it)
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      bf16x8 v = __builtin_bit_cast(bf16x8, ra[j].q[0]);
+      bf16x8 w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)v[e];
+        float g = f * sc[e] + sh[e];
+        g = relu ? fmaxf(g, 0.f) : g;
+        w[e] = (bf16)(aff ? g : f);
+      }
+      uint4 q = __builtin_bit_cast(uint4, w);
+      const bool ok = (valid >> j) & 1u;
+      q = make_uint4(ok ? q.x : 0u, ok ? q.y : 0u, ok ? q.z : 0u, ok ? q.w : 0u);
+      if (a_l[j] >= 0) *reinterpret_cast<uint4*>(ldsA + a_l[j]) = q;
+    }
+#ifdef SATCV_STAMP
+    STAMP(q2);
+#endif
+    __syncthreads();
+#ifdef SATCV_STAMP
+    STAMP(q3);
+#endif
+    // ---- the next tile's loads: in flight during this tile's MFMA phase and epilogue
+    const int tn0 = n0, ty0 = y0, tx0 = x0;
+    if (t + 1 < t_hi) { tile_origin(t + 1, n0, y0, x0); valid = issue_loads(n0, y0, x0); }
+#ifdef SATCV_STAMP
+    STAMP(q4);
+#endif
+    // ---- 9 taps x CIN / 16 k-steps, fragment reads one step ahead of their MFMAs
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    {
+      constexpr int KS = CIN / 16, STEPS = 9 * KS;
+      FragT<T> af[2][MT], bf[2][NT];
+      auto read_step = [&](int st, int buf) {
+        const int tap = st / KS, ks = st % KS;
+        const int tap_off = ((tap / 3) * PITCH + (tap % 3)) * EL;
+        const int slot = ks * 2 + hh;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[buf][m] = lds_frag<T>(ldsA + slot * SLOT_STRIDE + a_off[m] + tap_off);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[buf][n] = lds_frag<T>(ldsW + ((tap * SLOTS + slot) * BN + n * 32 + r) * EL);
+      };
+      read_step(0, 0);
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        asm volatile("" ::: "memory");
+        if (st + 1 < STEPS) read_step(st + 1, (st + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) { if (!WABL(2)) mma32<T>(acc[m][n], af[st & 1][m], bf[st & 1][n]); }
+      }
+    }
+#ifdef SATCV_STAMP
+    STAMP(q5);
+#endif
+    __syncthreads();                                                        // every wave is past its last fragment read: the tile region is free
+#ifdef SATCV_STAMP
+    STAMP(q6);
+#endif
+    igemm_epilogue<T, TW, WM, WN, MT, NT, WABL(1)>(a, acc, tn0, ty0, tx0, 0, smem_raw, carry);
+#ifdef SATCV_STAMP
+    STAMP(q7);
+#endif
+    __syncthreads();                                                        // staged output read out before the next tile is written
+#ifdef SATCV_STAMP
+    STAMP(q8);
+    z[0] += q1 - q0; z[1] += q2 - q1; z[2] += q3 - q2; z[3] += q4 - q3; z[4] += q5 - q4; z[5] += q6 - q5; z[6] += q7 - q6; z[7] += q8 - q7;
+#endif
+  }
+  if (a.stats && tid < BN && tid < a.cout && t_lo < t_hi) {
+    satcv_stat_t* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
+    atomicAdd(rowp + tid, (satcv_stat_t)carry[0]);
+    atomicAdd(rowp + a.stats_ld + tid, (satcv_stat_t)carry[1]);
+  }
+#ifdef SATCV_STAMP
+  if (blockIdx.x < 8 && lane == 0)
+    for (int i = 0; i < 8; ++i) g_stamp_ws[blockIdx.x][wave][i] = z[i] / (unsigned long long)max(t_hi - t_lo, 1);
+#endif
+}
+
+// ------------------------------------------------------------------ host side
+template <int CIN, int NT, int WPS>
+static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
+  constexpr int TW = 32, TH = 8, BN = NT * 32, SLOTS = CIN / 8, RL = TH + 2, PITCH = TW + 2;
+  constexpr int PLANE = RL * PITCH * 8;
+  constexpr int WANT = (SLOTS >= 8 ? 16 : 128 / SLOTS) / 2;
+  constexpr int SPAD = ((WANT - PLANE % 64) % 64 + 64) % 64;
+  constexpr size_t A_BYTES = (size_t)SLOTS * (PLANE + SPAD) * 2;
+  constexpr size_t O_BYTES = (size_t)256 * (BN + 8) * 2 + (size_t)5 * 2 * BN * 4;
+  constexpr size_t R0 = ((A_BYTES > O_BYTES ? A_BYTES : O_BYTES) + 127) / 128 * 128;
+  constexpr size_t LDS = R0 + (size_t)9 * SLOTS * BN * 16;
+  static_assert(LDS <= 160 * 1024, "weights + tile exceed the LDS");
+  // tiling fields the shared epilogue reads
+  a.halh = a.halw = 1;
+  a.tiles_x = cdiv(a.w_, TW); a.tiles_y = cdiv(a.h, TH);
+  a.rpi = TH; a.imgs = 1; a.ngroups = a.n; a.seg = TH + 2; a.rl = RL; a.cl = TW + 2; a.pitch = PITCH; a.n_tiles = 1;
+  const long long total = (long long)a.n * a.tiles_y * a.tiles_x;
+  if (total <= 0 || total > 0x7fffffffLL) return SATCV_ERR_UNSUPPORTED;
+  if (dry) return SATCV_OK;
+  auto kern = igemm_ws_kernel<CIN, NT, WPS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+    attr_set = true;
+  }
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) { satcv_set_error("ws: device query failed"); return SATCV_ERR_HIP; }
+    ncu = p.multiProcessorCount;
+  }
+  // resident workgroups per CU: LDS- or wave-limited (4 waves each, WPS per SIMD requested)
+  int per_cu = (int)((160 * 1024) / LDS);
+  if (per_cu > WPS) per_cu = WPS;
+  if (per_cu < 1) per_cu = 1;
+  long long grid = (long long)ncu * per_cu;
+  if (grid > total) grid = total;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, st, a, (int)total);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { satcv_set_error("igemm_ws launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  return SATCV_OK;
+}
+
+// returns SATCV_ERR_UNSUPPORTED when the shape is outside this kernel's limits (the caller falls back to conv_igemm_fast.hip)
+int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
+  if (!g_opt_igemm_thin || dtype != SATCV_BF16) return SATCV_ERR_UNSUPPORTED;
+  const int cin = a.c0 + a.c1;
+  if (a.kh != 3 || a.kw != 3 || a.dil != 1 || a.stride != 1 || a.mode_in || a.mode_out || a.pool_y || a.accumulate || a.out_scale) return SATCV_ERR_UNSUPPORTED;
+  if (!(cin == 16 || cin == 32 || cin == 64) || !(a.cout == 32 || a.cout == 64) || a.cout_pad != a.cout || a.cstat != a.cout) return SATCV_ERR_UNSUPPORTED;
+  if (a.x1 && (a.c0 % 8 != 0)) return SATCV_ERR_UNSUPPORTED;
+  if (a.h < 8 || a.ldy % 8 != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;
+  // small problems stay on the general kernel unless forced (tests): the persistent grid needs enough tiles to fill the chip
+  const long long tiles = (long long)a.n * cdiv(a.h, 8) * cdiv(a.w_, 32);
+  if (g_opt_igemm_thin < 2 && tiles < 2048) return SATCV_ERR_UNSUPPORTED;
+  if (a.cout == 32) {
+    if (cin == 16) return ws_cfg<16, 1, 2>(a, st, dry);
+    if (cin == 32) return ws_cfg<32, 1, 2>(a, st, dry);
+    return ws_cfg<64, 1, 2>(a, st, dry);
+  }
+  if (cin == 16) return ws_cfg<16, 2, 2>(a, st, dry);
+  if (cin == 32) return ws_cfg<32, 2, 2>(a, st, dry);
+  return SATCV_ERR_UNSUPPORTED;           // 64 -> 64: weights (74 KB) + tile leave one workgroup per CU
+}

@@ -19,6 +19,14 @@
 #define SATCV_WABLATE 0
 #endif
 #define WABL(bit) ((SATCV_WABLATE & (bit)) != 0)
+#ifdef SATCV_STAMP
+// diagnostic build only: per-wave cycle sums of the phases of the pixel-tile loop (s_memtime), first 8 workgroups
+__device__ unsigned long long g_wstamp[8][4][8];
+#define WSTAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int satcv_debug_read_wstamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamp), sizeof(g_wstamp)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 struct WgradArgs {
   const void* x0; const void* x1; int c0, c1;
@@ -78,6 +86,10 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, (TW == 8 ? 1 : 2)) void wgrad_k
   const int ci_blk = blk % a.n_ci_blk, co_blk = blk / a.n_ci_blk;
   const int ci0 = ci_blk * CI_T, co0 = co_blk * CO_T;
 
+#ifdef SATCV_STAMP
+  unsigned long long w0, w1, w2, w3, w4, w5, w6, zs[6] = {0, 0, 0, 0, 0, 0};
+  WSTAMP(w0);
+#endif
   f32x16 acc[NTAPS];
 #pragma unroll
   for (int t = 0; t < NTAPS; ++t)
@@ -280,16 +292,48 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, (TW == 8 ? 1 : 2)) void wgrad_k
       store_tile();
     }
     __syncthreads();
+#ifdef SATCV_STAMP
+    WSTAMP(w1);
+    int ntl = 0;
+#endif
     for (int pt = sp; pt < a.total_ptiles; pt += a.nsplit) {
       const int nxt = pt + a.nsplit;
+#ifdef SATCV_STAMP
+      WSTAMP(w2); ++ntl;
+#endif
       if (nxt < a.total_ptiles) load_tile(nxt);
+#ifdef SATCV_STAMP
+      WSTAMP(w3);
+#endif
       mfma_phase();
+#ifdef SATCV_STAMP
+      WSTAMP(w4);
+#endif
       __syncthreads();
+#ifdef SATCV_STAMP
+      WSTAMP(w5);
+#endif
       if (nxt < a.total_ptiles) {
         store_tile();
+#ifdef SATCV_STAMP
+        WSTAMP(w6);
+        zs[3] += w6 - w5;
+#endif
         __syncthreads();
       }
+#ifdef SATCV_STAMP
+      { unsigned long long w7; WSTAMP(w7); zs[0] += w3 - w2; zs[1] += w4 - w3; zs[2] += w5 - w4; zs[4] += w7 - (nxt < a.total_ptiles ? w6 : w5); }
+#endif
     }
+#ifdef SATCV_STAMP
+    if (blockIdx.x < 8 && lane == 0) {
+      for (int i = 0; i < 5; ++i) g_wstamp[blockIdx.x][wave][i] = zs[i] / (unsigned long long)max(ntl, 1);
+      g_wstamp[blockIdx.x][wave][5] = w1 - w0;
+      g_wstamp[blockIdx.x][wave][6] = ntl;
+      WSTAMP(w2);
+      g_wstamp[blockIdx.x][wave][7] = w2;
+    }
+#endif
   } else {
     for (int pt = sp; pt < a.total_ptiles; pt += a.nsplit) {
       __syncthreads();
@@ -319,6 +363,292 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, (TW == 8 ? 1 : 2)) void wgrad_k
     }
   }
   // ---- partial slab: ws[sp][tap][ci][co]
+  if (wks == 0) {
+#pragma unroll
+    for (int tap = 0; tap < NTAPS; ++tap) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const int co = co0 + wco * 32 + r;
+        a.ws[((size_t)(sp * NTAPS + tap) * a.kpad + ci) * a.npad + co] = acc[tap][i];
+      }
+    }
+  }
+#ifdef SATCV_STAMP
+  if (blockIdx.x < 8 && lane == 0) { unsigned long long w9; WSTAMP(w9); g_wstamp[blockIdx.x][wave][7] = w9 - g_wstamp[blockIdx.x][wave][7]; }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Double-buffered form of the kernel above (the one the training step runs; the kernel above stays as the fallback for halo
+// tiles beyond the register budget and for fp32).  s_memtime stamps of the single-buffered loop on 512 -> 512 channels at
+// 16 x 16 (tools/wstamp_probe.py): of 10,400 cycles per pixel tile 3,400 went into issuing the next tile's loads (per-item
+// table look-ups, divisions, bounds tests and 64-bit addresses, every tile anew), 1,800 into the LDS stores behind a barrier and
+// only 4,800 into the MFMA phase (two workgroups per CU sharing the matrix pipe).  Here:
+//   * everything tile-invariant about a staged item (LDS slot, halo coordinates, channel group, source, BatchNorm scale / shift
+//     of its 8 channels) is computed ONCE per thread and kept in registers; per tile an item costs a bounds test and one address;
+//   * no vector-memory instruction sits in a lane-dependent branch (items outside the image load pixel 0 and are zeroed by a select
+//     when they go to LDS), so hipcc's counted s_waitcnt stay exact;
+//   * two LDS stages, ONE barrier per pixel tile: while tile t is multiplied, tile t+1 moves from registers to the other stage and
+//     tile t+2 is loaded into the registers it frees, one item between two groups of MFMAs (never a burst of loads: a burst keeps the
+//     wave in its issue phase while the vector-memory pipe takes the instructions in, with the matrix pipe idle);
+//   * 8 waves per workgroup (the k-steps of a staged tile are split over two or more wave groups, summed through LDS at the end
+//     in fixed order), one workgroup per CU.
+template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS, int PIX>
+__global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const WgradArgs a) {
+  using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
+  constexpr int NTHREADS = NCI * NCO * NKS * 64;
+  constexpr int BMPIX = PIX, TH = BMPIX / TW;
+  constexpr int CI_T = G::CI_T, CO_T = G::CO_T, XP = G::XP, DP = G::DP;
+  constexpr int GX = CI_T / 8, GD = CO_T / 8;
+  static_assert(NTHREADS % GX == 0 && NTHREADS % GD == 0, "a thread's channel group must be loop-invariant");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int x_elems = a.rl * a.cl * XP;
+  const int stage_elems = ((x_elems + BMPIX * DP) + 7) / 8 * 8;
+  T* lds0 = reinterpret_cast<T*>(smem_raw);
+  int* tab = reinterpret_cast<int*>(lds0 + 2 * stage_elems);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wci = wave % NCI, wco = (wave / NCI) % NCO, wks = wave / (NCI * NCO);
+  const int r = lane & 31, hh = lane >> 5;
+  int blk, sp;
+  {
+    const int nblk = a.n_ci_blk * a.n_co_blk, id = blockIdx.x;
+    if ((a.nsplit & 7) == 0) { const int xcd = id & 7, j = id >> 3; blk = j % nblk; sp = (j / nblk) * 8 + xcd; }
+    else { blk = id % nblk; sp = id / nblk; }
+  }
+  const int ci_blk = blk % a.n_ci_blk, co_blk = blk / a.n_ci_blk;
+  const int ci0 = ci_blk * CI_T, co0 = co_blk * CO_T;
+
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  for (int q = tid; q < BMPIX; q += NTHREADS) {
+    const int t = q / TW, cx = q % TW;
+    const int k = t / a.rpi;
+    const int l0 = (k < a.imgs) ? k * a.seg + (t - k * a.rpi) : 0;
+    tab[q] = (l0 * a.cl + cx) * XP;
+  }
+
+  // ---- per-thread, tile-invariant description of the staged items
+  const int x_items = a.rl * a.cl * GX;
+  constexpr int d_items = BMPIX * GD;
+  constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+  constexpr int XI = (XMAXPIX * GX + NTHREADS - 1) / NTHREADS;
+  constexpr int DI = (d_items + NTHREADS - 1) / NTHREADS;
+  constexpr int NU = XI + DI;
+  const int gx = tid % GX, cgx = ci0 + gx * 8;
+  const bool chv = cgx < a.cin_lim;
+  const bool xsecond = chv && a.x1 != nullptr && cgx >= a.c0;
+  const T* xsrc = xsecond ? reinterpret_cast<const T*>(a.x1) + (cgx - a.c0) : reinterpret_cast<const T*>(a.x0) + (chv ? cgx : 0);
+  const int xcs = xsecond ? a.c1 : a.c0;
+  // BatchNorm scale / shift of the producing layer for the CI_T channels of this block: a small LDS table read when an item is
+  // written (16 registers per thread otherwise: the kernel sits at the 256-register cap of two waves per SIMD)
+  float* ldsS = reinterpret_cast<float*>(tab + BMPIX);                     // [GX][16]: 8 scale + 8 shift per channel group
+  const bool aff = a.in_scale != nullptr;
+  if (aff && tid < GX * 16) {
+    const int g = tid / 16, e = tid % 16, ch = ci0 + g * 8 + (e & 7);
+    ldsS[tid] = ch < a.cin_lim ? (e < 8 ? a.in_scale[ch] : a.in_shift[ch]) : (e < 8 ? 1.f : 0.f);
+  }
+  const bool relu = a.in_relu != 0;
+  int x_dst[XI], x_rel[XI];
+#pragma unroll
+  for (int j = 0; j < XI; ++j) {
+    const int it = tid + j * NTHREADS;
+    const int pix = it / GX;
+    const int c = pix % a.cl, L = pix / a.cl;
+    const int k = L / a.seg;
+    const int yy = L - k * a.seg - a.halh;
+    x_dst[j] = it < x_items ? pix * XP + gx * 8 : -1;
+    x_rel[j] = (k << 20) | ((yy + 64) << 10) | c;
+  }
+  const int gd = tid % GD, cv = co0 + gd * 8;
+  const bool cvv = cv < a.n_lim;
+  const T* dyp = reinterpret_cast<const T*>(a.dy);
+  int d_ij = 0, d_o = cv;
+  if (a.mode_dy == 1) { d_ij = cv / a.cout_t; d_o = cv - d_ij * a.cout_t; }
+  const int d_iy = a.mode_dy == 1 ? d_ij / a.f : 0, d_ix = a.mode_dy == 1 ? d_ij % a.f : 0;
+  const int dfm = a.mode_dy == 1 ? a.f : 1;
+  int d_dst[DI], d_rel[DI];
+#pragma unroll
+  for (int j = 0; j < DI; ++j) {
+    const int it = tid + j * NTHREADS;
+    const int q = it / GD;
+    const int t = q / TW, cx = q % TW;
+    const int k = (a.imgs == 1) ? 0 : t / a.rpi;
+    d_dst[j] = it < d_items ? q * DP + gd * 8 : -1;
+    d_rel[j] = ((it < d_items && k < a.imgs && cvv) ? (1 << 30) : 0) | (k << 20) | ((t - k * a.rpi) << 10) | cx;
+  }
+
+  Raw8<T> xr[XI], dr[DI];
+  unsigned xmask = 0, dmask = 0;
+  int n0 = 0, y0 = 0, x0 = 0;                        // origin of the tile whose loads are being issued
+  auto tile_origin = [&](int pt) {
+    int m = pt;
+    const int tx = m % a.tiles_x; m /= a.tiles_x;
+    const int ty = m % a.tiles_y;
+    n0 = (m / a.tiles_y) * a.imgs; y0 = ty * TH; x0 = tx * TW;
+  };
+  auto load_x = [&](int j) {
+    const int c = x_rel[j] & 1023, yy = ((x_rel[j] >> 10) & 1023) - 64, k = x_rel[j] >> 20;
+    const int n = n0 + k, y = y0 + yy + a.sy, x = x0 + c - a.halw + a.sx;
+    const bool ok = (x_dst[j] >= 0) && chv && (n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_);
+    const int p = ok ? (n * a.h + y) * a.w_ + x : 0;
+    xmask = (xmask & ~(1u << j)) | ((ok ? 1u : 0u) << j);
+    if (!WABL(1)) xr[j] = gload8<T>(xsrc + (size_t)p * xcs);
+    else xr[j] = zero8<T>();
+  };
+  auto load_d = [&](int j) {
+    const int cx = d_rel[j] & 1023, row = (d_rel[j] >> 10) & 1023, k = (d_rel[j] >> 20) & 1023;
+    const int n = n0 + k, y = y0 + row, x = x0 + cx;
+    const bool ok = (d_rel[j] >> 30) && (n < a.n) && (y < a.h) && (x < a.w_);
+    const size_t off = ok ? ((size_t)((n * a.h + y) * dfm + d_iy) * (a.w_ * dfm) + x * dfm + d_ix) * a.lddy + d_o : 0;
+    dmask = (dmask & ~(1u << j)) | ((ok ? 1u : 0u) << j);
+    if (!WABL(1)) dr[j] = gload8<T>(dyp + off);
+    else dr[j] = zero8<T>();
+  };
+  auto store_x = [&](int j, T* ldsX) {
+    Raw8<T> v = xr[j];
+    if (aff) {
+      float sc[8], sh[8];
+      {
+        const float4* sp4 = reinterpret_cast<const float4*>(ldsS + gx * 16);
+        const float4 s0 = sp4[0], s1 = sp4[1], h0 = sp4[2], h1 = sp4[3];
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+        sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+      }
+      if constexpr (std::is_same<T, bf16>::value) {
+        bf16x8 b = __builtin_bit_cast(bf16x8, v.q[0]);
+        bf16x8 w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float g = (float)b[e] * sc[e] + sh[e]; g = relu ? fmaxf(g, 0.f) : g; w[e] = (bf16)g; }
+        v.q[0] = __builtin_bit_cast(uint4, w);
+      } else {
+        float* f = reinterpret_cast<float*>(&v.q[0]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float g = f[e] * sc[e] + sh[e]; f[e] = relu ? fmaxf(g, 0.f) : g; }
+      }
+    }
+    v = select8<T>((xmask >> j) & 1u, v);
+    if (WABL(8)) { keep8<T>(v); return; }
+    if (x_dst[j] >= 0) lstore8<T>(ldsX + x_dst[j], v);
+  };
+  auto store_d = [&](int j, T* ldsD) {
+    const Raw8<T> v = select8<T>((dmask >> j) & 1u, dr[j]);
+    if (WABL(8)) { keep8<T>(v); return; }
+    if (d_dst[j] >= 0) lstore8<T>(ldsD + d_dst[j], v);
+  };
+
+  // ---- the tiles of this workgroup: sp, sp + nsplit, ...
+  const int ntl = sp < a.total_ptiles ? (a.total_ptiles - 1 - sp) / a.nsplit + 1 : 0;
+  __syncthreads();                                   // the scale / shift table is read by the first stores below
+  if (ntl > 0) {
+    tile_origin(sp);
+#pragma unroll
+    for (int j = 0; j < XI; ++j) load_x(j);
+#pragma unroll
+    for (int j = 0; j < DI; ++j) load_d(j);
+#pragma unroll
+    for (int j = 0; j < XI; ++j) store_x(j, lds0);
+#pragma unroll
+    for (int j = 0; j < DI; ++j) store_d(j, lds0 + x_elems);
+    tile_origin(sp + (ntl > 1 ? 1 : 0) * a.nsplit);
+#pragma unroll
+    for (int j = 0; j < XI; ++j) load_x(j);
+#pragma unroll
+    for (int j = 0; j < DI; ++j) load_d(j);
+  }
+  __syncthreads();
+  constexpr int KSW = (BMPIX / 16) / NKS;              // k-steps of 16 pixels per wave and tile
+  constexpr int SLOTS = KSW * NTAPS;                   // MFMAs per wave and tile = places for a staging unit
+  for (int i = 0; i < ntl; ++i) {
+    T* ldsX = lds0 + (i & 1) * stage_elems;
+    T* ldsD = ldsX + x_elems;
+    T* othX = lds0 + ((i + 1) & 1) * stage_elems;
+    T* othD = othX + x_elems;
+    const bool do_store = i + 1 < ntl;
+    // the registers hold tile i+1; its items go to the other stage one by one and are re-issued for tile i+2 (the last two
+    // iterations re-load the last tile instead of branching around vector-memory instructions)
+    tile_origin(sp + (i + 2 < ntl ? i + 2 : ntl - 1) * a.nsplit);
+    auto side = [&](int slot) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if ((u * SLOTS) / NU != slot) continue;
+        if (u < XI) { if (do_store) store_x(u, othX); load_x(u); }
+        else { if (do_store) store_d(u - XI, othD); load_d(u - XI); }
+      }
+    };
+#pragma unroll
+    for (int kk = 0; kk < KSW; ++kk) {
+      const int ks = wks + kk * NKS;
+      if constexpr (std::is_same<T, bf16>::value) {
+        const int gi = lane >> 4, i16 = lane & 15;
+        const int chb = 16 * (gi & 1) + 4 * (i16 & 3);
+        const int qa = ks * 16 + 8 * (gi >> 1) + (i16 >> 2);
+        const int qb = qa + 4;
+        bf16x4 blo = tr_read(ldsD + qa * DP + wco * 32 + chb);
+        bf16x4 bhi = tr_read(ldsD + qb * DP + wco * 32 + chb);
+        bf16x8 bfr = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const int xoa = tab[qa] + wci * 32 + chb;
+        const int xob = tab[qb] + wci * 32 + chb;
+        bf16x4 alo[2], ahi[2];
+        alo[0] = tr_read(ldsX + xoa);
+        ahi[0] = tr_read(ldsX + xob);
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+          if (tap + 1 < NTAPS) {
+            const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
+            const int toff = ((ky * a.dil) * a.cl + kx * a.dil) * XP;
+            alo[(tap + 1) & 1] = tr_read(ldsX + xoa + toff);
+            ahi[(tap + 1) & 1] = tr_read(ldsX + xob + toff);
+          }
+          side(kk * NTAPS + tap);
+          __builtin_amdgcn_sched_barrier(0);
+          bf16x8 afr = __builtin_shufflevector(alo[tap & 1], ahi[tap & 1], 0, 1, 2, 3, 4, 5, 6, 7);
+          if (!WABL(2)) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[tap], 0, 0, 0);
+          else acc[tap][0] += (float)afr[0] + (float)bfr[0];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = ks * 16 + 2 * j + hh;
+          const float b = ldsD[q * DP + wco * 32 + r];
+          const int xo = tab[q] + wci * 32 + r;
+#pragma unroll
+          for (int tap = 0; tap < NTAPS; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int toff = (NTAPS == 1) ? 0 : ((ky * a.dil) * a.cl + kx * a.dil) * XP;
+            if (j == 0) side(kk * NTAPS + tap);
+            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(ldsX[xo + toff], b, acc[tap], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- combine the k-slice waves of a tile through LDS (fixed order), one tap at a time
+  if constexpr (NKS > 1) {
+    float* red = reinterpret_cast<float*>(smem_raw);          // staging buffers are dead now
+    const int tile_id = wci + NCI * wco;
+#pragma unroll
+    for (int tap = 0; tap < NTAPS; ++tap) {
+      __syncthreads();
+      if (wks > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[((tile_id * (NKS - 1) + (wks - 1)) * 16 + i) * 64 + lane] = acc[tap][i];
+      }
+      __syncthreads();
+      if (wks == 0) {
+#pragma unroll 1
+        for (int k = 0; k < NKS - 1; ++k)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[tap][i] += red[((tile_id * (NKS - 1) + k) * 16 + i) * 64 + lane];
+      }
+    }
+  }
   if (wks == 0) {
 #pragma unroll
     for (int tap = 0; tap < NTAPS; ++tap) {
@@ -408,7 +738,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------ host side
-struct WgradPlan { int tw, nci, nco, nks, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk, pix; size_t ws_bytes; };
+struct WgradPlan { int tw, nci, nco, nks, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk, pix, db; size_t ws_bytes; };
+extern int g_opt_wgrad_db;        // api.hip: satcv_set_option("wgrad_db", ...)
 
 static bool wgrad_pix256() {
   static const bool on = [] { const char* e = getenv("SATCV_WGRAD_PIX256"); return !e || atoi(e) != 0; }();
@@ -452,6 +783,10 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   // their per-block pixel share would get too coarse to balance.
   const int nblk = p.n_ci_blk * p.n_co_blk;
   long long ns = cdiv(nblk >= 128 ? 768 : 512, nblk);
+  // double-buffered kernel (8 waves, one workgroup per CU): 256 workgroups fill the chip once; each should walk >= 16 pixel tiles so
+  // that its set-up and its slab write (~16k cycles) stay small beside the tile loop
+  p.db = (g_opt_wgrad_db != 0 && d->dil == 1 && d->dtype == SATCV_BF16) ? 1 : 0;
+  if (p.db) ns = nblk >= 256 ? 1 : 256 / nblk;
   if (ns > ptiles) ns = ptiles;
   if (ns > 768) ns = 768;
   if (ns < 1) ns = 1;
@@ -508,8 +843,73 @@ static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream
   return SATCV_OK;
 }
 
+template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS, int PIX = 128>
+static int wgrad_db_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy = 0, int sx = 0) {
+  using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
+  constexpr int TH = PIX / TW, NTHREADS = NCI * NCO * NKS * 64, GX = G::CI_T / 8;
+  WgradArgs a;
+  a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_relu = d->in_relu;
+  a.dy = d->dy; a.lddy = d->lddy; a.ws = d->workspace;
+  a.n = d->n; a.h = d->h; a.w_ = d->w_; a.kh = NTAPS == 1 ? 1 : d->kh; a.kw = NTAPS == 1 ? 1 : d->kw; a.dil = d->dil;
+  a.sy = sy; a.sx = sx;
+  a.mode_dy = d->mode_dy; a.f = d->f; a.cout_t = d->cout;
+  a.kpad = p.kpad; a.npad = p.npad;
+  a.cin_lim = d->c0 + d->c1; a.n_lim = d->mode_dy ? d->f * d->f * d->cout : d->cout;
+  a.halh = a.dil * (a.kh - 1) / 2; a.halw = a.dil * (a.kw - 1) / 2;
+  a.tiles_x = cdiv(d->w_, TW);
+  if (d->h >= TH) { a.rpi = TH; a.imgs = 1; a.tiles_y = cdiv(d->h, TH); a.ngroups = d->n; }
+  else { a.rpi = d->h; a.imgs = TH / d->h; a.tiles_y = 1; a.ngroups = cdiv(d->n, a.imgs); }
+  a.seg = a.rpi + 2 * a.halh; a.rl = a.imgs * a.seg; a.cl = TW + 2 * a.halw;
+  a.n_ci_blk = p.n_ci_blk; a.n_co_blk = p.n_co_blk; a.nsplit = p.nsplit;
+  a.total_ptiles = a.ngroups * a.tiles_y * a.tiles_x;
+  // register-staged items per thread (same bound as in the kernel)
+  constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+  constexpr int XI = (XMAXPIX * GX + NTHREADS - 1) / NTHREADS;
+  if ((long long)a.rl * a.cl * GX > (long long)XI * NTHREADS) return SATCV_ERR_UNSUPPORTED;
+  if (a.rl >= 1024 || a.cl >= 1024 || a.imgs >= 1024) return SATCV_ERR_UNSUPPORTED;
+  const size_t stage = (((size_t)a.rl * a.cl * G::XP + (size_t)PIX * G::DP) + 7) / 8 * 8;
+  size_t lds = 2 * stage * sizeof(T) + (size_t)PIX * sizeof(int) + (size_t)GX * 16 * sizeof(float);
+  const size_t red = (size_t)NCI * NCO * (NKS > 1 ? NKS - 1 : 0) * 16 * 64 * sizeof(float);
+  if (lds < red) lds = red;
+  if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
+  auto kern = wgrad_db_kernel<T, TW, NCI, NCO, NKS, NTAPS, PIX>;
+  if (lds > 48 * 1024) {
+    static size_t have = 0;
+    if (lds > have) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+      have = lds;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(p.n_ci_blk * p.n_co_blk * p.nsplit), dim3(NTHREADS), lds, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { satcv_set_error("wgrad_db launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  return SATCV_OK;
+}
+
+// the double-buffered kernel (bf16): 8 waves = (ci, co) tiles x k-slices
+template <typename T, int TW>
+static int wgrad_db_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy, int sx) {
+  if (p.ntaps == 1) return wgrad_db_launch<T, TW, 1, 4, 2, 1>(d, p, st, sy, sx);
+  if (p.nci == 1 && p.nco == 4) return wgrad_db_launch<T, TW, 1, 4, 2, 9>(d, p, st);
+  if (p.nci == 2 && p.nco == 2) return wgrad_db_launch<T, TW, 2, 2, 2, 9>(d, p, st);
+  if constexpr (TW == 32) {
+    if (p.pix == 256 && p.nci == 1 && p.nco == 1) return wgrad_db_launch<T, TW, 1, 1, 8, 9, 256>(d, p, st);
+  }
+  if (p.nci == 1 && p.nco == 2) return wgrad_db_launch<T, TW, 1, 2, 4, 9>(d, p, st);
+  if (p.nci == 2 && p.nco == 1) return wgrad_db_launch<T, TW, 2, 1, 4, 9>(d, p, st);
+  return wgrad_db_launch<T, TW, 1, 1, 8, 9>(d, p, st);
+}
+
 template <typename T, int TW>
 static int wgrad_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy = 0, int sx = 0) {
+  if constexpr (std::is_same<T, bf16>::value) {
+    if (p.db) {
+      const int rc = wgrad_db_cfg<T, TW>(d, p, st, sy, sx);
+      if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+    }
+  }
   if (p.ntaps == 1) return wgrad_launch<T, TW, 1, 4, 1, 1>(d, p, st, sy, sx);
   if (p.nci == 1 && p.nco == 4) return wgrad_launch<T, TW, 1, 4, 1, 9>(d, p, st);
   if (p.nci == 2 && p.nco == 2) return wgrad_launch<T, TW, 2, 2, 1, 9>(d, p, st);

@@ -84,8 +84,11 @@ __device__ __forceinline__ void mma32(f32x16& acc, const FragT<T>& a, const Frag
 // acc[MT][NT] (32x32 MFMA tiles of this wave) -> y: per-channel multiplier / bias / ReLU, rounding to T, BN sum / sum-of-squares of
 // the STORED values, tile staged in LDS [BM][BN+pad] and written with 16-byte coalesced stores (NHWC rows; depth-to-space rows
 // for the transposed conv).  Call with every wave past its last LDS fragment read (the staging aliases the operand images).
+// carry: persistent kernels pass two per-thread doubles (threads < BN own one output channel each); the tile's statistics are added
+// there instead of going to the replica rows with atomics, and the caller flushes them once per workgroup (stats_flush).
 template <typename T, int TW, int WM, int WN, int MT, int NT, bool SKIP_STORES = false>
-__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[MT][NT], int n0, int y0, int x0, int nbase, unsigned char* smem_raw) {
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[MT][NT], int n0, int y0, int x0, int nbase, unsigned char* smem_raw,
+                                               double* carry = nullptr) {
   constexpr int NTHREADS = WM * WN * 64, BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int OPITCH = BN + 16 / (int)sizeof(T);                   // output staging pitch (elements)
   T* ldsO = reinterpret_cast<T*>(smem_raw);
@@ -162,9 +165,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
 #pragma unroll
       for (int w = 0; w < WM; ++w) { t1 += ldsS[(w * 2 + 0) * BN + tid]; t2 += ldsS[(w * 2 + 1) * BN + tid]; }
       const int cch = cn % a.cstat;
-      satcv_stat_t* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
-      atomicAdd(rowp + cch, (satcv_stat_t)t1);
-      atomicAdd(rowp + a.stats_ld + cch, (satcv_stat_t)t2);
+      if (carry) { carry[0] += (double)t1; carry[1] += (double)t2; }
+      else {
+        satcv_stat_t* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
+        atomicAdd(rowp + cch, (satcv_stat_t)t1);
+        atomicAdd(rowp + a.stats_ld + cch, (satcv_stat_t)t2);
+      }
     }
   }
   // coalesced 16-byte stores of whole channel rows
@@ -248,3 +254,5 @@ static inline int igemm_pick_tw(int w) {
 // software-pipelined variant (conv_igemm_fast.hip); returns SATCV_ERR_UNSUPPORTED when the
 // shape is outside its static limits so that the caller falls back to the generic kernel.
 int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run = false);
+// persistent weights-stationary kernel of the thin 3x3 layers (conv_igemm_ws.hip); SATCV_ERR_UNSUPPORTED outside its limits
+int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run);

@@ -204,6 +204,170 @@ def test_wgrad_padded_input_and_affine(ops, td):
     close(back(dk), dk_ref, td, 'wgrad affine dil3', k=(5.0 if td == torch.float32 else 0.5))
 
 
+# ------------------------------------------------- the double-buffered 256 x 128 tile, forced on small shapes
+@pytest.fixture
+def force_db(ops):
+    from satellite_computervision_amd._lib import lib, check
+    import ctypes
+    old = ctypes.c_int32()
+    check(lib.satcv_get_option(b'igemm_db', ctypes.byref(old)))
+    check(lib.satcv_set_option(b'igemm_db', 2))
+    yield
+    check(lib.satcv_set_option(b'igemm_db', old.value))
+
+
+DB_CASES = [
+    # n, h, w, cin, cout: Cout % 128 == 0 and Cin >= 64 (the kernel's shape limits); every tile width (32 / 16 / 8), several images
+    # per tile, ragged grids, odd image counts, one and many K-chunks (chunk parity of the two LDS stages)
+    (1, 16, 16, 64, 128), (2, 16, 16, 1024, 512), (2, 16, 16, 512, 512), (3, 8, 8, 512, 1024), (2, 32, 32, 512, 256),
+    (2, 32, 32, 128, 256), (1, 64, 64, 256, 128), (3, 20, 24, 64, 128), (5, 8, 8, 80, 128), (1, 40, 72, 96, 128), (7, 4, 4, 64, 128),
+    (2, 12, 12, 64, 256),
+]
+
+
+@pytest.mark.parametrize('td', [torch.bfloat16])
+@pytest.mark.parametrize('case', DB_CASES)
+def test_conv2d_double_buffered_tile(ops, td, case, force_db):
+    """forward (with BN statistics) and data gradient of the 3x3 conv through the 8-wave double-buffered configuration."""
+    n, h, w, cin, cout = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (3, 3, cin, cout), td, 0.2)
+    b = rng.standard_normal(cout)
+    ref = K.conv2d_same(x, kern, b, 1)
+    wf, _ = ops.pack_weights(f32dev(kern), cin, ops.DTYPE_CODE[td], want_dgrad=False)
+    stats = ops.new_stats(cout, dev())
+    y = ops.conv2d(to_dev(x, td), wf, cout, bias=f32dev(b), stats=stats)
+    got = back(y, cout)
+    close(got, ref, td, f'db conv {case}')
+    s = stats.sum(0).double().cpu().numpy()
+    np.testing.assert_allclose(s[0, :cout], got.sum((0, 1, 2)), rtol=2e-4, atol=2e-3 * np.sqrt(n * h * w))
+    np.testing.assert_allclose(s[1, :cout], (got ** 2).sum((0, 1, 2)), rtol=2e-4)
+    # data gradient of the transposed problem: dy has `cin` channels here, dx `cout` (a multiple of 128)
+    kern2 = rnd(rng, (3, 3, cout, cin), td, 0.2)
+    dy = rnd(rng, (n, h, w, cin), td)
+    dx_ref, _, _ = K.conv2d_same_bwd(np.zeros((n, h, w, cout)), kern2, dy, 1)
+    _, wd = ops.pack_weights(f32dev(kern2), cout, ops.DTYPE_CODE[td])
+    dx = ops.conv2d_dgrad(to_dev(dy, td), wd, cout)
+    close(back(dx, cout), dx_ref, td, f'db dgrad {case}')
+
+
+def test_conv2d_double_buffered_dual_source_affine(ops, force_db):
+    """decoder conv1 through the double-buffered tile: concat([skip, up]) -> BN -> ReLU in the loader, 512 + 512 -> 128 channels."""
+    td = torch.bfloat16
+    rng = np.random.default_rng(12)
+    n, h, w, c0, c1, cout = 2, 16, 16, 256, 256, 128
+    xa, xb = rnd(rng, (n, h, w, c0), td), rnd(rng, (n, h, w, c1), td)
+    sc, sh = rng.standard_normal(c0 + c1), rng.standard_normal(c0 + c1)
+    kern = rnd(rng, (3, 3, c0 + c1, cout), td, 0.2)
+    sc32, sh32 = sc.astype(np.float32).astype(np.float64), sh.astype(np.float32).astype(np.float64)
+    a = np.maximum(np.concatenate([xa, xb], -1) * sc32 + sh32, 0)
+    a = torch.tensor(a, dtype=torch.float32).to(td).double().numpy()
+    ref = K.conv2d_same(a, kern, None, 1)
+    wf, _ = ops.pack_weights(f32dev(kern), c0 + c1, ops.DTYPE_CODE[td], want_dgrad=False)
+    y = ops.conv2d(to_dev(xa, td), wf, cout, x1=to_dev(xb, td), in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
+    close(back(y, cout), ref, td, 'db dual-source conv', k=2.0)
+
+
+# ------------------------------------------------- the persistent weights-stationary kernel of the thin layers, forced on small shapes
+@pytest.fixture
+def force_thin(ops):
+    from satellite_computervision_amd._lib import lib, check
+    import ctypes
+    old = ctypes.c_int32()
+    check(lib.satcv_get_option(b'igemm_thin', ctypes.byref(old)))
+    check(lib.satcv_set_option(b'igemm_thin', 2))
+    yield
+    check(lib.satcv_set_option(b'igemm_thin', old.value))
+
+
+WS_CASES = [
+    # n, h, w, cin (real), cout: every (stored Cin, Cout) pair the kernel serves; ragged grids (W not a multiple of 32, H not of 8), one
+    # and many tiles per workgroup, more tiles than workgroups (1 x 256 x 256 = 256 tiles; 9 x 136 x 200 = 1071 tiles > 512 workgroups)
+    (2, 32, 32, 4, 32), (1, 64, 64, 32, 32), (2, 40, 72, 64, 32), (1, 256, 256, 64, 32), (3, 20, 24, 32, 64), (2, 64, 96, 16, 64),
+    (1, 8, 32, 32, 32), (2, 9, 33, 64, 32), (9, 136, 200, 16, 32),
+]
+
+
+@pytest.mark.parametrize('case', WS_CASES)
+def test_conv2d_weights_stationary_thin_kernel(ops, case, force_thin):
+    """forward (bias + BN statistics) and data gradient through conv_igemm_ws.hip"""
+    td = torch.bfloat16
+    n, h, w, cin, cout = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (3, 3, cin, cout), td, 0.2)
+    b = rng.standard_normal(cout)
+    ref = K.conv2d_same(x, kern, b, 1)
+    cpad = rup(cin, 16)
+    wf, _ = ops.pack_weights(f32dev(kern), cpad, ops.DTYPE_CODE[td], want_dgrad=False)
+    stats = ops.new_stats(cout, dev())
+    y = ops.conv2d(to_dev(x, td, cpad), wf, cout, bias=f32dev(b), stats=stats)
+    got = back(y, cout)
+    close(got, ref, td, f'ws conv {case}')
+    s = stats.sum(0).double().cpu().numpy()
+    np.testing.assert_allclose(s[0, :cout], got.sum((0, 1, 2)), rtol=2e-4, atol=2e-3 * np.sqrt(n * h * w))
+    np.testing.assert_allclose(s[1, :cout], (got ** 2).sum((0, 1, 2)), rtol=2e-4)
+    if cin >= 16 and cout in (16, 32, 64):
+        # data gradient of the transposed problem (dy: cout channels -> dx: cin channels) when that pair is served too
+        cin2, cout2 = cout, cin if cin in (32, 64) else 32
+        kern2 = rnd(rng, (3, 3, cout2, cin2), td, 0.2)
+        dy = rnd(rng, (n, h, w, cin2), td)
+        dx_ref, _, _ = K.conv2d_same_bwd(np.zeros((n, h, w, cout2)), kern2, dy, 1)
+        _, wd = ops.pack_weights(f32dev(kern2), cout2, ops.DTYPE_CODE[td])
+        dx = ops.conv2d_dgrad(to_dev(dy, td), wd, cout2)
+        close(back(dx, cout2), dx_ref, td, f'ws dgrad {case}')
+
+
+def test_conv2d_weights_stationary_dual_source_affine(ops, force_thin):
+    """dec0.conv1 through the thin kernel: concat([skip 32, up 32]) -> BN -> ReLU in the loader, -> 32 channels, ragged grid"""
+    td = torch.bfloat16
+    rng = np.random.default_rng(13)
+    n, h, w, c0, c1, cout = 2, 40, 72, 32, 32, 32
+    xa, xb = rnd(rng, (n, h, w, c0), td), rnd(rng, (n, h, w, c1), td)
+    sc, sh = rng.standard_normal(c0 + c1), rng.standard_normal(c0 + c1)
+    kern = rnd(rng, (3, 3, c0 + c1, cout), td, 0.2)
+    sc32, sh32 = sc.astype(np.float32).astype(np.float64), sh.astype(np.float32).astype(np.float64)
+    a = np.maximum(np.concatenate([xa, xb], -1) * sc32 + sh32, 0)
+    a = torch.tensor(a, dtype=torch.float32).to(td).double().numpy()
+    ref = K.conv2d_same(a, kern, None, 1)
+    wf, _ = ops.pack_weights(f32dev(kern), c0 + c1, ops.DTYPE_CODE[td], want_dgrad=False)
+    y = ops.conv2d(to_dev(xa, td), wf, cout, x1=to_dev(xb, td), in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
+    close(back(y, cout), ref, td, 'ws dual-source conv', k=2.0)
+    # a single 16-channel source with an affine and no ReLU
+    x = rnd(rng, (n, h, w, 16), td)
+    sc, sh = rng.standard_normal(16), rng.standard_normal(16)
+    kern = rnd(rng, (3, 3, 16, 64), td, 0.2)
+    a = x * sc.astype(np.float32).astype(np.float64) + sh.astype(np.float32).astype(np.float64)
+    a = torch.tensor(a, dtype=torch.float32).to(td).double().numpy()
+    ref = K.conv2d_same(a, kern, None, 1)
+    wf, _ = ops.pack_weights(f32dev(kern), 16, ops.DTYPE_CODE[td], want_dgrad=False)
+    y = ops.conv2d(to_dev(x, td), wf, 64, in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=False)
+    close(back(y, 64), ref, td, 'ws affine conv', k=2.0)
+
+
+@pytest.mark.parametrize('td', DT)
+@pytest.mark.parametrize('case', [(2, 32, 32, 32, 32, 32), (2, 16, 16, 64, 64, 128), (1, 64, 64, 32, 0, 64), (3, 8, 8, 128, 128, 128), (1, 40, 72, 64, 32, 32),
+                                  (2, 16, 16, 512, 512, 256)])
+def test_wgrad_dual_source_with_affine(ops, td, case):
+    """decoder conv1 weight gradient: X = ReLU(BN(concat([skip, up]))) formed in the loader from two sources (utils/model_tools.py:307-312),
+    dilation 1 -- the double-buffered kernel's path (per-thread source / scale / shift, LDS scale table)."""
+    n, h, w, c0, c1, cout = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    xa = rnd(rng, (n, h, w, c0), td)
+    xb = rnd(rng, (n, h, w, c1), td) if c1 else None
+    cin = c0 + c1
+    dy = rnd(rng, (n, h, w, cout), td)
+    sc, sh = rng.standard_normal(cin).astype(np.float32), rng.standard_normal(cin).astype(np.float32)
+    x = np.concatenate([xa, xb], -1) if c1 else xa
+    a = np.maximum(x * sc.astype(np.float64) + sh.astype(np.float64), 0)
+    if td == torch.bfloat16:
+        a = torch.tensor(a, dtype=torch.float32).to(td).double().numpy()
+    _, dk_ref, _ = K.conv2d_same_bwd(a, np.zeros((3, 3, cin, cout)), dy, 1)
+    dk = ops.conv2d_wgrad(to_dev(xa, td), to_dev(dy, td), cin, cout, x1=to_dev(xb, td) if c1 else None, in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
+    close(back(dk), dk_ref, td, f'wgrad dual+affine {case}', k=(5.0 if td == torch.float32 else 0.5))
+
+
 # ------------------------------------------------------------------ transposed conv
 @pytest.mark.parametrize('td', DT)
 @pytest.mark.parametrize('case', [(2, 8, 8, 64, 32, 2), (1, 16, 16, 128, 64, 2), (2, 4, 4, 256, 128, 2), (1, 6, 6, 32, 32, 3),

@@ -19,9 +19,14 @@ ap.add_argument('--dtype', default='bfloat16')
 ap.add_argument('--reps', type=int, default=20)
 ap.add_argument('--json', default=None)
 ap.add_argument('--only', default=None, help='substring filter on the label')
+ap.add_argument('--opt', action='append', default=[], help='kernel-selection knob key=value (satcv_set_option), repeatable')
 args = ap.parse_args()
 
 from satellite_computervision_amd import model_tools as mt, ops
+from satellite_computervision_amd._lib import lib, check
+for kv in args.opt:
+    k, v = kv.split('=')
+    check(lib.satcv_set_option(k.encode(), int(v)))
 mt.reset_uids(); mt.set_seed(0); mt.set_compute_dtype(args.dtype)
 model = mt.get_unet_model(2, args.channels)
 model.compile(optimizer=mt.Adam(9e-4), loss=lambda a, b: mt.weighted_categorical_crossentropy(a, b, [1.0, 20.0]))
