@@ -183,6 +183,12 @@ typedef struct satcv_bnbwd_desc {
   int32_t n, h, w_, c;
   int32_t dtype;
   int32_t linear;                      /* 1: BatchNormalization without the ReLU (residual branch): g = da, no mask   */
+  /* optional second source (c_split > 0): the BatchNormalization of concat([skip, up]) (utils/model_tools.py:307-308) in ONE pass
+   * over the gradient `da` of the concatenation -- channels [0, c_split) are read from yraw / written to dy as above, channels
+   * [c_split, c) from yraw1 (stride ldy1) / to dy1 (stride lddy1).  Dense form only (no dpool, no dbias).                     */
+  const void* yraw1; int32_t ldy1;
+  void* dy1; int32_t lddy1;
+  int32_t c_split;
 } satcv_bnbwd_desc;
 int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream);
 int satcv_bn_bwd_finalize(satcv_stat_t* sums, int32_t sums_ld, int32_t c, float count, float* dgamma,

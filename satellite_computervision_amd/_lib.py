@@ -60,7 +60,8 @@ class BnBwdDesc(C.Structure):
                 ('scale', c_vp), ('shift', c_vp), ('mean', c_vp), ('rstd', c_vp),
                 ('sums', c_vp), ('sums_ld', c_i32), ('coef', c_vp),
                 ('dy', c_vp), ('lddy_out', c_i32), ('dbias', c_vp),
-                ('n', c_i32), ('h', c_i32), ('w_', c_i32), ('c', c_i32), ('dtype', c_i32), ('linear', c_i32)]
+                ('n', c_i32), ('h', c_i32), ('w_', c_i32), ('c', c_i32), ('dtype', c_i32), ('linear', c_i32),
+                ('yraw1', c_vp), ('ldy1', c_i32), ('dy1', c_vp), ('lddy1', c_i32), ('c_split', c_i32)]
 
 
 class HeadDesc(C.Structure):

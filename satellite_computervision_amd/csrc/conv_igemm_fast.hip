@@ -535,6 +535,11 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
         if (rc != SATCV_ERR_UNSUPPORTED) return rc;
       }
     }
+    // 64 output channels (decoder / encoder level 1): the same 8-wave double-buffered loop on a 256-pixel x 64-channel tile
+    if (db_mode >= 3 && a.dil == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && nspace % 64 == 0 && nspace % 128 != 0 && cin >= 64) {
+      const int rc = fast_cfg<T, TW, 4, 2, 2, 1, 1, TAPS, false, true>(a, st, dry);
+      if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+    }
   }
   // 32-channel chunks only for 1x1 taps (the 9-tap weight slab of a 32-channel chunk would not leave
   // room for 2-3 workgroups per CU)

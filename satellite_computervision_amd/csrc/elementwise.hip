@@ -371,6 +371,44 @@ __global__ void bn_bwd_kernel(const satcv_bnbwd_desc d) {
       // first arg-max of the activated window (only when routing a pooled gradient)
       int am[8]; float gp[8];
       const bool full = dp && py < hp && px < wp;
+      if (f == 2 && full && da) {
+        // the common case (MaxPooling2D((2, 2)), utils/model_tools.py:281) in ONE pass: the four raw values, the four dense gradients
+        // and the pooled gradient are loaded once, back to back (9 loads in flight per thread instead of 4 + a dependent 9)
+        float v4[4][8], g4[4][8];
+        const size_t p00 = (size_t)(img * h + py * 2) * w + px * 2;
+        const size_t pixs[4] = {p00, p00 + 1, p00 + w, p00 + w + 1};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load8<T>(yr + pixs[q] * d.ldy + g * 8, v4[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load8<T>(da + pixs[q] * d.ldda + g * 8, g4[q]);
+        load8<T>(dp + ((size_t)(img * hp + py) * wp + px) * d.lddp + g * 8, gp);
+        float a4[4][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float mx = -INFINITY; am[e] = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            a4[q][e] = v4[q][e] * sc[e] + sh[e];
+            const float a = round_to<T>(fmaxf(a4[q][e], 0.f));
+            if (a > mx) { mx = a; am[e] = q; }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float gg = g4[q][e];
+            if (am[e] == q) gg += gp[e];
+            gg = (a4[q][e] > 0.f || d.linear) ? gg : 0.f;
+            const float xh = (v4[q][e] - mu[e]) * rs[e];
+            if (APPLY) { const float t = sc[e] * (gg - c1[e] - xh * c2[e]); o[e] = round_to<T>(t); s1[e] += o[e]; }
+            else { s1[e] += gg; s2[e] += gg * xh; }
+          }
+          if (APPLY) store8<T>(dy + pixs[q] * d.lddy_out + g * 8, o);
+        }
+        continue;
+      }
       if (full) {
         float mx[8];
 #pragma unroll
@@ -437,7 +475,12 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbw
   const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = gid < per * G;
   const int g = gid % G;
-  const T* da = (const T*)d.da + g * 8; const T* yr = (const T*)d.yraw + g * 8; T* dy = (T*)d.dy + g * 8;
+  // (second source of a concatenation: a thread's channel group, and with it its source / destination, never changes)
+  const bool second = d.c_split > 0 && g * 8 >= d.c_split;
+  const T* da = (const T*)d.da + g * 8;
+  const T* yr = second ? (const T*)d.yraw1 + (g * 8 - d.c_split) : (const T*)d.yraw + g * 8;
+  T* dy = second ? (T*)d.dy1 + (g * 8 - d.c_split) : (T*)d.dy + g * 8;
+  const int ldy = second ? d.ldy1 : d.ldy, lddy = second ? d.lddy1 : d.lddy_out;
   float sc[8], sh[8], mu[8], rs[8], c1[8], c2[8], s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -451,7 +494,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbw
     for (unsigned p0 = gid / G; p0 < npix; p0 += per) {
       const unsigned p = rev ? npix - 1 - p0 : p0;
       float v[8], gr[8], o[8];
-      load8<T>(yr + (size_t)p * d.ldy, v);
+      load8<T>(yr + (size_t)p * ldy, v);
       load8<T>(da + (size_t)p * d.ldda, gr);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -461,7 +504,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbw
         if (APPLY) { const float t = sc[e] * (gg - c1[e] - xh * c2[e]); o[e] = round_to<T>(t); s1[e] += o[e]; }
         else { s1[e] += gg; s2[e] += gg * xh; }
       }
-      if (APPLY) store8<T>(dy + (size_t)p * d.lddy_out, o);
+      if (APPLY) store8<T>(dy + (size_t)p * lddy, o);
     }
   }
   if (!APPLY) block_channel_reduce(lds, s1, s2, g, active, c, d.sums, d.sums_ld);
@@ -483,6 +526,11 @@ static int bnbwd_check(const satcv_bnbwd_desc* d, bool apply) {
   SATCV_CHECK(!d->dpool || d->f >= 1, "bn_bwd: pool factor");
   if (apply) SATCV_CHECK(d->coef && d->dy, "bn_bwd_apply: coef/dy missing");
   else SATCV_CHECK(d->sums && d->sums_ld >= d->c, "bn_bwd_reduce: sums missing");
+  if (d->c_split > 0) {
+    SATCV_CHECK(d->c_split % 8 == 0 && d->c_split < d->c && d->yraw1 && d->ldy1 >= d->c - d->c_split && !d->dpool && d->da && !d->dbias &&
+                (long long)d->n * d->h * d->w_ < 0x7fffffffLL, "bn_bwd: second source needs the dense form (da, no dpool / dbias), c_split %% 8 == 0");
+    if (apply) SATCV_CHECK(d->dy1 && d->lddy1 >= d->c - d->c_split, "bn_bwd_apply: dy1 missing");
+  }
   return SATCV_OK;
 }
 extern "C" int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream) {

@@ -645,12 +645,12 @@ class Plan:
         self.loss_buf = self._z(1, dtype=torch.float32)
 
         def bn_bwd_steps(da, ldda, dp, lddp, f, yraw, ldy, aff, aoff, sums, sums_off, sums_ld, c, hh, ww, dy, lddy, dbias,
-                         dgamma, dbeta, accum=0, linear=0, frozen=False):
+                         dgamma, dbeta, accum=0, linear=0, frozen=False, second=None):
             coef = self._z(2, c, dtype=torch.float32)
             d = ops.make_bnbwd_desc(yraw=yraw, ldy=ldy, scale=_fp(aff['scale'], aoff), shift=_fp(aff['shift'], aoff),
                                     mean=_fp(aff['mean'], aoff), rstd=_fp(aff['rstd'], aoff), n=n, h=hh, w_=ww, c=c, dtype=dt,
                                     da=da, ldda=ldda, dpool=dp, lddp=lddp, f=f, sums=_fp(sums, sums_off), sums_ld=sums_ld,
-                                    coef=_fp(coef), dy=dy, lddy_out=lddy, dbias=dbias, linear=linear)
+                                    coef=_fp(coef), dy=dy, lddy_out=lddy, dbias=dbias, linear=linear, **(second or {}))
             self.keep.append(d)
             cnt = float(n * hh * ww)
             red = lambda st: check(lib.satcv_bn_bwd_reduce(C.byref(d), st))
@@ -929,6 +929,18 @@ class Plan:
                 if g[2] != ctot:
                     raise NotImplementedError('decoder concat gradient in a channel slice')
                 gptr_ = g[0].data_ptr() + g[1] * es
+                if not (tb.node.op == 'convT' and BIAS_NOISE) and ca % 8 == 0:
+                    # ONE reduce / finalize / apply over the whole concatenation: the gradient of the concatenated tensor is read
+                    # once per pass in full lines (the two half launches each touched every line of it for half of its bytes)
+                    r_, f_, a_ = bn_bwd_steps(gptr_, ctot, None, 0, 1, ra.srcs[0][0].data_ptr(), ca, aff, 0, sums, 0, ctot, ctot, hh, ww,
+                                              dskip.data_ptr(), ca, None, rt.gptr(bn + '/gamma'), rt.gptr(bn + '/beta'), frozen=bn in self.frozen,
+                                              second=dict(yraw1=rb.srcs[0][0].data_ptr(), ldy1=cb, dy1=du.data_ptr(), lddy1=cb, c_split=ca))
+                    self.bwd += [f_, a_] if (pre is not None or r_ is None) else [r_, f_, a_]
+                    gact[ta.id] = (dskip, 0, ca)
+                    self.dbg['dskip:' + bn] = dskip
+                    self.dbg['du:' + bn] = du
+                    graw[tb.id] = du
+                    continue
                 ra_, fa_, aa_ = bn_bwd_steps(gptr_, ctot, None, 0, 1, ra.srcs[0][0].data_ptr(), ca, aff, 0, sums, 0, ctot, ca, hh, ww,
                                              dskip.data_ptr(), ca, None, rt.gptr(bn + '/gamma'), rt.gptr(bn + '/beta'), frozen=bn in self.frozen)
                 rb_, fb_, ab_ = bn_bwd_steps(gptr_ + ca * es, ctot, None, 0, 1, rb.srcs[0][0].data_ptr(), cb, aff, ca, sums, ca, ctot, cb,

@@ -222,9 +222,11 @@ def bn_relu_pool(yraw, scale, shift, f, want_act=True, want_pool=True, stats=Non
 
 
 def make_bnbwd_desc(*, yraw, ldy, scale, shift, mean, rstd, n, h, w_, c, dtype, da=None, ldda=0, dpool=None, lddp=0, f=1,
-                    sums=None, sums_ld=0, coef=None, dy=None, lddy_out=0, dbias=None, linear=0):
+                    sums=None, sums_ld=0, coef=None, dy=None, lddy_out=0, dbias=None, linear=0, yraw1=None, ldy1=0, dy1=None, lddy1=0,
+                    c_split=0):
     d = BnBwdDesc()
     d.linear = linear
+    d.yraw1, d.ldy1, d.dy1, d.lddy1, d.c_split = yraw1, ldy1, dy1, lddy1, c_split
     d.da, d.ldda, d.dpool, d.lddp, d.f = da, ldda, dpool, lddp, f
     d.yraw, d.ldy = yraw, ldy
     d.scale, d.shift, d.mean, d.rstd = scale, shift, mean, rstd
@@ -253,6 +255,27 @@ def bn_relu_bwd(yraw, scale, shift, mean, rstd, da=None, dpool=None, f=1, want_d
     check(lib.satcv_bn_bwd_finalize(ptr(sums), c, c, float(n * h * w_), ptr(dgamma), ptr(dbeta), ptr(coef), 0, stream_ptr()))
     check(lib.satcv_bn_bwd_apply(C.byref(d), stream_ptr()))
     return dy, dgamma, dbeta, dbias
+
+
+def bn_relu_bwd_concat(y0, y1, scale, shift, mean, rstd, da):
+    """Backward of relu(BN_train(concat([y0, y1]))) (decoder_block, utils/model_tools.py:307-309) in one pass per kernel over the
+    gradient `da` of the concatenation.  Returns (dy0, dy1, dgamma, dbeta)."""
+    n, h, w_, c0 = y0.shape
+    c1 = y1.shape[-1]
+    c = c0 + c1
+    dev, dtype = y0.device, DTYPE_CODE[y0.dtype]
+    sums = new_stats(c, dev)
+    coef = torch.empty(2, c, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty_like(dgamma)
+    dy0, dy1 = torch.empty_like(y0), torch.empty_like(y1)
+    d = make_bnbwd_desc(yraw=_p(y0), ldy=c0, scale=_p(scale), shift=_p(shift), mean=_p(mean), rstd=_p(rstd), n=n, h=h, w_=w_, c=c, dtype=dtype,
+                        da=_p(da), ldda=c, sums=_p(sums), sums_ld=c, coef=_p(coef), dy=_p(dy0), lddy_out=c0,
+                        yraw1=_p(y1), ldy1=c1, dy1=_p(dy1), lddy1=c1, c_split=c0)
+    check(lib.satcv_bn_bwd_reduce(C.byref(d), stream_ptr()))
+    check(lib.satcv_bn_bwd_finalize(ptr(sums), c, c, float(n * h * w_), ptr(dgamma), ptr(dbeta), ptr(coef), 0, stream_ptr()))
+    check(lib.satcv_bn_bwd_apply(C.byref(d), stream_ptr()))
+    return dy0, dy1, dgamma, dbeta
 
 
 # ------------------------------------------------------------------------------ head

@@ -447,6 +447,32 @@ def test_bn_relu_pool_and_backward(ops, td, f):
     np.testing.assert_allclose(back(h2), b - m_ref * g / np.sqrt(v_ref + 1e-3), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('td', DT)
+@pytest.mark.parametrize('case', [(2, 12, 18, 32, 32), (1, 16, 16, 64, 32), (3, 5, 7, 16, 48)])
+def test_bn_backward_of_a_concatenation_in_one_pass(ops, td, case):
+    """BatchNormalization + ReLU of concat([skip, up]) (utils/model_tools.py:307-309): the dual-source dense backward against the oracle's
+    backward of the materialised concatenation"""
+    n, h, w, c0, c1 = case
+    c = c0 + c1
+    rng = np.random.default_rng(31 + c0)
+    y = rnd(rng, (n, h, w, c), td) * 1.5 + 0.3
+    if td == torch.bfloat16:
+        y = torch.tensor(y, dtype=torch.float32).to(td).double().numpy()
+    g, b = rng.standard_normal(c).astype(np.float32).astype(np.float64), rng.standard_normal(c).astype(np.float32).astype(np.float64)
+    stats = ops.new_stats(c, dev())
+    stats[0, 0] = f32dev(y.sum((0, 1, 2))); stats[1, 1] = f32dev((y ** 2).sum((0, 1, 2)))
+    mm, mv = torch.zeros(c, device=dev()), torch.ones(c, device=dev())
+    scale, shift, mean, rstd = ops.bn_finalize_train(stats, n * h * w, f32dev(g), f32dev(b), mm, mv)
+    z, m_ref, v_ref = K.batchnorm_train(y, g, b)
+    da = rnd(rng, (n, h, w, c), td)
+    dy_ref, dg_ref, db_ref = K.batchnorm_train_bwd(y, g, m_ref, v_ref, K.relu_bwd(K.relu(z), da))
+    dy0, dy1, dgamma, dbeta = ops.bn_relu_bwd_concat(to_dev(y[..., :c0], td), to_dev(y[..., c0:], td), scale, shift, mean, rstd, to_dev(da, td))
+    close(back(dy0), dy_ref[..., :c0], td, 'concat bn bwd dy0', k=4.0)
+    close(back(dy1), dy_ref[..., c0:], td, 'concat bn bwd dy1', k=4.0)
+    close(back(dgamma), dg_ref, td, 'concat dgamma', k=4.0)
+    close(back(dbeta), db_ref, td, 'concat dbeta', k=4.0)
+
+
 # ------------------------------------------------------------------- head and losses
 @pytest.mark.parametrize('td', DT)
 @pytest.mark.parametrize('ncls,activation', [(2, 'softmax'), (5, 'softmax'), (1, 'sigmoid')])

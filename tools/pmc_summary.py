@@ -5,7 +5,8 @@ coalesced stream, i.e. HALF the bytes -> doubled here; WRITE_SIZE is exact for 1
 Counter unit: KiB."""
 import csv, glob, json, sys, collections
 fdir, wdir, out = sys.argv[1], sys.argv[2], sys.argv[3]
-CLASSES = (('Li9ELb', 'igemm_3x3'), ('igemm_fast', 'igemm_1x1_convT'), ('igemm_kernel', 'igemm_generic'), ('wgrad_kernel', 'wgrad'), ('wgrad_reduce', 'wgrad_reduce'),
+commit = sys.argv[4] if len(sys.argv) > 4 else 'unknown'
+CLASSES = (('Li9ELb', 'igemm_3x3'), ('igemm_fast', 'igemm_1x1_convT'), ('igemm_kernel', 'igemm_generic'), ('wgrad_kernel', 'wgrad'), ('wgrad_db_kernel', 'wgrad'), ('wgrad_reduce', 'wgrad_reduce'), ('igemm_ws', 'igemm_3x3'),
            ('bn_bwd', 'bn_bwd'), ('bn_relu_pool', 'bn_relu_pool'), ('head_', 'head'), ('adam', 'adam'), ('pack_kernel', 'pack'))
 
 def load(d):
@@ -29,7 +30,7 @@ for k in sorted(set(fe) | set(wr)):
     calls = max(fc, wc, 1)
     res[k] = {'launches': calls, 'fetch_bytes_raw': fb, 'fetch_bytes_corrected_x2': 2 * fb, 'write_bytes': wb,
               'hbm_bytes_per_launch': (2 * fb + wb) / calls}
-json.dump({'note': 'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request); separate --pmc passes; '
+json.dump({'commit': commit, 'note': 'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request); separate --pmc passes; '
                    'bench.py --steps 3 --warmup 2 (5 training steps, batch 64)', 'classes': res}, open(out, 'w'), indent=1)
 for k, v in res.items():
     print(f"{k:24s} launches {v['launches']:5d}  HBM bytes/launch {v['hbm_bytes_per_launch']/1e6:9.1f} MB")
