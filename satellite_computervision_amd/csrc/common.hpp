@@ -216,6 +216,23 @@ __device__ __forceinline__ Raw8<T> affine8r(const Raw8<T>& r, const float4 (&rs)
   }
   return o;
 }
+// 8 stored elements held in registers -> fp32
+template <typename T>
+__device__ __forceinline__ void unpack8(const Raw8<T>& r, float (&out)[8]) {
+  if constexpr (std::is_same<T, bf16>::value) {
+    const bf16x8 v = __builtin_bit_cast(bf16x8, r.q[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+  } else if constexpr (std::is_same<T, float>::value) {
+    const float* f = reinterpret_cast<const float*>(&r.q[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = f[i];
+  } else {
+    const fp8* b = reinterpret_cast<const fp8*>(&r.q);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (float)b[i];
+  }
+}
 // ablation builds: keep a loaded item alive without storing it
 template <typename T>
 __device__ __forceinline__ void keep8(const Raw8<T>& r) {

@@ -371,37 +371,46 @@ __global__ void bn_bwd_kernel(const satcv_bnbwd_desc d) {
       // first arg-max of the activated window (only when routing a pooled gradient)
       int am[8]; float gp[8];
       const bool full = dp && py < hp && px < wp;
-      if (f == 2 && full && da) {
+      if (!APPLY && f == 2 && full && da) {
+        // (reduce pass only: the apply pass measured SLOWER in this form, packed or not: 208 -> 260 us at level 0)
         // the common case (MaxPooling2D((2, 2)), utils/model_tools.py:281) in ONE pass: the four raw values, the four dense gradients
-        // and the pooled gradient are loaded once, back to back (9 loads in flight per thread instead of 4 + a dependent 9)
-        float v4[4][8], g4[4][8];
+        // and the pooled gradient are loaded once, back to back (9 loads in flight per thread instead of 4 + a dependent 9); they stay
+        // PACKED in registers (the unpacked form cost the apply pass its occupancy: 198 -> 285 us)
+        Raw8<T> v4[4], g4[4];
         const size_t p00 = (size_t)(img * h + py * 2) * w + px * 2;
         const size_t pixs[4] = {p00, p00 + 1, p00 + w, p00 + w + 1};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) load8<T>(yr + pixs[q] * d.ldy + g * 8, v4[q]);
+        for (int q = 0; q < 4; ++q) v4[q] = gload8<T>(yr + pixs[q] * d.ldy + g * 8);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) load8<T>(da + pixs[q] * d.ldda + g * 8, g4[q]);
+        for (int q = 0; q < 4; ++q) g4[q] = gload8<T>(da + pixs[q] * d.ldda + g * 8);
         load8<T>(dp + ((size_t)(img * hp + py) * wp + px) * d.lddp + g * 8, gp);
-        float a4[4][8];
+        {
+          float mx[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float mx = -INFINITY; am[e] = 0;
+          for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; am[e] = 0; }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            a4[q][e] = v4[q][e] * sc[e] + sh[e];
-            const float a = round_to<T>(fmaxf(a4[q][e], 0.f));
-            if (a > mx) { mx = a; am[e] = q; }
+            float v[8];
+            unpack8<T>(v4[q], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float a = round_to<T>(fmaxf(v[e] * sc[e] + sh[e], 0.f));
+              if (a > mx[e]) { mx[e] = a; am[e] = q; }
+            }
           }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float o[8];
+          float v[8], gr[8], o[8];
+          unpack8<T>(v4[q], v);
+          unpack8<T>(g4[q], gr);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float gg = g4[q][e];
+            float gg = gr[e];
             if (am[e] == q) gg += gp[e];
-            gg = (a4[q][e] > 0.f || d.linear) ? gg : 0.f;
-            const float xh = (v4[q][e] - mu[e]) * rs[e];
+            const float a = v[e] * sc[e] + sh[e];
+            gg = (a > 0.f || d.linear) ? gg : 0.f;
+            const float xh = (v[e] - mu[e]) * rs[e];
             if (APPLY) { const float t = sc[e] * (gg - c1[e] - xh * c2[e]); o[e] = round_to<T>(t); s1[e] += o[e]; }
             else { s1[e] += gg; s2[e] += gg * xh; }
           }

@@ -68,6 +68,9 @@ class ParamSpec:
 # no effect on any output.  Here the gradient is the exact 0 (the bias stays at its value) unless SATCV_BN_BIAS_NOISE=1 asks for
 # the summed-noise form; the atomics it needs are also the one remaining source of run-to-run differences in a training step.
 BIAS_NOISE = os.environ.get('SATCV_BN_BIAS_NOISE', '0') == '1'
+# weight-gradient launches (second stream) enqueued AFTER the data gradient of their layer instead of before it: they then start beside the
+# HBM-bound BatchNorm-backward kernels of the next layer rather than beside their own layer's MFMA-bound data gradient
+WGRAD_LATE = os.environ.get('SATCV_WGRAD_LATE', '0') == '1'
 
 
 def rup(a, b):
@@ -872,7 +875,9 @@ class Plan:
                 self.dbg['dy:' + lay.name] = dy
                 self.dbg['_ctx:' + lay.name] = dict(da=da, dp=dp, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout)
                 pk = rt.packed[lay.name]
-                self.bwd.append(wgrad_step(r, dy.data_ptr(), cout, lay, pk['cin'], cout, hh, ww, cx['k'], cx['dil'], accum=accum))
+                wstep = wgrad_step(r, dy.data_ptr(), cout, lay, pk['cin'], cout, hh, ww, cx['k'], cx['dil'], accum=accum)
+                if not WGRAD_LATE:
+                    self.bwd.append(wstep)
                 if tin.node.op != 'input':
                     cinp = r.c
                     prev = gact.get(tin.id)
@@ -884,6 +889,8 @@ class Plan:
                                                dil=cx['dil'], dtype=dt, accumulate=1 if prev is not None else 0))
                     gact[tin.id] = (gin, 0, cinp)
                     self.dbg['dx:' + lay.name] = gin
+                if WGRAD_LATE:
+                    self.bwd.append(wstep)
             elif op == 'dropout':
                 tin, tout = node.inputs[0], node.outputs[0]
                 g = gact.get(tout.id)
@@ -959,11 +966,15 @@ class Plan:
                     continue
                 lay, r, cout, f = node.layer, cx['r'], cx['cout'], cx['f']
                 pk = rt.packed[lay.name]
-                self.bwd.append(wgrad_step(r, du.data_ptr(), cout, lay, pk['cin'], cout, r.h, r.w, 1, 1, f=f))
+                wstep = wgrad_step(r, du.data_ptr(), cout, lay, pk['cin'], cout, r.h, r.w, 1, 1, f=f)
+                if not WGRAD_LATE:
+                    self.bwd.append(wstep)
                 cinp = r.c
                 gin = self._z(n, r.h, r.w, cinp)
                 self.bwd.append(dgrad_step(tin, x0=du.data_ptr(), c0=cout, w=pk['dgrad'].data_ptr(), y=gin.data_ptr(), ldy=cinp, n=n, h=r.h,
                                            w_=r.w, cout=cinp, cout_pad=rup(cinp, 32), kh=1, kw=1, dil=1, mode_in=1, f=f, dtype=dt))
+                if WGRAD_LATE:
+                    self.bwd.append(wstep)
                 gact[tin.id] = (gin, 0, cinp)
                 self.dbg['dx:' + lay.name] = gin
         if prev_node is not None:
