@@ -113,12 +113,14 @@ extern "C" int satcv_prof_collect(int32_t kind, double* total_ms, int64_t* launc
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 int g_opt_igemm_db = env_int("SATCV_DB", 1);
 int g_opt_wgrad_db = env_int("SATCV_WGRAD_DB", 1);
+int g_opt_igemm_sched = env_int("SATCV_IGEMM_SCHED", 0);
 int g_opt_igemm_thin = env_int("SATCV_THIN", 0);      // measured equal to the general kernel (round 2): opt-in
 static int* opt_slot(const char* key) {
   if (!key) return nullptr;
   if (!strcmp(key, "igemm_db")) return &g_opt_igemm_db;
   if (!strcmp(key, "igemm_thin")) return &g_opt_igemm_thin;
   if (!strcmp(key, "wgrad_db")) return &g_opt_wgrad_db;
+  if (!strcmp(key, "igemm_sched")) return &g_opt_igemm_sched;
   return nullptr;
 }
 extern "C" int satcv_set_option(const char* key, int32_t value) {

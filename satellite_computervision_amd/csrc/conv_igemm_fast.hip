@@ -18,7 +18,7 @@
 //     halos run on the same XCD (private L2).
 #include "igemm_common.hpp"
 #include <cstdlib>
-extern int g_opt_igemm_db, g_opt_igemm_thin;      // api.hip: satcv_set_option
+extern int g_opt_igemm_db, g_opt_igemm_thin, g_opt_igemm_sched;      // api.hip: satcv_set_option
 
 // compile-time ablation switches for profiling builds (-DSATCV_ABLATE=bits): 1 skip global stores, 2 skip MFMA,
 // 4 skip activation loads, 8 skip weight loads, 16 skip the LDS fragment reads, 32 skip the whole epilogue, 64 skip the LDS stores
@@ -309,10 +309,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
         for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
     // one K-chunk: software-pipelined fragment reads -- the LDS reads of step s+1 are issued before the MFMAs of step s (the
     // compiler otherwise waits for every read right before its MFMAs and the matrix pipe idles for the LDS latency)
-    auto compute_chunk = [&](int boff, auto&& side) {
+    // rot: the tap step this wave starts a chunk with (the order of the steps is free).  In the 8-wave double-buffered tile the two
+    // waves of a SIMD otherwise run the same stream in lockstep -- both in their fragment-read bursts, both at their MFMAs --; starting
+    // waves 4-7 half a chunk later de-phases them (MI355X_MICROARCH.md, two waves per SIMD, item 9)
+    // (rot is a wave-uniform run-time value: the tap offsets of a staggered wave are scalar additions instead of instruction immediates;
+    //  two compile-time copies of the loop cost 200 bytes of scratch per lane)
+    auto compute_chunk = [&](int boff, auto&& side, int rot) {
       constexpr int STEPS = TAPS * KS;
       FragT<T> af[2][MT], bf[2][NT];
-      auto read_step = [&](int st, int buf) {
+      auto read_step = [&](int st_, int buf) {
+        int st = st_;
+        if constexpr (DB) { st += rot; st -= st >= STEPS ? STEPS : 0; }
         const int tap = st / KS, ks = st % KS;
         const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap % 3;
         const int tap_off = (ky * dil * pitch + kx * dil) * EL;
@@ -350,6 +357,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
       // units of one chunk's staging in program order: A items (store c+1, then re-issue for c+2), the scale / shift values (needed by
       // the A stores above, so re-issued after them), weight items; unit u runs in tap step u (the surplus in the last step)
       constexpr int NUNITS = AI + 1 + BI, STEPS_ = TAPS * KS;
+      const int rot = ((a.dbg & 1) && __builtin_amdgcn_readfirstlane(wave) >= NTHREADS / 128) ? (STEPS_ + 1) / 2 : 0;      // the younger half of the waves
       for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         const int cur = (chunk & 1) * stage_elems, oth = stage_elems - cur;
         const bool do_store = chunk + 1 < a.nchunks, do_load = chunk + 2 < a.nchunks;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
         STAMP(t1);
         STAMP(t2);
 #endif
-        compute_chunk(cur, [&](int st) {
+        auto side = [&](int st) {
 #pragma unroll
           for (int u = 0; u < NUNITS; ++u) {
             if ((u < STEPS_ ? u : STEPS_ - 1) != st) continue;
@@ -369,7 +377,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
             else if (u == AI) load_p(cs_);
             else { if (do_store) store_b(oth, u - AI - 1); load_b(cs_, u - AI - 1); }
           }
-        });
+        };
+        compute_chunk(cur, side, rot);
 #ifdef SATCV_STAMP
         STAMP(t3);
 #endif
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #ifdef SATCV_STAMP
       STAMP(t1);
 #endif
-      compute_chunk(0, [](int) {});
+      compute_chunk(0, [](int) {}, 0);
 #ifdef SATCV_STAMP
       STAMP(t2);
 #endif
@@ -528,18 +537,17 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   if constexpr (TAPS == 9 && std::is_same<T, bf16>::value) {
     // deep 3x3 layers: 256-pixel x 128-channel tile, 8 waves, double-buffered stages (SATCV_DB=0 keeps the 128 x 128 tile)
     const int db_mode = g_opt_igemm_db;
+    a.dbg = g_opt_igemm_sched;            // bit 0: staggered tap order for waves 4-7 of the double-buffered tile
     if (db_mode && a.dil == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && nspace % 128 == 0 && cin >= 64) {
       const long long tiles256 = (long long)cdiv(a.n * a.h * a.w_, 256) * (nspace / 128);
+      // (a 512-pixel x 128-channel tile -- wave tile 64 x 128, 128 accumulator registers -- needs ~300 bytes of scratch per lane at the
+      //  256-register cap of two waves per SIMD: not kept)
       if (db_mode >= 2 || tiles256 >= 192) {
         const int rc = fast_cfg<T, TW, 4, 2, 2, 2, 1, TAPS, false, true>(a, st, dry);
         if (rc != SATCV_ERR_UNSUPPORTED) return rc;
       }
     }
-    // 64 output channels (decoder / encoder level 1): the same 8-wave double-buffered loop on a 256-pixel x 64-channel tile
-    if (db_mode >= 3 && a.dil == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && nspace % 64 == 0 && nspace % 128 != 0 && cin >= 64) {
-      const int rc = fast_cfg<T, TW, 4, 2, 2, 1, 1, TAPS, false, true>(a, st, dry);
-      if (rc != SATCV_ERR_UNSUPPORTED) return rc;
-    }
+    // (a 256-pixel x 64-channel form of the same loop for the 64-channel layers measured equal to the 128 x 64 tile: not kept)
   }
   // 32-channel chunks only for 1x1 taps (the 9-tap weight slab of a 32-channel chunk would not leave
   // room for 2-3 workgroups per CU)
