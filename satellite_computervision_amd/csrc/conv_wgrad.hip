@@ -963,7 +963,7 @@ extern "C" int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream) {
   SATCV_CHECK(d->cin > 0 && d->cin <= d->c0 + d->c1 && d->cout > 0, "wgrad: bad cin/cout");
   SATCV_CHECK(d->n > 0 && d->h > 0 && d->w_ > 0 && d->dil >= 1, "wgrad: bad dims");
   SATCV_CHECK(!d->mode_dy || (d->f >= 2 && d->kh == 1 && d->kw == 1 && d->cout % 8 == 0), "wgrad: transposed conv needs 1x1 taps, f>=2");
-  SATCV_CHECK(!d->x1 || d->c0 % 32 == 0, "wgrad: dual source needs c0 %% 32 == 0");
+  SATCV_CHECK(!d->x1 || d->c0 % 8 == 0, "wgrad: dual source needs c0 %% 8 == 0");      // (a thread's 8-channel item never straddles the two sources)
   WgradPlan p;
   int rc = wgrad_plan(d, p); if (rc) return rc;
   SATCV_CHECK((size_t)d->workspace_bytes >= p.ws_bytes, "wgrad: workspace %lld < %zu", (long long)d->workspace_bytes, p.ws_bytes);

@@ -700,8 +700,8 @@ class Plan:
         def wgrad_step(r, dy, lddy, lay, cin_real, cout, hh, ww, k, dil, f=0, accum=0):
             nonlocal ws_need
             sa = self._src_args(r)
-            if sa['x1'] is not None and sa['c0'] % 32:
-                raise NotImplementedError(f'{lay.name}: training a convolution over a concatenation needs a first part of a multiple of 32 channels '
+            if sa['x1'] is not None and sa['c0'] % 8:
+                raise NotImplementedError(f'{lay.name}: training a convolution over a concatenation needs a first part of a multiple of 8 channels '
                                           f'(got {sa["c0"]}); inference has no such limit')
             d = ops.make_wgrad_desc(dy=dy, lddy=lddy, dw=rt.gptr(lay.name + '/kernel'), cin=cin_real, cout=cout, n=n, h=hh, w_=ww,
                                     dtype=dt, kh=k, kw=k, dil=dil, mode_dy=1 if f else 0, f=f if f else 1, transposed=1 if f else 0, accumulate=accum, **sa)

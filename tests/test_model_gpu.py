@@ -1124,10 +1124,10 @@ def test_keras_hdf5_weight_files_load_into_the_model(mt, tmp_path):
 
 
 @pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
-def test_sixteen_filter_unet_inference(mt, dtype):
-    """filters=[16, 32]: 16-channel transposed convolutions (a depth-to-space tile then spans several sub-pixel positions) against the
-    NumPy oracle; training such a network is refused with a clear message (the weight-gradient kernel reads a concatenation in
-    32-channel blocks)."""
+def test_sixteen_filter_unet_inference_and_training(mt, dtype):
+    """filters=[16, 32]: 16-channel transposed convolutions (a depth-to-space tile then spans several sub-pixel positions) and a decoder
+    conv over concat([16-channel skip, 16-channel up]) -- inference AND one training step (loss, every gradient) against the NumPy
+    oracle (the round-1 weight-gradient kernel refused concatenations whose first part was not a multiple of 32 channels)."""
     from oracle.unet import UNetOracle
     filters, factors = [16, 32], [2, 2]
     mt.reset_uids(); mt.set_seed(11)
@@ -1143,9 +1143,21 @@ def test_sixteen_filter_unet_inference(mt, dtype):
     t = np.eye(2, dtype=np.float32)[(rng.random((3, 32, 48)) < 0.3).astype(int)]
     p_ref, _ = o.forward(x, training=False)
     np.testing.assert_allclose(m.predict(x)[0], p_ref, atol=3e-5 if dtype == 'float32' else 6e-2)
-    m.compile(optimizer=mt.Adam(1e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 3.0]))
-    with pytest.raises(NotImplementedError, match='multiple of 32'):
-        m.train_on_batch(x, t)
+    m.compile(optimizer=mt.Adam(0.0), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 3.0]))
+    pr, _ = o.forward(x, training=True)
+    loss_ref, dprobs, _ = OL.weighted_categorical_crossentropy(t.astype(np.float64), pr, [1.0, 3.0])
+    g_ref = o.backward(dprobs)
+    loss = m.train_on_batch(x, t)
+    f32 = dtype == 'float32'
+    np.testing.assert_allclose(loss, loss_ref, rtol=2e-5 if f32 else 3e-2)
+    rt = m.runtime
+    for k in o.trainable:
+        if k.endswith('.bias') and not k.startswith('probs'):
+            continue
+        g = rt.get_grad(names[k]).cpu().numpy().astype(np.float64)
+        l2 = np.linalg.norm(g - g_ref[k]) / max(np.linalg.norm(g_ref[k]), 1e-30)
+        cos = (g * g_ref[k]).sum() / max(np.linalg.norm(g) * np.linalg.norm(g_ref[k]), 1e-30)
+        assert (l2 < 1e-2) if f32 else (cos > 0.9), f'grad {k}: relL2 {l2:.3e} cos {cos:.4f}'
 
 
 def test_retrain_model_from_keras_h5(mt, tmp_path):
