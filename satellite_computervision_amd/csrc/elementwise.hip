@@ -139,7 +139,18 @@ __global__ void pack_batched_kernel(const satcv_pack_job* __restrict__ jobs, con
     int lo = 0, hi = njobs - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= g) lo = mid; else hi = mid - 1; }
     const satcv_pack_job j = jobs[lo];
-    const long long it = g - prefix[lo];
+    long long it = g - prefix[lo];
+    if (j.mode == 1 && (j.kpad / 8) % 4 == 0 && j.npad % 16 == 0) {
+      // data-gradient image of a 3x3 kernel: k runs over Cout (contiguous in the Keras kernel), nn over Cin (stride Cout).  With nn on
+      // the lanes every lane read its 32 bytes from another 128-byte line (4x the lines); here 4 lanes cover the 4 x 32 bytes of one
+      // line (4 consecutive k8 of one nn) and 16 consecutive nn follow -- same items, another thread-to-item map
+      const int nb = j.npad / 16, kb = (j.kpad / 8) / 4;
+      const int l = (int)(it % 64); long long t = it / 64;
+      const int nblk = (int)(t % nb); t /= nb;
+      const int kblk = (int)(t % kb); const long long tap_ = t / kb;
+      const int k8_ = kblk * 4 + (l & 3), nn_ = nblk * 16 + (l >> 2);
+      it = (tap_ * (j.kpad / 8) + k8_) * j.npad + nn_;
+    }
     const int nn = (int)(it % j.npad);
     const int k8 = (int)((it / j.npad) % (j.kpad / 8));
     const int tap = (int)(it / ((long long)j.npad * (j.kpad / 8)));
