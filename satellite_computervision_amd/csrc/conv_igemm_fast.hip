@@ -586,6 +586,9 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   // (8-wave variants of the thin tiles -- 16 accumulator registers, 6 waves/SIMD -- were measured 8-20 % SLOWER: occupancy is
   //  no longer what limits the bytes in flight)
   if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 1, TAPS>(a, st, dry);
+  // (round 2, measured on the 32-output-channel layers at 256 x 256 and not kept: a 512-pixel x 32-channel tile with 128 x 32 per wave,
+  //  8-15 % slower; a persistent form of this tile -- resident grid, tile loop around the body, set-up once -- needs 56-160 bytes of
+  //  scratch per lane at 3-4 waves per SIMD and is 8-25 % slower: occupancy is what these layers need)
   return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS>(a, st, dry);
 }
 
