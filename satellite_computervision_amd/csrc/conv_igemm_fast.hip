@@ -570,6 +570,15 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
       return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS, true>(a, st, dry);
     }
     if (ks2) {
+      if constexpr (std::is_same<T, bf16>::value) {
+        // deep 1x1 / transposed convolutions (K = Cin >= 512; at 256 it measured slower): 64-channel chunks -- with 32 a chunk is 8 MFMAs per wave between two
+        // barrier pairs; SATCV_DB=0 keeps the 32-channel form
+        const bool ks4 = g_opt_igemm_db != 0 && (cin % 64 == 0) && cin >= 512 && (!a.x1 || a.c0 % 64 == 0) && (a.mode_in != 1 || a.c0 % 64 == 0);
+        if (ks4 && nspace >= 128 && nspace % 128 == 0) {
+          const int rc = fast_cfg<T, TW, 2, 2, 2, 2, 4, TAPS, false, false, 2>(a, st, dry);
+          if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+        }
+      }
       if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS>(a, st, dry);
       if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 2, TAPS>(a, st, dry);
       return fast_cfg<T, TW, 4, 1, 2, 1, 2, TAPS>(a, st, dry);
