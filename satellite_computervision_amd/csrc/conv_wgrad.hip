@@ -737,6 +737,52 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restr
   }
 }
 
+// many slabs, few outputs (thin layers: 128-256 slabs of a 9 x 32 x 32 kernel): 16 lanes per float4 output instead of 4, four loads in
+// flight per lane -- the 4-lane form walked 64 slabs per lane with two loads in flight and took ~40 us for 9 MB.  Fixed summation
+// order (lane l sums slabs l, l + 16, ... in four interleaved accumulators; the 16 lane sums are added in increasing lane order).
+__global__ __launch_bounds__(256) void wgrad_reduce16_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab, int taps, int kpad,
+                                                             int npad, int cin, int nvalid, int accumulate) {
+  __shared__ float4 part[16][16];
+  const int nv4 = nvalid / 4;
+  const long long total = (long long)taps * cin * nv4;
+  const size_t slab = (size_t)taps * kpad * npad;
+  const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  for (long long base = (long long)blockIdx.x * 16; base < total; base += (long long)gridDim.x * 16) {
+    const long long it = base + ol;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int co = 0, ci = 0, tap = 0;
+    if (it < total) {
+      co = (int)(it % nv4) * 4;
+      ci = (int)((it / nv4) % cin);
+      tap = (int)(it / ((long long)nv4 * cin));
+      const float* p = ws + ((size_t)tap * kpad + ci) * npad + co;
+      float4 a0 = s, a1 = s, a2 = s, a3 = s;
+      int sp = sl;
+      for (; sp + 48 < nslab; sp += 64) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)sp * slab), v1 = *reinterpret_cast<const float4*>(p + (size_t)(sp + 16) * slab);
+        const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(sp + 32) * slab), v3 = *reinterpret_cast<const float4*>(p + (size_t)(sp + 48) * slab);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+      }
+      for (; sp < nslab; sp += 16) { const float4 v = *reinterpret_cast<const float4*>(p + (size_t)sp * slab); a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w; }
+      s = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+    }
+    part[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && it < total) {
+      float4 r = part[0][ol];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) { const float4 v = part[k][ol]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+      float4* dst = reinterpret_cast<float4*>(dw + ((size_t)tap * cin + ci) * nvalid + co);
+      if (accumulate) { const float4 o = *dst; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+      *dst = r;
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ host side
 struct WgradPlan { int tw, nci, nco, nks, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk, pix, db; size_t ws_bytes; };
 extern int g_opt_wgrad_db;        // api.hip: satcv_set_option("wgrad_db", ...)
@@ -759,11 +805,14 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   p.ntaps = d->kh * d->kw;
   if (!(p.ntaps == 1 || (d->kh == 3 && d->kw == 3))) { satcv_set_error("wgrad: only 1x1 and 3x3 taps"); return SATCV_ERR_UNSUPPORTED; }
   p.tw = pick_tw_w(d->w_);
-  if (p.ntaps == 1) { p.nci = 1; p.nco = 4; }
+  const bool db_ok = g_opt_wgrad_db != 0 && d->dil == 1 && d->dtype == SATCV_BF16;
+  // 1x1 / transposed convolutions: 16 accumulator registers per (ci, co) tile, so the double-buffered kernel's 8 waves cover a
+  // 64 x 128 block (each dY tile is re-read by half as many ci blocks: these launches are staging-bound, ~110 us whatever their size)
+  if (p.ntaps == 1) { p.nci = (db_ok && cinx % 64 == 0) ? 2 : 1; p.nco = 4; }
   else if (nspace % 128 == 0) { p.nci = 1; p.nco = 4; }
   else if (nspace % 64 == 0) { p.nci = (cinx % 64 == 0) ? 2 : 1; p.nco = 2; }
   else { p.nci = (cinx % 64 == 0) ? 2 : 1; p.nco = 1; }
-  p.nks = 4 / (p.nci * p.nco);                 // always 4 waves per workgroup
+  p.nks = 4 / (p.nci * p.nco) > 0 ? 4 / (p.nci * p.nco) : 1;                 // 4 waves per workgroup (single-buffered kernel)
   const int ci_t = 32 * p.nci, co_t = 32 * p.nco;
   p.n_ci_blk = cdiv(cinx, ci_t); p.n_co_blk = cdiv(nspace, co_t);
   p.kpad = p.n_ci_blk * ci_t; p.npad = p.n_co_blk * co_t;
@@ -785,7 +834,7 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   long long ns = cdiv(nblk >= 128 ? 768 : 512, nblk);
   // double-buffered kernel (8 waves, one workgroup per CU): 256 workgroups fill the chip once; each should walk >= 16 pixel tiles so
   // that its set-up and its slab write (~16k cycles) stay small beside the tile loop
-  p.db = (g_opt_wgrad_db != 0 && d->dil == 1 && d->dtype == SATCV_BF16) ? 1 : 0;
+  p.db = db_ok ? 1 : 0;
   if (p.db) ns = nblk >= 256 ? 1 : 256 / nblk;
   if (ns > ptiles) ns = ptiles;
   if (ns > 768) ns = 768;
@@ -891,6 +940,7 @@ static int wgrad_db_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStr
 // the double-buffered kernel (bf16): 8 waves = (ci, co) tiles x k-slices
 template <typename T, int TW>
 static int wgrad_db_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy, int sx) {
+  if (p.ntaps == 1 && p.nci == 2) return wgrad_db_launch<T, TW, 2, 4, 1, 1>(d, p, st, sy, sx);
   if (p.ntaps == 1) return wgrad_db_launch<T, TW, 1, 4, 2, 1>(d, p, st, sy, sx);
   if (p.nci == 1 && p.nco == 4) return wgrad_db_launch<T, TW, 1, 4, 2, 9>(d, p, st);
   if (p.nci == 2 && p.nco == 2) return wgrad_db_launch<T, TW, 2, 2, 2, 9>(d, p, st);
@@ -939,6 +989,14 @@ static int wgrad_any(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t 
 static int wgrad_reduce_launch(const satcv_wgrad_desc* d, const WgradPlan& p, float* dw, int nvalid, hipStream_t st) {
   const long long total = (long long)p.ntaps * d->cin * nvalid;
   if (!d->transposed && nvalid % 4 == 0 && p.npad % 4 == 0 && ((uintptr_t)dw % 16) == 0 && ((uintptr_t)d->workspace % 16) == 0) {
+    if (p.nsplit >= 32) {
+      int grid16 = (int)((total / 4 + 15) / 16); if (grid16 > 16384) grid16 = 16384;
+      hipLaunchKernelGGL(wgrad_reduce16_kernel, dim3(grid16), dim3(256), 0, st, (const float*)d->workspace, dw, p.nsplit, p.ntaps, p.kpad, p.npad, d->cin, nvalid,
+                         d->accumulate);
+      hipError_t e16 = hipGetLastError();
+      if (e16 != hipSuccess) { satcv_set_error("wgrad reduce launch: %s", hipGetErrorString(e16)); return SATCV_ERR_HIP; }
+      return SATCV_OK;
+    }
     int grid4 = (int)((total / 4 + 63) / 64); if (grid4 > 8192) grid4 = 8192;
     hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(grid4), dim3(256), 0, st, (const float*)d->workspace, dw, p.nsplit, p.ntaps, p.kpad, p.npad, d->cin, nvalid,
                        d->accumulate);
