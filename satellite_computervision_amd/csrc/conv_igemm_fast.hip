@@ -446,7 +446,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
     STAMP(k3);
 #endif
 
-    igemm_epilogue<T, TW, WM, WN, MT, NT, ABL(1)>(a, acc, n0, y0, x0, nbase, smem_raw);
+    igemm_epilogue<T, TW, WM, WN, MT, NT, ABL(1), !DYN>(a, acc, n0, y0, x0, nbase, smem_raw);      // (the dilated-halo instantiations sit at their register cap)
 #ifdef SATCV_STAMP
     {
       unsigned long long k4;
