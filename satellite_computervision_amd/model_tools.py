@@ -43,8 +43,12 @@ def set_compute_dtype(name):
 
 
 def set_seed(seed):
-    global _RNG
+    global _RNG, _SHUFFLE_RNG
     _RNG = np.random.default_rng(seed)
+    _SHUFFLE_RNG = np.random.default_rng([int(seed) & 0xffffffff, 0x5f5])      # fit(shuffle=True) permutations
+
+
+_SHUFFLE_RNG = np.random.default_rng(0x5f5)
 
 
 def reset_uids():
@@ -677,17 +681,24 @@ class TensorBoard:
 
 
 # ----------------------------------------------------------------------------- Model
-def _as_batches(x, y, batch_size):
-    """ndarray pair / Sequence / iterable of (x, y) -> generator of batches (possibly endless)."""
+def _as_batches(x, y, batch_size, order=None):
+    """ndarray pair / Sequence / iterable of (x, y) -> generator of batches (possibly endless).  order: optional permutation of the
+    samples of array inputs (Keras' fit(shuffle=True) draws a new one every epoch)."""
     multi = isinstance(x, (list, tuple)) and len(x) > 0 and all(isinstance(a, (np.ndarray, torch.Tensor)) for a in x)
     if multi or y is not None or isinstance(x, (np.ndarray, torch.Tensor)):
         n = x[0].shape[0] if multi else x.shape[0]
         bs = batch_size or 32
 
+        def take(a, i):
+            if order is None:
+                return a[i:i + bs]
+            idx = order[i:i + bs]
+            return a[torch.as_tensor(idx, device=a.device)] if isinstance(a, torch.Tensor) else a[idx]
+
         def gen():
             for i in range(0, n, bs):
-                xb = [a[i:i + bs] for a in x] if multi else x[i:i + bs]
-                yield (xb, y[i:i + bs]) if y is not None else xb
+                xb = [take(a, i) for a in x] if multi else take(x, i)
+                yield (xb, take(y, i)) if y is not None else xb
         return gen(), (n + bs - 1) // bs
     if hasattr(x, '__getitem__') and hasattr(x, '__len__'):          # keras.utils.Sequence
 
@@ -1138,7 +1149,7 @@ class Model:
 
     def _run_epoch(self, batches, steps, train):
         rt = self.runtime
-        loss_sum = torch.zeros(1, dtype=torch.float32, device=rt.dev)
+        loss_sum = torch.zeros(1, dtype=torch.float32, device=rt.dev)          # sum of batch loss x batch size: Keras weights the epoch mean by samples
         conf, cnt = None, 0
         sync = getattr(self, '_sync_grads', None)
         for i, b in enumerate(batches):
@@ -1159,21 +1170,23 @@ class Model:
                 plan.loss_buf.zero_()
                 plan.run_forward(st)
                 self._loss_launch(plan, st)
-            loss_sum += plan.loss_buf
+            loss_sum += plan.loss_buf * float(plan.n)
             hd = plan.head
             if self._metrics and hd['act'] == 0:
                 if conf is None:
                     conf = torch.zeros(hd['ncls'], hd['ncls'], dtype=torch.int64, device=rt.dev)
                 check(lib.satcv_confusion(hd['classes'].data_ptr(), plan.y_true.data_ptr(), hd['ncls'], hd['classes'].numel(),
                                           conf.data_ptr(), ops.stream_ptr()))
-            cnt += 1
+            cnt += plan.n
         loss = float(loss_sum.item()) / max(cnt, 1)
         c = conf.cpu().numpy() if conf is not None else np.zeros((1, 1))
         return self._metric_values(c, loss)
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, validation_data=None, steps_per_epoch=None,
-            validation_steps=None, initial_epoch=0, **kw):
-        """Model.fit as the notebooks call it (notebooks/UNET_G4G_2019_solar.ipynb:1267-1275)."""
+            validation_steps=None, initial_epoch=0, shuffle=True, **kw):
+        """Model.fit as the notebooks call it (notebooks/UNET_G4G_2019_solar.ipynb:1267-1275).  shuffle (Keras default True) applies to
+        array inputs only, as in Keras: a new sample permutation every epoch (seeded by set_seed); generators / Sequences / datasets are
+        consumed in their own order."""
         if isinstance(x, (np.ndarray, torch.Tensor)):
             self._shape_of(x)
             if y is not None and len(y) != len(x):
@@ -1187,7 +1200,11 @@ class Model:
         for epoch in range(initial_epoch, epochs):
             t0 = time.time()
             if it is None or steps_per_epoch is None:
-                it, _ = _as_batches(x, y, batch_size)
+                order = None
+                if shuffle and (isinstance(x, (np.ndarray, torch.Tensor)) or (isinstance(x, (list, tuple)) and y is not None)):
+                    nsamp = x[0].shape[0] if isinstance(x, (list, tuple)) else x.shape[0]
+                    order = _SHUFFLE_RNG.permutation(nsamp)
+                it, _ = _as_batches(x, y, batch_size, order)
             vals = self._run_epoch(it, steps_per_epoch, True)
             logs = dict(zip(self.metrics_names, vals))
             if validation_data is not None:
@@ -1284,7 +1301,11 @@ def retrain_model(model_file, checkpoint, eval_data, metric, weights_file=None, 
     """utils/model_tools.py:1128-1176: load a saved model (a path -- own container or Keras .h5 -- or a Model object), optionally a
     separate weights file (`by_name` / `skip_mismatch` as in Model.load_weights), evaluate it on `eval_data`, seed
     `checkpoint.best` with the current value of `metric`, set the learning rate and optionally freeze all but the last layer.
-    Returns (model, checkpoint) like the reference.  A model restored from a file carries no loss: pass
+    Returns (model, checkpoint) like the reference.  `freeze`: `m.layers` holds the WEIGHTED layers here, so `layers[:-1]` keeps the
+    `probs` head trainable -- the documented intent ("freeze all but the last layer").  In tf.keras the last entry of `model.layers`
+    of a `get_unet_model` network is the weightless `classes` Lambda (utils/model_tools.py:406), so the reference's identical slice
+    (:1174-1175) freezes the head as well and leaves nothing to train; set `m.get_layer('probs').trainable = False` for that.
+    A model restored from a file carries no loss: pass
     custom_objects={'compile': dict(optimizer=..., loss=..., metrics=[...])} to compile it here (tf.keras restores that from the
     file's training_config, which names Python functions this build cannot import)."""
     m = load_model(model_file, custom_objects=custom_objects) if isinstance(model_file, (str, os.PathLike)) else model_file
