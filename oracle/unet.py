@@ -68,7 +68,7 @@ def unet_param_specs(nclasses, nchannels, filters, factors):
 class UNetOracle:
     def __init__(self, nclasses, nchannels, filters=(32, 64, 128, 256, 512),
                  factors=(2, 2, 2, 2, 2), bias=None, dtype=np.float64, seed=0,
-                 bessel=False):
+                 bessel=True):
         self.nclasses, self.nchannels = nclasses, nchannels
         self.filters, self.factors = list(filters), list(factors)
         self.dtype, self.bessel = dtype, bessel
