@@ -394,9 +394,16 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, (TW == 8 ? 1 : 2)) void wgrad_k
 //     wave in its issue phase while the vector-memory pipe takes the instructions in, with the matrix pipe idle);
 //   * 8 waves per workgroup (the k-steps of a staged tile are split over two or more wave groups, summed through LDS at the end
 //     in fixed order), one workgroup per CU.
-template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS, int PIX>
+//
+// NW > 1 (1x1 / transposed convolutions only): a wave owns NW co tiles of one ci tile, i.e. the workgroup covers a
+// (32 NCI) x (32 NCO NW) block.  A 1x1 wave holds 16 accumulator registers per tile, so the 64 x 128 block of the NW = 1 form moved
+// 49 KB from L2 to LDS per 8 MFMAs of a wave: the five transposed-conv gradients of the U-Net each re-read ~400 MB through L2 and took
+// 80-95 us whatever their shape.  The 128 x 256 block (4 x 2 waves x 4 tiles, 64-pixel stages) halves those bytes per MFMA.
+template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS, int PIX, int NW = 1>
 __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const WgradArgs a) {
-  using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
+  static_assert(NW == 1 || NTAPS == 1, "several co tiles per wave only for single-tap kernels");
+  using G = WgradGeom<TW, NCI, NCO * NW, NTAPS, T>;
+  constexpr int NACC = NTAPS * NW;
   constexpr int NTHREADS = NCI * NCO * NKS * 64;
   constexpr int BMPIX = PIX, TH = BMPIX / TW;
   constexpr int CI_T = G::CI_T, CO_T = G::CO_T, XP = G::XP, DP = G::DP;
@@ -420,9 +427,9 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
   const int ci_blk = blk % a.n_ci_blk, co_blk = blk / a.n_ci_blk;
   const int ci0 = ci_blk * CI_T, co0 = co_blk * CO_T;
 
-  f32x16 acc[NTAPS];
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int t = 0; t < NTAPS; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
   // ---- per-thread, tile-invariant description of the staged items
   const int x_items = a.rl * a.cl * GX;
   constexpr int d_items = BMPIX * GD;
-  constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+  constexpr int XMAXPIX = NTAPS == 1 ? BMPIX : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);      // (no halo without taps)
   constexpr int XI = (XMAXPIX * GX + NTHREADS - 1) / NTHREADS;
   constexpr int DI = (d_items + NTHREADS - 1) / NTHREADS;
   constexpr int NU = XI + DI;
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
   }
   __syncthreads();
   constexpr int KSW = (BMPIX / 16) / NKS;              // k-steps of 16 pixels per wave and tile
-  constexpr int SLOTS = KSW * NTAPS;                   // MFMAs per wave and tile = places for a staging unit
+  constexpr int SLOTS = KSW * NACC;                    // MFMAs per wave and tile = places for a staging unit
   for (int i = 0; i < ntl; ++i) {
     T* ldsX = lds0 + (i & 1) * stage_elems;
     T* ldsD = ldsX + x_elems;
@@ -584,7 +591,33 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
 #pragma unroll
     for (int kk = 0; kk < KSW; ++kk) {
       const int ks = wks + kk * NKS;
-      if constexpr (std::is_same<T, bf16>::value) {
+      if constexpr (NW > 1) {
+        // one X fragment, NW dY fragments (the mirror image of the tap loop below, where dY is shared and X moves)
+        const int gi = lane >> 4, i16 = lane & 15;
+        const int chb = 16 * (gi & 1) + 4 * (i16 & 3);
+        const int qa = ks * 16 + 8 * (gi >> 1) + (i16 >> 2);
+        const int qb = qa + 4;
+        const bf16x4 alo = tr_read(ldsX + tab[qa] + wci * 32 + chb);
+        const bf16x4 ahi = tr_read(ldsX + tab[qb] + wci * 32 + chb);
+        const bf16x8 afr = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16* da = ldsD + qa * DP + wco * NW * 32 + chb;
+        const bf16* db = ldsD + qb * DP + wco * NW * 32 + chb;
+        bf16x4 blo[2], bhi[2];
+        blo[0] = tr_read(da);
+        bhi[0] = tr_read(db);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          if (w + 1 < NW) {
+            blo[(w + 1) & 1] = tr_read(da + (w + 1) * 32);
+            bhi[(w + 1) & 1] = tr_read(db + (w + 1) * 32);
+          }
+          side(kk * NW + w);
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 bfr = __builtin_shufflevector(blo[w & 1], bhi[w & 1], 0, 1, 2, 3, 4, 5, 6, 7);
+          if (!WABL(2)) acc[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[w], 0, 0, 0);
+          else acc[w][0] += (float)afr[0] + (float)bfr[0];
+        }
+      } else if constexpr (std::is_same<T, bf16>::value) {
         const int gi = lane >> 4, i16 = lane & 15;
         const int chb = 16 * (gi & 1) + 4 * (i16 & 3);
         const int qa = ks * 16 + 8 * (gi >> 1) + (i16 >> 2);
@@ -634,7 +667,7 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
     float* red = reinterpret_cast<float*>(smem_raw);          // staging buffers are dead now
     const int tile_id = wci + NCI * wco;
 #pragma unroll
-    for (int tap = 0; tap < NTAPS; ++tap) {
+    for (int tap = 0; tap < NACC; ++tap) {
       __syncthreads();
       if (wks > 0) {
 #pragma unroll
@@ -651,12 +684,13 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
   }
   if (wks == 0) {
 #pragma unroll
-    for (int tap = 0; tap < NTAPS; ++tap) {
+    for (int t = 0; t < NACC; ++t) {
+      const int tap = NW > 1 ? 0 : t, w = NW > 1 ? t : 0;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ci = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const int co = co0 + wco * 32 + r;
-        a.ws[((size_t)(sp * NTAPS + tap) * a.kpad + ci) * a.npad + co] = acc[tap][i];
+        const int co = co0 + (wco * NW + w) * 32 + r;
+        a.ws[((size_t)(sp * NTAPS + tap) * a.kpad + ci) * a.npad + co] = acc[t][i];
       }
     }
   }
@@ -784,7 +818,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce16_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ host side
-struct WgradPlan { int tw, nci, nco, nks, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk, pix, db; size_t ws_bytes; };
+struct WgradPlan { int tw, nci, nco, nw, nks, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk, pix, db; size_t ws_bytes; };
 extern int g_opt_wgrad_db;        // api.hip: satcv_set_option("wgrad_db", ...)
 
 static bool wgrad_pix256() {
@@ -808,12 +842,15 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   const bool db_ok = g_opt_wgrad_db != 0 && d->dil == 1 && d->dtype == SATCV_BF16;
   // 1x1 / transposed convolutions: 16 accumulator registers per (ci, co) tile, so the double-buffered kernel's 8 waves cover a
   // 64 x 128 block (each dY tile is re-read by half as many ci blocks: these launches are staging-bound, ~110 us whatever their size)
-  if (p.ntaps == 1) { p.nci = (db_ok && cinx % 64 == 0) ? 2 : 1; p.nco = 4; }
+  // ... and, where the layer has them, a 128 x 256 block with four co tiles per wave (see wgrad_db_kernel)
+  p.nw = 1;
+  if (p.ntaps == 1 && db_ok && cinx % 128 == 0 && nspace % 256 == 0 && g_opt_wgrad_db != 2) { p.nci = 4; p.nco = 2; p.nw = 4; }
+  else if (p.ntaps == 1) { p.nci = (db_ok && cinx % 64 == 0) ? 2 : 1; p.nco = 4; }
   else if (nspace % 128 == 0) { p.nci = 1; p.nco = 4; }
   else if (nspace % 64 == 0) { p.nci = (cinx % 64 == 0) ? 2 : 1; p.nco = 2; }
   else { p.nci = (cinx % 64 == 0) ? 2 : 1; p.nco = 1; }
   p.nks = 4 / (p.nci * p.nco) > 0 ? 4 / (p.nci * p.nco) : 1;                 // 4 waves per workgroup (single-buffered kernel)
-  const int ci_t = 32 * p.nci, co_t = 32 * p.nco;
+  const int ci_t = 32 * p.nci, co_t = 32 * p.nco * p.nw;
   p.n_ci_blk = cdiv(cinx, ci_t); p.n_co_blk = cdiv(nspace, co_t);
   p.kpad = p.n_ci_blk * ci_t; p.npad = p.n_co_blk * co_t;
   // thin layers (a handful of (ci, co) blocks at full resolution) are bound by bytes in flight: stage 256 pixels per step
@@ -822,6 +859,7 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   // (and only the 1 x 1 block form in bf16: every other 256-pixel instantiation spills into scratch, which is ruinous)
   p.pix = (p.ntaps == 9 && p.tw == 32 && p.nci == 1 && p.nco == 1 && d->dtype == SATCV_BF16 && p.n_ci_blk * p.n_co_blk <= 3 && d->h >= 8 && d->w_ >= 256 &&
            d->dil == 1 && wgrad_pix256()) ? 256 : 128;
+  if (p.nw > 1) p.pix = 64;
   const int th = p.pix / p.tw;
   const int tiles_x = cdiv(d->w_, p.tw);
   long long ptiles;
@@ -892,9 +930,9 @@ static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream
   return SATCV_OK;
 }
 
-template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS, int PIX = 128>
+template <typename T, int TW, int NCI, int NCO, int NKS, int NTAPS, int PIX = 128, int NW = 1>
 static int wgrad_db_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy = 0, int sx = 0) {
-  using G = WgradGeom<TW, NCI, NCO, NTAPS, T>;
+  using G = WgradGeom<TW, NCI, NCO * NW, NTAPS, T>;
   constexpr int TH = PIX / TW, NTHREADS = NCI * NCO * NKS * 64, GX = G::CI_T / 8;
   WgradArgs a;
   a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1;
@@ -913,7 +951,7 @@ static int wgrad_db_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStr
   a.n_ci_blk = p.n_ci_blk; a.n_co_blk = p.n_co_blk; a.nsplit = p.nsplit;
   a.total_ptiles = a.ngroups * a.tiles_y * a.tiles_x;
   // register-staged items per thread (same bound as in the kernel)
-  constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+  constexpr int XMAXPIX = NTAPS == 1 ? PIX : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
   constexpr int XI = (XMAXPIX * GX + NTHREADS - 1) / NTHREADS;
   if ((long long)a.rl * a.cl * GX > (long long)XI * NTHREADS) return SATCV_ERR_UNSUPPORTED;
   if (a.rl >= 1024 || a.cl >= 1024 || a.imgs >= 1024) return SATCV_ERR_UNSUPPORTED;
@@ -922,7 +960,7 @@ static int wgrad_db_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStr
   const size_t red = (size_t)NCI * NCO * (NKS > 1 ? NKS - 1 : 0) * 16 * 64 * sizeof(float);
   if (lds < red) lds = red;
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
-  auto kern = wgrad_db_kernel<T, TW, NCI, NCO, NKS, NTAPS, PIX>;
+  auto kern = wgrad_db_kernel<T, TW, NCI, NCO, NKS, NTAPS, PIX, NW>;
   if (lds > 48 * 1024) {
     static size_t have = 0;
     if (lds > have) {
@@ -940,6 +978,7 @@ static int wgrad_db_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStr
 // the double-buffered kernel (bf16): 8 waves = (ci, co) tiles x k-slices
 template <typename T, int TW>
 static int wgrad_db_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy, int sx) {
+  if (p.ntaps == 1 && p.nw == 4) return wgrad_db_launch<T, TW, 4, 2, 1, 1, 64, 4>(d, p, st, sy, sx);
   if (p.ntaps == 1 && p.nci == 2) return wgrad_db_launch<T, TW, 2, 4, 1, 1>(d, p, st, sy, sx);
   if (p.ntaps == 1) return wgrad_db_launch<T, TW, 1, 4, 2, 1>(d, p, st, sy, sx);
   if (p.nci == 1 && p.nco == 4) return wgrad_db_launch<T, TW, 1, 4, 2, 9>(d, p, st);
@@ -958,6 +997,7 @@ static int wgrad_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t 
     if (p.db) {
       const int rc = wgrad_db_cfg<T, TW>(d, p, st, sy, sx);
       if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+      if (p.ntaps == 1 && (p.nci != 1 || p.nw != 1)) { satcv_set_error("wgrad: block plan without a kernel"); return rc; }   // (the plan's slab geometry is the db kernel's)
     }
   }
   if (p.ntaps == 1) return wgrad_launch<T, TW, 1, 4, 1, 1>(d, p, st, sy, sx);

@@ -372,7 +372,8 @@ def test_wgrad_dual_source_with_affine(ops, td, case):
 @pytest.mark.parametrize('td', DT)
 @pytest.mark.parametrize('case', [(2, 8, 8, 64, 32, 2), (1, 16, 16, 128, 64, 2), (2, 4, 4, 256, 128, 2), (1, 6, 6, 32, 32, 3),
                                   (2, 32, 32, 64, 32, 2), (2, 24, 24, 64, 32, 2), (1, 64, 64, 64, 32, 2), (2, 32, 32, 128, 64, 2),
-                                  (2, 8, 8, 1024, 512, 2), (2, 16, 16, 512, 256, 2)])
+                                  (2, 8, 8, 1024, 512, 2), (2, 16, 16, 512, 256, 2),
+                                  (3, 5, 7, 128, 64, 2), (2, 24, 40, 256, 64, 2), (1, 12, 12, 128, 128, 2)])      # ragged maps on the 128 x 256 wgrad block
 def test_conv2d_transpose(ops, td, case):
     n, h, w, cin, cout, f = case
     rng = np.random.default_rng(hash(case) % 2**31)
