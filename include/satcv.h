@@ -118,6 +118,16 @@ typedef struct satcv_conv_desc {
    * pool_ld: layers.MaxPooling2D (utils/model_tools.py:281) of an encoder block in the folded inference graph.  Pipelined kernel
    * only (satcv_conv2d_igemm_pipelined), mode_out 0, h and w_ divisible by pool_f. */
   void* pool_y; int32_t pool_ld, pool_f;
+  /* optional: the REDUCE pass of the BatchNormalization backward (satcv_bn_bwd_reduce, utils/model_tools.py:179-180 differentiated) of
+   * the layer whose activation gradient this launch writes (the launch is a data gradient: y = dL/d act), done in the epilogue while
+   * the tile is on chip.  With bst_y set, `stats` receives  sum g  and  sum g * xhat  in the layout satcv_bn_bwd_finalize reads
+   * (instead of sum / sum of squares), where g = y as stored, zeroed where bst_scale*v + bst_shift <= 0 (unless bst_relu == 0),
+   * xhat = (v - bst_mean) * bst_rstd and v = that layer's raw convolution output at the same pixel and channel: bst_y (channel
+   * stride bst_ld) for channels < bst_split, bst_y1 (stride bst_ld1, channel - bst_split) above it -- bst_y1 NULL: one source.
+   * Pipelined kernel, bf16, plain output mode, no accumulate / out_relu / pool_y, and only when the map is a whole number of the
+   * kernel's tiles: satcv_conv2d_igemm_pipelined() answers 0 otherwise and the caller keeps the separate reduce launch. */
+  const void* bst_y; const void* bst_y1; int32_t bst_ld, bst_ld1, bst_split;
+  const float* bst_scale; const float* bst_shift; const float* bst_mean; const float* bst_rstd; int32_t bst_relu;
 } satcv_conv_desc;
 int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream);
 /* 1 if this descriptor runs on the pipelined kernel (required by out_scale / pool_y / the fp8 dtypes), else 0; no launch. */

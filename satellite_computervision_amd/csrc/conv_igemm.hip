@@ -328,6 +328,14 @@ static int igemm_fill_args(const satcv_conv_desc* d, IgemmArgs& a) {
     a.hs = d->hin; a.ws = d->win;
   }
   a.dbg = 0;
+  a.bst_y = d->bst_y; a.bst_y1 = d->bst_y1; a.bst_ld = d->bst_ld; a.bst_ld1 = d->bst_ld1; a.bst_split = d->bst_y1 ? d->bst_split : 0;
+  a.bst_scale = d->bst_scale; a.bst_shift = d->bst_shift; a.bst_mean = d->bst_mean; a.bst_rstd = d->bst_rstd; a.bst_relu = d->bst_relu;
+  if (d->bst_y) {
+    SATCV_CHECK(d->stats && d->bst_scale && d->bst_shift && d->bst_mean && d->bst_rstd, "igemm: bst_y needs stats and the four BatchNorm vectors");
+    SATCV_CHECK(!d->accumulate && !d->mode_out && !d->out_relu && !d->pool_y && d->cstat == d->cout, "igemm: bst_y needs a plain, non-accumulating store");
+    SATCV_CHECK(d->bst_ld >= (d->bst_y1 ? d->bst_split : d->cout) && (!d->bst_y1 || (d->bst_split > 0 && d->bst_split < d->cout && d->bst_ld1 >= d->cout - d->bst_split)),
+                "igemm: bst_y channel strides");
+  }
   if (a.mode_in == 1) {
     // K = f*f*c0 virtual channels gathered from one source
     SATCV_CHECK(!d->x1, "igemm: s2d with dual source");
@@ -368,7 +376,7 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   }
   if (rc != SATCV_ERR_UNSUPPORTED) { /* launched (or failed hard) */ }
   else if (d->dtype == SATCV_FP8 || d->dtype == SATCV_FP8X) { satcv_set_error("igemm: this fp8 shape is outside the pipelined kernel's limits"); rc = SATCV_ERR_UNSUPPORTED; }
-  else if (d->out_scale || d->pool_y) { satcv_set_error("igemm: out_scale / pool_y need the pipelined kernel"); rc = SATCV_ERR_UNSUPPORTED; }
+  else if (d->out_scale || d->pool_y || d->bst_y) { satcv_set_error("igemm: out_scale / pool_y / bst_y need the pipelined kernel"); rc = SATCV_ERR_UNSUPPORTED; }
   else if (d->dtype == SATCV_BF16) rc = launch_t<bf16>(a, st);
   else if (d->dtype == SATCV_F32) rc = launch_t<float>(a, st);
   else { satcv_set_error("igemm: bad dtype %d", d->dtype); rc = SATCV_ERR_INVALID; }

@@ -496,7 +496,15 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   if (a.mode_out == 0 && a.cout % (16 / (int)sizeof(T)) != 0 && a.cout < a.ldy) { /* tail handled by scalar stores */ }
   const size_t lds_stage = (((size_t)KC * a.rl * a.pitch + (size_t)TAPS * KC * BN) * sizeof(T) + (size_t)(KC / EL) * 128) * (DB ? 2 : 1);      // + slot padding (< 128 B per plane)
   if (DB && (TL || a.mode_in != 0)) return SATCV_ERR_UNSUPPORTED;
-  const size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
+  size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
+  if (a.bst_y) {
+    // fused BatchNorm-backward reduce: only the epilogue's interior-tile path does it, so EVERY tile must be one; a second staging
+    // tile holds the layer's raw outputs
+    if (sizeof(T) != 2 || a.imgs != 1 || a.h % TH != 0 || a.w_ % TW != 0 || a.cout % BN != 0 || a.cout % 8 != 0 || a.bst_ld % 8 != 0 ||
+        ((uintptr_t)a.bst_y % 16) != 0 || (a.bst_y1 && (a.bst_split % 8 != 0 || a.bst_ld1 % 8 != 0 || ((uintptr_t)a.bst_y1 % 16) != 0)))
+      return SATCV_ERR_UNSUPPORTED;
+    lds_out += (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T);
+  }
   const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
   if (dry) return SATCV_OK;

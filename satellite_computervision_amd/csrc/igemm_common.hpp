@@ -23,6 +23,9 @@ struct IgemmArgs {
   int nchunks;
   int halh_tl, halw_tl;            // tap-loop form: offset of tap (0, 0) in source pixels
   int taploop, cpt;                // tap-loop form of a dilated 3x3 conv: K = 9 taps x cpt channel chunks, one shifted tile per tap
+  // BatchNorm-backward reduce pass of the layer whose activation gradient this launch writes (satcv.h: bst_*)
+  const void* bst_y; const void* bst_y1; int bst_ld, bst_ld1, bst_split;
+  const float* bst_scale; const float* bst_shift; const float* bst_mean; const float* bst_rstd; int bst_relu;
   int dbg;                         // ablation bits (env SATCV_DBG): 1 skip stores, 2 skip MFMA, 4 skip A loads, 8 skip B loads
 };
 
@@ -100,6 +103,41 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
   // cycles per 256 x 32 tile (19 % of a thin-layer tile) of which most was mask and address bookkeeping.
   if (FAST && a.imgs == 1 && !a.accumulate && !a.pool_y && !a.out_relu && n0 < a.n && y0 + BM / TW <= a.h && x0 + TW <= a.w_ &&
       nbase + BN <= a.cout && !SKIP_STORES && sizeof(T) == 2 && (a.mode_out == 0 || a.cstat % 8 == 0)) {
+    constexpr int VPR = BN / 8;                   // 16-byte vectors per tile row
+    static_assert(NTHREADS % VPR == 0, "column group of a thread must be loop-invariant");
+    const int vq = tid % VPR;                     // this thread's 16-byte column group (fixed: NTHREADS is a multiple of VPR)
+    // ---- fused BatchNorm-backward reduce (bst_*, satcv.h): this launch writes dL/d act of a conv -> BN -> ReLU layer; the sums that
+    // layer's BN backward needs (sum g, sum g * xhat over the batch) are formed here from the tile in the accumulators and the
+    // layer's raw outputs v at the same pixels, instead of by a separate pass that re-reads both tensors from HBM.  v arrives by
+    // 16-byte row loads (issued first, hidden behind the accumulator -> LDS pass) in a second staging tile.
+    const bool bst = sizeof(T) == 2 && a.bst_y != nullptr;
+    // (the 128 x 128 tile of 4 waves would pay for 8 held row vectors with its third workgroup per CU: it parks them in LDS at once)
+    constexpr bool YHOLD = !(MT * NT >= 4 && NTHREADS <= 256);
+    constexpr int YIT = (BM * VPR + NTHREADS - 1) / NTHREADS;
+    uint4 yv[YIT];
+#pragma unroll
+    for (int j = 0; j < YIT; ++j) yv[j] = make_uint4(0u, 0u, 0u, 0u);
+    T* ldsY = reinterpret_cast<T*>(smem_raw + (size_t)BM * OPITCH * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float));
+    if (bst) {
+      const int cg = nbase + vq * 8;
+      const bool sec = a.bst_y1 != nullptr && cg >= a.bst_split;
+      const size_t yld = sec ? (size_t)a.bst_ld1 : (size_t)a.bst_ld;
+      const T* ys = (sec ? reinterpret_cast<const T*>(a.bst_y1) + (cg - a.bst_split) : reinterpret_cast<const T*>(a.bst_y) + cg) +
+                    ((size_t)(n0 * a.h + y0) * a.w_ + x0) * yld;
+#pragma unroll
+      for (int j = 0; j < YIT; ++j) {
+        const int it = tid + j * NTHREADS;
+        const int q = it < BM * VPR ? it / VPR : 0;
+        yv[j] = *reinterpret_cast<const uint4*>(ys + ((size_t)(q / TW) * a.w_ + q % TW) * yld);
+      }
+      if constexpr (!YHOLD) {
+#pragma unroll
+        for (int j = 0; j < YIT; ++j) {
+          const int it = tid + j * NTHREADS;
+          if (it < BM * VPR) *reinterpret_cast<uint4*>(ldsY + (it / VPR) * OPITCH + vq * 8) = yv[j];
+        }
+      }
+    }
     float st1[NT], st2[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -120,6 +158,38 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         }
       }
       st1[n] = s1; st2[n] = s2;
+    }
+    if (bst) {
+      if constexpr (YHOLD) {
+#pragma unroll
+        for (int j = 0; j < YIT; ++j) {
+          const int it = tid + j * NTHREADS;
+          if (it < BM * VPR) *reinterpret_cast<uint4*>(ldsY + (it / VPR) * OPITCH + vq * 8) = yv[j];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int cl_ = (wn * NT + n) * 32 + r;
+        const int cch = nbase + cl_;
+        const float bv = a.bias ? a.bias[cch] : 0.f;
+        const float osc = a.out_scale ? a.out_scale[cch] : 1.f;
+        const float sc = a.bst_scale[cch], sh = a.bst_shift[cch], mu = a.bst_mean[cch], rs = a.bst_rstd[cch];
+        const bool lin = a.bst_relu == 0;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int q = (wm * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const float fv = (float)(T)(acc[m][n][i] * osc + bv);       // the value as stored (what the apply pass will read)
+            const float v = (float)ldsY[q * OPITCH + cl_];
+            const float gg = (v * sc + sh > 0.f || lin) ? fv : 0.f;
+            s1 += gg; s2 += gg * ((v - mu) * rs);
+          }
+        }
+        st1[n] = s1; st2[n] = s2;
+      }
     }
     if (a.stats) {
 #pragma unroll
@@ -143,9 +213,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         atomicAdd(rowp + a.stats_ld + cch, (satcv_stat_t)t2);
       }
     }
-    constexpr int VPR = BN / 8;                   // 16-byte vectors per tile row
-    static_assert(NTHREADS % VPR == 0, "column group of a thread must be loop-invariant");
-    const int vq = tid % VPR;                     // this thread's 16-byte column group (fixed: NTHREADS is a multiple of VPR)
     T* yp; size_t row_pitch, col_pitch;
     if (a.mode_out == 1) {
       // depth-to-space (transposed conv): the column group belongs to ONE sub-pixel position (iy, ix) of cstat channels

@@ -693,8 +693,40 @@ class Plan:
             sums = self._z(STAT_ROWS, 2, c, dtype=torch.float64)
             return dict(mean=_fp(aff['mean']), rstd=_fp(aff['rstd']), sums=_fp(sums), sums_ld=c), sums
 
+        def bst_target(t):
+            """(bst fields, sums buffer, channels) if the data-gradient launch that writes dL/d t -- t the activated output of a
+            conv -> BN -> ReLU node or of the decoder's BN over [skip, up] -- may also form the sums of that BatchNorm's backward
+            (satcv.h: bst_*): the gradient has this one contributor, so the tile in the accumulators IS the whole gradient."""
+            if not getattr(rt.model, 'fuse_dgrad_bn_bwd', True) or dt != ops.BF16 or t.id in gact or t.id in gpool or len(consumers[t.id]) != 1:
+                return None
+            P, pc = t.node, ctx.get(id(t.node))
+            if P.op == 'cba' and P.attrs.get('bn', True) and P.layer.bn_name not in self.frozen:
+                c, aff, aoff = pc['cout'], pc['aff'], pc['aoff']
+                b = dict(y=pc['y'].data_ptr() + pc['yoff'] * es, ld=pc['ldy'], relu=1 if P.attrs.get('relu', True) else 0)
+            elif P.op == 'concat_bn_relu' and P.layer.name not in self.frozen:
+                ra, rb, aff, ca, cb = pc['ra'], pc['rb'], pc['aff'], pc['ca'], pc['cb']
+                if (P.inputs[1].node.op == 'convT' and BIAS_NOISE) or ca % 8:
+                    return None            # (the two-launch form of that BN backward keeps its own reduce passes)
+                c, aoff = ca + cb, 0
+                b = dict(y=ra.srcs[0][0].data_ptr(), ld=ca, y1=rb.srcs[0][0].data_ptr(), ld1=cb, split=ca, relu=1)
+            else:
+                return None
+            b.update(scale=_fp(aff['scale'], aoff), shift=_fp(aff['shift'], aoff), mean=_fp(aff['mean'], aoff), rstd=_fp(aff['rstd'], aoff))
+            return b, c
+
         def dgrad_step(t, **kw):
-            """data-gradient launch writing the activation gradient of tensor t"""
+            """data-gradient launch writing the activation gradient of tensor t (and, where the kernel can, the sums of the
+            BatchNorm backward of the node that produced t: one pass over two tensors less per such layer)"""
+            bt = None if kw.get('accumulate') else bst_target(t)
+            if bt is not None and bt[1] == kw['cout']:
+                sums = self._z(STAT_ROWS, 2, bt[1], dtype=torch.float64)
+                kw2 = dict(kw, bst=bt[0], stats=_fp(sums), stats_ld=bt[1])
+                probe = ops.make_conv_desc(**kw2)
+                if lib.satcv_conv2d_igemm_pipelined(C.byref(probe)) == 1:
+                    fused[t.id] = sums
+                    fn = self._conv_step(role='dgrad', **kw2)
+                    fn.label += ' +bnred'
+                    return fn
             return self._conv_step(role='dgrad', **kw)
 
         def wgrad_step(r, dy, lddy, lay, cin_real, cout, hh, ww, k, dil, f=0, accum=0):

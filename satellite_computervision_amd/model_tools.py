@@ -732,6 +732,7 @@ class Model:
         self.compute_dtype = dtype or _DEFAULT_DTYPE
         self.bn_bessel = True       # tf.keras (TF 2.x) BatchNormalization on NHWC input runs the fused kernel, whose running variance is the Bessel-corrected batch variance; False = Keras 3 / unfused behaviour
         self.fuse_head_bn_bwd = os.environ.get('SATCV_FUSE_HEAD_BN_BWD', '1') != '0'   # head backward also does the reduce pass of the last BN
+        self.fuse_dgrad_bn_bwd = os.environ.get('SATCV_FUSE_DGRAD_BN_BWD', '1') != '0'  # data-gradient epilogues do the reduce pass of the BN below them
         self.wgrad_side_stream = os.environ.get('SATCV_WGRAD_STREAM', '1') != '0'      # weight gradients on a second HIP stream
         self.sync_bn = os.environ.get('SATCV_SYNC_BN', '0') == '1'      # data parallel: BatchNorm statistics over ALL replicas (parallel.py)
         self._rt = None

@@ -80,7 +80,7 @@ def pack_weights(kernel_f32, cin_pad, dtype, transposed=False, want_dgrad=True, 
 # --------------------------------------------------------------------------- conv
 def make_conv_desc(*, x0, c0, w, y, ldy, n, h, w_, cout, cout_pad, dtype, x1=None, c1=0, in_scale=None, in_shift=None,
                    in_relu=0, bias=None, stats=None, stats_ld=0, kh=3, kw=3, dil=1, mode_in=0, mode_out=0, f=1,
-                   cstat=None, out_relu=0, accumulate=0, stride=1, hin=0, win=0, out_scale=None, pool_y=None, pool_ld=0, pool_f=0):
+                   cstat=None, out_relu=0, accumulate=0, stride=1, hin=0, win=0, out_scale=None, pool_y=None, pool_ld=0, pool_f=0, bst=None):
     d = ConvDesc()
     d.x0, d.x1, d.c0, d.c1 = x0, x1, c0, c1
     d.in_scale, d.in_shift, d.in_relu = in_scale, in_shift, int(in_relu)
@@ -94,6 +94,9 @@ def make_conv_desc(*, x0, c0, w, y, ldy, n, h, w_, cout, cout_pad, dtype, x1=Non
     d.out_relu, d.dtype, d.accumulate = int(out_relu), dtype, int(accumulate)
     d.stride, d.hin, d.win, d.out_scale = stride, hin, win, out_scale
     d.pool_y, d.pool_ld, d.pool_f = pool_y, pool_ld, pool_f
+    if bst:       # fused BatchNorm-backward reduce of the layer whose activation gradient this launch writes (satcv.h: bst_*)
+        d.bst_y, d.bst_ld, d.bst_y1, d.bst_ld1, d.bst_split = bst['y'], bst['ld'], bst.get('y1'), bst.get('ld1', 0), bst.get('split', 0)
+        d.bst_scale, d.bst_shift, d.bst_mean, d.bst_rstd, d.bst_relu = bst['scale'], bst['shift'], bst['mean'], bst['rstd'], int(bst.get('relu', 1))
     return d
 
 
@@ -102,7 +105,7 @@ def _p(t):
 
 
 def conv2d(x, w_packed, cout, *, kh=3, kw=3, dil=1, bias=None, x1=None, in_scale=None, in_shift=None, in_relu=False,
-           stats=None, out=None, out_relu=False, stride=1):
+           stats=None, out=None, out_relu=False, stride=1, bst=None):
     """layers.Conv2D(cout,(kh,kw),padding='same',dilation_rate=dil) (utils/model_tools.py:178) on
     NHWC storage tensors; optional fused input BatchNorm-affine+ReLU and output sum/sumsq.  stride > 1 (ResNet backbone of the
     build-defined DeepLab): symmetric padding dil*(k-1)/2, output (h-1)//stride+1."""
@@ -115,7 +118,10 @@ def conv2d(x, w_packed, cout, *, kh=3, kw=3, dil=1, bias=None, x1=None, in_scale
     d = make_conv_desc(x0=_p(x), c0=c0, x1=_p(x1), c1=c1, w=_p(w_packed), y=_p(y), ldy=y.shape[-1], n=n, h=h, w_=w_,
                        cout=cout, cout_pad=cpad, dtype=dtype, in_scale=_p(in_scale), in_shift=_p(in_shift),
                        in_relu=in_relu, bias=_p(bias), stats=_p(stats), stats_ld=stats.shape[-1] if stats is not None else 0,
-                       kh=kh, kw=kw, dil=dil, out_relu=out_relu, stride=stride, hin=hin if stride > 1 else 0, win=win if stride > 1 else 0)
+                       kh=kh, kw=kw, dil=dil, out_relu=out_relu, stride=stride, hin=hin if stride > 1 else 0, win=win if stride > 1 else 0,
+                       bst={k: (_p(v) if torch.is_tensor(v) else v) for k, v in bst.items()} if bst else None)
+    if bst and lib.satcv_conv2d_igemm_pipelined(C.byref(d)) != 1:
+        raise ValueError('conv2d: this shape cannot carry the fused BatchNorm-backward reduce (bst); run satcv_bn_bwd_reduce separately')
     check(lib.satcv_conv2d_igemm(C.byref(d), stream_ptr()))
     return y
 

@@ -474,6 +474,64 @@ def test_bn_backward_of_a_concatenation_in_one_pass(ops, td, case):
     close(back(dbeta), db_ref, td, 'concat dbeta', k=4.0)
 
 
+@pytest.mark.parametrize('case', [
+    (2, 32, 32, 32, 32, 0, 3),       # thin 256 x 32 tile
+    (2, 32, 64, 64, 64, 0, 3),       # 128 x 64
+    (1, 32, 32, 128, 128, 0, 3),     # 128 x 128 tile (row vectors parked in LDS at once)
+    (2, 16, 16, 256, 128, 0, 3),     # TW = 16
+    (4, 16, 16, 512, 512, 0, 3),     # double-buffered 256 x 128 tile
+    (2, 32, 32, 32, 64, 32, 3),      # gradient of a decoder concatenation: raw outputs in two tensors
+    (2, 16, 16, 128, 128, 64, 3),
+    (2, 32, 32, 64, 64, 0, 1),       # 1 x 1
+])
+def test_data_gradient_with_fused_bn_backward_sums(ops, case):
+    """The data gradient of a conv whose input is ReLU(BN(v)) writes dL/d act; its epilogue also forms sum g and sum g * xhat of that
+    BatchNorm's backward (include/satcv.h: bst_*; utils/model_tools.py:178-180 differentiated).  Checked against float64 sums of the
+    STORED gradient, and against the separate reduce launch it replaces."""
+    n, h, w, cin, cout, split, k = case
+    td = torch.bfloat16
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (k, k, cin, cout), td, 0.2)
+    v = rnd(rng, (n, h, w, cout), td) * 1.5 + 0.25
+    v = torch.tensor(v, dtype=torch.float32).to(td).double().numpy()
+    sc, sh = rng.standard_normal(cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32) * 0.5
+    mu, rs = rng.standard_normal(cout).astype(np.float32) * 0.3, (0.5 + rng.random(cout)).astype(np.float32)
+    wf, _ = ops.pack_weights(f32dev(kern), cin, ops.DTYPE_CODE[td])
+    v0 = to_dev(v[..., :split] if split else v, td)
+    v1 = to_dev(v[..., split:], td) if split else None
+    for relu in (1, 0):
+        stats = ops.new_stats(cout, dev())
+        bst = dict(y=v0, ld=v0.shape[-1], scale=f32dev(sc), shift=f32dev(sh), mean=f32dev(mu), rstd=f32dev(rs), relu=relu)
+        if split:
+            bst.update(y1=v1, ld1=v1.shape[-1], split=split)
+        y = ops.conv2d(to_dev(x, td), wf, cout, kh=k, kw=k, stats=stats, bst=bst)
+        plain = ops.conv2d(to_dev(x, td), wf, cout, kh=k, kw=k)
+        assert torch.equal(y, plain), 'the fused sums must not change the stored gradient'
+        g = back(y, cout)
+        mask = (v * sc.astype(np.float64) + sh.astype(np.float64) > 0) if relu else np.ones_like(v, bool)
+        gg = np.where(mask, g, 0.0)
+        xh = (v - mu.astype(np.float64)) * rs.astype(np.float64)
+        s1_ref, s2_ref = gg.sum((0, 1, 2)), (gg * xh).sum((0, 1, 2))
+        got = stats.sum(0).double().cpu().numpy()
+        tol = 2e-4 * np.sqrt(n * h * w) * max(1.0, float(np.abs(g).max()))
+        np.testing.assert_allclose(got[0], s1_ref, rtol=1e-4, atol=tol, err_msg=f'sum g {case} relu={relu}')
+        np.testing.assert_allclose(got[1], s2_ref, rtol=1e-4, atol=tol * float(np.abs(xh).max()), err_msg=f'sum g xhat {case} relu={relu}')
+
+
+def test_fused_bn_backward_sums_are_refused_on_partial_tiles(ops):
+    """a map that is not a whole number of tiles keeps the separate reduce launch: the query says so and conv2d raises"""
+    td = torch.bfloat16
+    rng = np.random.default_rng(3)
+    n, h, w, c = 1, 12, 20, 32
+    wf, _ = ops.pack_weights(f32dev(rnd(rng, (3, 3, c, c), td, 0.2)), c, ops.DTYPE_CODE[td])
+    v = to_dev(rnd(rng, (n, h, w, c), td), td)
+    one = torch.ones(c, device=dev())
+    with pytest.raises(ValueError):
+        ops.conv2d(to_dev(rnd(rng, (n, h, w, c), td), td), wf, c, stats=ops.new_stats(c, dev()),
+                   bst=dict(y=v, ld=c, scale=one, shift=one, mean=one, rstd=one, relu=1))
+
+
 # ------------------------------------------------------------------- head and losses
 @pytest.mark.parametrize('td', DT)
 @pytest.mark.parametrize('ncls,activation', [(2, 'softmax'), (5, 'softmax'), (1, 'sigmoid')])
