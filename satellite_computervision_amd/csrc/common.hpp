@@ -140,19 +140,28 @@ __device__ __forceinline__ Raw8<T> zero8() {
   }
   return r;
 }
+// bf16 item: y = x * sc + sh in fp32, rounded to bf16, then the ReLU as a signed 16-bit maximum on the packed pairs (a negative float
+// is a negative integer, -0 becomes +0): lim = 0 clamps, lim = 0x80008000 passes everything.  One v_pk_max_i16 per channel pair instead
+// of a v_max_f32 AND a v_cndmask on the runtime relu flag per channel (the loaders of the thin layers are VALU-bound).
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu_pk_bf16(unsigned w, unsigned lim) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2v, w), __builtin_bit_cast(short2v, lim)));
+}
+__device__ __forceinline__ Raw8<bf16> affine8_lim(const Raw8<bf16>& r, const float* sc, const float* sh, unsigned lim) {
+  bf16x8 v = __builtin_bit_cast(bf16x8, r.q[0]);
+  bf16x8 w;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) w[e] = (bf16)((float)v[e] * sc[e] + sh[e]);
+  uint4 u = __builtin_bit_cast(uint4, w);
+  Raw8<bf16> o;
+  o.q[0] = make_uint4(relu_pk_bf16(u.x, lim), relu_pk_bf16(u.y, lim), relu_pk_bf16(u.z, lim), relu_pk_bf16(u.w, lim));
+  return o;
+}
 template <typename T>
 __device__ __forceinline__ Raw8<T> affine8(const Raw8<T>& r, const float* sc, const float* sh, int relu) {
   Raw8<T> o;
   if constexpr (std::is_same<T, bf16>::value) {
-    bf16x8 v = __builtin_bit_cast(bf16x8, r.q[0]);
-    bf16x8 w;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t = (float)v[e] * sc[e] + sh[e];
-      t = relu ? fmaxf(t, 0.f) : t;
-      w[e] = (bf16)t;
-    }
-    o.q[0] = __builtin_bit_cast(uint4, w);
+    o = affine8_lim(r, sc, sh, relu ? 0u : 0x80008000u);
   } else if constexpr (std::is_same<T, fp8>::value) {
     const fp8* f = reinterpret_cast<const fp8*>(&r.q);
     fp8* g = reinterpret_cast<fp8*>(&o.q);
@@ -188,15 +197,7 @@ __device__ __forceinline__ Raw8<T> affine8r(const Raw8<T>& r, const float4 (&rs)
   const float sh[8] = {rs[2].x, rs[2].y, rs[2].z, rs[2].w, rs[3].x, rs[3].y, rs[3].z, rs[3].w};
   Raw8<T> o;
   if constexpr (std::is_same<T, bf16>::value) {
-    bf16x8 v = __builtin_bit_cast(bf16x8, r.q[0]);
-    bf16x8 w;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t = (float)v[e] * sc[e] + sh[e];
-      t = relu ? fmaxf(t, 0.f) : t;
-      w[e] = (bf16)t;
-    }
-    o.q[0] = __builtin_bit_cast(uint4, w);
+    o = affine8_lim(r, sc, sh, relu ? 0u : 0x80008000u);
   } else if constexpr (std::is_same<T, fp8>::value) {
     const fp8* f = reinterpret_cast<const fp8*>(&r.q);
     fp8* g = reinterpret_cast<fp8*>(&o.q);

@@ -443,7 +443,8 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
   // ---- per-thread, tile-invariant description of the staged items
   const int x_items = a.rl * a.cl * GX;
   constexpr int d_items = BMPIX * GD;
-  constexpr int XMAXPIX = NTAPS == 1 ? BMPIX : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);      // (no halo without taps)
+  // (no halo without taps; the 256-pixel tile is only planned for maps of at least its height: one image, one halo)
+  constexpr int XMAXPIX = NTAPS == 1 ? BMPIX : (PIX == 256 ? (TH + 2) * (TW + 2) : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2));
   constexpr int XI = (XMAXPIX * GX + NTHREADS - 1) / NTHREADS;
   constexpr int DI = (d_items + NTHREADS - 1) / NTHREADS;
   constexpr int NU = XI + DI;
@@ -460,8 +461,17 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
     const int g = tid / 16, e = tid % 16, ch = ci0 + g * 8 + (e & 7);
     ldsS[tid] = ch < a.cin_lim ? (e < 8 ? a.in_scale[ch] : a.in_shift[ch]) : (e < 8 ? 1.f : 0.f);
   }
-  const bool relu = a.in_relu != 0;
-  int x_dst[XI], x_rel[XI];
+  // ReLU as a lower bound on the packed bf16 pair (signed 16-bit max: negative floats are negative integers): 0, or the most negative
+  // value when the layer has no activation -- one packed instruction per channel pair, no per-element select on the runtime flag
+  const unsigned relu_lim = a.in_relu != 0 ? 0u : 0x80008000u;
+  const float relu_lo = a.in_relu != 0 ? 0.f : -INFINITY;
+  // The staged items of a thread are tile-invariant up to the tile's base pixel: element offset from that pixel, LDS destination
+  // (base + a compile-time multiple: NTHREADS is a multiple of the channel groups) and the halo coordinates packed for the per-tile
+  // validity test.  The tile loop was VALU-bound on exactly this bookkeeping (337 vector instructions per 18 MFMAs on the thin
+  // layers, a third of them in per-item (n, y, x) -> address arithmetic with quarter-rate 64-bit multiplies).
+  constexpr int XSTEP = (NTHREADS / GX) * XP, DSTEP = (NTHREADS / GD) * DP;
+  const int x_dst0 = (tid / GX) * XP + gx * 8;
+  int x_rel[XI], x_eoff[XI];
 #pragma unroll
   for (int j = 0; j < XI; ++j) {
     const int it = tid + j * NTHREADS;
@@ -469,52 +479,61 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
     const int c = pix % a.cl, L = pix / a.cl;
     const int k = L / a.seg;
     const int yy = L - k * a.seg - a.halh;
-    x_dst[j] = it < x_items ? pix * XP + gx * 8 : -1;
-    x_rel[j] = (k << 20) | ((yy + 64) << 10) | c;
+    // bit 30: the item exists and its channels do; k | yy + 64 | c as before
+    x_rel[j] = ((it < x_items && chv) ? (1 << 30) : 0) | (k << 20) | ((yy + 64) << 10) | c;
+    x_eoff[j] = ((k * a.h + yy + a.sy) * a.w_ + (c - a.halw + a.sx)) * xcs;
   }
   const int gd = tid % GD, cv = co0 + gd * 8;
   const bool cvv = cv < a.n_lim;
-  const T* dyp = reinterpret_cast<const T*>(a.dy);
-  int d_ij = 0, d_o = cv;
-  if (a.mode_dy == 1) { d_ij = cv / a.cout_t; d_o = cv - d_ij * a.cout_t; }
+  int d_ij = 0, d_o = cvv ? cv : 0;
+  if (a.mode_dy == 1 && cvv) { d_ij = cv / a.cout_t; d_o = cv - d_ij * a.cout_t; }
   const int d_iy = a.mode_dy == 1 ? d_ij / a.f : 0, d_ix = a.mode_dy == 1 ? d_ij % a.f : 0;
   const int dfm = a.mode_dy == 1 ? a.f : 1;
-  int d_dst[DI], d_rel[DI];
+  // dY: pixel (n, y, x) of the tile grid sits at ((n h + y) dfm + d_iy) (w dfm) + x dfm + d_ix of the stored gradient
+  const T* dyp = reinterpret_cast<const T*>(a.dy) + ((size_t)d_iy * (a.w_ * dfm) + d_ix) * a.lddy + d_o;
+  const int d_dst0 = (tid / GD) * DP + gd * 8;
+  int d_rel[DI], d_eoff[DI];
 #pragma unroll
   for (int j = 0; j < DI; ++j) {
     const int it = tid + j * NTHREADS;
     const int q = it / GD;
     const int t = q / TW, cx = q % TW;
     const int k = (a.imgs == 1) ? 0 : t / a.rpi;
-    d_dst[j] = it < d_items ? q * DP + gd * 8 : -1;
-    d_rel[j] = ((it < d_items && k < a.imgs && cvv) ? (1 << 30) : 0) | (k << 20) | ((t - k * a.rpi) << 10) | cx;
+    const int row = t - k * a.rpi;
+    d_rel[j] = ((it < d_items && k < a.imgs && cvv) ? (1 << 30) : 0) | (k << 20) | (row << 10) | cx;
+    d_eoff[j] = (((k * a.h + row) * dfm) * (a.w_ * dfm) + cx * dfm) * a.lddy;
   }
 
   Raw8<T> xr[XI], dr[DI];
   unsigned xmask = 0, dmask = 0;
-  int n0 = 0, y0 = 0, x0 = 0;                        // origin of the tile whose loads are being issued
+  // per tile (wave-uniform): limits of the halo coordinates that fall inside the image, base element offsets of the two tensors
+  int klim = 0, ylo = 0, yhi = 0, clo = 0, chi = 0, rhi = 0, xhi = 0;
+  size_t xbase = 0, dbase = 0;
   auto tile_origin = [&](int pt) {
     int m = pt;
     const int tx = m % a.tiles_x; m /= a.tiles_x;
     const int ty = m % a.tiles_y;
-    n0 = (m / a.tiles_y) * a.imgs; y0 = ty * TH; x0 = tx * TW;
+    const int n0 = (m / a.tiles_y) * a.imgs, y0 = ty * TH, x0 = tx * TW;
+    klim = a.n - n0;
+    ylo = 64 - (y0 + a.sy); yhi = 64 + a.h - (y0 + a.sy);                 // on the stored yy + 64
+    clo = a.halw - a.sx - x0; chi = a.w_ + a.halw - a.sx - x0;
+    rhi = a.h - y0; xhi = a.w_ - x0;
+    const size_t bp = ((size_t)n0 * a.h + y0) * a.w_ + x0;
+    xbase = bp * xcs;
+    dbase = (((size_t)n0 * a.h + y0) * dfm * (a.w_ * dfm) + (size_t)x0 * dfm) * a.lddy;
   };
   auto load_x = [&](int j) {
-    const int c = x_rel[j] & 1023, yy = ((x_rel[j] >> 10) & 1023) - 64, k = x_rel[j] >> 20;
-    const int n = n0 + k, y = y0 + yy + a.sy, x = x0 + c - a.halw + a.sx;
-    const bool ok = (x_dst[j] >= 0) && chv && (n < a.n) && (y >= 0) && (y < a.h) && (x >= 0) && (x < a.w_);
-    const int p = ok ? (n * a.h + y) * a.w_ + x : 0;
+    const int c = x_rel[j] & 1023, yy = (x_rel[j] >> 10) & 1023, k = (x_rel[j] >> 20) & 1023;
+    const bool ok = (x_rel[j] >> 30) && (k < klim) && (yy >= ylo) && (yy < yhi) && (c >= clo) && (c < chi);
     xmask = (xmask & ~(1u << j)) | ((ok ? 1u : 0u) << j);
-    if (!WABL(1)) xr[j] = gload8<T>(xsrc + (size_t)p * xcs);
+    if (!WABL(1)) xr[j] = gload8<T>(xsrc + xbase + (ok ? x_eoff[j] : 0));
     else xr[j] = zero8<T>();
   };
   auto load_d = [&](int j) {
     const int cx = d_rel[j] & 1023, row = (d_rel[j] >> 10) & 1023, k = (d_rel[j] >> 20) & 1023;
-    const int n = n0 + k, y = y0 + row, x = x0 + cx;
-    const bool ok = (d_rel[j] >> 30) && (n < a.n) && (y < a.h) && (x < a.w_);
-    const size_t off = ok ? ((size_t)((n * a.h + y) * dfm + d_iy) * (a.w_ * dfm) + x * dfm + d_ix) * a.lddy + d_o : 0;
+    const bool ok = (d_rel[j] >> 30) && (k < klim) && (row < rhi) && (cx < xhi);
     dmask = (dmask & ~(1u << j)) | ((ok ? 1u : 0u) << j);
-    if (!WABL(1)) dr[j] = gload8<T>(dyp + off);
+    if (!WABL(1)) dr[j] = gload8<T>(dyp + dbase + (ok ? d_eoff[j] : 0));
     else dr[j] = zero8<T>();
   };
   auto store_x = [&](int j, T* ldsX) {
@@ -528,25 +547,21 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
         sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
       }
       if constexpr (std::is_same<T, bf16>::value) {
-        bf16x8 b = __builtin_bit_cast(bf16x8, v.q[0]);
-        bf16x8 w;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { float g = (float)b[e] * sc[e] + sh[e]; g = relu ? fmaxf(g, 0.f) : g; w[e] = (bf16)g; }
-        v.q[0] = __builtin_bit_cast(uint4, w);
+        v = affine8_lim(v, sc, sh, relu_lim);
       } else {
         float* f = reinterpret_cast<float*>(&v.q[0]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { float g = f[e] * sc[e] + sh[e]; f[e] = relu ? fmaxf(g, 0.f) : g; }
+        for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e] * sc[e] + sh[e], relu_lo);
       }
     }
     v = select8<T>((xmask >> j) & 1u, v);
     if (WABL(8)) { keep8<T>(v); return; }
-    if (x_dst[j] >= 0) lstore8<T>(ldsX + x_dst[j], v);
+    if (tid + j * NTHREADS < x_items) lstore8<T>(ldsX + x_dst0 + j * XSTEP, v);
   };
   auto store_d = [&](int j, T* ldsD) {
     const Raw8<T> v = select8<T>((dmask >> j) & 1u, dr[j]);
     if (WABL(8)) { keep8<T>(v); return; }
-    if (d_dst[j] >= 0) lstore8<T>(ldsD + d_dst[j], v);
+    if (tid + j * NTHREADS < d_items) lstore8<T>(ldsD + d_dst0 + j * DSTEP, v);
   };
 
   // ---- the tiles of this workgroup: sp, sp + nsplit, ...
@@ -634,7 +649,7 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
         for (int tap = 0; tap < NTAPS; ++tap) {
           if (tap + 1 < NTAPS) {
             const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
-            const int toff = ((ky * a.dil) * a.cl + kx * a.dil) * XP;
+            const int toff = (ky * (TW + 2) + kx) * XP;      // dilation 1 (the only plan of this kernel): cl = TW + 2, an instruction immediate
             alo[(tap + 1) & 1] = tr_read(ldsX + xoa + toff);
             ahi[(tap + 1) & 1] = tr_read(ldsX + xob + toff);
           }
@@ -951,10 +966,11 @@ static int wgrad_db_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStr
   a.n_ci_blk = p.n_ci_blk; a.n_co_blk = p.n_co_blk; a.nsplit = p.nsplit;
   a.total_ptiles = a.ngroups * a.tiles_y * a.tiles_x;
   // register-staged items per thread (same bound as in the kernel)
-  constexpr int XMAXPIX = NTAPS == 1 ? PIX : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+  constexpr int XMAXPIX = NTAPS == 1 ? PIX : (PIX == 256 ? (TH + 2) * (TW + 2) : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2));
   constexpr int XI = (XMAXPIX * GX + NTHREADS - 1) / NTHREADS;
   if ((long long)a.rl * a.cl * GX > (long long)XI * NTHREADS) return SATCV_ERR_UNSUPPORTED;
   if (a.rl >= 1024 || a.cl >= 1024 || a.imgs >= 1024) return SATCV_ERR_UNSUPPORTED;
+  if (NTAPS == 9 && (a.dil != 1 || a.cl != TW + 2)) return SATCV_ERR_UNSUPPORTED;       // the kernel's tap offsets are compile-time
   const size_t stage = (((size_t)a.rl * a.cl * G::XP + (size_t)PIX * G::DP) + 7) / 8 * 8;
   size_t lds = 2 * stage * sizeof(T) + (size_t)PIX * sizeof(int) + (size_t)GX * 16 * sizeof(float);
   const size_t red = (size_t)NCI * NCO * (NKS > 1 ? NKS - 1 : 0) * 16 * 64 * sizeof(float);
