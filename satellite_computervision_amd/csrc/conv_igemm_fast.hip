@@ -314,12 +314,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
     // waves 4-7 half a chunk later de-phases them (MI355X_MICROARCH.md, two waves per SIMD, item 9)
     // (rot is a wave-uniform run-time value: the tap offsets of a staggered wave are scalar additions instead of instruction immediates;
     //  two compile-time copies of the loop cost 200 bytes of scratch per lane)
-    auto compute_chunk = [&](int boff, auto&& side, int rot) {
+    auto compute_chunk = [&](int boff, auto&& side) {
       constexpr int STEPS = TAPS * KS;
       FragT<T> af[2][MT], bf[2][NT];
       auto read_step = [&](int st_, int buf) {
-        int st = st_;
-        if constexpr (DB) { st += rot; st -= st >= STEPS ? STEPS : 0; }
+        // (compile-time step -> tap: the offsets below are instruction immediates.  A runtime rotation of the tap order for half of the
+        //  waves -- tried against the issue imbalance between the older and the younger waves -- put 2-3 address instructions in front of
+        //  every fragment read, ~150 per chunk, for no gain)
+        const int st = st_;
         const int tap = st / KS, ks = st % KS;
         const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap % 3;
         const int tap_off = (ky * dil * pitch + kx * dil) * EL;
@@ -357,7 +359,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
       // units of one chunk's staging in program order: A items (store c+1, then re-issue for c+2), the scale / shift values (needed by
       // the A stores above, so re-issued after them), weight items; unit u runs in tap step u (the surplus in the last step)
       constexpr int NUNITS = AI + 1 + BI, STEPS_ = TAPS * KS;
-      const int rot = ((a.dbg & 1) && __builtin_amdgcn_readfirstlane(wave) >= NTHREADS / 128) ? (STEPS_ + 1) / 2 : 0;      // the younger half of the waves
       for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         const int cur = (chunk & 1) * stage_elems, oth = stage_elems - cur;
         const bool do_store = chunk + 1 < a.nchunks, do_load = chunk + 2 < a.nchunks;
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
             else { if (do_store) store_b(oth, u - AI - 1); load_b(cs_, u - AI - 1); }
           }
         };
-        compute_chunk(cur, side, rot);
+        compute_chunk(cur, side);
 #ifdef SATCV_STAMP
         STAMP(t3);
 #endif
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #ifdef SATCV_STAMP
       STAMP(t1);
 #endif
-      compute_chunk(0, [](int) {}, 0);
+      compute_chunk(0, [](int) {});
 #ifdef SATCV_STAMP
       STAMP(t2);
 #endif
@@ -545,7 +546,7 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   if constexpr (TAPS == 9 && std::is_same<T, bf16>::value) {
     // deep 3x3 layers: 256-pixel x 128-channel tile, 8 waves, double-buffered stages (SATCV_DB=0 keeps the 128 x 128 tile)
     const int db_mode = g_opt_igemm_db;
-    a.dbg = g_opt_igemm_sched;            // bit 0: staggered tap order for waves 4-7 of the double-buffered tile
+    a.dbg = g_opt_igemm_sched;            // (experiment bits; none wired at present)
     if (db_mode && a.dil == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && nspace % 128 == 0 && cin >= 64) {
       const long long tiles256 = (long long)cdiv(a.n * a.h * a.w_, 256) * (nspace / 128);
       // (a 512-pixel x 128-channel tile -- wave tile 64 x 128, 128 accumulator registers -- needs ~300 bytes of scratch per lane at the
