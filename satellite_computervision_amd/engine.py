@@ -71,6 +71,7 @@ BIAS_NOISE = os.environ.get('SATCV_BN_BIAS_NOISE', '0') == '1'
 # weight-gradient launches (second stream) enqueued AFTER the data gradient of their layer instead of before it: they then start beside the
 # HBM-bound BatchNorm-backward kernels of the next layer rather than beside their own layer's MFMA-bound data gradient
 WGRAD_LATE = os.environ.get('SATCV_WGRAD_LATE', '0') == '1'
+FUSE_DGRAD_ALL = os.environ.get('SATCV_FUSE_DGRAD_BN_BWD', '1') == '2'      # 2: every eligible data gradient carries the BN-backward sums
 
 
 def rup(a, b):
@@ -718,7 +719,13 @@ class Plan:
             """data-gradient launch writing the activation gradient of tensor t (and, where the kernel can, the sums of the
             BatchNorm backward of the node that produced t: one pass over two tensors less per such layer)"""
             bt = None if kw.get('accumulate') else bst_target(t)
-            if bt is not None and bt[1] == kw['cout']:
+            # where it pays (measured per layer of the five-level U-Net, batch 64; DESIGN.md §3): the extra tile read hides under a
+            # K loop of >= 1152 (3x3 x 128 channels) and under the 1x1 kernels; a thin 3x3 whose output -- the gradient of a decoder
+            # concatenation -- is at least twice as wide as its input replaces a pass over twice its own input.  The thin and middle
+            # layers in between are HBM-bound themselves: there the read costs the conv what the separate pass had cost.
+            kdepth = kw.get('kh', 1) * kw.get('kw', 1) * (kw.get('c0', 0) + (kw.get('c1', 0) or 0))
+            pays = FUSE_DGRAD_ALL or kdepth >= 1152 or kw.get('kh', 1) == 1 or (kw['cout'] >= 2 * kw.get('c0', 0) and kdepth <= 288)
+            if bt is not None and bt[1] == kw['cout'] and pays:
                 sums = self._z(STAT_ROWS, 2, bt[1], dtype=torch.float64)
                 kw2 = dict(kw, bst=bt[0], stats=_fp(sums), stats_ld=bt[1])
                 probe = ops.make_conv_desc(**kw2)
