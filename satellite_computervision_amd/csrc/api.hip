@@ -114,7 +114,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 int g_opt_igemm_db = env_int("SATCV_DB", 1);
 int g_opt_wgrad_db = env_int("SATCV_WGRAD_DB", 1);
 int g_opt_igemm_sched = env_int("SATCV_IGEMM_SCHED", 0);
-int g_opt_igemm_thin = env_int("SATCV_THIN", 0);      // measured equal to the general kernel (round 2): opt-in
+int g_opt_igemm_thin = env_int("SATCV_THIN", 1);      // 0 off, 1 where the launch fills the chip (>= 2048 tiles), 2 always (tests)
 static int* opt_slot(const char* key) {
   if (!key) return nullptr;
   if (!strcmp(key, "igemm_db")) return &g_opt_igemm_db;
@@ -129,7 +129,9 @@ extern "C" int satcv_set_option(const char* key, int32_t value) {
   *p = value;
   return SATCV_OK;
 }
+extern int g_ws_launches;          // conv_igemm_ws.hip
 extern "C" int satcv_get_option(const char* key, int32_t* value) {
+  if (key && value && !strcmp(key, "igemm_thin_launches")) { *value = g_ws_launches; return SATCV_OK; }
   int* p = opt_slot(key);
   SATCV_CHECK(p && value, "get_option: unknown key '%s'", key ? key : "(null)");
   *value = *p;

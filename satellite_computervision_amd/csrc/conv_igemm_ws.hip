@@ -16,6 +16,7 @@
 #include "igemm_common.hpp"
 #include <cstdlib>
 extern int g_opt_igemm_thin;      // api.hip: satcv_set_option("igemm_thin", ...)
+int g_ws_launches = 0;            // launches served by this kernel (satcv_get_option("igemm_thin_launches"): tests check the path taken)
 
 #ifndef SATCV_ABLATE
 #define SATCV_ABLATE 0
@@ -68,15 +69,19 @@ __global__ __launch_bounds__(256, WPS) void igemm_ws_kernel(const IgemmArgs a, c
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sc[e] = a.in_scale ? a.in_scale[ch0 + e] : 1.f; sh[e] = a.in_scale ? a.in_shift[ch0 + e] : 0.f; }
   const bool aff = a.in_scale != nullptr;
-  const bool relu = a.in_relu != 0;
+  const unsigned relu_lim = a.in_relu != 0 ? 0u : 0x80008000u;            // ReLU as a packed 16-bit max (common.hpp: affine8_lim)
 
-  int a_l[AI], a_yx[AI];
+  // per staged item, tile-invariant: LDS destination, halo coordinates relative to the tile origin, element offset from the tile's
+  // base pixel (the per-tile cost of an item is four compares against wave-uniform limits, a select and one 64-bit add: the
+  // (n, y, x) -> address arithmetic with its quarter-rate multiplies was a third of the vector instructions of the tile loop)
+  int a_l[AI], a_yx[AI], a_eoff[AI];
 #pragma unroll
   for (int j = 0; j < AI; ++j) {
     const int it = tid + j * NTHREADS;
     const int pix = it / SLOTS, c = pix % CL, L = pix / CL;
     a_l[j] = it < A_ITEMS ? slot_t * SLOT_STRIDE + (L * PITCH + c) * EL : -1;
-    a_yx[j] = ((L - 1) << 16) | ((c - 1) & 0xffff);                         // halo coordinates relative to the tile origin
+    a_yx[j] = ((L - 1) << 16) | ((c - 1) & 0xffff);
+    a_eoff[j] = ((L - 1) * a.w_ + (c - 1)) * cs;
   }
   int a_off[MT];
 #pragma unroll
@@ -90,17 +95,22 @@ __global__ __launch_bounds__(256, WPS) void igemm_ws_kernel(const IgemmArgs a, c
     const int ty = v % a.tiles_y;
     n0 = v / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
   };
+  auto next_origin = [&](int& n0, int& y0, int& x0) {                       // the tiles of a workgroup are consecutive: no division per tile
+    x0 += TW;
+    if (x0 >= a.w_) { x0 = 0; y0 += TH; if (y0 >= a.h) { y0 = 0; ++n0; } }
+  };
   Raw8<T> ra[AI];
   unsigned valid = 0;                                                       // bit j: item j lies inside the image (else zero padding)
   auto issue_loads = [&](int n0, int y0, int x0) -> unsigned {
     unsigned vm = 0;
+    const int ylo = -y0, yhi = a.h - y0, xlo = -x0, xhi = a.w_ - x0;        // wave-uniform limits of the halo coordinates
+    const T* base = src + ((size_t)(n0 * a.h + y0) * a.w_ + x0) * cs;
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
-      const int y = y0 + (a_yx[j] >> 16), x = x0 + (int)(short)(a_yx[j] & 0xffff);
-      const bool ok = a_l[j] >= 0 && y >= 0 && y < a.h && x >= 0 && x < a.w_;
-      const int p = ok ? (n0 * a.h + y) * a.w_ + x : 0;                     // (items outside load pixel 0 and are zeroed below: no branch
-      vm |= (ok ? 1u : 0u) << j;                                            //  around a vector-memory instruction in the loop)
-      if (!WABL(4)) ra[j] = gload8<T>(src + (size_t)p * cs);
+      const int dy = a_yx[j] >> 16, dx = (int)(short)(a_yx[j] & 0xffff);
+      const bool ok = a_l[j] >= 0 && dy >= ylo && dy < yhi && dx >= xlo && dx < xhi;
+      vm |= (ok ? 1u : 0u) << j;                                            // (items outside load the base pixel and are zeroed below: no
+      if (!WABL(4)) ra[j] = gload8<T>(base + (ok ? a_eoff[j] : 0));          //  branch around a vector-memory instruction in the loop)
       else ra[j] = zero8<T>();
     }
     return vm;
@@ -132,19 +142,10 @@ __global__ __launch_bounds__(256, WPS) void igemm_ws_kernel(const IgemmArgs a, c
     // ---- registers -> LDS (BatchNorm affine + ReLU of the producing layer, zero padding AFTER it)
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
-      bf16x8 v = __builtin_bit_cast(bf16x8, ra[j].q[0]);
-      bf16x8 w;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float f = (float)v[e];
-        float g = f * sc[e] + sh[e];
-        g = relu ? fmaxf(g, 0.f) : g;
-        w[e] = (bf16)(aff ? g : f);
-      }
-      uint4 q = __builtin_bit_cast(uint4, w);
-      const bool ok = (valid >> j) & 1u;
-      q = make_uint4(ok ? q.x : 0u, ok ? q.y : 0u, ok ? q.z : 0u, ok ? q.w : 0u);
-      if (a_l[j] >= 0) *reinterpret_cast<uint4*>(ldsA + a_l[j]) = q;
+      Raw8<T> v = ra[j];
+      if (aff) v = affine8_lim(v, sc, sh, relu_lim);
+      v = select8<T>((valid >> j) & 1u, v);
+      if (a_l[j] >= 0) lstore8<T>(ldsA + a_l[j], v);
     }
 #ifdef SATCV_STAMP
     STAMP(q2);
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, WPS) void igemm_ws_kernel(const IgemmArgs a, c
 #endif
     // ---- the next tile's loads: in flight during this tile's MFMA phase and epilogue
     const int tn0 = n0, ty0 = y0, tx0 = x0;
-    if (t + 1 < t_hi) { tile_origin(t + 1, n0, y0, x0); valid = issue_loads(n0, y0, x0); }
+    if (t + 1 < t_hi) { next_origin(n0, y0, x0); valid = issue_loads(n0, y0, x0); }
 #ifdef SATCV_STAMP
     STAMP(q4);
 #endif
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256, WPS) void igemm_ws_kernel(const IgemmArgs a, c
 #ifdef SATCV_STAMP
     STAMP(q6);
 #endif
-    igemm_epilogue<T, TW, WM, WN, MT, NT, WABL(1)>(a, acc, tn0, ty0, tx0, 0, smem_raw, carry);
+    igemm_epilogue<T, TW, WM, WN, MT, NT, WABL(1), true, false>(a, acc, tn0, ty0, tx0, 0, smem_raw, carry);
 #ifdef SATCV_STAMP
     STAMP(q7);
 #endif
@@ -258,6 +259,7 @@ static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   long long grid = (long long)ncu * per_cu;
   if (grid > total) grid = total;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, st, a, (int)total);
+  ++g_ws_launches;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("igemm_ws launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
   return SATCV_OK;
@@ -270,13 +272,14 @@ int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   if (a.kh != 3 || a.kw != 3 || a.dil != 1 || a.stride != 1 || a.mode_in || a.mode_out || a.pool_y || a.accumulate || a.out_scale || a.bst_y) return SATCV_ERR_UNSUPPORTED;
   if (!(cin == 16 || cin == 32 || cin == 64) || !(a.cout == 32 || a.cout == 64) || a.cout_pad != a.cout || a.cstat != a.cout) return SATCV_ERR_UNSUPPORTED;
   if (a.x1 && (a.c0 % 8 != 0)) return SATCV_ERR_UNSUPPORTED;
-  if (a.h < 8 || a.ldy % 8 != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;
+  if (a.h % 8 != 0 || a.w_ % 32 != 0 || a.out_relu || a.ldy % 8 != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;      // whole 8 x 32 tiles: the kernel compiles the interior-tile epilogue only
   // small problems stay on the general kernel unless forced (tests): the persistent grid needs enough tiles to fill the chip
   const long long tiles = (long long)a.n * cdiv(a.h, 8) * cdiv(a.w_, 32);
-  if (g_opt_igemm_thin < 2 && tiles < 2048) return SATCV_ERR_UNSUPPORTED;
+  if (g_opt_igemm_thin == 1 && tiles < 2048) return SATCV_ERR_UNSUPPORTED;
   if (a.cout == 32) {
-    if (cin == 16) return ws_cfg<16, 1, 2>(a, st, dry);
-    if (cin == 32) return ws_cfg<32, 1, 2>(a, st, dry);
+    // three workgroups per CU where the registers allow (<= 168): 16 -> 32 at 256 x 256 132 -> 116 us, 32 -> 32 equal or better
+    if (cin == 16) return ws_cfg<16, 1, 3>(a, st, dry);
+    if (cin == 32) return ws_cfg<32, 1, 3>(a, st, dry);
     return ws_cfg<64, 1, 2>(a, st, dry);
   }
   if (cin == 16) return ws_cfg<16, 2, 2>(a, st, dry);

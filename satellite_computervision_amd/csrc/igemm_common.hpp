@@ -89,7 +89,9 @@ __device__ __forceinline__ void mma32(f32x16& acc, const FragT<T>& a, const Frag
 // for the transposed conv).  Call with every wave past its last LDS fragment read (the staging aliases the operand images).
 // carry: persistent kernels pass two per-thread doubles (threads < BN own one output channel each); the tile's statistics are added
 // there instead of going to the replica rows with atomics, and the caller flushes them once per workgroup (stats_flush).
-template <typename T, int TW, int WM, int WN, int MT, int NT, bool SKIP_STORES = false, bool FAST = true>
+// GENERAL = false: the caller guarantees interior tiles (whole tiles inside the image, every column valid, plain store): only the fast
+// path is compiled -- the persistent thin-layer kernel sits at its register cap and the masked path's live state spilled.
+template <typename T, int TW, int WM, int WN, int MT, int NT, bool SKIP_STORES = false, bool FAST = true, bool GENERAL = true>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[MT][NT], int n0, int y0, int x0, int nbase, unsigned char* smem_raw,
                                                double* carry = nullptr) {
   constexpr int NTHREADS = WM * WN * 64, BM = WM * MT * 32, BN = WN * NT * 32;
@@ -101,8 +103,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
   // ---- fast path (wave-uniform test): one whole image tile inside the image, every column valid, plain NHWC rows, no ReLU / pool /
   // accumulation -- no validity masks, no per-element selects, no divisions in the store loop.  The general path below cost ~4,700
   // cycles per 256 x 32 tile (19 % of a thin-layer tile) of which most was mask and address bookkeeping.
-  if (FAST && a.imgs == 1 && !a.accumulate && !a.pool_y && !a.out_relu && n0 < a.n && y0 + BM / TW <= a.h && x0 + TW <= a.w_ &&
-      nbase + BN <= a.cout && !SKIP_STORES && sizeof(T) == 2 && (a.mode_out == 0 || a.cstat % 8 == 0)) {
+  if (FAST && (!GENERAL || (a.imgs == 1 && !a.accumulate && !a.pool_y && !a.out_relu && n0 < a.n && y0 + BM / TW <= a.h && x0 + TW <= a.w_ &&
+      nbase + BN <= a.cout && (a.mode_out == 0 || a.cstat % 8 == 0))) && !SKIP_STORES && sizeof(T) == 2) {
     constexpr int VPR = BN / 8;                   // 16-byte vectors per tile row
     static_assert(NTHREADS % VPR == 0, "column group of a thread must be loop-invariant");
     const int vq = tid % VPR;                     // this thread's 16-byte column group (fixed: NTHREADS is a multiple of VPR)
@@ -110,7 +112,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     // layer's BN backward needs (sum g, sum g * xhat over the batch) are formed here from the tile in the accumulators and the
     // layer's raw outputs v at the same pixels, instead of by a separate pass that re-reads both tensors from HBM.  v arrives by
     // 16-byte row loads (issued first, hidden behind the accumulator -> LDS pass) in a second staging tile.
-    const bool bst = sizeof(T) == 2 && a.bst_y != nullptr;
+    const bool bst = GENERAL && sizeof(T) == 2 && a.bst_y != nullptr;      // (the fast-only instantiations never carry the fused sums)
     // (the 128 x 128 tile of 4 waves would pay for 8 held row vectors with its third workgroup per CU: it parks them in LDS at once)
     constexpr bool YHOLD = !(MT * NT >= 4 && NTHREADS <= 256);
     constexpr int YIT = (BM * VPR + NTHREADS - 1) / NTHREADS;
@@ -232,6 +234,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     }
     return;
   }
+  if constexpr (!GENERAL) return;
   // validity of the 16 accumulator rows of each MFMA tile (pixels outside the image must not enter the statistics): rows of one
   // MFMA tile span 32/TW tile rows; the column test needs no division
   unsigned pvmask[MT];

@@ -282,11 +282,19 @@ def force_thin(ops):
 
 
 WS_CASES = [
-    # n, h, w, cin (real), cout: every (stored Cin, Cout) pair the kernel serves; ragged grids (W not a multiple of 32, H not of 8), one
-    # and many tiles per workgroup, more tiles than workgroups (1 x 256 x 256 = 256 tiles; 9 x 136 x 200 = 1071 tiles > 512 workgroups)
-    (2, 32, 32, 4, 32), (1, 64, 64, 32, 32), (2, 40, 72, 64, 32), (1, 256, 256, 64, 32), (3, 20, 24, 32, 64), (2, 64, 96, 16, 64),
-    (1, 8, 32, 32, 32), (2, 9, 33, 64, 32), (9, 136, 200, 16, 32),
+    # n, h, w, cin (real), cout: every (stored Cin, Cout) pair the kernel serves on maps of whole 8 x 32 tiles; one and many tiles per
+    # workgroup, more tiles than workgroups (9 x 136 x 224 = 1071 tiles); the two ragged maps fall back to the general kernel
+    (2, 32, 32, 4, 32), (1, 64, 64, 32, 32), (2, 40, 96, 64, 32), (1, 256, 256, 64, 32), (3, 24, 32, 32, 64), (2, 64, 96, 16, 64),
+    (1, 8, 32, 32, 32), (2, 16, 64, 64, 32), (9, 136, 224, 16, 32), (2, 9, 33, 64, 32), (3, 20, 24, 32, 64),
 ]
+
+
+def ws_launches():
+    from satellite_computervision_amd._lib import lib, check
+    import ctypes
+    v = ctypes.c_int32()
+    check(lib.satcv_get_option(b'igemm_thin_launches', ctypes.byref(v)))
+    return v.value
 
 
 @pytest.mark.parametrize('case', WS_CASES)
@@ -302,7 +310,9 @@ def test_conv2d_weights_stationary_thin_kernel(ops, case, force_thin):
     cpad = rup(cin, 16)
     wf, _ = ops.pack_weights(f32dev(kern), cpad, ops.DTYPE_CODE[td], want_dgrad=False)
     stats = ops.new_stats(cout, dev())
+    before = ws_launches()
     y = ops.conv2d(to_dev(x, td, cpad), wf, cout, bias=f32dev(b), stats=stats)
+    assert ws_launches() - before == (1 if (h % 8 == 0 and w % 32 == 0) else 0), 'path taken'
     got = back(y, cout)
     close(got, ref, td, f'ws conv {case}')
     s = stats.sum(0).double().cpu().numpy()
@@ -320,10 +330,10 @@ def test_conv2d_weights_stationary_thin_kernel(ops, case, force_thin):
 
 
 def test_conv2d_weights_stationary_dual_source_affine(ops, force_thin):
-    """dec0.conv1 through the thin kernel: concat([skip 32, up 32]) -> BN -> ReLU in the loader, -> 32 channels, ragged grid"""
+    """dec0.conv1 through the thin kernel: concat([skip 32, up 32]) -> BN -> ReLU in the loader, -> 32 channels"""
     td = torch.bfloat16
     rng = np.random.default_rng(13)
-    n, h, w, c0, c1, cout = 2, 40, 72, 32, 32, 32
+    n, h, w, c0, c1, cout = 2, 40, 96, 32, 32, 32
     xa, xb = rnd(rng, (n, h, w, c0), td), rnd(rng, (n, h, w, c1), td)
     sc, sh = rng.standard_normal(c0 + c1), rng.standard_normal(c0 + c1)
     kern = rnd(rng, (3, 3, c0 + c1, cout), td, 0.2)
