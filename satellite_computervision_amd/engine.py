@@ -720,11 +720,11 @@ class Plan:
             BatchNorm backward of the node that produced t: one pass over two tensors less per such layer)"""
             bt = None if kw.get('accumulate') else bst_target(t)
             # where it pays (measured per layer of the five-level U-Net, batch 64; DESIGN.md §3): the extra tile read hides under a
-            # K loop of >= 1152 (3x3 x 128 channels) and under the 1x1 kernels; a thin 3x3 whose output -- the gradient of a decoder
-            # concatenation -- is at least twice as wide as its input replaces a pass over twice its own input.  The thin and middle
-            # layers in between are HBM-bound themselves: there the read costs the conv what the separate pass had cost.
+            # K loop of >= 1152 (3x3 x 128 channels) and under the 1x1 kernels.  The thin and middle layers are HBM-bound
+            # themselves -- there the read costs the conv what the separate pass had cost -- and the thin ones run on the
+            # persistent weights-stationary kernel, which does not carry the sums.
             kdepth = kw.get('kh', 1) * kw.get('kw', 1) * (kw.get('c0', 0) + (kw.get('c1', 0) or 0))
-            pays = FUSE_DGRAD_ALL or kdepth >= 1152 or kw.get('kh', 1) == 1 or (kw['cout'] >= 2 * kw.get('c0', 0) and kdepth <= 288)
+            pays = FUSE_DGRAD_ALL or kdepth >= 1152 or kw.get('kh', 1) == 1
             if bt is not None and bt[1] == kw['cout'] and pays:
                 sums = self._z(STAT_ROWS, 2, bt[1], dtype=torch.float64)
                 kw2 = dict(kw, bst=bt[0], stats=_fp(sums), stats_ld=bt[1])
