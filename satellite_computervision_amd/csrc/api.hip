@@ -114,7 +114,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 int g_opt_igemm_db = env_int("SATCV_DB", 1);
 int g_opt_wgrad_db = env_int("SATCV_WGRAD_DB", 1);
 int g_opt_igemm_sched = env_int("SATCV_IGEMM_SCHED", 0);
-int g_opt_igemm_thin = env_int("SATCV_THIN", 1);      // 0 off, 1 where the launch fills the chip (>= 2048 tiles), 2 always (tests)
+int g_opt_igemm_thin = env_int("SATCV_THIN", 1);      // 0 off, 1 / 2 on wherever the shape limits allow (independent of the batch size)
 static int* opt_slot(const char* key) {
   if (!key) return nullptr;
   if (!strcmp(key, "igemm_db")) return &g_opt_igemm_db;

@@ -110,7 +110,9 @@ __global__ __launch_bounds__(256, WPS) void igemm_ws_kernel(const IgemmArgs a, c
       const int dy = a_yx[j] >> 16, dx = (int)(short)(a_yx[j] & 0xffff);
       const bool ok = a_l[j] >= 0 && dy >= ylo && dy < yhi && dx >= xlo && dx < xhi;
       vm |= (ok ? 1u : 0u) << j;                                            // (items outside load the base pixel and are zeroed below: no
-      if (!WABL(4)) ra[j] = gload8<T>(base + (ok ? a_eoff[j] : 0));          //  branch around a vector-memory instruction in the loop)
+      int off = ok ? a_eoff[j] : 0;                                         //  branch around a vector-memory instruction in the loop)
+      asm volatile("" : "+v"(off));                                         // (select on 32 bits: the compiler otherwise keeps every offset sign-extended, 2 registers per item)
+      if (!WABL(4)) ra[j] = gload8<T>(base + off);
       else ra[j] = zero8<T>();
     }
     return vm;
@@ -269,13 +271,12 @@ static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
 int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   if (!g_opt_igemm_thin || dtype != SATCV_BF16) return SATCV_ERR_UNSUPPORTED;
   const int cin = a.c0 + a.c1;
-  if (a.kh != 3 || a.kw != 3 || a.dil != 1 || a.stride != 1 || a.mode_in || a.mode_out || a.pool_y || a.accumulate || a.out_scale || a.bst_y) return SATCV_ERR_UNSUPPORTED;
+  if (a.kh != 3 || a.kw != 3 || a.dil != 1 || a.stride != 1 || a.mode_in || a.mode_out || a.pool_y || a.accumulate || a.bst_y) return SATCV_ERR_UNSUPPORTED;
   if (!(cin == 16 || cin == 32 || cin == 64) || !(a.cout == 32 || a.cout == 64) || a.cout_pad != a.cout || a.cstat != a.cout) return SATCV_ERR_UNSUPPORTED;
   if (a.x1 && (a.c0 % 8 != 0)) return SATCV_ERR_UNSUPPORTED;
-  if (a.h % 8 != 0 || a.w_ % 32 != 0 || a.out_relu || a.ldy % 8 != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;      // whole 8 x 32 tiles: the kernel compiles the interior-tile epilogue only
-  // small problems stay on the general kernel unless forced (tests): the persistent grid needs enough tiles to fill the chip
-  const long long tiles = (long long)a.n * cdiv(a.h, 8) * cdiv(a.w_, 32);
-  if (g_opt_igemm_thin == 1 && tiles < 2048) return SATCV_ERR_UNSUPPORTED;
+  if (a.h % 8 != 0 || a.w_ % 32 != 0 || a.ldy % 8 != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;      // whole 8 x 32 tiles: the kernel compiles the interior-tile epilogue only
+  // (no tile-count threshold: the kernel choice must not depend on the batch size -- inference is bit-identical across batch splits,
+  //  tests/test_model_gpu.py::test_full_size_batch_invariance_property, and the two kernels sum K in different orders)
   if (a.cout == 32) {
     // three workgroups per CU where the registers allow (<= 168): 16 -> 32 at 256 x 256 132 -> 116 us, 32 -> 32 equal or better
     if (cin == 16) return ws_cfg<16, 1, 3>(a, st, dry);

@@ -141,26 +141,34 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
       }
     }
     float st1[NT], st2[NT];
+    // (RELU: the folded inference graph clamps in the epilogue; only the interior-tile-only instantiations -- the persistent
+    //  thin-layer kernel -- take such launches here, everything else sends them down the general path)
+    auto first_pass = [&](auto RELU) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int cl_ = (wn * NT + n) * 32 + r;
-      const int cch = (nbase + cl_) % a.cstat;
-      const float bv = a.bias ? a.bias[cch] : 0.f;
-      const float osc = a.out_scale ? a.out_scale[cch] : 1.f;
-      float s1 = 0.f, s2 = 0.f;
+      for (int n = 0; n < NT; ++n) {
+        const int cl_ = (wn * NT + n) * 32 + r;
+        const int cch = (nbase + cl_) % a.cstat;
+        const float bv = a.bias ? a.bias[cch] : 0.f;
+        const float osc = a.out_scale ? a.out_scale[cch] : 1.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int q = (wm * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          const T tv = (T)(acc[m][n][i] * osc + bv);
-          ldsO[q * OPITCH + cl_] = tv;
-          const float fv = (float)tv;
-          s1 += fv; s2 += fv * fv;
+          for (int i = 0; i < 16; ++i) {
+            const int q = (wm * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            float vv = acc[m][n][i] * osc + bv;
+            if (decltype(RELU)::value) vv = fmaxf(vv, 0.f);
+            const T tv = (T)vv;
+            ldsO[q * OPITCH + cl_] = tv;
+            const float fv = (float)tv;
+            s1 += fv; s2 += fv * fv;
+          }
         }
+        st1[n] = s1; st2[n] = s2;
       }
-      st1[n] = s1; st2[n] = s2;
-    }
+    };
+    if (!GENERAL && a.out_relu) first_pass(std::true_type{});
+    else first_pass(std::false_type{});
     if (bst) {
       if constexpr (YHOLD) {
 #pragma unroll

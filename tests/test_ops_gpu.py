@@ -484,6 +484,19 @@ def test_bn_backward_of_a_concatenation_in_one_pass(ops, td, case):
     close(back(dbeta), db_ref, td, 'concat dbeta', k=4.0)
 
 
+@pytest.fixture
+def general_kernel_only(ops):
+    """thin shapes on the general kernel too: the test below compares a fused launch bit for bit with the plain one, and the fused form
+    is not served by the persistent thin-layer kernel (a different summation order)"""
+    from satellite_computervision_amd._lib import lib, check
+    import ctypes
+    old = ctypes.c_int32()
+    check(lib.satcv_get_option(b'igemm_thin', ctypes.byref(old)))
+    check(lib.satcv_set_option(b'igemm_thin', 0))
+    yield
+    check(lib.satcv_set_option(b'igemm_thin', old.value))
+
+
 @pytest.mark.parametrize('case', [
     (2, 32, 32, 32, 32, 0, 3),       # thin 256 x 32 tile
     (2, 32, 64, 64, 64, 0, 3),       # 128 x 64
@@ -494,7 +507,7 @@ def test_bn_backward_of_a_concatenation_in_one_pass(ops, td, case):
     (2, 16, 16, 128, 128, 64, 3),
     (2, 32, 32, 64, 64, 0, 1),       # 1 x 1
 ])
-def test_data_gradient_with_fused_bn_backward_sums(ops, case):
+def test_data_gradient_with_fused_bn_backward_sums(ops, case, general_kernel_only):
     """The data gradient of a conv whose input is ReLU(BN(v)) writes dL/d act; its epilogue also forms sum g and sum g * xhat of that
     BatchNorm's backward (include/satcv.h: bst_*; utils/model_tools.py:178-180 differentiated).  Checked against float64 sums of the
     STORED gradient, and against the separate reduce launch it replaces."""
