@@ -888,7 +888,14 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   // double-buffered kernel (8 waves, one workgroup per CU): 256 workgroups fill the chip once; each should walk >= 16 pixel tiles so
   // that its set-up and its slab write (~16k cycles) stay small beside the tile loop
   p.db = db_ok ? 1 : 0;
-  if (p.db) ns = nblk >= 256 ? 1 : 256 / nblk;
+  // ... but only HALF the chip: a resident workgroup of this kernel (8 waves x ~250 registers) owns its CU for the kernel's whole
+  // duration, and with all 256 CUs taken the main stream's next kernels -- the few-block BatchNorm finalize launches above all -- wait
+  // for the weight gradient to END (bn_bwd_finalize: 5 -> 12-280 us in the step).  The weight gradients have slack (their stream is
+  // busy 4 of 10 ms): 160 workgroups make each of them ~12 % slower and the step 1.5 % faster (10.29 -> 10.13 ms, A/B/A/B; 128: the
+  // same step, weight gradients 25 % slower; 224: -1.0 %; 96: the weight gradients become the critical path, +3 %).
+  // SATCV_WGRAD_WGS overrides.
+  static const int db_wgs = [] { const char* e = getenv("SATCV_WGRAD_WGS"); const int v = e ? atoi(e) : 160; return v >= 8 ? v : 160; }();
+  if (p.db) ns = nblk >= db_wgs ? 1 : db_wgs / nblk;
   if (ns > ptiles) ns = ptiles;
   if (ns > 768) ns = 768;
   if (ns < 1) ns = 1;
