@@ -70,7 +70,10 @@ class ParamSpec:
 BIAS_NOISE = os.environ.get('SATCV_BN_BIAS_NOISE', '0') == '1'
 # weight-gradient launches (second stream) enqueued AFTER the data gradient of their layer instead of before it: they then start beside the
 # HBM-bound BatchNorm-backward kernels of the next layer rather than beside their own layer's MFMA-bound data gradient
-WGRAD_LATE = os.environ.get('SATCV_WGRAD_LATE', '0') == '1'
+# a layer's weight gradient is enqueued BEHIND its data gradient (both only need dy): with the weight gradients on 160 workgroups the
+# step time is the same either way (9.54 ms, three A/B pairs) and the 3x3 data gradients run without their own layer's weight
+# gradient beside them (roofline.frac 0.251 -> 0.262); SATCV_WGRAD_LATE=0 restores the earlier order
+WGRAD_LATE = os.environ.get('SATCV_WGRAD_LATE', '1') == '1'
 FUSE_DGRAD_ALL = os.environ.get('SATCV_FUSE_DGRAD_BN_BWD', '1') == '2'      # 2: every eligible data gradient carries the BN-backward sums
 
 
