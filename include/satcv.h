@@ -150,6 +150,8 @@ typedef struct satcv_wgrad_desc {
   float* workspace; int64_t workspace_bytes;
   int32_t dtype;
   int32_t accumulate;                /* dw += result (a layer applied to several inputs: shared weights) */
+  int32_t whole_chip;                /* 1: nothing runs beside this launch (the last weight gradient of a backward pass): one workgroup
+                                        per CU instead of the 160 that leave room for the other stream's kernels */
 } satcv_wgrad_desc;
 int64_t satcv_conv2d_wgrad_workspace(const satcv_wgrad_desc* d);
 int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream);

@@ -53,7 +53,7 @@ class WgradDesc(C.Structure):
                 ('n', c_i32), ('h', c_i32), ('w_', c_i32),
                 ('kh', c_i32), ('kw', c_i32), ('dil', c_i32),
                 ('mode_dy', c_i32), ('f', c_i32), ('transposed', c_i32),
-                ('workspace', c_vp), ('workspace_bytes', c_i64), ('dtype', c_i32), ('accumulate', c_i32)]
+                ('workspace', c_vp), ('workspace_bytes', c_i64), ('dtype', c_i32), ('accumulate', c_i32), ('whole_chip', c_i32)]
 
 
 class BnBwdDesc(C.Structure):

@@ -895,7 +895,8 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   // same step, weight gradients 25 % slower; 224: -1.0 %; 96: the weight gradients become the critical path, +3 %).
   // SATCV_WGRAD_WGS overrides.
   static const int db_wgs = [] { const char* e = getenv("SATCV_WGRAD_WGS"); const int v = e ? atoi(e) : 160; return v >= 8 ? v : 160; }();
-  if (p.db) ns = nblk >= db_wgs ? 1 : db_wgs / nblk;
+  const int wgs = d->whole_chip ? 256 : db_wgs;
+  if (p.db) ns = nblk >= wgs ? 1 : wgs / nblk;
   if (ns > ptiles) ns = ptiles;
   if (ns > 768) ns = 768;
   if (ns < 1) ns = 1;

@@ -739,14 +739,15 @@ class Plan:
                     return fn
             return self._conv_step(role='dgrad', **kw)
 
-        def wgrad_step(r, dy, lddy, lay, cin_real, cout, hh, ww, k, dil, f=0, accum=0):
+        def wgrad_step(r, dy, lddy, lay, cin_real, cout, hh, ww, k, dil, f=0, accum=0, last=False):
             nonlocal ws_need
             sa = self._src_args(r)
             if sa['x1'] is not None and sa['c0'] % 8:
                 raise NotImplementedError(f'{lay.name}: training a convolution over a concatenation needs a first part of a multiple of 8 channels '
                                           f'(got {sa["c0"]}); inference has no such limit')
             d = ops.make_wgrad_desc(dy=dy, lddy=lddy, dw=rt.gptr(lay.name + '/kernel'), cin=cin_real, cout=cout, n=n, h=hh, w_=ww,
-                                    dtype=dt, kh=k, kw=k, dil=dil, mode_dy=1 if f else 0, f=f if f else 1, transposed=1 if f else 0, accumulate=accum, **sa)
+                                    dtype=dt, kh=k, kw=k, dil=dil, mode_dy=1 if f else 0, f=f if f else 1, transposed=1 if f else 0, accumulate=accum,
+                                    whole_chip=1 if last else 0, **sa)
             nb = lib.satcv_conv2d_wgrad_workspace(C.byref(d))
             if nb < 0:
                 raise RuntimeError(lib.satcv_last_error().decode())
@@ -917,7 +918,9 @@ class Plan:
                 self.dbg['dy:' + lay.name] = dy
                 self.dbg['_ctx:' + lay.name] = dict(da=da, dp=dp, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout)
                 pk = rt.packed[lay.name]
-                wstep = wgrad_step(r, dy.data_ptr(), cout, lay, pk['cin'], cout, hh, ww, cx['k'], cx['dil'], accum=accum)
+                # (the weight gradient of a layer fed by a model input is the last launch of the backward pass: nothing runs beside it)
+                wstep = wgrad_step(r, dy.data_ptr(), cout, lay, pk['cin'], cout, hh, ww, cx['k'], cx['dil'], accum=accum,
+                                   last=tin.node.op == 'input' and len(m.inputs) == 1 and os.environ.get('SATCV_WGRAD_LAST_FULL', '1') != '0')
                 if not WGRAD_LATE:
                     self.bwd.append(wstep)
                 if tin.node.op != 'input':
