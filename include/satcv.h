@@ -362,8 +362,8 @@ int satcv_prof_collect(int32_t kind, double* total_ms, int64_t* launches, double
 /* kernel-selection knobs (tests force a tile configuration on small shapes; probes A/B variants in one process).  Keys:
  * "igemm_db"  0 = 128x128 single-buffered tile only, 1 = automatic (default), 2 = the double-buffered 256x128 tile wherever
  *             its shape limits allow;
- * "igemm_thin" 0 = general kernel, 1 (default) = the persistent weights-stationary kernel for thin 3x3 layers (Cin 16/32/64 -> Cout 32,
- *             Cin 16/32 -> Cout 64, maps of whole 8 x 32 tiles), whatever the batch size (2 = the same; kept for older callers);
+ * "igemm_thin" 0 = general kernel, 1 (default) = the persistent weights-stationary kernel for thin 3x3 layers (Cin 16/32/64 -> Cout 32/64,
+ *             maps of whole 8 x 32 tiles), whatever the batch size (2 = the same; kept for older callers);
  *             "igemm_thin_launches" (read-only) counts the launches it has served in this process (tests check the path taken).
  * "wgrad_db"  1 (default) = double-buffered weight-gradient kernel where its limits allow, 0 = the single-buffered one, 2 = the
  *             64 x 128 block for 1 x 1 / transposed-conv gradients instead of the 128 x 256 one.

@@ -1,5 +1,5 @@
 // Weights-stationary 3x3 convolution for the THIN full- and half-resolution layers of the U-Net (Cin <= 64 stored channels,
-// Cout 32 or 64; Conv2D of utils/model_tools.py:178, 312, 315 at decoder / encoder levels 0 and 1, forward and data gradient).
+// Cout 32 or 64, every pair of them; Conv2D of utils/model_tools.py:178, 312, 315 at decoder / encoder levels 0 and 1, forward and data gradient).
 //
 // Why a kernel of its own (s_memtime stamps of the general kernel on 64 -> 32 channels at 256 x 256, tools/stamp_probe.py): of the
 // ~24,500 cycles a workgroup spent per 256-pixel tile only 3,500 were the MFMA phase; 4,300 went into the gather-table setup, 5,500 into
@@ -29,10 +29,12 @@ extern "C" int satcv_debug_read_stamps_ws(unsigned long long* out) { return hipM
 #define STAMP_V(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
-template <int CIN, int NT, int WPS>
-__global__ __launch_bounds__(256, WPS) void igemm_ws_kernel(const IgemmArgs a, const int total_tiles) {
+// WN = 2 (64 -> 64 channels): 8 waves, each pair of waves shares its 64 pixels and splits the 64 output channels -- the 74 KB weight
+// tensor and the 44 KB tile leave ONE workgroup per CU, and 8 waves keep the two waves per SIMD of the other forms
+template <int CIN, int NT, int WPS, int WN = 1>
+__global__ __launch_bounds__(256 * WN, WPS) void igemm_ws_kernel(const IgemmArgs a, const int total_tiles) {
   typedef bf16 T;
-  constexpr int TW = 32, TH = 8, WM = 4, WN = 1, MT = 2, BM = 256, BN = NT * 32, NTHREADS = 256, EL = 8;
+  constexpr int TW = 32, TH = 8, WM = 4, MT = 2, BM = 256, BN = WN * NT * 32, NTHREADS = 256 * WN, EL = 8;
   constexpr int SLOTS = CIN / EL, CL = TW + 2, PITCH = CL, RL = TH + 2;
   constexpr int PLANE = RL * PITCH * EL;                                   // elements of one slot plane
   // 8 consecutive lanes store 8 / SLOTS pixels x SLOTS slots with one ds_write_b128 (serviced in groups of 8 lanes over 32 banks):
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(256, WPS) void igemm_ws_kernel(const IgemmArgs a, c
   T* ldsW = reinterpret_cast<T*>(smem_raw + R0_BYTES);                      // [tap][slot][BN][8], resident for the whole launch
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, hh = lane >> 5;
   const int slot_t = tid % SLOTS;                                           // NTHREADS % SLOTS == 0: a thread's channel slot is fixed
   const T* wp = reinterpret_cast<const T*>(a.w);
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256, WPS) void igemm_ws_kernel(const IgemmArgs a, c
   int a_off[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const int q = (wave * MT + m) * 32 + r;
+    const int q = (wm * MT + m) * 32 + r;
     a_off[m] = ((q / TW) * PITCH + (q % TW)) * EL;
   }
 
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256, WPS) void igemm_ws_kernel(const IgemmArgs a, c
 #pragma unroll
         for (int m = 0; m < MT; ++m) af[buf][m] = lds_frag<T>(ldsA + slot * SLOT_STRIDE + a_off[m] + tap_off);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bf[buf][n] = lds_frag<T>(ldsW + ((tap * SLOTS + slot) * BN + n * 32 + r) * EL);
+        for (int n = 0; n < NT; ++n) bf[buf][n] = lds_frag<T>(ldsW + ((tap * SLOTS + slot) * BN + (wn * NT + n) * 32 + r) * EL);
       };
       read_step(0, 0);
 #pragma unroll
@@ -223,9 +226,9 @@ __global__ __launch_bounds__(256, WPS) void igemm_ws_kernel(const IgemmArgs a, c
 }
 
 // ------------------------------------------------------------------ host side
-template <int CIN, int NT, int WPS>
+template <int CIN, int NT, int WPS, int WN = 1>
 static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
-  constexpr int TW = 32, TH = 8, BN = NT * 32, SLOTS = CIN / 8, RL = TH + 2, PITCH = TW + 2;
+  constexpr int TW = 32, TH = 8, BN = WN * NT * 32, SLOTS = CIN / 8, RL = TH + 2, PITCH = TW + 2;
   constexpr int PLANE = RL * PITCH * 8;
   constexpr int WANT = (SLOTS >= 8 ? 16 : 128 / SLOTS) / 2;
   constexpr int SPAD = ((WANT - PLANE % 64) % 64 + 64) % 64;
@@ -241,7 +244,7 @@ static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   const long long total = (long long)a.n * a.tiles_y * a.tiles_x;
   if (total <= 0 || total > 0x7fffffffLL) return SATCV_ERR_UNSUPPORTED;
   if (dry) return SATCV_OK;
-  auto kern = igemm_ws_kernel<CIN, NT, WPS>;
+  auto kern = igemm_ws_kernel<CIN, NT, WPS, WN>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
@@ -260,7 +263,7 @@ static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   if (per_cu < 1) per_cu = 1;
   long long grid = (long long)ncu * per_cu;
   if (grid > total) grid = total;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, st, a, (int)total);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256 * WN), LDS, st, a, (int)total);
   ++g_ws_launches;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("igemm_ws launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
@@ -285,5 +288,7 @@ int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   }
   if (cin == 16) return ws_cfg<16, 2, 2>(a, st, dry);
   if (cin == 32) return ws_cfg<32, 2, 2>(a, st, dry);
-  return SATCV_ERR_UNSUPPORTED;           // 64 -> 64: weights (74 KB) + tile leave one workgroup per CU
+  // 64 -> 64: weights (74 KB) + tile leave one workgroup per CU, so it has 8 waves (128 x 128 at batch 64: 154 -> 120 us with the fused
+  // input BatchNorm; at batch 8, two tiles per workgroup, 23.4 -> 24.7 us)
+  return ws_cfg<64, 1, 1, 2>(a, st, dry);
 }

@@ -286,6 +286,7 @@ WS_CASES = [
     # workgroup, more tiles than workgroups (9 x 136 x 224 = 1071 tiles); the two ragged maps fall back to the general kernel
     (2, 32, 32, 4, 32), (1, 64, 64, 32, 32), (2, 40, 96, 64, 32), (1, 256, 256, 64, 32), (3, 24, 32, 32, 64), (2, 64, 96, 16, 64),
     (1, 8, 32, 32, 32), (2, 16, 64, 64, 32), (9, 136, 224, 16, 32), (2, 9, 33, 64, 32), (3, 20, 24, 32, 64),
+    (2, 24, 64, 64, 64), (1, 128, 128, 64, 64),      # the 8-wave form
 ]
 
 
