@@ -274,7 +274,8 @@ static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
 int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   if (!g_opt_igemm_thin || dtype != SATCV_BF16) return SATCV_ERR_UNSUPPORTED;
   const int cin = a.c0 + a.c1;
-  if (a.kh != 3 || a.kw != 3 || a.dil != 1 || a.stride != 1 || a.mode_in || a.mode_out || a.pool_y || a.accumulate || a.bst_y) return SATCV_ERR_UNSUPPORTED;
+  if (a.kh != 3 || a.kw != 3 || a.dil != 1 || a.stride != 1 || a.mode_in || a.mode_out || a.accumulate || a.bst_y) return SATCV_ERR_UNSUPPORTED;
+  if (a.pool_y && (8 % a.pool_f != 0 || 32 % a.pool_f != 0)) return SATCV_ERR_UNSUPPORTED;      // pooling windows inside one 8 x 32 tile
   if (!(cin == 16 || cin == 32 || cin == 64) || !(a.cout == 32 || a.cout == 64) || a.cout_pad != a.cout || a.cstat != a.cout) return SATCV_ERR_UNSUPPORTED;
   if (a.x1 && (a.c0 % 8 != 0)) return SATCV_ERR_UNSUPPORTED;
   if (a.h % 8 != 0 || a.w_ % 32 != 0 || a.ldy % 8 != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;      // whole 8 x 32 tiles: the kernel compiles the interior-tile epilogue only

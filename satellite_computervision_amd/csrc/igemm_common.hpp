@@ -240,6 +240,32 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
       const int t = q / TW, cx = q % TW;
       *reinterpret_cast<uint4*>(yp + (size_t)t * row_pitch + (size_t)cx * col_pitch) = *reinterpret_cast<const uint4*>(ldsO + q * OPITCH + vq * 8);
     }
+    if constexpr (!GENERAL) {
+      // fused max-pool of the tile just stored (folded inference encoder blocks; the interior-tile-only instantiations take these
+      // launches here, see the general form at the end of this function): every window of the tile is whole and inside the image
+      if (a.pool_y) {
+        const int f = a.pool_f, pw = TW / f, ph = (BM / TW) / f;
+        const int hp = a.h / f, wp = a.w_ / f;
+        T* pp = reinterpret_cast<T*>(a.pool_y) + nbase + vq * 8;
+        for (int it = tid; it < ph * pw * VPR; it += NTHREADS) {
+          const int pq = it / VPR;
+          const int t0 = (pq / pw) * f, c0 = (pq % pw) * f;
+          float mx[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
+          for (int i = 0; i < f; ++i)
+            for (int j = 0; j < f; ++j) {
+              const T* sp = ldsO + ((t0 + i) * TW + c0 + j) * OPITCH + vq * 8;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], (float)sp[e]);
+            }
+          T o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (T)mx[e];
+          *reinterpret_cast<uint4*>(pp + ((size_t)(n0 * hp + (y0 + t0) / f) * wp + (x0 + c0) / f) * a.pool_ld) = *reinterpret_cast<const uint4*>(o);
+        }
+      }
+    }
     return;
   }
   if constexpr (!GENERAL) return;
