@@ -513,21 +513,31 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbw
     s1[e] = 0.f; s2[e] = 0.f;
   }
   if (active) {
+    // running pointers (one 64-bit add per tensor and pixel): the `(size_t)p * ld` form cost six quarter-rate 64-bit multiplies per
+    // pixel because of the reversed order's select
+    const unsigned pfirst = gid / G;
+    const long long step = rev ? -(long long)per : (long long)per;
+    const long long pstart = rev ? (long long)npix - 1 - pfirst : (long long)pfirst;
+    const T* yq = yr + pstart * ldy;
+    const T* dq = da + pstart * d.ldda;
+    T* oq = dy + pstart * lddy;
+    const long long ystep = step * ldy, dstep = step * d.ldda, ostep = step * lddy;
+    const float lin_lo = d.linear ? -INFINITY : 0.f;      // (a > 0 || linear)  ==  a > lin_lo
 #pragma unroll 4
-    for (unsigned p0 = gid / G; p0 < npix; p0 += per) {
-      const unsigned p = rev ? npix - 1 - p0 : p0;
+    for (unsigned p0 = pfirst; p0 < npix; p0 += per) {
       float v[8], gr[8], o[8];
-      load8<T>(yr + (size_t)p * ldy, v);
-      load8<T>(da + (size_t)p * d.ldda, gr);
+      load8<T>(yq, v);
+      load8<T>(dq, gr);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float a = v[e] * sc[e] + sh[e];
-        const float gg = (a > 0.f || d.linear) ? gr[e] : 0.f;
+        const float gg = (a > lin_lo) ? gr[e] : 0.f;
         const float xh = (v[e] - mu[e]) * rs[e];
         if (APPLY) { const float t = sc[e] * (gg - c1[e] - xh * c2[e]); o[e] = round_to<T>(t); s1[e] += o[e]; }
         else { s1[e] += gg; s2[e] += gg * xh; }
       }
-      if (APPLY) store8<T>(dy + (size_t)p * lddy, o);
+      if (APPLY) store8<T>(oq, o);
+      yq += ystep; dq += dstep; oq += ostep;
     }
   }
   if (!APPLY) block_channel_reduce(lds, s1, s2, g, active, c, d.sums, d.sums_ld);
