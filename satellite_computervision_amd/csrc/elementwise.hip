@@ -5,9 +5,13 @@
 #include <cstdlib>
 
 #define EW_BLOCK 256
-// grid-stride kernels: at most 3 workgroups per CU, so that every workgroup is resident from the start.  With 8 per CU (2048) the
-// kernels ran 1.6 "rounds" -- a half-empty tail round -- and crowded out the weight-gradient stream: 5070 -> 5350 tiles/s.
-static inline int ew_grid(long long items, int cap = 256 * 3) {
+// grid-stride kernels: a bounded number of workgroups per CU.  Round 1 (weight gradients resident on every CU): 3 per CU, so that
+// every workgroup is resident from the start -- with 8 per CU the kernels ran 1.6 "rounds" and crowded out the weight-gradient
+// stream (5070 -> 5350 tiles/s).  With the weight gradients on 160 workgroups (round 2) the count hardly matters: 2 per CU +2.7 %
+// step time, 3 / 6 / 8 / 12 / 16 within 0.3 %, 6 the best by a hair (9.50 vs 9.52 ms).  SATCV_EW_PER_CU overrides.
+static inline int ew_grid(long long items, int cap = 0) {
+  static const int dflt = [] { const char* e = getenv("SATCV_EW_PER_CU"); const int v = e ? atoi(e) : 6; return 256 * (v >= 1 ? v : 6); }();
+  if (cap <= 0) cap = dflt;
   long long b = (items + EW_BLOCK - 1) / EW_BLOCK;
   if (b < 1) b = 1;
   if (b > cap) b = cap;
