@@ -223,9 +223,11 @@ __global__ void bn_finalize_train_kernel(satcv_stat_t* stats, int ld, int c, flo
   static_assert(SATCV_STAT_ROWS == 32, "one lane per replica row");
   const int ch = blockIdx.x * (blockDim.x / 32) + threadIdx.x / 32, r = threadIdx.x & 31;
   double s1 = 0.0, s2 = 0.0;
+  float gam = 0.f, bet = 0.f, mm0 = 0.f, mv0 = 0.f;       // the parameters travel with the replica rows: one load round trip, not two
   if (ch < c) {
     satcv_stat_t* row = stats + (size_t)r * 2 * ld;
     s1 = row[ch]; s2 = row[ld + ch];
+    if (r == 0) { gam = gamma[ch]; bet = beta[ch]; if (mm) { mm0 = mm[ch]; mv0 = mv[ch]; } }
     row[ch] = 0.0; row[ld + ch] = 0.0;
   }
 #pragma unroll
@@ -236,12 +238,12 @@ __global__ void bn_finalize_train_kernel(satcv_stat_t* stats, int ld, int c, flo
   float var = (float)(s2 / (double)count - mean_d * mean_d);      // E[x^2] - E[x]^2 without the fp32 cancellation
   var = fmaxf(var, 0.f);
   const float rstd = rsqrtf(var + eps);
-  const float sc = gamma[ch] * rstd;
-  scale[ch] = sc; shift[ch] = beta[ch] - mean * sc;
+  const float sc = gam * rstd;
+  scale[ch] = sc; shift[ch] = bet - mean * sc;
   mean_o[ch] = mean; rstd_o[ch] = rstd;
   if (mm) {
     const float vv = bessel ? var * (count / fmaxf(count - 1.f, 1.f)) : var;
-    float a = mm[ch], b = mv[ch];
+    float a = mm0, b = mv0;
     for (int u = 0; u < updates; ++u) { a = a * momentum + mean * (1.f - momentum); b = b * momentum + vv * (1.f - momentum); }
     mm[ch] = a; mv[ch] = b;
   }
