@@ -34,6 +34,26 @@ extern "C" int satcv_device_info(int32_t* out4) {
   return SATCV_OK;
 }
 
+// ---------------------------------------------------------------- dynamic-LDS opt-in, once per (kernel, device)
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: the cache is keyed by both and guarded, so a
+// process that drives several GPUs, or several threads with distinct streams, gets it on every device (re-entrant
+// given distinct contexts / streams) without a driver call on the launch path of every layer.
+#include <map>
+static std::mutex g_lds_mu;
+static std::map<std::pair<const void*, int>, size_t> g_lds_have;
+int satcv_ensure_dynamic_lds(const void* kern, size_t bytes) {
+  if (bytes <= 48 * 1024) return SATCV_OK;
+  int dev = 0;
+  SATCV_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_lds_mu);
+  size_t& have = g_lds_have[std::make_pair(kern, dev)];
+  if (bytes > have) {
+    SATCV_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+  }
+  return SATCV_OK;
+}
+
 // ---------------------------------------------------------------- graph capture
 extern "C" int satcv_graph_begin(void* stream) {
   SATCV_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));

@@ -41,6 +41,9 @@ void satcv_set_error(const char* fmt, ...);
     }                                                                          \
   } while (0)
 
+// opt a kernel into > 48 KB of dynamic LDS, once per (kernel, device); thread-safe (api.hip)
+int satcv_ensure_dynamic_lds(const void* kern, size_t bytes);
+
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- 8-element vectors of the storage type (16 B for bf16, 32 B for f32) ----

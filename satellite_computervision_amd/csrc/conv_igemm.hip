@@ -251,10 +251,7 @@ static int launch_cfg(IgemmArgs& a, hipStream_t st) {
   const size_t lds = ((size_t)(KC / 8) * a.rl * a.pitch * 8 + (size_t)a.kh * a.kw * (KC / 8) * BN * 8) * sizeof(T);
   if (lds > 160 * 1024) { satcv_set_error("igemm: LDS %zu too large", lds); return SATCV_ERR_UNSUPPORTED; }
   auto kern = igemm_kernel<T, TW, WM, WN, MT, NT, KS>;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
-  }
+  { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
   const long long blocks = (long long)a.ngroups * a.tiles_y * a.tiles_x * a.n_tiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) { satcv_set_error("igemm: bad grid %lld", blocks); return SATCV_ERR_INVALID; }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WM * WN * 64), lds, st, a);

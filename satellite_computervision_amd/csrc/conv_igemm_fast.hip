@@ -501,7 +501,9 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   if (a.bst_y) {
     // fused BatchNorm-backward reduce: only the epilogue's interior-tile path does it, so EVERY tile must be one; a second staging
     // tile holds the layer's raw outputs
-    if (sizeof(T) != 2 || a.imgs != 1 || a.h % TH != 0 || a.w_ % TW != 0 || a.cout % BN != 0 || a.cout % 8 != 0 || a.bst_ld % 8 != 0 ||
+    // (the dilated-halo instantiation DYN compiles only the general epilogue, which does not form the fused sums: refuse it here, before
+    //  the dry-run answer, so that satcv_conv2d_igemm_pipelined never promises sums the launch will not produce)
+    if (sizeof(T) != 2 || (TAPS == 9 && a.dil != 1 && !TL) || a.imgs != 1 || a.h % TH != 0 || a.w_ % TW != 0 || a.cout % BN != 0 || a.cout % 8 != 0 || a.bst_ld % 8 != 0 ||
         ((uintptr_t)a.bst_y % 16) != 0 || (a.bst_y1 && (a.bst_split % 8 != 0 || a.bst_ld1 % 8 != 0 || ((uintptr_t)a.bst_y1 % 16) != 0)))
       return SATCV_ERR_UNSUPPORTED;
     lds_out += (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T);
@@ -518,16 +520,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, false, TL, DB, WPS>;
   if constexpr (TAPS == 9 && !DB && WPS == 0) { if (dyn) kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, true>; }
   if ((DB || WPS) && dyn) return SATCV_ERR_UNSUPPORTED;
-  if (lds > 48 * 1024) {
-    // once per instantiation and LDS high-water mark (a driver call on the launch path of every layer otherwise)
-    static size_t lds_set[2] = {0, 0};
-    size_t& have = lds_set[dyn ? 1 : 0];
-    if (lds > have) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
-      have = lds;
-    }
-  }
+  { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
   const long long blocks = (long long)a.ngroups * a.tiles_y * a.tiles_x * a.n_tiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return SATCV_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHREADS), lds, st, a);

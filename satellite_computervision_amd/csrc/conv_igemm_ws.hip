@@ -245,12 +245,7 @@ static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   if (total <= 0 || total > 0x7fffffffLL) return SATCV_ERR_UNSUPPORTED;
   if (dry) return SATCV_OK;
   auto kern = igemm_ws_kernel<CIN, NT, WPS, WN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-    if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
-    attr_set = true;
-  }
+  { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS); if (rc) return rc; }
   static int ncu = 0;
   if (!ncu) {
     int dev = 0; hipDeviceProp_t p;

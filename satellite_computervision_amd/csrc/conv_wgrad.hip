@@ -943,10 +943,7 @@ static int wgrad_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream
   if (lds < 3 * 4096) lds = 3 * 4096;          // k-slice reduction scratch
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
   auto kern = wgrad_kernel<T, TW, NCI, NCO, NKS, NTAPS, PIX>;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
-  }
+  { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
   hipLaunchKernelGGL(kern, dim3(p.n_ci_blk * p.n_co_blk * p.nsplit), dim3(NCI * NCO * NKS * 64), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("wgrad launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
@@ -985,14 +982,7 @@ static int wgrad_db_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStr
   if (lds < red) lds = red;
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
   auto kern = wgrad_db_kernel<T, TW, NCI, NCO, NKS, NTAPS, PIX, NW>;
-  if (lds > 48 * 1024) {
-    static size_t have = 0;
-    if (lds > have) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) { satcv_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
-      have = lds;
-    }
-  }
+  { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
   hipLaunchKernelGGL(kern, dim3(p.n_ci_blk * p.n_co_blk * p.nsplit), dim3(NTHREADS), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("wgrad_db launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }

@@ -1187,7 +1187,8 @@ class Model:
             validation_steps=None, initial_epoch=0, shuffle=True, **kw):
         """Model.fit as the notebooks call it (notebooks/UNET_G4G_2019_solar.ipynb:1267-1275).  shuffle (Keras default True) applies to
         array inputs only, as in Keras: a new sample permutation every epoch (seeded by set_seed); generators / Sequences / datasets are
-        consumed in their own order."""
+        consumed in their own order.  shuffle='batch' permutes whole batches.  Data-parallel callers shard the arrays BEFORE fit():
+        every rank draws the same permutation from the shared seed, so ranks given the same full array would train on identical batches."""
         if isinstance(x, (np.ndarray, torch.Tensor)):
             self._shape_of(x)
             if y is not None and len(y) != len(x):
@@ -1204,7 +1205,11 @@ class Model:
                 order = None
                 if shuffle and (isinstance(x, (np.ndarray, torch.Tensor)) or (isinstance(x, (list, tuple)) and y is not None)):
                     nsamp = x[0].shape[0] if isinstance(x, (list, tuple)) else x.shape[0]
-                    order = _SHUFFLE_RNG.permutation(nsamp)
+                    if shuffle == 'batch':          # Keras: shuffle in batch-sized chunks (whole batches change places, their contents do not)
+                        bs_ = batch_size or 32
+                        order = np.concatenate([np.arange(b * bs_, min((b + 1) * bs_, nsamp)) for b in _SHUFFLE_RNG.permutation(-(-nsamp // bs_))])
+                    else:
+                        order = _SHUFFLE_RNG.permutation(nsamp)
                 it, _ = _as_batches(x, y, batch_size, order)
             vals = self._run_epoch(it, steps_per_epoch, True)
             logs = dict(zip(self.metrics_names, vals))

@@ -1,7 +1,8 @@
-cd /root/repo; mkdir -p gpurun_out/red; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/red -o red -- python3 /root/repo/tools/step_probe.py --only wgrad > /root/repo/gpurun_out/red/probe.txt 2>&1
+R=${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel)}
+cd $R; mkdir -p gpurun_out/red; cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d /tmp/red -o red -- python3 $R/tools/step_probe.py --only wgrad > $R/gpurun_out/red/probe.txt 2>&1
 f=$(find /tmp/red -name "*kernel_trace.csv" | head -1)
-python3 - "$f" <<'PY' > /root/repo/gpurun_out/red/reduce_launches.txt
+python3 - "$f" <<'PY' > $R/gpurun_out/red/reduce_launches.txt
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))

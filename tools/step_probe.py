@@ -4,6 +4,10 @@ launch), with its algorithmic FLOPs / bytes and the per-layer roofline max(flops
     python tools/step_probe.py [--batch 64] [--dtype bfloat16] [--reps 20] [--json out.json]
 
 The table is what DESIGN.md section 3/6 quotes; commit its output under profiles/.
+
+Replaying single launches leaves the BatchNorm statistics / backward sums buffers with several launches' worth of sums (the
+finalize kernels that clear them are not replayed): one whole training step runs at the end so that the model is usable again,
+but do not draw numerical conclusions from a process that ran this probe.
 """
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -86,5 +90,10 @@ for name, pred in (('3x3 fwd+dgrad', lambda r: r['label'].startswith('conv_') an
     us, gf, roof, cnt = tot(pred)
     if cnt:
         print(f"TOTAL {name:14s}: {cnt:3d} launches {us:9.1f} us  {gf / max(us, 1e-9) / 1e3:7.1f} TF/s  sum-of-rooflines {roof:8.1f} us  frac {roof / us:.3f}")
+for t in plan.keep:            # sums buffers are the float64 tensors of the plan: clear them, then one clean step
+    if isinstance(t, torch.Tensor) and t.dtype == torch.float64:
+        t.zero_()
+model.train_step_device(x, y)
+torch.cuda.synchronize()
 if args.json:
     json.dump(dict(args=vars(args), rows=rows), open(args.json, 'w'), indent=1)
