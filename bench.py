@@ -108,6 +108,22 @@ def pmc_traffic_per_launch():
     return None, None
 
 
+def head_commit():
+    """commit of the tree being measured: git when the checkout has its history, else the stamp build() left beside the
+    library (satellite_computervision_amd/_build_commit.txt travels to the GPU box, .git does not)."""
+    import subprocess
+    try:
+        r = subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            return r.stdout.strip()
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, 'satellite_computervision_amd', '_build_commit.txt')).read().strip()
+    except Exception:
+        return 'unknown'
+
+
 def _cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -224,7 +240,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--infer', action='store_true', help='(default) also time bf16 / fp8 inference and the config-5 chip rate, reported under "extra"')
     ap.add_argument('--no-infer', action='store_true', help='skip the inference timings')
-    ap.add_argument('--full-infer', action='store_true', help='also DeepLab-v3 (config 3) inference timings')
+    ap.add_argument('--full-infer', action='store_true', help='(kept for old command lines: the DeepLab-v3 config-3 timings are part of the default run)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -329,8 +345,10 @@ def main():
         extra['infer_fp8_tiles_per_s'] = round(world * B * 10 / (time.perf_counter() - t1), 1)
         model.disable_fp8_inference()
         # BASELINE configs[2]: DeepLab-v3 (ResNet-50 OS16 + the reference's ASPP block), NAIP-like 512x512x4 tiles, inference
-        dl = mt.get_deeplabv3_model(2, 4) if args.full_infer else None
-        for bs in ((1, 16) if args.full_infer else ()):
+        # (batch 1 = the configuration BASELINE names; batch 16 shows what batching the tiles buys.  < 1 s together)
+        mt.reset_uids()
+        dl = mt.get_deeplabv3_model(2, 4)
+        for bs in (1, 16):
             xd = torch.from_numpy((np.random.default_rng(6).integers(0, 256, (bs, 512, 512, 4)) / 255.0).astype(np.float32)).cuda()
             for _ in range(3):
                 dl.predict_on_device(xd)
@@ -362,7 +380,7 @@ def main():
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'loss': 'weighted_categorical_crossentropy',
                        'optimizer': 'adam(9e-4)'},
             'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                         'traffic': traffic, 'traffic_unit': 'MB per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src,
+                         'traffic': traffic, 'traffic_unit': 'MB per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src, 'head_commit': head_commit(),
                          'algorithmic_bytes_per_launch_MB': round(a3['bytes'] / a3['launches'] / 1e6, 1),
                          'algorithmic_gflop_per_step': round(a3['flops'] / 1e9, 1),
                          'kernel': '3x3 implicit-GEMM conv (forward + data gradient)', 'launches_per_step': launches_per_step,

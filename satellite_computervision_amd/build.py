@@ -30,8 +30,22 @@ def _digest(paths):
     return h.hexdigest()
 
 
+def _stamp_commit():
+    """the commit this tree was built at, kept beside the library (the GPU box gets no .git): bench.py reports it next to
+    the commit its PMC traffic summary was measured at."""
+    try:
+        root = os.path.dirname(HERE)
+        r = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            dirty = subprocess.run(['git', '-C', root, 'status', '--porcelain', '--untracked-files=no'], capture_output=True, text=True, timeout=10).stdout.strip()
+            open(os.path.join(HERE, '_build_commit.txt'), 'w').write(r.stdout.strip() + ('+dirty' if dirty else ''))
+    except Exception:
+        pass
+
+
 def build(force=False, verbose=True, extra_flags=(), out=None, objdir=None):
     global OUT, OBJDIR
+    _stamp_commit()
     if out:
         OUT = out
     if objdir:

@@ -553,10 +553,11 @@ def test_config4_13_band_tiles_and_config5_1024_scene(mt):
     assert not got[:64].any() and not got[832:].any() and not got[:, :64].any() and not got[:, 832:].any()
 
 
-@pytest.mark.parametrize('dtype,size', [('float32', 64), ('bfloat16', 128)])
-def test_deeplabv3_resnet50_inference(mt, dtype, size):
+@pytest.mark.parametrize('dtype,size,batch', [('float32', 64, 2), ('bfloat16', 128, 2), ('bfloat16', 512, 1)])
+def test_deeplabv3_resnet50_inference(mt, dtype, size, batch):
     """BASELINE config 3 (build-defined): DeepLab-v3 ResNet-50 (OS16) + the reference's ASPP on NAIP-like 4-band
-    tiles, inference.  Self-consistency against the PyTorch-CPU restatement of the same graph and weights."""
+    tiles, inference -- including the configuration as BASELINE.json names it (512 x 512 x 4, batch 1, bf16).  Self-consistency
+    against the PyTorch-CPU float64 restatement of the same graph and weights."""
     from oracle import torch_unet as TU
     mt.reset_uids(); mt.set_seed(3)
     m = mt.get_deeplabv3_model(3, 4)
@@ -580,11 +581,11 @@ def test_deeplabv3_resnet50_inference(mt, dtype, size):
             plist.append({'kernel': torch.tensor(w[nd.layer.name + '/kernel'], dtype=torch.float64), 'bias': torch.tensor(w[nd.layer.name + '/bias'], dtype=torch.float64),
                           **{k: torch.tensor(w[f'{bn}/{k}'], dtype=torch.float64) for k in ('gamma', 'beta', 'moving_mean', 'moving_var')}})
     head = (torch.tensor(w['logits/kernel'], dtype=torch.float64), torch.tensor(w['logits/bias'], dtype=torch.float64))
-    x = (rng.integers(0, 256, (2, size, size, 4)) / 255.0).astype(np.float32)            # NAIP uint8 / 255 (utils/processing.py:601)
+    x = (rng.integers(0, 256, (batch, size, size, 4)) / 255.0).astype(np.float32)        # NAIP uint8 / 255 (utils/processing.py:601)
     with torch.no_grad():
         p_ref, c_ref = TU.deeplab_forward(plist, head, torch.tensor(x, dtype=torch.float64))
     probs, classes = m.predict(x)
-    assert probs.shape == (2, size, size, 3) and classes.shape == (2, size, size) and classes.dtype == np.int32
+    assert probs.shape == (batch, size, size, 3) and classes.shape == (batch, size, size) and classes.dtype == np.int32
     p_ref = p_ref.numpy()
     np.testing.assert_allclose(probs, p_ref, atol=2e-4 if dtype == 'float32' else 6e-2)
     srt = np.sort(p_ref, -1)
@@ -592,7 +593,7 @@ def test_deeplabv3_resnet50_inference(mt, dtype, size):
     assert np.array_equal(classes[ok], c_ref.numpy()[ok])
     with pytest.raises(NotImplementedError):
         m.compile(optimizer=mt.Adam(), loss=lambda a, b: mt.weighted_categorical_crossentropy(a, b, [1, 1, 1]))
-        m.train_on_batch(x, np.zeros((2, size, size, 3), np.float32))
+        m.train_on_batch(x, np.zeros((batch, size, size, 3), np.float32))
 
 
 @pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
