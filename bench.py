@@ -311,6 +311,9 @@ def main():
 
     extra = {'loss_last': loss, 'kernel_ms_per_step': {k: round(v['ms'] / args.steps, 3) for k, v in prof.items()},
              'kernel_tflops': {k: round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 1) for k, v in prof.items()}}
+    if dist is not None:
+        extra['grad_exchange'] = {'via': 'satcv_allreduce_grads (C ABI, RCCL)' if parallel.cabi_comm() is not None else f'torch.distributed {dist.get_backend()}',
+                                  'payload': sync.payload, 'bucket_MiB': sync.per * 4 / 2 ** 20, 'calls': parallel._comm['calls']}
     if not args.no_infer:
         xb, _ = pool[0]
         for _ in range(3):
@@ -399,6 +402,7 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier(**BARRIER_KW)
+        parallel.destroy_cabi_comm()
         dist.destroy_process_group()
 
 

@@ -38,7 +38,8 @@ enum { SATCV_F32 = 0, SATCV_BF16 = 1,
                         affine_requant, head_fwd */,
        SATCV_FP8X = 3 /* same NHWC e4m3 activations, but weights packed in 16-channel granules ([tap][K/16][Npad][16]) and
                          the convolution on the block-scaled K=64 MFMA (2x the bf16 rate); needs channels % 64 == 0.
-                         Only pack_weights and conv2d_igemm take it. */ };
+                         Only pack_weights and conv2d_igemm take it. */,
+       SATCV_F64 = 4 /* the statistics rows (satcv_stat_t); only satcv_allreduce takes it */ };
 /* rows of replicated per-channel accumulators (sum rows in order to consume) */
 #define SATCV_STAT_ROWS 32
 
@@ -350,6 +351,33 @@ int satcv_confusion(const int32_t* classes, const float* y_true, int32_t ncls, i
  * step_count itself so that the launch is graph-replayable. */
 int satcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
                     float beta2, float eps, float* state, const float* lr_mul, void* stream);
+
+/* ---------------------------------------------------- data-parallel collectives
+ * The reference has no multi-device code; this is the north-star's data-parallel `Model.fit`
+ * (notebooks/UNET_G4G_2019_solar.ipynb:1267-1275 run on N replicas): one process per GPU, ONE exchange per step -- the
+ * sum of the flat fp32 gradient over the replicas, RCCL over xGMI.  RCCL is bound at run time (dlopen of librccl.so.1, or the
+ * path in SATCV_RCCL_LIB): SATCV_ERR_UNSUPPORTED from every entry point below when it cannot be loaded.
+ *
+ * satcv_comm_unique_id: rank 0 fills 128 bytes and hands them to every rank through any side channel.
+ * satcv_comm_init:      collective over all ranks, on the calling thread's CURRENT device; the handle is owned by the
+ *                       caller and released with satcv_comm_destroy (also collective).  One communicator per device/process.
+ * satcv_allreduce_grads: sum of grads[lo, hi) over the ranks, in place, asynchronous on `stream`, sent in buckets of
+ *                       `bucket_elems` floats cut from the END of the range (reverse-layer order: the layers nearest the loss are
+ *                       final first) inside one RCCL group.  payload SATCV_F32, or SATCV_BF16: the range is rounded to bf16
+ *                       into `scratch` (caller-owned, >= (hi - lo) * 2 bytes), summed in bf16 on the wire (half the bytes: 37 MB
+ *                       instead of 74 MB for get_unet_model(2, 4)) and widened back.  The mean is the optimizer's business
+ *                       (satcv_adam_step's grad_scale = 1 / world).
+ * satcv_allreduce:      in-place sum (average != 0: mean) of `count` elements of SATCV_F32 / SATCV_BF16 / SATCV_F64 -- the
+ *                       BatchNorm statistics rows under SyncBN, loss / confusion-matrix scalars at log points. */
+#define SATCV_COMM_ID_BYTES 128
+typedef struct satcv_comm satcv_comm;
+int satcv_comm_unique_id(void* id128);
+int satcv_comm_init(satcv_comm** comm_out, int32_t rank, int32_t world, const void* id128);
+int satcv_comm_destroy(satcv_comm* comm);
+int satcv_comm_info(const satcv_comm* comm, int32_t* rank, int32_t* world);
+int satcv_allreduce_grads(satcv_comm* comm, float* grads, int64_t lo, int64_t hi, int64_t bucket_elems, int32_t payload,
+                          void* scratch, void* stream);
+int satcv_allreduce(satcv_comm* comm, void* buf, int64_t count, int32_t dtype, int32_t average, void* stream);
 
 /* ------------------------------------------------------- stream utilities */
 int satcv_graph_begin(void* stream);

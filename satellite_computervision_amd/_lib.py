@@ -13,7 +13,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SATCV_LIB') or os.path.join(_HERE, 'libsatcv.so')     # SATCV_LIB: profiling variants only
 
-F32, BF16, FP8, FP8X = 0, 1, 2, 3
+F32, BF16, FP8, FP8X, F64 = 0, 1, 2, 3, 4
 STAT_ROWS = 32
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -119,6 +119,12 @@ _SIGS = {
     'satcv_loss_global_fwd_bwd': (C.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     'satcv_confusion': (C.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
     'satcv_adam_step': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp]),
+    'satcv_comm_unique_id': (C.c_int, [c_vp]),
+    'satcv_comm_init': (C.c_int, [C.POINTER(c_vp), c_i32, c_i32, c_vp]),
+    'satcv_comm_destroy': (C.c_int, [c_vp]),
+    'satcv_comm_info': (C.c_int, [c_vp, C.POINTER(c_i32), C.POINTER(c_i32)]),
+    'satcv_allreduce_grads': (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp]),
+    'satcv_allreduce': (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     'satcv_graph_begin': (C.c_int, [c_vp]),
     'satcv_graph_end': (C.c_int, [c_vp, C.POINTER(c_vp)]),
     'satcv_graph_launch': (C.c_int, [c_vp, c_vp]),

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libsatcv.so')
 OBJDIR = os.path.join(HERE, 'csrc', '_obj')
-SOURCES = ['api.hip', 'conv_igemm.hip', 'conv_igemm_fast.hip', 'conv_igemm_ws.hip', 'conv_wgrad.hip', 'elementwise.hip', 'input_pipeline.hip']
+SOURCES = ['api.hip', 'comm.hip', 'conv_igemm.hip', 'conv_igemm_fast.hip', 'conv_igemm_ws.hip', 'conv_wgrad.hip', 'elementwise.hip', 'input_pipeline.hip']
 EXTRA = []
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-Wno-unused-variable', '-Wno-pass-failed']
@@ -70,9 +70,9 @@ def build(force=False, verbose=True, extra_flags=(), out=None, objdir=None):
             sys.stderr.write(r.stderr[-2000:])
         return obj
 
-    with ThreadPoolExecutor(max_workers=7) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs + ['-ldl']
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stderr[-4000:]}')

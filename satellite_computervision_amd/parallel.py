@@ -39,6 +39,46 @@ def init_from_env(backend=None):
 FORCE = os.environ.get('SATCV_FORCE_COLLECTIVES', '0') == '1'
 
 
+# ---- the C-ABI communicator (include/satcv.h: satcv_comm_*): with the RCCL backend the gradient exchange and the SyncBN means go
+# through libsatcv's own ncclAllReduce wrapper -- what a caller binding the C ABI from the reference side would use -- on a
+# communicator bootstrapped over the default process group.  torch.distributed stays the rendezvous (and the whole path for gloo,
+# i.e. the CPU tests).  SATCV_CABI_COMM=0 keeps everything on torch.distributed.
+CABI_COMM = os.environ.get('SATCV_CABI_COMM', '1') != '0'
+_comm = {'handle': None, 'tried': False, 'calls': 0}
+
+
+def cabi_comm():
+    """opaque satcv_comm* (an int) for the default group on RCCL, created collectively on first use; None otherwise."""
+    if _comm['tried'] or not (CABI_COMM and dist.is_initialized() and dist.get_backend() == 'nccl' and torch.cuda.is_available()):
+        return _comm['handle']
+    import ctypes as C
+    from ._lib import lib
+    _comm['tried'] = True
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ident = (C.c_ubyte * 128)()
+    ok = 1
+    if rank == 0:
+        ok = 1 if lib.satcv_comm_unique_id(ident) == 0 else 0
+    box = [bytes(ident) if ok else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    if box[0] is None:            # RCCL could not be bound by the library on rank 0: every rank stays on torch.distributed
+        return None
+    buf = (C.c_ubyte * 128).from_buffer_copy(box[0])
+    h = C.c_void_p()
+    if lib.satcv_comm_init(C.byref(h), rank, world, buf) != 0:
+        raise RuntimeError('satcv_comm_init: ' + lib.satcv_last_error().decode())
+    _comm['handle'] = h.value
+    return _comm['handle']
+
+
+def destroy_cabi_comm():
+    if _comm['handle'] is not None:
+        from ._lib import lib
+        lib.satcv_comm_destroy(_comm['handle'])
+    _comm['handle'], _comm['tried'] = None, False
+
+
 def world_size(group=None):
     return dist.get_world_size(group) if dist.is_initialized() else 1
 
@@ -52,12 +92,20 @@ def allreduce_mean_(t, group=None):
     """In-place mean over ranks (RCCL has a native AVG; gloo sums then scales)."""
     if not active(group):
         return t
-    if dist.get_backend(group) == 'nccl':
+    comm = cabi_comm() if (group is None and t.is_cuda and t.is_contiguous() and t.dtype in _CABI_DT) else None
+    if comm is not None:
+        from ._lib import lib, check
+        check(lib.satcv_allreduce(comm, t.data_ptr(), t.numel(), _CABI_DT[t.dtype], 1, torch.cuda.current_stream().cuda_stream))
+        _comm['calls'] += 1
+    elif dist.get_backend(group) == 'nccl':
         dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         t.div_(dist.get_world_size(group))
     return t
+
+
+_CABI_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float64: 4}
 
 
 class GradSync:
@@ -70,9 +118,15 @@ class GradSync:
     lie above the highest still-pending offset while the encoder's backward is still running; `__call__` sends what is left
     (the first ~10 MB) and makes the current stream wait for everything."""
 
-    def __init__(self, numel, bucket_bytes=16 << 20, group=None, overlap=True):
+    def __init__(self, numel, bucket_bytes=16 << 20, group=None, overlap=True, payload=None):
         self.group, self.overlap = group, overlap
         per = max(bucket_bytes // 4, 1)
+        self.per = per
+        # wire format of the gradient: fp32 (74.1 MB for get_unet_model(2, 4)) or bf16 (37 MB: rounded, summed in bf16, widened
+        # back; C-ABI communicator only).  SATCV_GRAD_PAYLOAD=bf16 selects it for every GradSync of the process.
+        self.payload = payload or os.environ.get('SATCV_GRAD_PAYLOAD', 'fp32')
+        self._scratch = None
+        self._side_ev = None
         self.bounds = []
         hi = numel
         while hi > 0:
@@ -99,14 +153,48 @@ class GradSync:
             ev = torch.cuda.Event()
             ev.record(cur)
             stream.wait_event(ev)
+        comm = self._comm(flat)
+        if comm is not None:
+            # every whole bucket above lo as ONE range: satcv_allreduce_grads cuts it from the end into the same buckets
+            hi_b = self.bounds[self._next][1]
+            while self._next >= 0 and self.bounds[self._next][0] >= lo:
+                lo_b = self.bounds[self._next][0]
+                self._next -= 1
+            self._send(comm, flat, lo_b, hi_b, run_on)
+            if run_on is not cur:
+                self._side_ev = torch.cuda.Event()
+                self._side_ev.record(run_on)
+            return
         with torch.cuda.stream(run_on):
             while self._next >= 0 and self.bounds[self._next][0] >= lo:
                 a, b = self.bounds[self._next]
                 self._works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                 self._next -= 1
 
+    def _comm(self, flat):
+        return cabi_comm() if (self.group is None and flat.is_cuda and flat.dtype == torch.float32) else None
+
+    def _send(self, comm, flat, a, b, stream):
+        from ._lib import lib, check
+        scratch = None
+        if self.payload == 'bf16':
+            if self._scratch is None or self._scratch.numel() < flat.numel():
+                self._scratch = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+            scratch = self._scratch.data_ptr() + 2 * a
+        check(lib.satcv_allreduce_grads(comm, flat.data_ptr(), a, b, self.per, 1 if scratch else 0, scratch, stream.cuda_stream))
+        _comm['calls'] += 1
+
     def __call__(self, flat):
         if self._active():
+            comm = self._comm(flat)
+            if comm is not None:
+                cur = torch.cuda.current_stream()
+                if self._side_ev is not None:      # ranges already in flight on the weight-gradient stream
+                    cur.wait_event(self._side_ev)
+                    self._side_ev = None
+                if self._next >= 0:
+                    self._send(comm, flat, 0, self.bounds[self._next][1], cur)
+                    self._next = -1
             while self._next >= 0:
                 a, b = self.bounds[self._next]
                 self._works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -228,7 +228,7 @@ x = rng.random((B, 64, 64, 4)).astype(np.float32)
 y = np.eye(2, dtype=np.float32)[(rng.random((B, 64, 64)) < 0.3).astype(np.int64)]
 
 
-def run(sync_on, sync_bn=False, overlap=True):
+def run(sync_on, sync_bn=False, overlap=True, payload=None):
     mt.reset_uids(); mt.set_seed(11)
     m = mt.get_unet_model(2, 4, filters=[32, 64, 128], factors=[2, 2, 2])
     m.compute_dtype = "bfloat16"
@@ -237,6 +237,8 @@ def run(sync_on, sync_bn=False, overlap=True):
     sync = parallel.make_grad_sync(m, bucket_bytes=256 << 10, overlap=overlap) if sync_on else None
     if sync_on:
         assert sync._active() and len(sync.bounds) > 3
+        if payload:
+            sync.payload = payload
     for _ in range(3):
         m.train_step_device(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), sync)
     torch.cuda.synchronize()
@@ -250,8 +252,27 @@ w2, s2 = run(True, sync_bn=True)        # + ReduceOp.AVG of the BatchNorm statis
 w3, s3 = run(True, overlap=False)
 t = torch.arange(8, dtype=torch.float64, device="cuda")
 parallel.allreduce_mean_(t)
+# the exchange went through libsatcv's own communicator (include/satcv.h: satcv_comm_init / satcv_allreduce_grads / satcv_allreduce)
+via_cabi = parallel.cabi_comm() is not None and parallel._comm["calls"] > 10
+# bf16 wire format: a one-rank sum returns every element rounded to bf16 once (ranges cut into buckets from the end, ragged tail)
+import ctypes as C
+from satellite_computervision_amd._lib import lib, check
+g = torch.randn(100003, device="cuda")
+ref = g.clone()
+ref[7:100001] = ref[7:100001].bfloat16().float()
+scratch = torch.empty(100003, dtype=torch.bfloat16, device="cuda")
+check(lib.satcv_allreduce_grads(parallel.cabi_comm(), g.data_ptr(), 7, 100001, 4096, 1, scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+g2 = torch.randn(100003, device="cuda"); ref2 = g2.clone()
+check(lib.satcv_allreduce_grads(parallel.cabi_comm(), g2.data_ptr(), 0, 100003, 4096, 0, None, torch.cuda.current_stream().cuda_stream))
+torch.cuda.synchronize()
+rank, world = C.c_int32(-1), C.c_int32(-1)
+check(lib.satcv_comm_info(parallel.cabi_comm(), C.byref(rank), C.byref(world)))
+w4, s4 = run(True, payload="bf16")      # training with the 37 MB payload: close to, not identical with, the fp32 exchange
+close = bool(torch.isfinite(w4).all()) and float((w4 - w0).abs().max()) < 2e-2 and not torch.equal(w4, w0)
 print("RESULT", int(torch.equal(w0, w1)), int(torch.equal(s0, s1)), int(torch.equal(w0, w2)), int(torch.equal(s0, s2)), int(torch.equal(w0, w3)),
-      int(torch.equal(t.cpu(), torch.arange(8, dtype=torch.float64))))
+      int(torch.equal(t.cpu(), torch.arange(8, dtype=torch.float64))), int(via_cabi), int(torch.equal(g, ref)), int(torch.equal(g2, ref2)),
+      int(rank.value == 0 and world.value == 1), int(close))
+parallel.destroy_cabi_comm()
 dist.destroy_process_group()
 '''
 
@@ -261,7 +282,9 @@ def test_rccl_single_rank_path(tmp_path):
     """the RCCL code path on the one GPU a test box has: backend "nccl" with a one-rank communicator and
     SATCV_FORCE_COLLECTIVES=1, so the bucketed async all-reduce on the weight-gradient stream, the stream waits, ReduceOp.AVG
     (SyncBN buffers) and barrier(device_ids=...) all execute.  A one-rank sum / mean is the identity: parameters and moving
-    statistics after three steps must be BIT-IDENTICAL to the run without any exchange."""
+    statistics after three steps must be BIT-IDENTICAL to the run without any exchange.  The exchange runs through the C ABI's own
+    communicator (satcv_comm_init over an id broadcast on the process group, satcv_allreduce_grads, satcv_allreduce); its bf16
+    payload returns each element rounded once.  SATCV_CABI_COMM=0 (second run) keeps the torch.distributed path alive."""
     script = tmp_path / 'rccl_worker.py'
     script.write_text(RCCL_WORKER)
     env = dict(os.environ, REPO=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT='29691', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0',
@@ -269,7 +292,7 @@ def test_rccl_single_rank_path(tmp_path):
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     flags = [int(v) for v in [l for l in r.stdout.splitlines() if l.startswith('RESULT')][0].split()[1:]]
-    assert flags == [1, 1, 1, 1, 1, 1], flags
+    assert flags == [1] * 11, flags
 
 
 @pytest.mark.gpu
