@@ -157,6 +157,35 @@ typedef struct satcv_wgrad_desc {
 int64_t satcv_conv2d_wgrad_workspace(const satcv_wgrad_desc* d);
 int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream);
 
+/* Fused backward of a thin conv -> BatchNormalization -> ReLU block (conv_batch_act, utils/model_tools.py:174-186; Keras autodiff of
+ * Conv2D :178 + BatchNormalization :179 + Activation :180 inside Model.fit): ONE launch replaces satcv_bn_bwd_apply + the data-gradient
+ * satcv_conv2d_igemm + satcv_conv2d_wgrad of the layer.  dy = scale * (g * [scale*y+shift > 0] - c1 - xhat * c2) is formed in
+ * registers from g (gradient w.r.t. the activated output) and yraw (the conv's stored output) with coef = [c1 | c2] from
+ * satcv_bn_bwd_finalize, never written to memory, and used for both products:
+ *     dx (n, h, w, lddx)  = conv3x3(dy, w_dgrad)           w_dgrad: the data-gradient operand image of satcv_pack_weights
+ *     dw (3, 3, cin, cout) [+]= sum_pixels x (x) dy        x = x0 (| x1) with the optional in_scale / in_shift / in_relu of the forward
+ * Limits (else satcv_conv2d_bwd_fused_workspace returns -1 and the caller keeps the three launches): bf16, 3x3, dilation 1, stored input
+ * channels c0 + c1 = cin in {32, 64} with cout 32, or 64 with cout 64, maps of whole 8 x 32 tiles (h % 8 == 0, w_ % 32 == 0), g and yraw
+ * with the same channel stride ldg.  workspace: fp32 partial sums, one slab per resident workgroup (size from the query). */
+typedef struct satcv_bwdf_desc {
+  const void* g; const void* yraw; int32_t ldg;
+  const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_rstd;
+  const float* bn_coef;                /* [2][cout] */
+  int32_t linear;                      /* 1: BatchNormalization without ReLU (no mask) */
+  const void* x0; const void* x1; int32_t c0, c1;
+  const float* in_scale; const float* in_shift; int32_t in_relu;
+  const void* w_dgrad;
+  void* dx; int32_t lddx;
+  float* dw; int32_t cin, cout;
+  int32_t n, h, w_;
+  int32_t kh, kw, dil;
+  float* workspace; int64_t workspace_bytes;
+  int32_t dtype;
+  int32_t accumulate;                  /* dw += result (shared weights) */
+} satcv_bwdf_desc;
+int64_t satcv_conv2d_bwd_fused_workspace(const satcv_bwdf_desc* d);
+int satcv_conv2d_bwd_fused(const satcv_bwdf_desc* d, void* stream);
+
 /* --------------------------------------------------------------- batch norm
  * layers.BatchNormalization (utils/model_tools.py:179,308,313,316): eps, momentum as given.
  * Training: consume the [ROWS][2][ld] sum/sumsq rows (and zero them), produce per-channel
@@ -384,7 +413,8 @@ int satcv_graph_begin(void* stream);
 int satcv_graph_end(void* stream, void** graph_exec_out);
 int satcv_graph_launch(void* graph_exec, void* stream);
 int satcv_graph_destroy(void* graph_exec);
-/* event pairs recorded around every igemm launch while enabled; total ms + count returned */
+/* event pairs recorded around every igemm launch while enabled; total ms + count returned.  kind (bit of kind_mask): 0 = 3x3 conv
+ * forward / data gradient, 1 = 1x1 / transposed-conv GEMMs, 2 = weight gradients, 3 = fused thin-layer backward (data + weight gradient) */
 int satcv_prof_enable(int32_t kind_mask);
 int satcv_prof_collect(int32_t kind, double* total_ms, int64_t* launches, double* flops);
 /* kernel-selection knobs (tests force a tile configuration on small shapes; probes A/B variants in one process).  Keys:

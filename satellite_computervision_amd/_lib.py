@@ -56,6 +56,17 @@ class WgradDesc(C.Structure):
                 ('workspace', c_vp), ('workspace_bytes', c_i64), ('dtype', c_i32), ('accumulate', c_i32), ('whole_chip', c_i32)]
 
 
+class BwdfDesc(C.Structure):
+    _fields_ = [('g', c_vp), ('yraw', c_vp), ('ldg', c_i32),
+                ('bn_scale', c_vp), ('bn_shift', c_vp), ('bn_mean', c_vp), ('bn_rstd', c_vp), ('bn_coef', c_vp), ('linear', c_i32),
+                ('x0', c_vp), ('x1', c_vp), ('c0', c_i32), ('c1', c_i32),
+                ('in_scale', c_vp), ('in_shift', c_vp), ('in_relu', c_i32),
+                ('w_dgrad', c_vp), ('dx', c_vp), ('lddx', c_i32),
+                ('dw', c_vp), ('cin', c_i32), ('cout', c_i32),
+                ('n', c_i32), ('h', c_i32), ('w_', c_i32), ('kh', c_i32), ('kw', c_i32), ('dil', c_i32),
+                ('workspace', c_vp), ('workspace_bytes', c_i64), ('dtype', c_i32), ('accumulate', c_i32)]
+
+
 class BnBwdDesc(C.Structure):
     _fields_ = [('da', c_vp), ('ldda', c_i32), ('dpool', c_vp), ('lddp', c_i32), ('f', c_i32),
                 ('yraw', c_vp), ('ldy', c_i32),
@@ -91,6 +102,8 @@ _SIGS = {
     'satcv_conv2d_igemm_pipelined': (C.c_int, [C.POINTER(ConvDesc)]),
     'satcv_conv2d_wgrad_workspace': (c_i64, [C.POINTER(WgradDesc)]),
     'satcv_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), c_vp]),
+    'satcv_conv2d_bwd_fused_workspace': (c_i64, [C.POINTER(BwdfDesc)]),
+    'satcv_conv2d_bwd_fused': (C.c_int, [C.POINTER(BwdfDesc), c_vp]),
     'satcv_bn_finalize_train': (C.c_int, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32,
                                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'satcv_bn_affine_infer': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp]),

@@ -82,8 +82,8 @@ extern "C" int satcv_graph_destroy(void* graph_exec) {
 
 // -------------------------------------------------------------------- profiling
 // kind 0: 3x3 (and dilated) implicit-GEMM conv fwd/dgrad; 1: 1x1 / transposed-conv GEMMs;
-// 2: weight-gradient kernel.
-#define PROF_KINDS 3
+// 2: weight-gradient kernel; 3: fused thin-layer backward (BatchNorm apply + data gradient + weight gradient).
+#define PROF_KINDS 4
 struct ProfRec { hipEvent_t a, b; double flops; };
 static std::mutex g_prof_mu;
 static int g_prof_mask = 0;

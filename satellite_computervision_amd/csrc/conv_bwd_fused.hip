@@ -1,0 +1,441 @@
+// Fused backward of a THIN conv -> BatchNorm -> ReLU block (utils/model_tools.py:174-186 at decoder levels 0 and 1): ONE launch does what
+// satcv_bn_bwd_apply + the data gradient + the weight gradient did in three.
+//
+// Why: on the full- and half-resolution levels every one of those three kernels already runs near the HBM rate it can reach, and together
+// they move the layer's tensors 7 times (apply: g, y in, dy out; data gradient: dy in, dx out; weight gradient: dy, x in).  Only fusion
+// removes traffic: here a workgroup loads g, y (the layer's output gradient and raw output) and x (its input) once per 8 x 32 tile,
+// forms dy = scale * (g * mask - c1 - xhat * c2) in registers (never stored to HBM), and uses the dy tile twice from LDS:
+//   * data gradient   dx[p][ci]       = sum_tap sum_co dy[p + 1 - tap][co] * W[tap][ci][co]     (A = dy halo tile, row reads; B = weights)
+//   * weight gradient dW[tap][ci][co] += sum_q x[q][ci] * dy[q + 1 - tap][co]                   (A = x, B = dy, transposing reads)
+// The weight gradient is summed over the interior pixels q of the tile against the SHIFTED dy halo (instead of over dy's interior
+// against an x halo): the sum over all tiles covers every (x, dy) pair once, and the halo of dy is there for the data gradient anyway.
+// 4 tensor passes (g, y, x in; dx out) instead of 7.  One LDS image of dy serves both products: [slot][row][pitch][8] planes, read by
+// rows (ds_read_b128) for the data gradient and transposed (ds_read_b64_tr_b16) for the weight gradient; the plane stride is 64 B
+// modulo 256 B, which keeps the four 64-byte segments of a transposing read on distinct banks.
+// PERSISTENT workgroups: the data-gradient weights sit in LDS for the whole launch, the weight-gradient accumulators (each wave owns
+// whole (ci-tile, co-tile, tap) products) live in registers across all tiles of the workgroup and leave as ONE fp32 slab per workgroup,
+// summed by the weight-gradient reduce kernel in fixed order.  The next tile's loads are in flight during the MFMA phases.
+#include "igemm_common.hpp"
+#include <cstdlib>
+#include <cstring>
+
+int wgrad_reduce_slabs(const float* ws, float* dw, int nslab, int taps, int kpad, int npad, int cin, int nvalid, int accumulate, hipStream_t st);   // conv_wgrad.hip
+void satcv_prof_begin(int kind, double flops, hipStream_t st);
+void satcv_prof_end(int kind, hipStream_t st);
+
+struct BwdfArgs {
+  IgemmArgs e;                                   // the data gradient's output side, as the shared epilogue reads it (y = dx, ldy, n, h, w_, cout = CIN)
+  const void* g; const void* yraw; int ldg;      // gradient w.r.t. the activated output, raw conv output (same channel stride)
+  const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_rstd; const float* bn_coef; int bn_c, linear;
+  const void* x0; const void* x1; int c0, c1;
+  const float* in_scale; const float* in_shift; int in_relu;
+  const void* w;                                 // data-gradient operand image [tap][COUT/8][CIN][8] (taps flipped: satcv_pack_weights mode 1)
+  float* ws;                                     // [gridDim.x][9][CIN][COUT] partial weight gradients
+  int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ bf16x4 tr_read4(const bf16* p) {
+  short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(p));
+  return __builtin_bit_cast(bf16x4, v);
+}
+
+// WPS = waves per SIMD the registers are budgeted for: 2 (256 registers; 4 waves x 2 workgroups per CU, or 8 waves x 1), or 1 for
+// 64 -> 64 channels, whose 36 weight-gradient accumulator tiles + in-flight tile do not fit 256 registers at any wave count
+template <int CIN, int COUT, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs a, const int total_tiles) {
+  typedef bf16 T;
+  constexpr int TW = 32, TH = 8, BM = 256, RL = TH + 2, CL = TW + 2, PITCH = CL, EL = 8, NTHREADS = NW * 64;
+  constexpr int SD = COUT / 8, SX = CIN / 8;                     // 16-byte channel slots of dy / x
+  constexpr int DSTRIDE = RL * PITCH * EL;                       // 5,440 B = 64 B modulo 256 B
+  constexpr int XSTRIDE = BM * EL + 32;                          // 4,096 B + 64 B
+  static_assert((DSTRIDE * 2) % 256 == 64 && (XSTRIDE * 2) % 256 == 64, "plane strides must be 64 B modulo 256 B");
+  constexpr int D_ITEMS = RL * CL * SD, DI = (D_ITEMS + NTHREADS - 1) / NTHREADS;
+  constexpr int X_ITEMS = BM * SX, XI = X_ITEMS / NTHREADS;
+  static_assert(X_ITEMS % NTHREADS == 0 && NTHREADS % SD == 0 && NTHREADS % SX == 0, "item -> thread mapping");
+  constexpr int XPIX_STEP = NTHREADS / SX;                       // interior pixels between two x items of a thread (a multiple of 32: same column)
+  static_assert(XPIX_STEP % 32 == 0, "x items of a thread must share a column");
+  constexpr int MT = 8 / NW, NT = CIN / 32;                      // data gradient: wave tile (MT x 32 pixels) x CIN
+  constexpr int NTILE = (CIN / 32) * (COUT / 32) * 9, WT = (NTILE + NW - 1) / NW;   // weight gradient: (ci-tile, co-tile, tap) products per wave
+  constexpr int W_ITEMS = 9 * SD * CIN;
+  constexpr size_t R0_BYTES = ((size_t)(SD * DSTRIDE + SX * XSTRIDE) * sizeof(T) + 127) / 128 * 128;
+  constexpr size_t W_BYTES = (size_t)W_ITEMS * EL * sizeof(T);
+  static_assert((size_t)BM * (CIN + 8) * sizeof(T) + 5 * 2 * CIN * sizeof(float) <= R0_BYTES, "output staging must fit the tile region");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* ldsD = reinterpret_cast<T*>(smem_raw);                                   // dy halo planes
+  T* ldsX = ldsD + SD * DSTRIDE;                                              // x interior planes
+  T* ldsW = reinterpret_cast<T*>(smem_raw + R0_BYTES);                        // [tap][SD][CIN][8], resident
+  float* tabD = reinterpret_cast<float*>(smem_raw + R0_BYTES + W_BYTES);      // [SD][4][8]: scale, shift, B, C of the BatchNorm backward
+  float* tabX = tabD + SD * 32;                                               // [SX][2][8]: scale, shift of the input's BatchNorm
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const T* wp = reinterpret_cast<const T*>(a.w);
+
+  // ---- once per workgroup: weights and the per-channel tables
+  for (int it = tid; it < W_ITEMS; it += NTHREADS) lstore8<T>(ldsW + (size_t)it * EL, gload8<T>(wp + (size_t)it * EL));
+  for (int ch = tid; ch < COUT; ch += NTHREADS) {
+    // dy = sc * (gm - c1 - xhat * c2), xhat = (y - mu) * rs   ==   sc * gm + B * y + C
+    const float sc = a.bn_scale[ch], sh = a.bn_shift[ch], mu = a.bn_mean[ch], rs = a.bn_rstd[ch], c1 = a.bn_coef[ch], c2 = a.bn_coef[a.bn_c + ch];
+    float* t = tabD + (ch >> 3) * 32 + (ch & 7);
+    t[0] = sc; t[8] = sh; t[16] = -sc * c2 * rs; t[24] = sc * (c2 * rs * mu - c1);
+  }
+  for (int ch = tid; ch < CIN; ch += NTHREADS) {
+    float* t = tabX + (ch >> 3) * 16 + (ch & 7);
+    t[0] = a.in_scale ? a.in_scale[ch] : 1.f; t[8] = a.in_scale ? a.in_shift[ch] : 0.f;
+  }
+  const float lin_lo = a.linear ? -INFINITY : 0.f;
+  const bool xaff = a.in_scale != nullptr;
+  const unsigned xrelu_lim = a.in_relu != 0 ? 0u : 0x80008000u;
+
+  // ---- staged items of this thread (tile-invariant): dy halo items (g and y at one halo pixel, 8 channels), x interior items
+  const int slot_d = tid % SD, slot_x = tid % SX;
+  // (halo row and column of an item packed in 10 bits, three items per register; the LDS destination and the source offset are
+  //  re-derived where they are used, with 24-bit multiplies: the kernel sits at the 256-register cap of two waves per SIMD and every
+  //  spilled value is reloaded by a scratch load that queues behind the prefetched tile on the in-order vmcnt counter)
+  constexpr int DPK = (DI + 2) / 3;
+  unsigned d_pk[DPK];
+#pragma unroll
+  for (int k = 0; k < DPK; ++k) d_pk[k] = 0;
+#pragma unroll
+  for (int j = 0; j < DI; ++j) {
+    const int it = tid + j * NTHREADS;
+    const int p = it / SD, c = p % CL, L = p / CL;
+    d_pk[j / 3] |= (unsigned)(it < D_ITEMS ? (L << 6) | c : 0x3ff) << (10 * (j % 3));
+  }
+  auto d_item = [&](int j) -> int { return (int)((d_pk[j / 3] >> (10 * (j % 3))) & 0x3ffu); };      // 0x3ff: no such item
+  const int g_rowstride = a.e.w_ * a.ldg;
+  // g and y are addressed as (wave-uniform halo-origin pointer of the tile) + (unsigned 32-bit lane offset): no 64-bit lane pointers
+  const unsigned gy_lane = (unsigned)slot_d * EL;
+  const int xch0 = slot_x * EL;
+  const bool xsecond = xch0 >= a.c0;
+  const T* xsrc = xsecond ? reinterpret_cast<const T*>(a.x1) + (xch0 - a.c0) : reinterpret_cast<const T*>(a.x0) + xch0;
+  const int xcs = xsecond ? a.c1 : a.c0;
+  const int xq0 = tid / SX;                                                   // first interior pixel of this thread
+  const int x_l0 = slot_x * XSTRIDE + xq0 * EL;
+  const int x_eoff0 = ((xq0 / TW) * a.e.w_ + (xq0 % TW)) * xcs, x_estep = (XPIX_STEP / TW) * a.e.w_ * xcs;
+
+  // ---- fragment addressing
+  int a_off[MT];                                                              // data gradient A operand: halo-image pixel of this lane's row
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int q = (wave * MT + m) * 32 + r;
+    a_off[m] = ((q / TW) * PITCH + (q % TW)) * EL;
+  }
+  // transposing reads (weight gradient): a 16-lane group reads 4 pixels x 16 channels; lane -> (plane, half item, pixel)
+  const int gi = lane >> 4, i16 = lane & 15;
+  const int chb = 16 * (gi & 1) + 4 * (i16 & 3);
+  const int pk = 8 * (gi >> 1) + (i16 >> 2);
+  const int tr_x = (chb >> 3) * XSTRIDE + pk * EL + (chb & 7);
+  const int tr_d = (chb >> 3) * DSTRIDE + pk * EL + (chb & 7);
+
+  auto tile_origin = [&](int v, int& n0, int& y0, int& x0) {
+    const int tx = v % a.tiles_x; v /= a.tiles_x;
+    const int ty = v % a.tiles_y;
+    n0 = v / a.tiles_y; y0 = ty * TH; x0 = tx * TW;
+  };
+  auto next_origin = [&](int& n0, int& y0, int& x0) {
+    x0 += TW;
+    if (x0 >= a.e.w_) { x0 = 0; y0 += TH; if (y0 >= a.e.h) { y0 = 0; ++n0; } }
+  };
+  Raw8<T> rg[DI], ry[DI], rx[XI];
+  unsigned valid = 0;
+  auto issue_loads = [&](int n0, int y0, int x0) -> unsigned {
+    unsigned vm = 0;
+    const int ylo = 1 - y0, yhi = a.e.h - y0 + 1, xlo = 1 - x0, xhi = a.e.w_ - x0 + 1;      // limits of the halo row / column inside the image
+    const long long bp = ((long long)(n0 * a.e.h + y0 - 1) * a.e.w_ + (x0 - 1)) * a.ldg;       // halo origin (may lie before the tensor: never dereferenced)
+    const T* gb = reinterpret_cast<const T*>(a.g) + bp;
+    const T* yb = reinterpret_cast<const T*>(a.yraw) + bp;
+    const unsigned centre = (unsigned)(g_rowstride + a.ldg) + gy_lane;                         // the tile's first pixel: always inside
+#pragma unroll
+    for (int j = 0; j < DI; ++j) {
+      const int pk_ = d_item(j), L = pk_ >> 6, c = pk_ & 63;
+      const bool ok = pk_ != 0x3ff && L >= ylo && L < yhi && c >= xlo && c < xhi;
+      vm |= (ok ? 1u : 0u) << j;
+      unsigned off = ok ? (unsigned)(__mul24(L, g_rowstride) + __mul24(c, a.ldg)) + gy_lane : centre;   // (outside: a valid pixel, zeroed at the LDS store)
+      asm volatile("" : "+v"(off));
+      rg[j] = gload8<T>(gb + off);
+      ry[j] = gload8<T>(yb + off);
+    }
+    return vm;
+  };
+  auto issue_x = [&](int n0, int y0, int x0) {
+    const size_t bp = (size_t)(n0 * a.e.h + y0) * a.e.w_ + x0;
+    const T* xb = xsrc + bp * xcs + x_eoff0;
+#pragma unroll
+    for (int j = 0; j < XI; ++j) rx[j] = gload8<T>(xb + (size_t)j * x_estep);
+  };
+
+  // ---- XCD-aware contiguous tile ranges (conv_igemm_ws.hip)
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, nx = G >> 3, remx = G & 7;
+  const int bid = (xcd < remx ? xcd * (nx + 1) : remx * (nx + 1) + (xcd - remx) * nx) + (blockIdx.x >> 3);
+  const int per = total_tiles / G, extra = total_tiles % G;
+  const int t_lo = bid * per + (bid < extra ? bid : extra), t_hi = t_lo + per + (bid < extra ? 1 : 0);
+
+  // weight-gradient products of this wave: id = wave + t * NW  ->  (tap, ci-tile, co-tile); scalar LDS offsets of their operands
+  f32x16 wacc[WT];
+  int w_xo[WT], w_do[WT];
+#pragma unroll
+  for (int t = 0; t < WT; ++t) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wacc[t][i] = 0.f;
+    const int id = __builtin_amdgcn_readfirstlane(wave) + t * NW;
+    const int tap = id % 9, pair = id / 9;
+    const int ci_t = pair % (CIN / 32), co_t = pair / (CIN / 32);
+    w_xo[t] = ci_t * 4 * XSTRIDE;
+    w_do[t] = co_t * 4 * DSTRIDE + ((2 - tap / 3) * PITCH + (2 - tap % 3)) * EL;      // dy[q + 1 - tap] in halo coordinates: q + 2 - tap
+  }
+
+  int n0, y0, x0;
+  if (t_lo < t_hi) { tile_origin(t_lo, n0, y0, x0); valid = issue_loads(n0, y0, x0); issue_x(n0, y0, x0); }
+  __syncthreads();                                                            // weights and tables are in LDS
+  for (int t = t_lo; t < t_hi; ++t) {
+    // ---- registers -> LDS: dy from (g, y) with the BatchNorm-backward coefficients, zero outside the image; x with its BatchNorm + ReLU
+    {
+      // this thread's 8 channels: scale, shift, B, C -- read once per tile (the opaque offset keeps the 32 values from being hoisted out
+      // of the tile loop, where they would stay live through the MFMA phases)
+      int toff = slot_d * 32;
+      asm volatile("" : "+v"(toff));
+      const float4* tp = reinterpret_cast<const float4*>(tabD + toff);
+      float prm[32];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float4 v4 = tp[k]; prm[4 * k] = v4.x; prm[4 * k + 1] = v4.y; prm[4 * k + 2] = v4.z; prm[4 * k + 3] = v4.w; }
+#pragma unroll
+      for (int j = 0; j < DI; ++j) {
+        float gv[8], yv[8];
+        unpack8<T>(rg[j], gv);
+        unpack8<T>(ry[j], yv);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float act = yv[e] * prm[e] + prm[8 + e];
+          const float gm = act > lin_lo ? gv[e] : 0.f;
+          o[e] = (bf16)(prm[e] * gm + (prm[16 + e] * yv[e] + prm[24 + e]));
+        }
+        Raw8<T> v;
+        v.q[0] = __builtin_bit_cast(uint4, o);
+        v = select8<T>((valid >> j) & 1u, v);
+        const int pk_ = d_item(j);
+        if (pk_ != 0x3ff) lstore8<T>(ldsD + slot_d * DSTRIDE + __mul24((pk_ >> 6) * CL + (pk_ & 63), EL), v);
+        __builtin_amdgcn_sched_barrier(0);                                    // (one item's unpacked values at a time)
+      }
+    }
+    {
+      float sc[8], sh[8];
+      if (xaff) {
+        int toff = slot_x * 16;
+        asm volatile("" : "+v"(toff));
+        const float4* tp = reinterpret_cast<const float4*>(tabX + toff);
+        const float4 s0 = tp[0], s1 = tp[1], h0 = tp[2], h1 = tp[3];
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+        sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+      }
+#pragma unroll
+      for (int j = 0; j < XI; ++j) {
+        Raw8<T> v = rx[j];
+        if (xaff) v = affine8_lim(v, sc, sh, xrelu_lim);
+        lstore8<T>(ldsX + x_l0 + j * (XPIX_STEP * EL), v);
+      }
+    }
+    __syncthreads();
+    // ---- the next tile's loads: in flight during this tile's MFMA phases and epilogue
+    const int tn0 = n0, ty0 = y0, tx0 = x0;
+    if (t + 1 < t_hi) { next_origin(n0, y0, x0); valid = issue_loads(n0, y0, x0); }
+
+    // ---- weight gradient: K = the 256 interior pixels, 16 per step (half a tile row); x by transposing reads, dy likewise at the tap's shift
+    // (product-major: the 16 k-steps of one (ci-tile, co-tile, tap) product run as one software-pipelined chain on its accumulator --
+    //  the fragment reads of step k + 1 are issued before the MFMA of step k and pinned there, so the LDS latency is exposed once per
+    //  product, not once per step; a wave's products are id = wave + tt * NW, only the last of which can fall beyond NTILE)
+#pragma unroll
+    for (int tt = 0; tt < WT; ++tt) {
+      if (tt < WT - 1 || __builtin_amdgcn_readfirstlane(wave) + (WT - 1) * NW < NTILE) {
+        const T* xa = ldsX + w_xo[tt] + tr_x;
+        const T* da = ldsD + w_do[tt] + tr_d;
+        // (a real loop over groups of four k-steps = two tile rows, the prefetched fragments carried across its iterations: fully unrolled,
+        //  the 48 MFMA blocks of a wave cost ~20 registers more than the kernel has; the read issued by the last step wraps to step 0
+        //  and is discarded)
+        bf16x4 fa[2][2], fb[2][2];
+        auto read_k = [&](const T* xp, const T* dp, int u, int buf) {           // u: k-step inside the group
+          const int xq = u * 16 * EL, dq = ((u >> 1) * PITCH + (u & 1) * 16) * EL;
+          fa[buf][0] = tr_read4(xp + xq); fa[buf][1] = tr_read4(xp + xq + 4 * EL);
+          fb[buf][0] = tr_read4(dp + dq); fb[buf][1] = tr_read4(dp + dq + 4 * EL);
+        };
+        read_k(xa, da, 0, 0);
+#pragma unroll 1
+        for (int grp = 0; grp < TH / 2; ++grp) {
+          const T* xp = xa + grp * (64 * EL);
+          const T* dp = da + grp * (2 * PITCH * EL);
+          const int wrap = grp + 1 < TH / 2 ? 1 : 1 - TH / 2;                     // next group, or back to the first after the last
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            asm volatile("" ::: "memory");
+            if (u < 3) read_k(xp, dp, u + 1, (u + 1) & 1);
+            else read_k(xp + wrap * (64 * EL), dp + wrap * (2 * PITCH * EL), 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 afr = __builtin_shufflevector(fa[u & 1][0], fa[u & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 bfr = __builtin_shufflevector(fb[u & 1][0], fb[u & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            wacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, wacc[tt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // (the next tile's x items are requested here rather than with g and y: 16 registers less through the weight-gradient phase)
+    if (t + 1 < t_hi) issue_x(n0, y0, x0);
+    // ---- data gradient (after the weight gradient: its accumulators are then live only from here to the epilogue): 9 taps x COUT / 16 k-steps on the dy halo image (conv_igemm_ws.hip's loop with dy as the input)
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    {
+      constexpr int KS = COUT / 16, STEPS = 9 * KS;
+      FragT<T> af[2][MT], bf[2][NT];
+      auto read_step = [&](int st, int buf) {
+        const int tap = st / KS, ks = st % KS;
+        const int tap_off = ((tap / 3) * PITCH + (tap % 3)) * EL;
+        const int slot = ks * 2 + hh;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[buf][m] = lds_frag<T>(ldsD + slot * DSTRIDE + a_off[m] + tap_off);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[buf][n] = lds_frag<T>(ldsW + ((tap * SD + slot) * CIN + n * 32 + r) * EL);
+      };
+      read_step(0, 0);
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        asm volatile("" ::: "memory");
+        if (st + 1 < STEPS) read_step(st + 1, (st + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) mma32<T>(acc[m][n], af[st & 1][m], bf[st & 1][n]);
+      }
+    }
+    __syncthreads();                                                          // every wave is past its last fragment read: the tile region is free
+    {
+      // dx tile: accumulators -> bf16 -> LDS [pixel][CIN + 8] -> 16-byte row stores (the shared igemm_epilogue's interior path without
+      // its statistics / bias / pooling branches: their live state cost this kernel ~30 registers it does not have)
+      constexpr int OPITCH = CIN + 8, VPR = CIN / 8;
+      T* ldsO = reinterpret_cast<T*>(smem_raw);
+      T* op = ldsO + ((wave * MT) * 32 + 4 * hh) * OPITCH + r;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) op[(m * 32 + (i & 3) + 8 * (i >> 2)) * OPITCH + n * 32] = (T)acc[m][n][i];
+      __syncthreads();
+      const int vq = tid % VPR;                                               // this thread's 16-byte column group (NTHREADS % VPR == 0)
+      T* yp = reinterpret_cast<T*>(a.e.y) + ((size_t)(tn0 * a.e.h + ty0) * a.e.w_ + tx0) * a.e.ldy + vq * 8;
+      const unsigned row_pitch = (unsigned)a.e.w_ * a.e.ldy;
+#pragma unroll 2
+      for (int it = tid; it < BM * VPR; it += NTHREADS) {
+        const int q = it / VPR;
+        *reinterpret_cast<uint4*>(yp + (size_t)((q / TW) * row_pitch + (q % TW) * (unsigned)a.e.ldy)) = *reinterpret_cast<const uint4*>(ldsO + q * OPITCH + vq * 8);
+      }
+    }
+    __syncthreads();                                                          // staged output read out before the next tile is written
+  }
+  // ---- this workgroup's partial weight gradient: ws[block][tap][ci][co]
+#pragma unroll
+  for (int tt = 0; tt < WT; ++tt) {
+    const int id = __builtin_amdgcn_readfirstlane(wave) + tt * NW;
+    if (id < NTILE) {
+      const int tap = id % 9, pair = id / 9;
+      const int ci_t = pair % (CIN / 32), co_t = pair / (CIN / 32);
+      float* dst = a.ws + ((size_t)(blockIdx.x * 9 + tap) * CIN + ci_t * 32) * COUT + co_t * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dst[(size_t)((i & 3) + 8 * (i >> 2) + 4 * hh) * COUT] = wacc[tt][i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+template <int CIN, int COUT, int NW>
+struct BwdfGeom {
+  static constexpr int SD = COUT / 8, SX = CIN / 8;
+  static constexpr size_t R0 = ((size_t)(SD * (10 * 34 * 8) + SX * (256 * 8 + 32)) * 2 + 127) / 128 * 128;
+  static constexpr size_t LDS = R0 + (size_t)9 * SD * CIN * 16 + (size_t)(SD * 32 + SX * 16) * 4;
+};
+
+static int g_ncu = 0;
+static int bwdf_grid(size_t lds, int waves, int wps, long long total) {
+  if (!g_ncu) {
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return -1;
+    g_ncu = p.multiProcessorCount;
+  }
+  int per_cu = (int)((160 * 1024) / lds);
+  const int by_waves = 4 * wps / waves;                             // wps waves per SIMD
+  if (per_cu > by_waves) per_cu = by_waves;
+  if (per_cu < 1) per_cu = 1;
+  long long grid = (long long)g_ncu * per_cu;
+  if (grid > total) grid = total;
+  return (int)grid;
+}
+
+static bool bwdf_shape_ok(const satcv_bwdf_desc* d, int& cin_s) {
+  cin_s = d->c0 + d->c1;
+  if (d->dtype != SATCV_BF16 || d->kh != 3 || d->kw != 3 || d->dil != 1) return false;
+  if (!((cin_s == 32 && d->cout == 32) || (cin_s == 64 && d->cout == 32) || (cin_s == 64 && d->cout == 64))) return false;
+  if (d->cin != cin_s) return false;                                // real == stored input channels (the slab has no padding rows)
+  if (d->x1 && d->c0 % 8 != 0) return false;
+  if (d->h % 8 != 0 || d->w_ % 32 != 0) return false;               // whole 8 x 32 tiles
+  if (d->ldg % 8 != 0 || d->lddx % 8 != 0 || ((uintptr_t)d->dx % 16) != 0 || ((uintptr_t)d->g % 16) != 0 || ((uintptr_t)d->yraw % 16) != 0) return false;
+  if ((long long)d->w_ * d->ldg >= (1 << 23)) return false;         // 24-bit multiplies of the halo offsets
+  return true;
+}
+
+template <int CIN, int COUT, int NW, int WPS>
+static int bwdf_launch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int64_t* ws_bytes) {
+  using G = BwdfGeom<CIN, COUT, NW>;
+  static_assert(G::LDS <= 160 * 1024, "tile + weights exceed the LDS");
+  const long long total = (long long)d->n * (d->h / 8) * (d->w_ / 32);
+  const int grid = bwdf_grid(G::LDS, NW, WPS, total);
+  if (grid <= 0) { satcv_set_error("bwd_fused: device query failed"); return SATCV_ERR_HIP; }
+  const size_t need = (size_t)grid * 9 * CIN * COUT * sizeof(float);
+  if (query) { *ws_bytes = (int64_t)need; return SATCV_OK; }
+  SATCV_CHECK((size_t)d->workspace_bytes >= need, "bwd_fused: workspace %lld < %zu", (long long)d->workspace_bytes, need);
+  BwdfArgs a;
+  memset(&a, 0, sizeof(a));
+  a.e.y = d->dx; a.e.ldy = d->lddx; a.e.n = d->n; a.e.h = d->h; a.e.w_ = d->w_; a.e.cout = CIN; a.e.cout_pad = CIN; a.e.cstat = CIN;
+  a.e.imgs = 1; a.e.rpi = 8; a.e.tiles_x = d->w_ / 32; a.e.tiles_y = d->h / 8; a.e.n_tiles = 1;
+  a.g = d->g; a.yraw = d->yraw; a.ldg = d->ldg;
+  a.bn_scale = d->bn_scale; a.bn_shift = d->bn_shift; a.bn_mean = d->bn_mean; a.bn_rstd = d->bn_rstd; a.bn_coef = d->bn_coef; a.bn_c = d->cout; a.linear = d->linear;
+  a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_relu = d->in_relu;
+  a.w = d->w_dgrad; a.ws = d->workspace; a.tiles_x = d->w_ / 32; a.tiles_y = d->h / 8;
+  auto kern = bwd_fused_kernel<CIN, COUT, NW, WPS>;
+  { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS); if (rc) return rc; }
+  const double flops = 4.0 * d->n * d->h * d->w_ * (double)CIN * COUT * 9;          // data gradient + weight gradient
+  satcv_prof_begin(3, flops, st);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), G::LDS, st, a, (int)total);
+  satcv_prof_end(3, st);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { satcv_set_error("bwd_fused launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  return wgrad_reduce_slabs(d->workspace, d->dw, grid, 9, CIN, COUT, d->cin, COUT, d->accumulate, st);
+}
+
+static int bwdf_dispatch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int64_t* ws_bytes) {
+  int cin_s;
+  if (!bwdf_shape_ok(d, cin_s)) return SATCV_ERR_UNSUPPORTED;
+  if (cin_s == 32) return bwdf_launch<32, 32, 4, 2>(d, st, query, ws_bytes);
+  if (d->cout == 32) return bwdf_launch<64, 32, 8, 2>(d, st, query, ws_bytes);
+  return bwdf_launch<64, 64, 4, 1>(d, st, query, ws_bytes);
+}
+
+extern "C" int64_t satcv_conv2d_bwd_fused_workspace(const satcv_bwdf_desc* d) {
+  int64_t nb = -1;
+  if (!d || bwdf_dispatch(d, nullptr, true, &nb) != SATCV_OK) return -1;
+  return nb;
+}
+
+extern "C" int satcv_conv2d_bwd_fused(const satcv_bwdf_desc* d, void* stream) {
+  SATCV_CHECK(d && d->g && d->yraw && d->x0 && d->w_dgrad && d->dx && d->dw && d->workspace, "bwd_fused: null pointer");
+  SATCV_CHECK(d->bn_scale && d->bn_shift && d->bn_mean && d->bn_rstd && d->bn_coef, "bwd_fused: BatchNorm coefficients missing");
+  SATCV_CHECK((d->c1 == 0) == (d->x1 == nullptr) && d->n > 0 && d->h > 0 && d->w_ > 0, "bwd_fused: bad dims");
+  const int rc = bwdf_dispatch(d, reinterpret_cast<hipStream_t>(stream), false, nullptr);
+  if (rc == SATCV_ERR_UNSUPPORTED) satcv_set_error("bwd_fused: shape outside the kernel's limits (ask satcv_conv2d_bwd_fused_workspace first)");
+  return rc;
+}

@@ -12,6 +12,7 @@
 // in fixed order (deterministic) into the Keras-layout gradient.
 #include "common.hpp"
 #include <cstdlib>
+#include <cstring>
 
 // compile-time ablation for profiling builds (-DSATCV_WABLATE=bits): 1 skip the global loads, 2 skip the MFMAs, 4 read every
 // fragment from LDS offset 0 (no address arithmetic / bank pattern), 8 skip the LDS staging stores
@@ -1068,6 +1069,17 @@ static int wgrad_reduce_launch(const satcv_wgrad_desc* d, const WgradPlan& p, fl
 
 void satcv_prof_begin(int kind, double flops, hipStream_t st);
 void satcv_prof_end(int kind, hipStream_t st);
+
+// slab sum for other producers of [nslab][taps][kpad][npad] partial weight gradients (conv_bwd_fused.hip): plain HWIO layout
+int wgrad_reduce_slabs(const float* ws, float* dw, int nslab, int taps, int kpad, int npad, int cin, int nvalid, int accumulate, hipStream_t st) {
+  satcv_wgrad_desc d;
+  memset(&d, 0, sizeof(d));
+  d.workspace = const_cast<float*>(ws); d.cin = cin; d.accumulate = accumulate; d.transposed = 0;
+  WgradPlan p;
+  memset(&p, 0, sizeof(p));
+  p.nsplit = nslab; p.ntaps = taps; p.kpad = kpad; p.npad = npad;
+  return wgrad_reduce_launch(&d, p, dw, nvalid, st);
+}
 
 extern "C" int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream) {
   SATCV_CHECK(d && d->x0 && d->dy && d->dw && d->workspace, "wgrad: null pointer");

@@ -176,6 +176,42 @@ def make_wgrad_desc(*, x0, c0, dy, lddy, dw, cin, cout, n, h, w_, dtype, x1=None
     return d
 
 
+def make_bwdf_desc(*, g, yraw, ldg, bn_scale, bn_shift, bn_mean, bn_rstd, bn_coef, x0, c0, w_dgrad, dx, lddx, dw, cin, cout, n, h, w_, dtype,
+                   linear=0, x1=None, c1=0, in_scale=None, in_shift=None, in_relu=0, kh=3, kw=3, dil=1, workspace=None, workspace_bytes=0,
+                   accumulate=0):
+    from ._lib import BwdfDesc
+    d = BwdfDesc()
+    d.g, d.yraw, d.ldg = g, yraw, ldg
+    d.bn_scale, d.bn_shift, d.bn_mean, d.bn_rstd, d.bn_coef, d.linear = bn_scale, bn_shift, bn_mean, bn_rstd, bn_coef, int(linear)
+    d.x0, d.x1, d.c0, d.c1 = x0, x1, c0, c1
+    d.in_scale, d.in_shift, d.in_relu = in_scale, in_shift, int(in_relu)
+    d.w_dgrad, d.dx, d.lddx, d.dw, d.cin, d.cout = w_dgrad, dx, lddx, dw, cin, cout
+    d.n, d.h, d.w_, d.kh, d.kw, d.dil = n, h, w_, kh, kw, dil
+    d.workspace, d.workspace_bytes, d.dtype, d.accumulate = workspace, workspace_bytes, dtype, int(accumulate)
+    return d
+
+
+def conv_bwd_fused(g, yraw, scale, shift, mean, rstd, coef, x, w_dgrad, cin, cout, *, x1=None, in_scale=None, in_shift=None, in_relu=False,
+                   linear=False, accumulate_into=None):
+    """BatchNorm-backward apply + data gradient + weight gradient of a thin conv -> BN -> ReLU block in one launch
+    (satcv_conv2d_bwd_fused).  Returns (dx, dw), or None when the shape is outside the kernel's limits."""
+    n, h, w_, c0 = x.shape
+    c1 = x1.shape[-1] if x1 is not None else 0
+    dx = torch.empty(n, h, w_, c0 + c1, dtype=x.dtype, device=x.device)
+    dw = accumulate_into if accumulate_into is not None else torch.empty(3, 3, cin, cout, dtype=torch.float32, device=x.device)
+    d = make_bwdf_desc(g=_p(g), yraw=_p(yraw), ldg=g.shape[-1], bn_scale=_p(scale), bn_shift=_p(shift), bn_mean=_p(mean), bn_rstd=_p(rstd),
+                       bn_coef=_p(coef), x0=_p(x), c0=c0, x1=_p(x1), c1=c1, in_scale=_p(in_scale), in_shift=_p(in_shift), in_relu=in_relu,
+                       w_dgrad=_p(w_dgrad), dx=_p(dx), lddx=c0 + c1, dw=_p(dw), cin=cin, cout=cout, n=n, h=h, w_=w_, dtype=DTYPE_CODE[x.dtype],
+                       linear=linear, accumulate=accumulate_into is not None)
+    nb = lib.satcv_conv2d_bwd_fused_workspace(C.byref(d))
+    if nb < 0:
+        return None
+    ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=x.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nb
+    check(lib.satcv_conv2d_bwd_fused(C.byref(d), stream_ptr()))
+    return dx, dw
+
+
 def conv2d_wgrad(x, dy, cin, cout, *, kh=3, kw=3, dil=1, x1=None, in_scale=None, in_shift=None, in_relu=False,
                  transposed_f=0, dw=None):
     """Kernel gradient, Keras layout: (kh,kw,cin,cout), or (f,f,cout,cin) for Conv2DTranspose."""

@@ -543,6 +543,62 @@ def test_data_gradient_with_fused_bn_backward_sums(ops, case, general_kernel_onl
         np.testing.assert_allclose(got[1], s2_ref, rtol=1e-4, atol=tol * float(np.abs(xh).max()), err_msg=f'sum g xhat {case} relu={relu}')
 
 
+@pytest.mark.parametrize('case', [
+    # n, h, w, c0, c1, cout, input affine + ReLU, linear BN
+    (2, 16, 64, 32, 0, 32, True, False),
+    (1, 8, 32, 32, 0, 32, False, False),       # one tile, plain input
+    (3, 24, 96, 32, 32, 32, True, False),      # concat([skip, up]) input (decoder_block's first conv)
+    (2, 16, 32, 32, 0, 32, True, True),        # BatchNormalization without ReLU
+    (5, 40, 64, 64, 0, 32, True, False),       # more tiles than resident workgroups' first round (ragged tile ranges)
+    (2, 16, 64, 64, 0, 64, True, False),       # 64 -> 64 (one wave per SIMD, 36 weight-gradient accumulator tiles)
+    (1, 24, 32, 32, 32, 64, False, False),
+])
+def test_fused_thin_layer_backward(ops, case):
+    """satcv_conv2d_bwd_fused: dy = scale * (g * mask - c1 - xhat * c2) formed in registers, data gradient and weight gradient from
+    the one dy tile (Conv2D :178 + BatchNormalization :179 + Activation :180 of utils/model_tools.py differentiated).  Against the
+    float64 oracle fed with the bf16-rounded dy, and against the three launches it replaces."""
+    n, h, w, c0, c1, cout, affine, linear = case
+    cin = c0 + c1
+    td = torch.bfloat16
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    xr = rnd(rng, (n, h, w, cin), td)
+    g = rnd(rng, (n, h, w, cout), td)
+    v = rnd(rng, (n, h, w, cout), td) * 1.5 + 0.25
+    v = torch.tensor(v, dtype=torch.float32).to(td).double().numpy()
+    kern = rnd(rng, (3, 3, cin, cout), td, 0.2)
+    sc, sh = (0.5 + rng.random(cout)).astype(np.float32) * rng.choice([-1, 1], cout), rng.standard_normal(cout).astype(np.float32) * 0.5
+    mu, rs = rng.standard_normal(cout).astype(np.float32) * 0.3, (0.5 + rng.random(cout)).astype(np.float32)
+    coef = (rng.standard_normal((2, cout)) * 0.1).astype(np.float32)
+    isc, ish = (0.5 + rng.random(cin)).astype(np.float32), (rng.standard_normal(cin) * 0.3).astype(np.float32)
+    # reference: the activated input, dy rounded to bf16 (what the three-launch path stores), then the float64 conv backward
+    a = np.maximum(xr * isc.astype(np.float64) + ish.astype(np.float64), 0) if affine else xr
+    a = torch.tensor(a, dtype=torch.float32).to(td).double().numpy()          # the loader rounds the activated input to bf16
+    f64 = lambda t: t.astype(np.float64)
+    mask = np.ones_like(v, bool) if linear else (v * f64(sc) + f64(sh) > 0)
+    xh = (v - f64(mu)) * f64(rs)
+    dy = f64(sc) * (np.where(mask, g, 0.0) - f64(coef[0]) - xh * f64(coef[1]))
+    dy = torch.tensor(dy, dtype=torch.float32).to(td).double().numpy()
+    dx_ref, dk_ref, _ = K.conv2d_same_bwd(a, kern, dy, 1)
+    _, wd = ops.pack_weights(f32dev(kern), cin, ops.DTYPE_CODE[td])
+    x0 = to_dev(xr[..., :c0], td)
+    x1 = to_dev(xr[..., c0:], td) if c1 else None
+    out = ops.conv_bwd_fused(to_dev(g, td), to_dev(v, td), f32dev(sc), f32dev(sh), f32dev(mu), f32dev(rs), f32dev(coef), x0, wd, cin, cout, x1=x1,
+                             in_scale=f32dev(isc) if affine else None, in_shift=f32dev(ish) if affine else None, in_relu=affine, linear=linear)
+    assert out is not None, 'shape must be served by the fused kernel'
+    dx, dw = out
+    close(back(dx), dx_ref, td, f'fused dx {case}', k=1.5)          # (dy differs from the reference's by at most one bf16 rounding per element)
+    close(back(dw), dk_ref, td, f'fused dw {case}', k=1.5)
+    # accumulate flag (shared weights): dw += result
+    dw2 = dw.clone()
+    ops.conv_bwd_fused(to_dev(g, td), to_dev(v, td), f32dev(sc), f32dev(sh), f32dev(mu), f32dev(rs), f32dev(coef), x0, wd, cin, cout, x1=x1,
+                       in_scale=f32dev(isc) if affine else None, in_shift=f32dev(ish) if affine else None, in_relu=affine, linear=linear,
+                       accumulate_into=dw2)
+    np.testing.assert_allclose(back(dw2), 2 * back(dw), rtol=1e-5, atol=1e-6)
+    # shapes outside the limits are refused, not mis-served
+    assert ops.conv_bwd_fused(to_dev(g[:, :6], td), to_dev(v[:, :6], td), f32dev(sc), f32dev(sh), f32dev(mu), f32dev(rs), f32dev(coef),
+                              to_dev(xr[:, :6, :, :c0], td), wd, cin, cout, x1=to_dev(xr[:, :6, :, c0:], td) if c1 else None) is None
+
+
 def test_fused_bn_backward_sums_are_refused_on_partial_tiles(ops):
     """a map that is not a whole number of tiles keeps the separate reduce launch: the query says so and conv2d raises"""
     td = torch.bfloat16
