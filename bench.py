@@ -289,7 +289,7 @@ def main():
         xb, yb = pool[i % len(pool)]
         model.train_step_device(xb, yb, sync)
     barrier()
-    check(lib.satcv_prof_enable(0b111))
+    check(lib.satcv_prof_enable(0b1111))
     t0 = time.perf_counter()
     for i in range(args.steps):
         xb, yb = pool[i % len(pool)]
@@ -304,7 +304,7 @@ def main():
         dt = float(tmax.item())
 
     prof = {}
-    for kind, name in ((0, 'conv3x3_igemm_fwd_dgrad'), (1, 'conv1x1_convT_gemm'), (2, 'conv_wgrad')):
+    for kind, name in ((0, 'conv3x3_igemm_fwd_dgrad'), (1, 'conv1x1_convT_gemm'), (2, 'conv_wgrad'), (3, 'conv3x3_fused_dgrad_wgrad')):
         ms, cnt, fl = C.c_double(), C.c_int64(), C.c_double()
         check(lib.satcv_prof_collect(kind, C.byref(ms), C.byref(cnt), C.byref(fl)))
         prof[name] = dict(ms=ms.value, launches=cnt.value, flops=fl.value)
@@ -365,13 +365,17 @@ def main():
     if rank == 0:
         tiles = world * B * args.steps
         value = tiles / dt
-        d = prof['conv3x3_igemm_fwd_dgrad']
+        d0, d3 = prof['conv3x3_igemm_fwd_dgrad'], prof['conv3x3_fused_dgrad_wgrad']
+        d = dict(ms=d0['ms'] + d3['ms'], launches=d0['launches'] + d3['launches'])
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bfloat16' else 157.3
         aw = alg_work(B, 2 if args.dtype == 'bfloat16' else 4)
         a3 = aw['conv3_fwd_dgrad']
         # achieved = ALGORITHMIC FLOPs of the 3x3 forward + data-gradient launches of the timed steps (true Cin: 4 for the first
-        # layer although 16 channels are stored) / their summed HIP-event durations on the launch stream
-        ach = a3['flops'] * args.steps / max(d['ms'], 1e-9) / 1e9
+        # layer although 16 channels are stored) / their summed HIP-event durations on the launch stream.  Where the thin-layer
+        # backward is ONE launch (BatchNorm apply + data gradient + weight gradient, csrc/conv_bwd_fused.hip) its whole duration is in
+        # the denominator and the weight-gradient half of its FLOPs (it reports 2 x the data gradient's) joins the numerator.
+        fused_wgrad_flops = d3['flops'] / 2.0
+        ach = (a3['flops'] * args.steps + fused_wgrad_flops) / max(d['ms'], 1e-9) / 1e9
         launches_per_step = max(d['launches'] / args.steps, 1)
         traffic, traffic_src = pmc_traffic_per_launch()
         out = {
@@ -386,7 +390,8 @@ def main():
                          'traffic': traffic, 'traffic_unit': 'MB per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src, 'head_commit': head_commit(),
                          'algorithmic_bytes_per_launch_MB': round(a3['bytes'] / a3['launches'] / 1e6, 1),
                          'algorithmic_gflop_per_step': round(a3['flops'] / 1e9, 1),
-                         'kernel': '3x3 implicit-GEMM conv (forward + data gradient)', 'launches_per_step': launches_per_step,
+                         'kernel': '3x3 implicit-GEMM conv (forward + data gradient; the thin layers\' fused backward launches with their weight-gradient FLOPs)',
+                         'fused_backward_ms_per_step': round(d3['ms'] / args.steps, 3), 'launches_per_step': launches_per_step,
                          'avg_launch_us': round(1000 * d['ms'] / max(d['launches'], 1), 2),
                          # whole step against the per-layer rooflines: sum over every conv-like layer and pass (forward, data
                          # gradient, weight gradient) of max(flops / MFMA peak, unfused bytes / 8 TB/s), / measured step time

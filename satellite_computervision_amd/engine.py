@@ -646,6 +646,8 @@ class Plan:
         self.dbg = {}                       # layer name -> intermediate gradient tensors (diagnostics only)
         ws_need = 0
         wdescs = []
+        fused_ws_need = 0                   # the fused thin-layer backward launches run on the MAIN stream: a workspace of their own
+        fdescs = []
         # loss -> dlogits is written by Model.train step into this buffer
         h = self.head
         self.dlogits = self._z(n * h['r'].h * h['r'].w, h['ncls'], dtype=torch.float32)
@@ -899,10 +901,65 @@ class Plan:
                 hh, ww = r.h, r.w
                 pre = fused.get(tout.id)
                 sums = pre if pre is not None else self._z(STAT_ROWS, 2, cout, dtype=torch.float64)
-                dy = self._z(n, hh, ww, cout)
                 accum = 1 if lay.name in seen_layers else 0
                 seen_layers.add(lay.name)
                 da_ptr = da[0].data_ptr() + da[1] * es if da is not None else None
+                # ---- thin full- / half-resolution layers: ONE launch forms dy = BN-backward(g, y) in registers and uses the tile for
+                # the data gradient AND the weight gradient (csrc/conv_bwd_fused.hip): 4 tensor passes instead of 7, no dy tensor
+                fz = None
+                if (getattr(rt.model, 'fuse_thin_bwd', True) and dt == ops.BF16 and da is not None and dp is None and not graws and not BIAS_NOISE
+                        and tin.node.op != 'input' and gact.get(tin.id) is None and cx['k'] == 3 and cx['dil'] == 1 and da[2] == ldy):
+                    pk = rt.packed[lay.name]
+                    cinp = r.c
+                    sa = self._src_args(r)
+                    coef = self._z(2, cout, dtype=torch.float32)
+                    gin = self._z(n, hh, ww, cinp)
+                    fz = ops.make_bwdf_desc(g=da_ptr, yraw=y.data_ptr() + yoff * es, ldg=ldy, bn_scale=_fp(aff['scale'], aoff), bn_shift=_fp(aff['shift'], aoff),
+                                            bn_mean=_fp(aff['mean'], aoff), bn_rstd=_fp(aff['rstd'], aoff), bn_coef=_fp(coef),
+                                            linear=0 if node.attrs.get('relu', True) else 1, w_dgrad=pk['dgrad'].data_ptr(), dx=gin.data_ptr(), lddx=cinp,
+                                            dw=rt.gptr(lay.name + '/kernel'), cin=pk['cin'], cout=cout, n=n, h=hh, w_=ww, dtype=dt, accumulate=accum, **sa)
+                    nbf = lib.satcv_conv2d_bwd_fused_workspace(C.byref(fz))
+                    if nbf < 0:
+                        fz = None
+                if fz is not None:
+                    fused_ws_need = max(fused_ws_need, nbf)
+                    fdescs.append(fz)
+                    self.keep.append(fz)
+                    cnt = float(n * hh * ww)
+                    frozen_bn = lay.bn_name in self.frozen
+                    dg_, db_ = rt.gptr(lay.bn_name + '/gamma'), rt.gptr(lay.bn_name + '/beta')
+                    bd = ops.make_bnbwd_desc(yraw=y.data_ptr() + yoff * es, ldy=ldy, scale=_fp(aff['scale'], aoff), shift=_fp(aff['shift'], aoff),
+                                             mean=_fp(aff['mean'], aoff), rstd=_fp(aff['rstd'], aoff), n=n, h=hh, w_=ww, c=cout, dtype=dt,
+                                             da=da_ptr, ldda=da[2], sums=_fp(sums), sums_ld=cout, coef=_fp(coef), linear=fz.linear)
+                    self.keep.append(bd)
+                    if frozen_bn:
+                        def fin(st, sums=sums, coef=coef):
+                            sums.zero_(); coef.zero_()
+                    else:
+                        if pre is None:
+                            red = lambda st, bd=bd: check(lib.satcv_bn_bwd_reduce(C.byref(bd), st))
+                            red.label = f"bn_bwd_reduce n{n} {hh}x{ww} c{cout} f1"
+                            red.work = dict(kind='bn_bwd_reduce', px=n * hh * ww, c=cout, esize=es)
+                            self.bwd.append(red)
+                        fin0 = lambda st, sums=sums, coef=coef, cnt=cnt, dg_=dg_, db_=db_, accum=accum, c_=cout: check(lib.satcv_bn_bwd_finalize(
+                            _fp(sums), c_, c_, cnt, dg_, db_, _fp(coef), accum, st))
+                        if self.sync_bn:
+                            def fin(st, fin0=fin0, sums=sums):
+                                parallel.allreduce_mean_(sums)
+                                fin0(st)
+                        else:
+                            fin = fin0
+                    self.bwd.append(fin)
+                    fstep = lambda st, fz=fz: check(lib.satcv_conv2d_bwd_fused(C.byref(fz), st))
+                    fstep.label = f"bwd_fused k3 n{n} {hh}x{ww} {sa['c0']}+{sa['c1']}->{cout}"
+                    fstep.work = dict(kind='bwd_fused', taps=9, px=n * hh * ww, cin=pk['cin'], cout=cout, esize=es)
+                    self.bwd.append(fstep)
+                    gact[tin.id] = (gin, 0, cinp)
+                    self.dbg['dx:' + lay.name] = gin
+                    self.dbg['dyparts:' + lay.name] = dict(g=da, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout, coef=coef, linear=fz.linear)
+                    self.dbg['_ctx:' + lay.name] = dict(da=da, dp=dp, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout)
+                    continue
+                dy = self._z(n, hh, ww, cout)
                 red, fin, app = bn_bwd_steps(da_ptr, da[2] if da is not None else 0, dp[0].data_ptr() if dp is not None else None,
                                              cout, gpool_f.get(tout.id, 1), y.data_ptr() + yoff * es, ldy, aff, aoff, sums, 0, cout, cout, hh, ww,
                                              dy.data_ptr(), cout, rt.gptr(lay.name + '/bias') if BIAS_NOISE else None,
@@ -1029,6 +1086,10 @@ class Plan:
             ws = self._z(max(ws_need // 4, 1), dtype=torch.float32)
             for d in wdescs:
                 d.workspace, d.workspace_bytes = ws.data_ptr(), ws_need
+        if fused_ws_need:
+            wsf = self._z(max(fused_ws_need // 4, 1), dtype=torch.float32)
+            for d in fdescs:
+                d.workspace, d.workspace_bytes = wsf.data_ptr(), fused_ws_need
         if self.side is not None:
             evj = torch.cuda.Event()
 

@@ -66,10 +66,19 @@ def oracle_for(tr, dtype):
     return o
 
 
+# Two training runs are two TRAJECTORIES: rounding differences (bf16 vs fp32 storage, or just another summation order) grow through
+# 240 Adam steps, and the nets they end in differ by more than any single-step tolerance.  Measured on MI355X over three seeds on 16
+# held-out tiles (tools/diag_train_iou.py): fp32-trained 0.9915 / 0.9959 / 0.9969, bf16-trained 0.9930 / 0.9943 / 0.9939 (three
+# launches per thin layer) and 0.9837 / 0.9965 / 0.9946 (fused thin-layer backward) -- a spread of 3e-3 ... 8e-3 in either direction
+# with final losses equal to three digits.  So: the PARITY bar (1e-3) is asserted where it is defined, device mask vs float64 oracle on
+# the SAME weights; between the two trained nets the test asserts the trajectory-noise bound.
+TRAJECTORY_IOU_TOL = 1.5e-2
+
+
 def test_bf16_training_lands_where_fp32_training_lands(trained):
     """configs[1] is bf16 TRAINING: 240 steps in bf16 and in fp32 from the same seed and batches.  Held-out 256x256 tiles:
     (1) each trained net's device mask scores within 1e-3 IoU of the float64 oracle forward on that net's own weights;
-    (2) the bf16-trained net's IoU is within 1e-3 of the fp32-trained net's (both trajectories learn the task equally well);
+    (2) the bf16-trained net learns the task as well as the fp32-trained one: IoU within the trajectory-noise bound above;
     (3) the loss curves track each other (bf16 storage rounding does not derail optimisation)."""
     xt, labt = trained['xt'], trained['labt']
     res = {}
@@ -82,14 +91,13 @@ def test_bf16_training_lands_where_fp32_training_lands(trained):
     print(f"five-level net, 240 steps: fp32-trained IoU oracle {res['float32']['ref']:.5f} device {res['float32']['dev']:.5f} "
           f"({res['float32']['diff']} px differ); bf16-trained IoU oracle {res['bfloat16']['ref']:.5f} device(bf16) {res['bfloat16']['dev']:.5f} "
           f"({res['bfloat16']['diff']} px differ); final epoch loss fp32 {lf[-1]:.5f} bf16 {lb[-1]:.5f}")
-    assert res['float32']['ref'] > 0.8 and res['bfloat16']['ref'] > 0.8          # both have learned the task
+    assert res['float32']['ref'] > 0.9 and res['bfloat16']['ref'] > 0.9          # both have learned the task
     for dtype in ('float32', 'bfloat16'):
         assert abs(res[dtype]['dev'] - res[dtype]['ref']) <= 1e-3, res
-    assert abs(res['bfloat16']['dev'] - res['float32']['dev']) <= 1e-3, res
-    assert abs(res['bfloat16']['ref'] - res['float32']['ref']) <= 1e-3, res
-    # loss curves: same shape (first epochs identical to a few %, last epochs both converged)
+    assert abs(res['bfloat16']['dev'] - res['float32']['dev']) <= TRAJECTORY_IOU_TOL, res
+    # loss curves: same shape (first epochs identical to a few %, last epochs both converged to the same level)
     assert abs(lb[0] - lf[0]) < 0.05 * lf[0] and lb[-1] < 0.25 * lb[0] and lf[-1] < 0.25 * lf[0]
-    assert abs(np.mean(lb[-10:]) - np.mean(lf[-10:])) < 0.5 * np.mean(lf[-10:]) + 5e-3
+    assert abs(np.mean(lb[-10:]) - np.mean(lf[-10:])) < 0.1 * np.mean(lf[-10:]) + 1e-3
 
 
 # Tolerance the fp8 path holds at full depth (measured on MI355X): on the trained five-level net the fp8 mask's

@@ -278,7 +278,20 @@ def test_full_unet_training_step_matches_oracle(mt, dtype):
             continue
         lay, cx = node.layer, plan.node_ctx[id(node)]
         r = cx['r']
-        dy = plan.dbg['dy:' + lay.name].double().cpu().numpy()
+        fused_bwd = 'dy:' + lay.name not in plan.dbg
+        if not fused_bwd:
+            dy = plan.dbg['dy:' + lay.name].double().cpu().numpy()
+        else:
+            # thin layers (csrc/conv_bwd_fused.hip): dy never reaches memory -- rebuild it from what the launch read (g, the raw conv
+            # output, the BatchNorm coefficients), rounded to the storage type as the kernel rounds it before its two products
+            pz = plan.dbg['dyparts:' + lay.name]
+            gt, goff, gld = pz['g']
+            gq = gt.double().reshape(-1, gld)[:, goff:goff + pz['cout']].reshape(n, 256 if False else cx['r'].h, cx['r'].w, pz['cout'])
+            yq = pz['y'].double().reshape(-1, pz['ldy'])[:, pz['yoff']:pz['yoff'] + pz['cout']].reshape(gq.shape)
+            af = {k_: pz['aff'][k_].double()[pz['aoff']:pz['aoff'] + pz['cout']] for k_ in ('scale', 'shift', 'mean', 'rstd')}
+            c1, c2 = pz['coef'].double()[0], pz['coef'].double()[1]
+            gm = gq if pz['linear'] else torch.where(yq * af['scale'] + af['shift'] > 0, gq, torch.zeros_like(gq))
+            dy = (af['scale'] * (gm - c1 - (yq - af['mean']) * af['rstd'] * c2)).to(td).double().cpu().numpy()
         a = torch.cat([t_ for t_, _ in r.srcs], -1).double()
         if r.affine is not None:
             a = a * r.affine['scale'].double() + r.affine['shift'].double()
@@ -292,7 +305,8 @@ def test_full_unet_training_step_matches_oracle(mt, dtype):
         dx_ref, dk_ref, _ = K.conv2d_same_bwd(a[..., :cin], kq, dy, 1)
         dk = rt.get_grad(lay.name + '/kernel').double().cpu().numpy()
         e = np.abs(dk - dk_ref).max() / max(np.abs(dk_ref).max(), 1e-30)
-        assert e < (2e-4 if f32 else 2e-3), f'local wgrad {lay.name} {kern.shape}: {e:.3e}'
+        # (fused layers: the kernel's dy and the rebuilt one can differ by one bf16 rounding on a few elements)
+        assert e < (2e-4 if f32 else (4e-3 if fused_bwd else 2e-3)), f'local wgrad {lay.name} {kern.shape}: {e:.3e}'
         key = 'dx:' + lay.name
         if key in plan.dbg and len(consumers_of(m, node.inputs[0])) == 1:
             dx = plan.dbg[key].double().cpu().numpy()[..., :cin]
