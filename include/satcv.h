@@ -182,6 +182,11 @@ typedef struct satcv_bwdf_desc {
   float* workspace; int64_t workspace_bytes;
   int32_t dtype;
   int32_t accumulate;                  /* dw += result (shared weights) */
+  /* optional: the sums of the BatchNorm backward of the layer BELOW -- the BatchNormalization + ReLU whose scale / shift are this
+   * launch's in_scale / in_shift (needs in_relu = 1) -- formed from the stored dx and the staged input: what satcv_bn_bwd_reduce would
+   * compute in a pass of its own over dx and that layer's raw output.  [ROWS][2][bst_sums_ld] rows as for satcv_bn_bwd_finalize. */
+  satcv_stat_t* bst_sums; int32_t bst_sums_ld;
+  const float* bst_mean; const float* bst_rstd;
 } satcv_bwdf_desc;
 int64_t satcv_conv2d_bwd_fused_workspace(const satcv_bwdf_desc* d);
 int satcv_conv2d_bwd_fused(const satcv_bwdf_desc* d, void* stream);

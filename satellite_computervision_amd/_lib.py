@@ -64,7 +64,8 @@ class BwdfDesc(C.Structure):
                 ('w_dgrad', c_vp), ('dx', c_vp), ('lddx', c_i32),
                 ('dw', c_vp), ('cin', c_i32), ('cout', c_i32),
                 ('n', c_i32), ('h', c_i32), ('w_', c_i32), ('kh', c_i32), ('kw', c_i32), ('dil', c_i32),
-                ('workspace', c_vp), ('workspace_bytes', c_i64), ('dtype', c_i32), ('accumulate', c_i32)]
+                ('workspace', c_vp), ('workspace_bytes', c_i64), ('dtype', c_i32), ('accumulate', c_i32),
+                ('bst_sums', c_vp), ('bst_sums_ld', c_i32), ('bst_mean', c_vp), ('bst_rstd', c_vp)]
 
 
 class BnBwdDesc(C.Structure):

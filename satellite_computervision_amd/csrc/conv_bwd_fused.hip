@@ -32,6 +32,9 @@ struct BwdfArgs {
   const void* w;                                 // data-gradient operand image [tap][COUT/8][CIN][8] (taps flipped: satcv_pack_weights mode 1)
   float* ws;                                     // [gridDim.x][9][CIN][COUT] partial weight gradients
   int tiles_x, tiles_y;
+  // BatchNorm-backward sums of the layer BELOW (the BatchNorm + ReLU whose scale / shift are this launch's in_scale / in_shift): sum gm and
+  // sum gm * xhat over the batch, gm = dx * [x > 0], into the same replica rows satcv_bn_bwd_reduce fills (satcv.h: bst_*)
+  satcv_stat_t* bst_sums; int bst_ld; const float* bst_mean; const float* bst_rstd;
 };
 
 __device__ __forceinline__ bf16x4 tr_read4(const bf16* p) {
@@ -59,7 +62,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
   constexpr int W_ITEMS = 9 * SD * CIN;
   constexpr size_t R0_BYTES = ((size_t)(SD * DSTRIDE + SX * XSTRIDE) * sizeof(T) + 127) / 128 * 128;
   constexpr size_t W_BYTES = (size_t)W_ITEMS * EL * sizeof(T);
-  static_assert((size_t)BM * (CIN + 8) * sizeof(T) + 5 * 2 * CIN * sizeof(float) <= R0_BYTES, "output staging must fit the tile region");
+  // dx staging tile [256][CIN + 8]: over the dy planes when it fits there (the x planes stay intact: the fused sums of the layer below
+  // read the activated x beside the staged dx), else a region of its own behind the tables
+  constexpr size_t O_BYTES = (size_t)BM * (CIN + 8) * sizeof(T);
+  constexpr bool O_ALIAS = O_BYTES <= (size_t)SD * DSTRIDE * sizeof(T);
+  constexpr size_t TAB_BYTES = (size_t)(SD * 32 + SX * 16) * sizeof(float);
+  constexpr size_t O_OFF = O_ALIAS ? 0 : (R0_BYTES + W_BYTES + TAB_BYTES + 127) / 128 * 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* ldsD = reinterpret_cast<T*>(smem_raw);                                   // dy halo planes
   T* ldsX = ldsD + SD * DSTRIDE;                                              // x interior planes
@@ -186,6 +194,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
     w_do[t] = co_t * 4 * DSTRIDE + ((2 - tap / 3) * PITCH + (2 - tap % 3)) * EL;      // dy[q + 1 - tap] in halo coordinates: q + 2 - tap
   }
 
+  // (not in the one-wave-per-SIMD instantiation: its 120 registers of prefetched tile leave no room for 16 more accumulators)
+  constexpr bool BST = WPS != 1;
+  float bs1[8], bs2[8];                                                       // fused sums of the layer below: this thread's 8 channels, all its tiles
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; }
   int n0, y0, x0;
   if (t_lo < t_hi) { tile_origin(t_lo, n0, y0, x0); valid = issue_loads(n0, y0, x0); issue_x(n0, y0, x0); }
   __syncthreads();                                                            // weights and tables are in LDS
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
       // dx tile: accumulators -> bf16 -> LDS [pixel][CIN + 8] -> 16-byte row stores (the shared igemm_epilogue's interior path without
       // its statistics / bias / pooling branches: their live state cost this kernel ~30 registers it does not have)
       constexpr int OPITCH = CIN + 8, VPR = CIN / 8;
-      T* ldsO = reinterpret_cast<T*>(smem_raw);
+      T* ldsO = reinterpret_cast<T*>(smem_raw + O_OFF);
       T* op = ldsO + ((wave * MT) * 32 + 4 * hh) * OPITCH + r;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -330,10 +343,24 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
       const int vq = tid % VPR;                                               // this thread's 16-byte column group (NTHREADS % VPR == 0)
       T* yp = reinterpret_cast<T*>(a.e.y) + ((size_t)(tn0 * a.e.h + ty0) * a.e.w_ + tx0) * a.e.ldy + vq * 8;
       const unsigned row_pitch = (unsigned)a.e.w_ * a.e.ldy;
+      const T* xact = ldsX + vq * XSTRIDE;                                    // this thread's channel group of the activated input
 #pragma unroll 2
       for (int it = tid; it < BM * VPR; it += NTHREADS) {
         const int q = it / VPR;
-        *reinterpret_cast<uint4*>(yp + (size_t)((q / TW) * row_pitch + (q % TW) * (unsigned)a.e.ldy)) = *reinterpret_cast<const uint4*>(ldsO + q * OPITCH + vq * 8);
+        const uint4 dv = *reinterpret_cast<const uint4*>(ldsO + q * OPITCH + vq * 8);
+        *reinterpret_cast<uint4*>(yp + (size_t)((q / TW) * row_pitch + (q % TW) * (unsigned)a.e.ldy)) = dv;
+        if (BST && a.bst_sums) {
+          // sums of the BatchNorm backward below from the STORED gradient and the staged activation a = relu(sc * v + sh):
+          // gm = dx * [a > 0];  sum gm * xhat = (sum dx * a - (sh + sc * mean) * sum gm) * rstd / sc   (a = 0 where the mask is 0)
+          const bf16x8 d8 = __builtin_bit_cast(bf16x8, dv);
+          const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(xact + q * EL);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float df = (float)d8[e], af = (float)a8[e];
+            bs1[e] += af > 0.f ? df : 0.f;
+            bs2[e] += df * af;
+          }
+        }
       }
     }
     __syncthreads();                                                          // staged output read out before the next tile is written
@@ -350,6 +377,25 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
       for (int i = 0; i < 16; ++i) dst[(size_t)((i & 3) + 8 * (i >> 2) + 4 * hh) * COUT] = wacc[tt][i];
     }
   }
+  // ---- fused sums: threads of one channel group are summed through LDS in a fixed order; one pair of atomics per channel and workgroup
+  if (BST && a.bst_sums && t_lo < t_hi) {
+    constexpr int VPR = CIN / 8, NPER = NTHREADS / VPR;                       // threads per channel group
+    float* red = reinterpret_cast<float*>(smem_raw);                          // [16][NTHREADS]: the tile region is free now
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[e * NTHREADS + tid] = bs1[e]; red[(8 + e) * NTHREADS + tid] = bs2[e]; }
+    __syncthreads();
+    if (tid < CIN) {
+      const int vq = tid >> 3, e = tid & 7;                                   // channel tid = vq * 8 + e; its contributors: threads t with t % VPR == vq
+      double t1 = 0.0, t2 = 0.0;
+      for (int k = 0; k < NPER; ++k) { t1 += (double)red[e * NTHREADS + k * VPR + vq]; t2 += (double)red[(8 + e) * NTHREADS + k * VPR + vq]; }
+      const double sc = (double)a.in_scale[tid], sh = (double)a.in_shift[tid], mu = (double)a.bst_mean[tid], rs = (double)a.bst_rstd[tid];
+      const double s2 = sc != 0.0 ? (t2 - (sh + sc * mu) * t1) * (rs / sc) : 0.0;
+      satcv_stat_t* rowp = a.bst_sums + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.bst_ld;
+      atomicAdd(rowp + tid, (satcv_stat_t)t1);
+      atomicAdd(rowp + a.bst_ld + tid, (satcv_stat_t)s2);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ host side
@@ -357,7 +403,12 @@ template <int CIN, int COUT, int NW>
 struct BwdfGeom {
   static constexpr int SD = COUT / 8, SX = CIN / 8;
   static constexpr size_t R0 = ((size_t)(SD * (10 * 34 * 8) + SX * (256 * 8 + 32)) * 2 + 127) / 128 * 128;
-  static constexpr size_t LDS = R0 + (size_t)9 * SD * CIN * 16 + (size_t)(SD * 32 + SX * 16) * 4;
+  static constexpr size_t O_BYTES = (size_t)256 * (CIN + 8) * 2;
+  static constexpr bool O_ALIAS = O_BYTES <= (size_t)SD * (10 * 34 * 8) * 2;
+  static constexpr size_t BASE = R0 + (size_t)9 * SD * CIN * 16 + (size_t)(SD * 32 + SX * 16) * 4;
+  static constexpr size_t LDS0 = O_ALIAS ? BASE : (BASE + 127) / 128 * 128 + O_BYTES;
+  static constexpr size_t RED = (size_t)16 * NW * 64 * 4;                      // end-of-kernel reduction scratch of the fused sums
+  static constexpr size_t LDS = LDS0 > RED ? LDS0 : RED;
 };
 
 static int g_ncu = 0;
@@ -378,6 +429,7 @@ static int bwdf_grid(size_t lds, int waves, int wps, long long total) {
 
 static bool bwdf_shape_ok(const satcv_bwdf_desc* d, int& cin_s) {
   cin_s = d->c0 + d->c1;
+  if (d->bst_sums && cin_s == 64 && d->cout == 64) return false;    // (that instantiation does not carry the fused sums)
   if (d->dtype != SATCV_BF16 || d->kh != 3 || d->kw != 3 || d->dil != 1) return false;
   if (!((cin_s == 32 && d->cout == 32) || (cin_s == 64 && d->cout == 32) || (cin_s == 64 && d->cout == 64))) return false;
   if (d->cin != cin_s) return false;                                // real == stored input channels (the slab has no padding rows)
@@ -406,6 +458,7 @@ static int bwdf_launch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int
   a.bn_scale = d->bn_scale; a.bn_shift = d->bn_shift; a.bn_mean = d->bn_mean; a.bn_rstd = d->bn_rstd; a.bn_coef = d->bn_coef; a.bn_c = d->cout; a.linear = d->linear;
   a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_relu = d->in_relu;
   a.w = d->w_dgrad; a.ws = d->workspace; a.tiles_x = d->w_ / 32; a.tiles_y = d->h / 8;
+  a.bst_sums = d->bst_sums; a.bst_ld = d->bst_sums_ld; a.bst_mean = d->bst_mean; a.bst_rstd = d->bst_rstd;
   auto kern = bwd_fused_kernel<CIN, COUT, NW, WPS>;
   { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS); if (rc) return rc; }
   const double flops = 4.0 * d->n * d->h * d->w_ * (double)CIN * COUT * 9;          // data gradient + weight gradient
@@ -420,7 +473,8 @@ static int bwdf_launch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int
 static int bwdf_dispatch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int64_t* ws_bytes) {
   int cin_s;
   if (!bwdf_shape_ok(d, cin_s)) return SATCV_ERR_UNSUPPORTED;
-  if (cin_s == 32) return bwdf_launch<32, 32, 4, 2>(d, st, query, ws_bytes);
+  // (32 -> 32: 8 waves x 1 workgroup per CU measured equal to 4 waves x 2 workgroups and leaves registers for the fused sums)
+  if (cin_s == 32) return bwdf_launch<32, 32, 8, 2>(d, st, query, ws_bytes);
   if (d->cout == 32) return bwdf_launch<64, 32, 8, 2>(d, st, query, ws_bytes);
   return bwdf_launch<64, 64, 4, 1>(d, st, query, ws_bytes);
 }
@@ -435,6 +489,8 @@ extern "C" int satcv_conv2d_bwd_fused(const satcv_bwdf_desc* d, void* stream) {
   SATCV_CHECK(d && d->g && d->yraw && d->x0 && d->w_dgrad && d->dx && d->dw && d->workspace, "bwd_fused: null pointer");
   SATCV_CHECK(d->bn_scale && d->bn_shift && d->bn_mean && d->bn_rstd && d->bn_coef, "bwd_fused: BatchNorm coefficients missing");
   SATCV_CHECK((d->c1 == 0) == (d->x1 == nullptr) && d->n > 0 && d->h > 0 && d->w_ > 0, "bwd_fused: bad dims");
+  SATCV_CHECK(!d->bst_sums || (d->in_scale && d->in_shift && d->in_relu && d->bst_mean && d->bst_rstd && d->bst_sums_ld >= d->c0 + d->c1),
+              "bwd_fused: the fused sums need the input's BatchNorm (in_scale / in_shift with ReLU, bst_mean / bst_rstd)");
   const int rc = bwdf_dispatch(d, reinterpret_cast<hipStream_t>(stream), false, nullptr);
   if (rc == SATCV_ERR_UNSUPPORTED) satcv_set_error("bwd_fused: shape outside the kernel's limits (ask satcv_conv2d_bwd_fused_workspace first)");
   return rc;

@@ -918,9 +918,22 @@ class Plan:
                                             bn_mean=_fp(aff['mean'], aoff), bn_rstd=_fp(aff['rstd'], aoff), bn_coef=_fp(coef),
                                             linear=0 if node.attrs.get('relu', True) else 1, w_dgrad=pk['dgrad'].data_ptr(), dx=gin.data_ptr(), lddx=cinp,
                                             dw=rt.gptr(lay.name + '/kernel'), cin=pk['cin'], cout=cout, n=n, h=hh, w_=ww, dtype=dt, accumulate=accum, **sa)
+                    # ... and, where the layer below is a BatchNorm + ReLU fed only by this gradient, the sums of ITS backward
+                    # (what satcv_bn_bwd_reduce would compute in a pass over dx and that layer's raw output): bst_*
+                    bt = bst_target(tin) if (sa['in_relu'] and sa['in_scale'] is not None) else None
+                    sums_below = None
+                    if bt is not None and bt[1] == cinp and bt[0].get('relu', 0) == 1:
+                        sums_below = self._z(STAT_ROWS, 2, cinp, dtype=torch.float64)
+                        fz.bst_sums, fz.bst_sums_ld, fz.bst_mean, fz.bst_rstd = _fp(sums_below), cinp, bt[0]['mean'], bt[0]['rstd']
                     nbf = lib.satcv_conv2d_bwd_fused_workspace(C.byref(fz))
+                    if nbf < 0 and sums_below is not None:              # (the 64 -> 64 form does not carry the sums)
+                        fz.bst_sums, fz.bst_sums_ld, fz.bst_mean, fz.bst_rstd = None, 0, None, None
+                        sums_below = None
+                        nbf = lib.satcv_conv2d_bwd_fused_workspace(C.byref(fz))
                     if nbf < 0:
                         fz = None
+                    elif sums_below is not None:
+                        fused[tin.id] = sums_below
                 if fz is not None:
                     fused_ws_need = max(fused_ws_need, nbf)
                     fdescs.append(fz)
@@ -951,7 +964,7 @@ class Plan:
                             fin = fin0
                     self.bwd.append(fin)
                     fstep = lambda st, fz=fz: check(lib.satcv_conv2d_bwd_fused(C.byref(fz), st))
-                    fstep.label = f"bwd_fused k3 n{n} {hh}x{ww} {sa['c0']}+{sa['c1']}->{cout}"
+                    fstep.label = f"bwd_fused k3 n{n} {hh}x{ww} {sa['c0']}+{sa['c1']}->{cout}{' +bnred' if fz.bst_sums else ''}"
                     fstep.work = dict(kind='bwd_fused', taps=9, px=n * hh * ww, cin=pk['cin'], cout=cout, esize=es)
                     self.bwd.append(fstep)
                     gact[tin.id] = (gin, 0, cinp)

@@ -178,7 +178,7 @@ def make_wgrad_desc(*, x0, c0, dy, lddy, dw, cin, cout, n, h, w_, dtype, x1=None
 
 def make_bwdf_desc(*, g, yraw, ldg, bn_scale, bn_shift, bn_mean, bn_rstd, bn_coef, x0, c0, w_dgrad, dx, lddx, dw, cin, cout, n, h, w_, dtype,
                    linear=0, x1=None, c1=0, in_scale=None, in_shift=None, in_relu=0, kh=3, kw=3, dil=1, workspace=None, workspace_bytes=0,
-                   accumulate=0):
+                   accumulate=0, bst_sums=None, bst_sums_ld=0, bst_mean=None, bst_rstd=None):
     from ._lib import BwdfDesc
     d = BwdfDesc()
     d.g, d.yraw, d.ldg = g, yraw, ldg
@@ -188,11 +188,12 @@ def make_bwdf_desc(*, g, yraw, ldg, bn_scale, bn_shift, bn_mean, bn_rstd, bn_coe
     d.w_dgrad, d.dx, d.lddx, d.dw, d.cin, d.cout = w_dgrad, dx, lddx, dw, cin, cout
     d.n, d.h, d.w_, d.kh, d.kw, d.dil = n, h, w_, kh, kw, dil
     d.workspace, d.workspace_bytes, d.dtype, d.accumulate = workspace, workspace_bytes, dtype, int(accumulate)
+    d.bst_sums, d.bst_sums_ld, d.bst_mean, d.bst_rstd = bst_sums, bst_sums_ld, bst_mean, bst_rstd
     return d
 
 
 def conv_bwd_fused(g, yraw, scale, shift, mean, rstd, coef, x, w_dgrad, cin, cout, *, x1=None, in_scale=None, in_shift=None, in_relu=False,
-                   linear=False, accumulate_into=None):
+                   linear=False, accumulate_into=None, bst=None):
     """BatchNorm-backward apply + data gradient + weight gradient of a thin conv -> BN -> ReLU block in one launch
     (satcv_conv2d_bwd_fused).  Returns (dx, dw), or None when the shape is outside the kernel's limits."""
     n, h, w_, c0 = x.shape
@@ -202,7 +203,8 @@ def conv_bwd_fused(g, yraw, scale, shift, mean, rstd, coef, x, w_dgrad, cin, cou
     d = make_bwdf_desc(g=_p(g), yraw=_p(yraw), ldg=g.shape[-1], bn_scale=_p(scale), bn_shift=_p(shift), bn_mean=_p(mean), bn_rstd=_p(rstd),
                        bn_coef=_p(coef), x0=_p(x), c0=c0, x1=_p(x1), c1=c1, in_scale=_p(in_scale), in_shift=_p(in_shift), in_relu=in_relu,
                        w_dgrad=_p(w_dgrad), dx=_p(dx), lddx=c0 + c1, dw=_p(dw), cin=cin, cout=cout, n=n, h=h, w_=w_, dtype=DTYPE_CODE[x.dtype],
-                       linear=linear, accumulate=accumulate_into is not None)
+                       linear=linear, accumulate=accumulate_into is not None,
+                       **(dict(bst_sums=_p(bst['sums']), bst_sums_ld=bst['sums'].shape[-1], bst_mean=_p(bst['mean']), bst_rstd=_p(bst['rstd'])) if bst else {}))
     nb = lib.satcv_conv2d_bwd_fused_workspace(C.byref(d))
     if nb < 0:
         return None

@@ -586,6 +586,23 @@ def test_fused_thin_layer_backward(ops, case):
                              in_scale=f32dev(isc) if affine else None, in_shift=f32dev(ish) if affine else None, in_relu=affine, linear=linear)
     assert out is not None, 'shape must be served by the fused kernel'
     dx, dw = out
+    if affine and not (cin == 64 and cout == 64):
+        # bst_*: the sums of the BatchNorm backward of the layer below (whose scale / shift are the input affine), from the stored dx
+        bmu, brs = (rng.standard_normal(cin) * 0.3).astype(np.float32), (0.5 + rng.random(cin)).astype(np.float32)
+        stats = ops.new_stats(cin, dev())
+        out2 = ops.conv_bwd_fused(to_dev(g, td), to_dev(v, td), f32dev(sc), f32dev(sh), f32dev(mu), f32dev(rs), f32dev(coef), x0, wd, cin, cout, x1=x1,
+                                  in_scale=f32dev(isc), in_shift=f32dev(ish), in_relu=True, linear=linear,
+                                  bst=dict(sums=stats, mean=f32dev(bmu), rstd=f32dev(brs)))
+        assert torch.equal(out2[0], dx), 'the fused sums must not change the stored gradient'
+        gst = back(dx)
+        gm = np.where(xr * isc.astype(np.float64) + ish.astype(np.float64) > 0, gst, 0.0)
+        xh = (xr - bmu.astype(np.float64)) * brs.astype(np.float64)
+        s1_ref, s2_ref = gm.sum((0, 1, 2)), (gm * xh).sum((0, 1, 2))
+        got = stats.sum(0).double().cpu().numpy()
+        tol = 2e-4 * np.sqrt(n * h * w) * max(1.0, float(np.abs(gst).max()))
+        np.testing.assert_allclose(got[0], s1_ref, rtol=1e-4, atol=tol, err_msg=f'fused sum g {case}')
+        # (xhat is rebuilt from the staged bf16 activation: one storage rounding per element more than the separate pass, unbiased)
+        np.testing.assert_allclose(got[1], s2_ref, rtol=2e-3, atol=8 * tol * float(np.abs(xh).max()), err_msg=f'fused sum g xhat {case}')
     close(back(dx), dx_ref, td, f'fused dx {case}', k=1.5)          # (dy differs from the reference's by at most one bf16 rounding per element)
     close(back(dw), dk_ref, td, f'fused dw {case}', k=1.5)
     # accumulate flag (shared weights): dw += result
