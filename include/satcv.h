@@ -236,11 +236,23 @@ typedef struct satcv_bnbwd_desc {
   const void* yraw1; int32_t ldy1;
   void* dy1; int32_t lddy1;
   int32_t c_split;
+  /* optional (apply pass of the two-source form): the first source is the ACTIVATED output a = relu(BN(y_enc)) of an encoder block
+   * (the skip of decoder_block, utils/model_tools.py:307) and dy its gradient: also accumulate the sums of THAT BatchNorm's backward
+   * in the activated form -- rows [0]: sum dy [a > 0], rows [1]: sum dy a over the c_split skip channels -- which
+   * satcv_bn_bwd_finalize2 converts.  Saves the pass satcv_bn_bwd_reduce would make over dy and y_enc. */
+  satcv_stat_t* sk_sums; int32_t sk_sums_ld;
 } satcv_bnbwd_desc;
 int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream);
 int satcv_bn_bwd_finalize(satcv_stat_t* sums, int32_t sums_ld, int32_t c, float count, float* dgamma,
                           float* dbeta, float* coef, int32_t accumulate, void* stream);
 int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream);
+/* finalize over two sets of rows: `sums` in the raw form satcv_bn_bwd_reduce writes (may be NULL), `act_sums` in the activated form
+ * (sum g [a > 0], sum g a with a = relu(scale * y + shift)) written by producers that only see the activated tensor: the sk_sums of
+ * satcv_bn_bwd_apply, a data-gradient launch whose bst_y is the max-pooled activation with unit bst_scale / bst_rstd and zero
+ * bst_shift / bst_mean.  sum g xhat = (sum g a - (shift + scale mean) sum g) rstd / scale.  Zeroes both sets of rows. */
+int satcv_bn_bwd_finalize2(satcv_stat_t* sums, int32_t sums_ld, satcv_stat_t* act_sums, int32_t act_sums_ld, int32_t c, float count,
+                           const float* scale, const float* shift, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                           float* coef, int32_t accumulate, void* stream);
 
 /* Residual blocks of the atrous CNN family (utils/model_tools.py:922-979: ReLU(BN(conv) + shortcut), plain Conv2D layers):
  * satcv_relu_bwd : g[i] = act[i] > 0 ? g[i] : 0 in place (gradient through the ReLU of a materialised activation; the masked

@@ -75,7 +75,8 @@ class BnBwdDesc(C.Structure):
                 ('sums', c_vp), ('sums_ld', c_i32), ('coef', c_vp),
                 ('dy', c_vp), ('lddy_out', c_i32), ('dbias', c_vp),
                 ('n', c_i32), ('h', c_i32), ('w_', c_i32), ('c', c_i32), ('dtype', c_i32), ('linear', c_i32),
-                ('yraw1', c_vp), ('ldy1', c_i32), ('dy1', c_vp), ('lddy1', c_i32), ('c_split', c_i32)]
+                ('yraw1', c_vp), ('ldy1', c_i32), ('dy1', c_vp), ('lddy1', c_i32), ('c_split', c_i32),
+                ('sk_sums', c_vp), ('sk_sums_ld', c_i32)]
 
 
 class HeadDesc(C.Structure):
@@ -112,6 +113,7 @@ _SIGS = {
     'satcv_bn_bwd_reduce': (C.c_int, [C.POINTER(BnBwdDesc), c_vp]),
     'satcv_bn_bwd_finalize': (C.c_int, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'satcv_bn_bwd_apply': (C.c_int, [C.POINTER(BnBwdDesc), c_vp]),
+    'satcv_bn_bwd_finalize2': (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'satcv_maxpool': (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'satcv_affine_requant': (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp]),
     'satcv_add_act': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp]),

@@ -278,8 +278,9 @@ extern "C" int satcv_bn_affine_infer(const float* gamma, const float* beta, cons
 // workgroup contributes is reproducible; the replica rows are double (satcv_stat_t), where the arrival order of the workgroups
 // only matters at 1e-16.
 __device__ __forceinline__ void block_channel_reduce(float* lds, const float (&a)[8], const float (&b)[8], int g, bool active,
-                                                     int c, satcv_stat_t* out, int out_ld) {
+                                                     int c, satcv_stat_t* out, int out_ld, int c_out = -1) {
   const int G = c / 8;
+  if (c_out < 0) c_out = c;                       // (c_out < c: only the first c_out channels own output rows -- the skip half of a concatenation)
   // [16][blockDim + 1]: a value row per partial sum, one column per thread -- the lanes of a wave write consecutive banks, and the
   // readers below (8 lanes per thread column, one per value row) are spread by the odd pitch.  (The [thread][16] form put every
   // fourth lane on the same bank: rocprofv3 counted 88 % of the LDS cycles of the BatchNorm kernels as bank conflicts.)
@@ -289,8 +290,8 @@ __device__ __forceinline__ void block_channel_reduce(float* lds, const float (&a
   __syncthreads();
   const int g0 = (int)((blockIdx.x * (long long)blockDim.x) % G);          // group of thread 0
   satcv_stat_t* row = out + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * out_ld;
-  for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
-    const int which = i / c, ch = i - which * c, gg = ch / 8, e = ch % 8;
+  for (int i = threadIdx.x; i < 2 * c_out; i += blockDim.x) {
+    const int which = i / c_out, ch = i - which * c_out, gg = ch / 8, e = ch % 8;
     float s = 0.f;
     for (int t = (gg - g0 + G) % G; t < (int)blockDim.x; t += G) s += lds[(which * 8 + e) * pitch + t];
     atomicAdd(row + which * out_ld + ch, (satcv_stat_t)s);
@@ -510,6 +511,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbw
   const T* yr = second ? (const T*)d.yraw1 + (g * 8 - d.c_split) : (const T*)d.yraw + g * 8;
   T* dy = second ? (T*)d.dy1 + (g * 8 - d.c_split) : (T*)d.dy + g * 8;
   const int ldy = second ? d.ldy1 : d.ldy, lddy = second ? d.lddy1 : d.lddy_out;
+  const bool sk = APPLY && d.sk_sums != nullptr && !second;
   float sc[8], sh[8], mu[8], rs[8], c1[8], c2[8], s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -539,7 +541,13 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbw
         const float a = v[e] * sc[e] + sh[e];
         const float gg = (a > lin_lo) ? gr[e] : 0.f;
         const float xh = (v[e] - mu[e]) * rs[e];
-        if (APPLY) { const float t = sc[e] * (gg - c1[e] - xh * c2[e]); o[e] = round_to<T>(t); s1[e] += o[e]; }
+        if (APPLY) {
+          const float t = sc[e] * (gg - c1[e] - xh * c2[e]); o[e] = round_to<T>(t);
+          // sk_sums: v is the ACTIVATED skip a = relu(BN(y_enc)) and o its gradient -- the first-source threads also form the sums of
+          // THAT BatchNorm's backward in the activated form: sum o [a > 0], sum o a (satcv_bn_bwd_finalize2 converts)
+          if (sk) { s1[e] += v[e] > 0.f ? o[e] : 0.f; s2[e] += o[e] * v[e]; }
+          else s1[e] += o[e];
+        }
         else { s1[e] += gg; s2[e] += gg * xh; }
       }
       if (APPLY) store8<T>(oq, o);
@@ -547,6 +555,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbw
     }
   }
   if (!APPLY) block_channel_reduce(lds, s1, s2, g, active, c, d.sums, d.sums_ld);
+  else if (d.sk_sums) block_channel_reduce(lds, s1, s2, g, active && !second, c, d.sk_sums, d.sk_sums_ld, d.c_split);
   else if (d.dbias) {
     for (int i = threadIdx.x; i < c; i += blockDim.x) lds[i] = 0.f;
     __syncthreads();
@@ -563,6 +572,7 @@ static int bnbwd_check(const satcv_bnbwd_desc* d, bool apply) {
   SATCV_CHECK(d->da || d->dpool, "bn_bwd: no incoming gradient");
   SATCV_CHECK(d->c > 0 && d->c % 8 == 0 && d->c <= 2048 && d->n > 0 && d->h > 0 && d->w_ > 0, "bn_bwd: bad dims");
   SATCV_CHECK(!d->dpool || d->f >= 1, "bn_bwd: pool factor");
+  SATCV_CHECK(!apply || !d->sk_sums || (d->c_split > 0 && !d->dbias && d->sk_sums_ld >= d->c_split), "bn_bwd_apply: sk_sums needs the two-source form");
   if (apply) SATCV_CHECK(d->coef && d->dy, "bn_bwd_apply: coef/dy missing");
   else SATCV_CHECK(d->sums && d->sums_ld >= d->c, "bn_bwd_reduce: sums missing");
   if (d->c_split > 0) {
@@ -590,7 +600,8 @@ extern "C" int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream) {
   const int f = d->dpool ? d->f : 1;
   const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
   if (!d->dpool && d->da && (long long)d->n * d->h * d->w_ < 0x7fffffffLL) {
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), d->c * sizeof(float), (hipStream_t)stream, *d, rev));
+    const size_t lds_b = d->sk_sums ? (EW_BLOCK + 1) * 16 * sizeof(float) : d->c * sizeof(float);
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), lds_b, (hipStream_t)stream, *d, rev));
   } else {
     DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), d->c * sizeof(float), (hipStream_t)stream, *d));
   }
@@ -612,6 +623,39 @@ __global__ void bn_bwd_finalize_kernel(satcv_stat_t* sums, int ld, int c, float 
   if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + s1 : s1;
   if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + s2 : s2;
   coef[ch] = s1 / count; coef[c + ch] = s2 / count;
+}
+// sums from producers that only had the ACTIVATED output a = relu(scale * y + shift) of the layer at hand (rows [0]: sum g [a > 0], rows
+// [1]: sum g a): sum g xhat = (sum g a - (shift + scale * mean) sum g) rstd / scale, since xhat = (a - shift - scale mean) rstd / scale
+// wherever the mask is 1.  Added to the raw-form rows of a satcv_bn_bwd_reduce over whatever part of the gradient was not fused.
+__global__ void bn_bwd_finalize2_kernel(satcv_stat_t* sums, int ld, satcv_stat_t* asums, int ald, int c, float count, const float* scale, const float* shift,
+                                        const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef, int accumulate) {
+  const int ch = blockIdx.x * (blockDim.x / 32) + threadIdx.x / 32, r = threadIdx.x & 31;
+  double d1 = 0.0, d2 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (ch < c) {
+    if (sums) { satcv_stat_t* row = sums + (size_t)r * 2 * ld; d1 = row[ch]; d2 = row[ld + ch]; row[ch] = 0.0; row[ld + ch] = 0.0; }
+    satcv_stat_t* arow = asums + (size_t)r * 2 * ald;
+    a1 = arow[ch]; a2 = arow[ald + ch]; arow[ch] = 0.0; arow[ald + ch] = 0.0;
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    d1 += __shfl_xor(d1, o, 64); d2 += __shfl_xor(d2, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
+  }
+  if (ch >= c || r != 0) return;
+  const double sc = (double)scale[ch], sh = (double)shift[ch], mu = (double)mean[ch], rs = (double)rstd[ch];
+  const double a2x = sc != 0.0 ? (a2 - (sh + sc * mu) * a1) * (rs / sc) : 0.0;
+  const float s1 = (float)(d1 + a1), s2 = (float)(d2 + a2x);
+  if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + s1 : s1;
+  if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + s2 : s2;
+  coef[ch] = s1 / count; coef[c + ch] = s2 / count;
+}
+extern "C" int satcv_bn_bwd_finalize2(satcv_stat_t* sums, int32_t sums_ld, satcv_stat_t* act_sums, int32_t act_sums_ld, int32_t c, float count,
+                                      const float* scale, const float* shift, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                      float* coef, int32_t accumulate, void* stream) {
+  SATCV_CHECK(act_sums && coef && scale && shift && mean && rstd && c > 0 && act_sums_ld >= c && (!sums || sums_ld >= c) && count > 0, "bn_bwd_finalize2: bad args");
+  hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3(cdiv(c, 8)), dim3(256), 0, (hipStream_t)stream, sums, sums_ld, act_sums, act_sums_ld, c, count, scale, shift,
+                     mean, rstd, dgamma, dbeta, coef, accumulate);
+  LAUNCH_OK("bn_bwd_finalize2");
+  return SATCV_OK;
 }
 extern "C" int satcv_bn_bwd_finalize(satcv_stat_t* sums, int32_t sums_ld, int32_t c, float count, float* dgamma, float* dbeta, float* coef, int32_t accumulate,
                                      void* stream) {

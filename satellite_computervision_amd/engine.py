@@ -644,6 +644,11 @@ class Plan:
         dt, es = rt.dtype, rt.esize
         gact, gpool, gpool_f, graw = {}, {}, {}, {}
         self.dbg = {}                       # layer name -> intermediate gradient tensors (diagnostics only)
+        _cnt = defaultdict(int)
+        for nd in m.nodes:
+            if nd.layer is not None:
+                _cnt[nd.layer.name] += 1
+        shared_layers = {k for k, v in _cnt.items() if v > 1}      # layers applied to several inputs (Siamese encoders)
         ws_need = 0
         wdescs = []
         fused_ws_need = 0                   # the fused thin-layer backward launches run on the MAIN stream: a workspace of their own
@@ -654,21 +659,41 @@ class Plan:
         self.loss_buf = self._z(1, dtype=torch.float32)
 
         def bn_bwd_steps(da, ldda, dp, lddp, f, yraw, ldy, aff, aoff, sums, sums_off, sums_ld, c, hh, ww, dy, lddy, dbias,
-                         dgamma, dbeta, accum=0, linear=0, frozen=False, second=None):
+                         dgamma, dbeta, accum=0, linear=0, frozen=False, second=None, act=None):
+            """act: dict(buf=[ROWS][2][c] rows in the ACTIVATED form, parts={'skip', 'pool'}) -- the parts of this layer's gradient whose
+            sums a producer already formed (the decoder's concat-BN apply pass for the skip gradient `da`, the data gradient of the next
+            encoder block for the pooled gradient `dp`); the separate reduce pass then only covers what is left."""
             coef = self._z(2, c, dtype=torch.float32)
-            d = ops.make_bnbwd_desc(yraw=yraw, ldy=ldy, scale=_fp(aff['scale'], aoff), shift=_fp(aff['shift'], aoff),
-                                    mean=_fp(aff['mean'], aoff), rstd=_fp(aff['rstd'], aoff), n=n, h=hh, w_=ww, c=c, dtype=dt,
-                                    da=da, ldda=ldda, dpool=dp, lddp=lddp, f=f, sums=_fp(sums, sums_off), sums_ld=sums_ld,
-                                    coef=_fp(coef), dy=dy, lddy_out=lddy, dbias=dbias, linear=linear, **(second or {}))
+            common = dict(yraw=yraw, ldy=ldy, scale=_fp(aff['scale'], aoff), shift=_fp(aff['shift'], aoff),
+                          mean=_fp(aff['mean'], aoff), rstd=_fp(aff['rstd'], aoff), n=n, h=hh, w_=ww, c=c, dtype=dt,
+                          f=f, sums=_fp(sums, sums_off), sums_ld=sums_ld, coef=_fp(coef), dy=dy, lddy_out=lddy, dbias=dbias, linear=linear)
+            d = ops.make_bnbwd_desc(da=da, ldda=ldda, dpool=dp, lddp=lddp, **common, **(second or {}))
             self.keep.append(d)
+            parts = act['parts'] if (act and not frozen) else set()
+            need_da, need_dp = da is not None and 'skip' not in parts, dp is not None and 'pool' not in parts
+            dr = d
+            if parts and (need_da or need_dp):          # reduce pass over the part no producer covered
+                dr = ops.make_bnbwd_desc(da=da if need_da else None, ldda=ldda if need_da else 0, dpool=dp if need_dp else None,
+                                         lddp=lddp if need_dp else 0, **common)
+                self.keep.append(dr)
             cnt = float(n * hh * ww)
-            red = lambda st: check(lib.satcv_bn_bwd_reduce(C.byref(d), st))
-            red.label = f"bn_bwd_reduce n{n} {hh}x{ww} c{c} f{f}"
+            red = lambda st: check(lib.satcv_bn_bwd_reduce(C.byref(dr), st))
+            red.label = f"bn_bwd_reduce n{n} {hh}x{ww} c{c} f{f}{' (part)' if dr is not d else ''}"
             red.work = dict(kind='bn_bwd_reduce', px=n * hh * ww, c=c, esize=es)
-            fin0 = lambda st: check(lib.satcv_bn_bwd_finalize(_fp(sums, sums_off), sums_ld, c, cnt, dgamma, dbeta, _fp(coef), accum, st))
+            if parts and not (need_da or need_dp):
+                red = None
+            if parts:
+                abuf = act['buf']
+                fin0 = lambda st: check(lib.satcv_bn_bwd_finalize2(_fp(sums, sums_off) if red is not None else None, sums_ld, _fp(abuf), c, c, cnt,
+                                                                   _fp(aff['scale'], aoff), _fp(aff['shift'], aoff), _fp(aff['mean'], aoff),
+                                                                   _fp(aff['rstd'], aoff), dgamma, dbeta, _fp(coef), accum, st))
+            else:
+                fin0 = lambda st: check(lib.satcv_bn_bwd_finalize(_fp(sums, sums_off), sums_ld, c, cnt, dgamma, dbeta, _fp(coef), accum, st))
             if self.sync_bn:
                 def fin(st):            # SyncBN: Σdy, Σdy·x̂ averaged over replicas (linear + idempotent, so the whole buffer is reduced)
                     parallel.allreduce_mean_(sums)
+                    if parts:
+                        parallel.allreduce_mean_(act['buf'])
                     fin0(st)
             else:
                 fin = fin0
@@ -680,8 +705,32 @@ class Plan:
                 def fin_frozen(st):
                     sums.zero_()
                     coef.zero_()
+                    if act:
+                        act['buf'].zero_()
                 return None, fin_frozen, app
             return red, fin, app
+
+        # ---- sums of an ENCODER block's BatchNorm backward formed by the producers of its two gradients (activated form, see
+        # satcv_bn_bwd_finalize2): encoder conv output tensor id -> dict(buf, parts)
+        act_sums = {}
+        POOL_SUMS = getattr(rt.model, 'fuse_pool_bn_sums', True) and dt == ops.BF16
+        ident = {}
+
+        def ident_vecs(c):
+            if c not in ident:
+                ident[c] = (torch.ones(c, dtype=torch.float32, device=rt.dev), torch.zeros(c, dtype=torch.float32, device=rt.dev))
+                self.keep.append(ident[c])
+            return ident[c]
+
+        def act_sums_for(t):
+            """the registry entry of encoder output t (a conv -> BN -> ReLU node that is pooled AND used as a skip), or None"""
+            if not POOL_SUMS or t.node.op != 'cba' or not t.node.attrs.get('bn', True) or not t.node.attrs.get('relu', True):
+                return None
+            if t.node.layer.bn_name in self.frozen or t.node.layer.name in shared_layers:
+                return None
+            if t.id not in act_sums:
+                act_sums[t.id] = dict(buf=self._z(STAT_ROWS, 2, t.channels, dtype=torch.float64), parts=set())
+            return act_sums[t.id]
 
         seen_layers = set()     # layers applied more than once (shared weights): later visits accumulate their gradients
         fused = {}      # tensor id -> sums buffer whose BN-backward reduce pass was done by the producer of the gradient
@@ -723,6 +772,22 @@ class Plan:
         def dgrad_step(t, **kw):
             """data-gradient launch writing the activation gradient of tensor t (and, where the kernel can, the sums of the
             BatchNorm backward of the node that produced t: one pass over two tensors less per such layer)"""
+            # the gradient of a max-pooled encoder output: this launch sees the pooled activation p = maxpool(relu(BN(y_enc))) (its own
+            # input), so its epilogue can form the pooled part of that BatchNorm's backward sums in the activated form -- sum dp [p > 0],
+            # sum dp p (bst_* with unit scale / rstd and zero shift / mean on the pooled tensor)
+            if (POOL_SUMS and not kw.get('accumulate') and t.node.op == 'pool' and len(consumers[t.id]) == 1 and t.id not in gact
+                    and len(vals[t.id].srcs) == 1 and vals[t.id].affine is None):
+                ent = act_sums_for(t.node.inputs[0])
+                if ent is not None and vals[t.id].srcs[0][1] == kw['cout'] == t.node.inputs[0].channels:
+                    one, zero = ident_vecs(kw['cout'])
+                    kwp = dict(kw, bst=dict(y=vals[t.id].srcs[0][0].data_ptr(), ld=kw['cout'], scale=_fp(one), shift=_fp(zero), mean=_fp(zero),
+                                            rstd=_fp(one), relu=1), stats=_fp(ent['buf']), stats_ld=kw['cout'])
+                    probe = ops.make_conv_desc(**kwp)
+                    if lib.satcv_conv2d_igemm_pipelined(C.byref(probe)) == 1:
+                        ent['parts'].add('pool')
+                        fn = self._conv_step(role='dgrad', **kwp)
+                        fn.label += ' +poolsums'
+                        return fn
             bt = None if kw.get('accumulate') else bst_target(t)
             # where it pays (measured per layer of the five-level U-Net, batch 64; DESIGN.md §3): the extra tile read hides under a
             # K loop of >= 1152 (3x3 x 128 channels) and under the 1x1 kernels.  The thin and middle layers are HBM-bound
@@ -977,7 +1042,8 @@ class Plan:
                                              cout, gpool_f.get(tout.id, 1), y.data_ptr() + yoff * es, ldy, aff, aoff, sums, 0, cout, cout, hh, ww,
                                              dy.data_ptr(), cout, rt.gptr(lay.name + '/bias') if BIAS_NOISE else None,
                                              rt.gptr(lay.bn_name + '/gamma'), rt.gptr(lay.bn_name + '/beta'), accum,
-                                             linear=0 if node.attrs.get('relu', True) else 1, frozen=lay.bn_name in self.frozen)
+                                             linear=0 if node.attrs.get('relu', True) else 1, frozen=lay.bn_name in self.frozen,
+                                             act=act_sums.get(tout.id) if (act_sums.get(tout.id) or {}).get('parts') else None)
                 self.bwd += [fin, app] if (pre is not None or red is None) else [red, fin, app]
                 for gr in graws:            # consumers of the un-normalised output add their gradient to dy (and to the bias gradient)
                     if gr[1] != 0 or gr[2] != cout:
@@ -1055,9 +1121,21 @@ class Plan:
                 if not (tb.node.op == 'convT' and BIAS_NOISE) and ca % 8 == 0:
                     # ONE reduce / finalize / apply over the whole concatenation: the gradient of the concatenated tensor is read
                     # once per pass in full lines (the two half launches each touched every line of it for half of its bytes)
+                    # the skip is the activated output of an encoder block that is also max-pooled: this apply pass has dskip and that
+                    # activation in registers -- it also forms the skip part of the encoder BatchNorm's backward sums (sk_sums)
+                    sec = dict(yraw1=rb.srcs[0][0].data_ptr(), ldy1=cb, dy1=du.data_ptr(), lddy1=cb, c_split=ca)
+                    ent = None
+                    if (bn not in self.frozen and ta.id not in gact and any(cn.op == 'pool' for cn in consumers[ta.id])
+                            and len([cn for cn in consumers[ta.id] if cn.op != 'pool']) == 1 and ta.channels == ca):
+                        ent = act_sums_for(ta)
+                    if ent is not None:
+                        sec.update(sk_sums=_fp(ent['buf']), sk_sums_ld=ca)
+                        ent['parts'].add('skip')
                     r_, f_, a_ = bn_bwd_steps(gptr_, ctot, None, 0, 1, ra.srcs[0][0].data_ptr(), ca, aff, 0, sums, 0, ctot, ctot, hh, ww,
                                               dskip.data_ptr(), ca, None, rt.gptr(bn + '/gamma'), rt.gptr(bn + '/beta'), frozen=bn in self.frozen,
-                                              second=dict(yraw1=rb.srcs[0][0].data_ptr(), ldy1=cb, dy1=du.data_ptr(), lddy1=cb, c_split=ca))
+                                              second=sec)
+                    if ent is not None:
+                        a_.label += ' +skipsums'
                     self.bwd += [f_, a_] if (pre is not None or r_ is None) else [r_, f_, a_]
                     gact[ta.id] = (dskip, 0, ca)
                     self.dbg['dskip:' + bn] = dskip
@@ -1119,3 +1197,4 @@ class Plan:
     def run_backward(self, st):
         for s in self.bwd:
             s(st)
+

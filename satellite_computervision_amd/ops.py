@@ -268,8 +268,9 @@ def bn_relu_pool(yraw, scale, shift, f, want_act=True, want_pool=True, stats=Non
 
 def make_bnbwd_desc(*, yraw, ldy, scale, shift, mean, rstd, n, h, w_, c, dtype, da=None, ldda=0, dpool=None, lddp=0, f=1,
                     sums=None, sums_ld=0, coef=None, dy=None, lddy_out=0, dbias=None, linear=0, yraw1=None, ldy1=0, dy1=None, lddy1=0,
-                    c_split=0):
+                    c_split=0, sk_sums=None, sk_sums_ld=0):
     d = BnBwdDesc()
+    d.sk_sums, d.sk_sums_ld = sk_sums, sk_sums_ld
     d.linear = linear
     d.yraw1, d.ldy1, d.dy1, d.lddy1, d.c_split = yraw1, ldy1, dy1, lddy1, c_split
     d.da, d.ldda, d.dpool, d.lddp, d.f = da, ldda, dpool, lddp, f

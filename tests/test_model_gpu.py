@@ -316,6 +316,42 @@ def test_full_unet_training_step_matches_oracle(mt, dtype):
     assert checked == 16
 
 
+def test_fused_backward_launches_agree_with_the_separate_ones(mt):
+    """bf16 training step of a three-level U-Net with every backward fusion on (thin layers: BatchNorm apply + data gradient + weight
+    gradient in one launch with the sums of the layer below; encoder BatchNorm sums formed by the concat-BN apply pass and by the next
+    block's data gradient; reduce passes in data-gradient / head epilogues) against the same step with one launch per pass: every
+    gradient agrees to the bf16 noise of two differently rounded chains (cos >= 0.999), and the fused launches did run."""
+    rng = np.random.default_rng(4)
+    n, hw = 3, 64
+    x = rng.random((n, hw, hw, 4)).astype(np.float32)
+    y = np.eye(2, dtype=np.float32)[(rng.random((n, hw, hw)) < 0.3).astype(np.int64)]
+
+    def run(fuse):
+        mt.reset_uids(); mt.set_seed(3)
+        m = mt.get_unet_model(2, 4, filters=[32, 64, 128], factors=[2, 2, 2])
+        m.compute_dtype = 'bfloat16'
+        m.fuse_thin_bwd = m.fuse_pool_bn_sums = m.fuse_dgrad_bn_bwd = m.fuse_head_bn_bwd = fuse
+        m.compile(optimizer=mt.Adam(1e-3), loss=lambda a, b: mt.weighted_categorical_crossentropy(a, b, [1.0, 3.0]))
+        plan = m.train_step_device(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+        torch.cuda.synchronize()
+        rt_ = m.runtime
+        inv = {v: k for k, v in mt.structural_names(m).items()}
+        g = {inv.get(p.name, p.name): rt_.get_grad(p.name).double().cpu().numpy().ravel() for p in m.param_specs if p.name in rt_.offsets}
+        return g, [getattr(f, 'label', '') or '' for f in plan.bwd]
+    g0, lab0 = run(False)
+    g1, lab1 = run(True)
+    assert not any('fused' in l or 'sums' in l or 'bnred' in l for l in lab0)
+    assert sum('bwd_fused' in l for l in lab1) == 3 and sum('+poolsums' in l for l in lab1) >= 2 and sum('+skipsums' in l for l in lab1) >= 2
+    assert sum('bn_bwd_reduce' in l for l in lab1) < sum('bn_bwd_reduce' in l for l in lab0) - 5
+    for k in g0:
+        a, b = g0[k], g1[k]
+        if np.abs(a).max() == 0:
+            assert np.abs(b).max() == 0, k
+            continue
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+        assert cos >= 0.999, f'{k}: cos {cos:.5f}'
+
+
 def test_trained_five_level_model_bf16_iou_within_1e3(mt):
     """North-star parity target on the FULL-DEPTH network: get_unet_model(2, 4) with the default five levels, trained on the GPU
     (fp32 storage) on a synthetic rectangles task, then scored on held-out 256x256 tiles -- the bf16 device mask's IoU is within
