@@ -101,8 +101,12 @@ def pmc_traffic_per_launch():
         try:
             d = json.load(open(path))
             c = d['classes'].get('igemm_3x3') or d['classes'].get('igemm_3x3_1x1_convT')
+            f = d['classes'].get('bwd_fused_3x3')             # the thin layers' fused backward launches belong to the 3x3 class
+            tot, nl = c['hbm_bytes_per_launch'] * c['launches'], c['launches']
+            if f:
+                tot, nl = tot + f['hbm_bytes_per_launch'] * f['launches'], nl + f['launches']
             src = f"{os.path.basename(path)} @ {d.get('commit', 'round-1 tree 138affc')}"
-            return round(c['hbm_bytes_per_launch'] / 1e6, 1), src
+            return round(tot / nl / 1e6, 1), src
         except Exception:
             continue
     return None, None
