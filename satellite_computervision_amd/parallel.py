@@ -155,15 +155,21 @@ class GradSync:
             stream.wait_event(ev)
         comm = self._comm(flat)
         if comm is not None:
-            # every whole bucket above lo as ONE range: satcv_allreduce_grads cuts it from the end into the same buckets
+            # every whole bucket above lo as ONE range: satcv_allreduce_grads cuts it from the end into the same buckets.  The
+            # collective runs on a stream of its OWN behind an event of `run_on` (as ProcessGroupNCCL's internal stream does for the
+            # torch path): on the weight-gradient stream itself it would hold back every later weight gradient until the peers have
+            # answered
             hi_b = self.bounds[self._next][1]
             while self._next >= 0 and self.bounds[self._next][0] >= lo:
                 lo_b = self.bounds[self._next][0]
                 self._next -= 1
-            self._send(comm, flat, lo_b, hi_b, run_on)
-            if run_on is not cur:
-                self._side_ev = torch.cuda.Event()
-                self._side_ev.record(run_on)
+            xs = self._exchange_stream(flat.device)
+            ev = torch.cuda.Event()
+            ev.record(run_on)
+            xs.wait_event(ev)
+            self._send(comm, flat, lo_b, hi_b, xs)
+            self._side_ev = torch.cuda.Event()
+            self._side_ev.record(xs)
             return
         with torch.cuda.stream(run_on):
             while self._next >= 0 and self.bounds[self._next][0] >= lo:
@@ -173,6 +179,11 @@ class GradSync:
 
     def _comm(self, flat):
         return cabi_comm() if (self.group is None and flat.is_cuda and flat.dtype == torch.float32) else None
+
+    def _exchange_stream(self, device):
+        if getattr(self, '_xs', None) is None:
+            self._xs = torch.cuda.Stream(device=device)
+        return self._xs
 
     def _send(self, comm, flat, a, b, stream):
         from ._lib import lib, check
@@ -188,13 +199,20 @@ class GradSync:
         if self._active():
             comm = self._comm(flat)
             if comm is not None:
+                # (every collective of the communicator on the ONE exchange stream; the current stream -- Adam comes next -- waits for it)
                 cur = torch.cuda.current_stream()
-                if self._side_ev is not None:      # ranges already in flight on the weight-gradient stream
+                xs = self._exchange_stream(flat.device)
+                if self._next >= 0:
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                    xs.wait_event(ev)
+                    self._send(comm, flat, 0, self.bounds[self._next][1], xs)
+                    self._next = -1
+                    self._side_ev = torch.cuda.Event()
+                    self._side_ev.record(xs)
+                if self._side_ev is not None:
                     cur.wait_event(self._side_ev)
                     self._side_ev = None
-                if self._next >= 0:
-                    self._send(comm, flat, 0, self.bounds[self._next][1], cur)
-                    self._next = -1
             while self._next >= 0:
                 a, b = self.bounds[self._next]
                 self._works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -70,6 +70,9 @@ for phase, steps in (('fwd', plan.fwd), ('bwd', plan.bwd)):
         elif w['kind'] == 'wgrad':
             fl = 2.0 * w['px'] * w['cin'] * w['cout'] * w['taps']
             by = w['px'] * (w['cin'] + w['cout'] * (w['taps'] if 'convT' in label else 1)) * es
+        elif w['kind'] == 'bwd_fused':          # BatchNorm apply + data gradient + weight gradient in one launch: g, y, x in, dx out
+            fl = 4.0 * w['px'] * w['cin'] * w['cout'] * w['taps']
+            by = w['px'] * (2 * w['cout'] + 2 * w['cin']) * es
         elif w['kind'] == 'bn_bwd_reduce':
             fl, by = 0.0, 2 * w['px'] * w['c'] * es
         else:
@@ -85,6 +88,7 @@ def tot(pred):
     return sum(r['us'] for r in sel), sum(r['gflop'] for r in sel), sum(r['roof_us'] for r in sel), len(sel)
 for name, pred in (('3x3 fwd+dgrad', lambda r: r['label'].startswith('conv_') and ' k3 ' in r['label']),
                    ('1x1/convT', lambda r: r['label'].startswith('conv_') and ' k1 ' in r['label']),
+                   ('fused bwd', lambda r: r['label'].startswith('bwd_fused')),
                    ('wgrad', lambda r: r['label'].startswith('wgrad')),
                    ('bn_bwd', lambda r: r['label'].startswith('bn_bwd'))):
     us, gf, roof, cnt = tot(pred)
