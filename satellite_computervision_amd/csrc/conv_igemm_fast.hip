@@ -540,7 +540,9 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
     // deep 3x3 layers: 256-pixel x 128-channel tile, 8 waves, double-buffered stages (SATCV_DB=0 keeps the 128 x 128 tile)
     const int db_mode = g_opt_igemm_db;
     a.dbg = g_opt_igemm_sched;            // (experiment bits; none wired at present)
-    if (db_mode && a.dil == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && nspace % 128 == 0 && cin >= 64) {
+    // (K = 9 x 64 is four chunks: the double-buffered tile's longer set-up and epilogue are not amortised -- 64 -> 128 channels at 128 x 128
+    //  258 vs 235 us, at 64 x 64 67.6 vs 63.3 us on the 128 x 128 tile; from 128 input channels on it wins, profiles/r03_db_vs_single.txt)
+    if (db_mode && a.dil == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && nspace % 128 == 0 && (cin >= 128 || db_mode >= 2)) {
       const long long tiles256 = (long long)cdiv(a.n * a.h * a.w_, 256) * (nspace / 128);
       // (a 512-pixel x 128-channel tile -- wave tile 64 x 128, 128 accumulator registers -- needs ~300 bytes of scratch per lane at the
       //  256-register cap of two waves per SIMD: not kept)
