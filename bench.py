@@ -101,10 +101,7 @@ def pmc_traffic_per_launch():
         try:
             d = json.load(open(path))
             c = d['classes'].get('igemm_3x3') or d['classes'].get('igemm_3x3_1x1_convT')
-            f = d['classes'].get('bwd_fused_3x3')             # the thin layers' fused backward launches belong to the 3x3 class
             tot, nl = c['hbm_bytes_per_launch'] * c['launches'], c['launches']
-            if f:
-                tot, nl = tot + f['hbm_bytes_per_launch'] * f['launches'], nl + f['launches']
             src = f"{os.path.basename(path)} @ {d.get('commit', 'round-1 tree 138affc')}"
             return round(tot / nl / 1e6, 1), src
         except Exception:
@@ -369,17 +366,28 @@ def main():
     if rank == 0:
         tiles = world * B * args.steps
         value = tiles / dt
-        d0, d3 = prof['conv3x3_igemm_fwd_dgrad'], prof['conv3x3_fused_dgrad_wgrad']
-        d = dict(ms=d0['ms'] + d3['ms'], launches=d0['launches'] + d3['launches'])
+        d, d3 = prof['conv3x3_igemm_fwd_dgrad'], prof['conv3x3_fused_dgrad_wgrad']
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bfloat16' else 157.3
         aw = alg_work(B, 2 if args.dtype == 'bfloat16' else 4)
         a3 = aw['conv3_fwd_dgrad']
-        # achieved = ALGORITHMIC FLOPs of the 3x3 forward + data-gradient launches of the timed steps (true Cin: 4 for the first
-        # layer although 16 channels are stored) / their summed HIP-event durations on the launch stream.  Where the thin-layer
-        # backward is ONE launch (BatchNorm apply + data gradient + weight gradient, csrc/conv_bwd_fused.hip) its whole duration is in
-        # the denominator and the weight-gradient half of its FLOPs (it reports 2 x the data gradient's) joins the numerator.
-        fused_wgrad_flops = d3['flops'] / 2.0
-        ach = (a3['flops'] * args.steps + fused_wgrad_flops) / max(d['ms'], 1e-9) / 1e9
+        # achieved = ALGORITHMIC FLOPs of the 3x3 implicit-GEMM launches of the timed steps (forward + data gradient; true Cin: 4 for the
+        # first layer although 16 channels are stored) / their summed HIP-event durations on the launch stream.  The data gradients of the
+        # thin layers whose whole backward is ONE fused launch (BatchNorm apply + data gradient + weight gradient, csrc/conv_bwd_fused.hip)
+        # are not executed by this kernel class any more: their FLOPs leave the numerator as their time left the denominator, and the fused
+        # launches (HBM-bound) are reported with their own roofline under extra.fused_backward.
+        fused = [f.work for f in plan.bwd if getattr(f, 'work', {}).get('kind') == 'bwd_fused']
+        fused_dgrad_flops = sum(2.0 * w['px'] * w['cin'] * w['cout'] * 9 for w in fused if not w.get('nodx'))
+        fused_bytes = sum(w['px'] * (2 * w['cout'] + (1 if w.get('nodx') else 2) * w['cin']) * w['esize']
+                          + (w['px'] // 4 * w['cout'] * (w['esize'] + 1) if w.get('pooled') else 0) for w in fused)
+        fused_dgrad_bytes = sum(w['px'] * (w['cin'] + w['cout']) * w['esize'] + 9 * w['cin'] * w['cout'] * w['esize'] for w in fused if not w.get('nodx'))
+        n_fused_dgrad = sum(1 for w in fused if not w.get('nodx'))
+        ach = (a3['flops'] - fused_dgrad_flops) * args.steps / max(d['ms'], 1e-9) / 1e9
+        extra['fused_backward'] = {'launches_per_step': len(fused), 'ms_per_step': round(d3['ms'] / args.steps, 3),
+                                   'algorithmic_MB_per_step': round(fused_bytes / 1e6, 1), 'bound': 'hbm',
+                                   'achieved_TBps': round(fused_bytes * args.steps / max(d3['ms'], 1e-9) / 1e9, 3), 'peak_TBps': PEAK_HBM_TBPS,
+                                   'frac': round(fused_bytes * args.steps / max(d3['ms'], 1e-9) / 1e9 / PEAK_HBM_TBPS, 4),
+                                   'tflops': round(d3['flops'] / max(d3['ms'], 1e-9) / 1e9, 1),
+                                   'data_gradient_gflop_per_step_inside': round(fused_dgrad_flops / 1e9, 1)}
         launches_per_step = max(d['launches'] / args.steps, 1)
         traffic, traffic_src = pmc_traffic_per_launch()
         out = {
@@ -392,17 +400,17 @@ def main():
                        'optimizer': 'adam(9e-4)'},
             'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                          'traffic': traffic, 'traffic_unit': 'MB per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src, 'head_commit': head_commit(),
-                         'algorithmic_bytes_per_launch_MB': round(a3['bytes'] / a3['launches'] / 1e6, 1),
+                         'algorithmic_bytes_per_launch_MB': round((a3['bytes'] - fused_dgrad_bytes) / max(a3['launches'] - n_fused_dgrad, 1) / 1e6, 1),
                          'algorithmic_gflop_per_step': round(a3['flops'] / 1e9, 1),
-                         'kernel': '3x3 implicit-GEMM conv (forward + data gradient; the thin layers\' fused backward launches with their weight-gradient FLOPs)',
-                         'fused_backward_ms_per_step': round(d3['ms'] / args.steps, 3), 'launches_per_step': launches_per_step,
+                         'kernel': '3x3 implicit-GEMM conv (forward + data gradient launches; the thin layers\' data gradients run inside the fused backward launches: extra.fused_backward)',
+                         'algorithmic_gflop_per_step_in_these_launches': round((a3['flops'] - fused_dgrad_flops) / 1e9, 1), 'launches_per_step': launches_per_step,
                          'avg_launch_us': round(1000 * d['ms'] / max(d['launches'], 1), 2),
                          # whole step against the per-layer rooflines: sum over every conv-like layer and pass (forward, data
                          # gradient, weight gradient) of max(flops / MFMA peak, unfused bytes / 8 TB/s), / measured step time
                          'step_roofline_ms': round(1000 * aw['all']['roof_s'], 3),
                          'step_frac': round(1000 * aw['all']['roof_s'] / (1000 * dt / args.steps), 4),
                          'stack_roofline_ms': round(1000 * a3['roof_s'], 3),
-                         'stack_roofline_frac': round(1000 * a3['roof_s'] / max(d['ms'] / args.steps, 1e-9), 4)},
+                         'stack_roofline_frac': round(1000 * a3['roof_s'] / max((d['ms'] + d3['ms']) / args.steps, 1e-9), 4)},
             'model_tflops': round(value * TRAIN_GFLOP_PER_TILE / 1000, 2),
             'extra': extra,
         }

@@ -187,6 +187,13 @@ typedef struct satcv_bwdf_desc {
    * compute in a pass of its own over dx and that layer's raw output.  [ROWS][2][bst_sums_ld] rows as for satcv_bn_bwd_finalize. */
   satcv_stat_t* bst_sums; int32_t bst_sums_ld;
   const float* bst_mean; const float* bst_rstd;
+  int32_t bst_act_form;                /* 1: the input x is itself an activation (in_scale NULL: a max-pooled encoder output); the rows get
+                                          sum dx [x > 0], sum dx x for satcv_bn_bwd_finalize2 */
+  /* optional, encoder_block (utils/model_tools.py:262-286): the block's activated output is ALSO max-pooled 2 x 2 -- g is the gradient
+   * of the skip, dpool (n, h/2, w/2, lddp) the gradient of MaxPooling2D's output and amax the arg-max bytes satcv_bn_relu_pool_amax
+   * wrote: the launch uses g + (amax == position in the window ? dpool : 0).  Limits: 32 -> 64 channels; or 16 stored channels -> 32
+   * with dx == NULL (the first block: fed by the model input, no data gradient). */
+  const void* dpool; int32_t lddp; const void* amax;
 } satcv_bwdf_desc;
 int64_t satcv_conv2d_bwd_fused_workspace(const satcv_bwdf_desc* d);
 int satcv_conv2d_bwd_fused(const satcv_bwdf_desc* d, void* stream);
@@ -211,6 +218,11 @@ int satcv_bn_affine_infer(const float* gamma, const float* beta, const float* mo
 int satcv_bn_relu_pool(const void* yraw, const float* scale, const float* shift, void* act, int32_t act_ld,
                        void* pooled, satcv_stat_t* stats, int32_t stats_ld, int32_t n, int32_t h,
                        int32_t w_, int32_t c, int32_t f, int32_t dtype, void* stream);
+/* the same, also writing amax (n, h/f, w/f, c) bytes: the position i * f + j of every window's first maximum (what the backward of
+ * MaxPooling2D routes the gradient to) -- read by the pooled form of satcv_conv2d_bwd_fused instead of re-scanning the windows */
+int satcv_bn_relu_pool_amax(const void* yraw, const float* scale, const float* shift, void* act, int32_t act_ld,
+                            void* pooled, void* amax, satcv_stat_t* stats, int32_t stats_ld, int32_t n, int32_t h,
+                            int32_t w_, int32_t c, int32_t f, int32_t dtype, void* stream);
 
 /* Backward of  a = relu(scale*y+shift)  (training-mode BN):
  *   g  = (da [+ unpool(dpool)]) * (a > 0)

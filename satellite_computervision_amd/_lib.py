@@ -65,7 +65,8 @@ class BwdfDesc(C.Structure):
                 ('dw', c_vp), ('cin', c_i32), ('cout', c_i32),
                 ('n', c_i32), ('h', c_i32), ('w_', c_i32), ('kh', c_i32), ('kw', c_i32), ('dil', c_i32),
                 ('workspace', c_vp), ('workspace_bytes', c_i64), ('dtype', c_i32), ('accumulate', c_i32),
-                ('bst_sums', c_vp), ('bst_sums_ld', c_i32), ('bst_mean', c_vp), ('bst_rstd', c_vp)]
+                ('bst_sums', c_vp), ('bst_sums_ld', c_i32), ('bst_mean', c_vp), ('bst_rstd', c_vp), ('bst_act_form', c_i32),
+                ('dpool', c_vp), ('lddp', c_i32), ('amax', c_vp)]
 
 
 class BnBwdDesc(C.Structure):
@@ -110,6 +111,7 @@ _SIGS = {
                                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'satcv_bn_affine_infer': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp]),
     'satcv_bn_relu_pool': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'satcv_bn_relu_pool_amax': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'satcv_bn_bwd_reduce': (C.c_int, [C.POINTER(BnBwdDesc), c_vp]),
     'satcv_bn_bwd_finalize': (C.c_int, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'satcv_bn_bwd_apply': (C.c_int, [C.POINTER(BnBwdDesc), c_vp]),

@@ -35,6 +35,9 @@ struct BwdfArgs {
   // BatchNorm-backward sums of the layer BELOW (the BatchNorm + ReLU whose scale / shift are this launch's in_scale / in_shift): sum gm and
   // sum gm * xhat over the batch, gm = dx * [x > 0], into the same replica rows satcv_bn_bwd_reduce fills (satcv.h: bst_*)
   satcv_stat_t* bst_sums; int bst_ld; const float* bst_mean; const float* bst_rstd;
+  int bst_act_form;                              // 1: leave the sums in the activated form (sum dx [x > 0], sum dx x): satcv_bn_bwd_finalize2 converts
+  // POOL: the block's output was also max-pooled 2 x 2 -- g = da + (amax == position in the window ? dpool : 0)
+  const void* dp; int lddp; const unsigned char* amax;
 };
 
 __device__ __forceinline__ bf16x4 tr_read4(const bf16* p) {
@@ -44,22 +47,25 @@ __device__ __forceinline__ bf16x4 tr_read4(const bf16* p) {
 
 // WPS = waves per SIMD the registers are budgeted for: 2 (256 registers; 4 waves x 2 workgroups per CU, or 8 waves x 1), or 1 for
 // 64 -> 64 channels, whose 36 weight-gradient accumulator tiles + in-flight tile do not fit 256 registers at any wave count
-template <int CIN, int COUT, int NW, int WPS>
+// POOL: encoder blocks -- the gradient of the activated output is da (skip) + the 2 x 2 max-pool's gradient routed by the arg-max bytes
+// the forward pooling kernel wrote.  NODG: no data gradient (the block is fed by the model input).  CINS: stored input channels when
+// fewer than the 32 rows of an MFMA tile (16 for the first block: the upper x planes are zero)
+template <int CIN, int COUT, int NW, int WPS, bool POOL = false, bool NODG = false, int CINS = CIN>
 __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs a, const int total_tiles) {
   typedef bf16 T;
   constexpr int TW = 32, TH = 8, BM = 256, RL = TH + 2, CL = TW + 2, PITCH = CL, EL = 8, NTHREADS = NW * 64;
-  constexpr int SD = COUT / 8, SX = CIN / 8;                     // 16-byte channel slots of dy / x
+  constexpr int SD = COUT / 8, SX = CIN / 8, SXR = CINS / 8;     // 16-byte channel slots of dy / x (SXR of them real)
   constexpr int DSTRIDE = RL * PITCH * EL;                       // 5,440 B = 64 B modulo 256 B
   constexpr int XSTRIDE = BM * EL + 32;                          // 4,096 B + 64 B
   static_assert((DSTRIDE * 2) % 256 == 64 && (XSTRIDE * 2) % 256 == 64, "plane strides must be 64 B modulo 256 B");
   constexpr int D_ITEMS = RL * CL * SD, DI = (D_ITEMS + NTHREADS - 1) / NTHREADS;
-  constexpr int X_ITEMS = BM * SX, XI = X_ITEMS / NTHREADS;
-  static_assert(X_ITEMS % NTHREADS == 0 && NTHREADS % SD == 0 && NTHREADS % SX == 0, "item -> thread mapping");
-  constexpr int XPIX_STEP = NTHREADS / SX;                       // interior pixels between two x items of a thread (a multiple of 32: same column)
+  constexpr int X_ITEMS = BM * SXR, XI = X_ITEMS / NTHREADS;
+  static_assert(X_ITEMS % NTHREADS == 0 && NTHREADS % SD == 0 && NTHREADS % SXR == 0, "item -> thread mapping");
+  constexpr int XPIX_STEP = NTHREADS / SXR;                       // interior pixels between two x items of a thread (a multiple of 32: same column)
   static_assert(XPIX_STEP % 32 == 0, "x items of a thread must share a column");
   constexpr int MT = 8 / NW, NT = CIN / 32;                      // data gradient: wave tile (MT x 32 pixels) x CIN
   constexpr int NTILE = (CIN / 32) * (COUT / 32) * 9, WT = (NTILE + NW - 1) / NW;   // weight gradient: (ci-tile, co-tile, tap) products per wave
-  constexpr int W_ITEMS = 9 * SD * CIN;
+  constexpr int W_ITEMS = NODG ? 0 : 9 * SD * CIN;
   constexpr size_t R0_BYTES = ((size_t)(SD * DSTRIDE + SX * XSTRIDE) * sizeof(T) + 127) / 128 * 128;
   constexpr size_t W_BYTES = (size_t)W_ITEMS * EL * sizeof(T);
   // dx staging tile [256][CIN + 8]: over the dy planes when it fits there (the x planes stay intact: the fused sums of the layer below
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
   constexpr size_t O_BYTES = (size_t)BM * (CIN + 8) * sizeof(T);
   constexpr bool O_ALIAS = O_BYTES <= (size_t)SD * DSTRIDE * sizeof(T);
   constexpr size_t TAB_BYTES = (size_t)(SD * 32 + SX * 16) * sizeof(float);
+  static_assert(!NODG || O_ALIAS || true, "");
   constexpr size_t O_OFF = O_ALIAS ? 0 : (R0_BYTES + W_BYTES + TAB_BYTES + 127) / 128 * 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* ldsD = reinterpret_cast<T*>(smem_raw);                                   // dy halo planes
@@ -81,13 +88,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
 
   // ---- once per workgroup: weights and the per-channel tables
   for (int it = tid; it < W_ITEMS; it += NTHREADS) lstore8<T>(ldsW + (size_t)it * EL, gload8<T>(wp + (size_t)it * EL));
+  if constexpr (SXR < SX) {                                                   // zero planes of the padded input channels (never staged again)
+    for (int it = tid; it < (SX - SXR) * BM; it += NTHREADS) lstore8<T>(ldsX + (SXR + it / BM) * XSTRIDE + (it % BM) * EL, zero8<T>());
+  }
   for (int ch = tid; ch < COUT; ch += NTHREADS) {
     // dy = sc * (gm - c1 - xhat * c2), xhat = (y - mu) * rs   ==   sc * gm + B * y + C
     const float sc = a.bn_scale[ch], sh = a.bn_shift[ch], mu = a.bn_mean[ch], rs = a.bn_rstd[ch], c1 = a.bn_coef[ch], c2 = a.bn_coef[a.bn_c + ch];
     float* t = tabD + (ch >> 3) * 32 + (ch & 7);
     t[0] = sc; t[8] = sh; t[16] = -sc * c2 * rs; t[24] = sc * (c2 * rs * mu - c1);
   }
-  for (int ch = tid; ch < CIN; ch += NTHREADS) {
+  for (int ch = tid; ch < CINS; ch += NTHREADS) {
     float* t = tabX + (ch >> 3) * 16 + (ch & 7);
     t[0] = a.in_scale ? a.in_scale[ch] : 1.f; t[8] = a.in_scale ? a.in_shift[ch] : 0.f;
   }
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
   const unsigned xrelu_lim = a.in_relu != 0 ? 0u : 0x80008000u;
 
   // ---- staged items of this thread (tile-invariant): dy halo items (g and y at one halo pixel, 8 channels), x interior items
-  const int slot_d = tid % SD, slot_x = tid % SX;
+  const int slot_d = tid % SD, slot_x = tid % SXR;
   // (halo row and column of an item packed in 10 bits, three items per register; the LDS destination and the source offset are
   //  re-derived where they are used, with 24-bit multiplies: the kernel sits at the 256-register cap of two waves per SIMD and every
   //  spilled value is reloaded by a scratch load that queues behind the prefetched tile on the in-order vmcnt counter)
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
   const bool xsecond = xch0 >= a.c0;
   const T* xsrc = xsecond ? reinterpret_cast<const T*>(a.x1) + (xch0 - a.c0) : reinterpret_cast<const T*>(a.x0) + xch0;
   const int xcs = xsecond ? a.c1 : a.c0;
-  const int xq0 = tid / SX;                                                   // first interior pixel of this thread
+  const int xq0 = tid / SXR;                                                  // first interior pixel of this thread
   const int x_l0 = slot_x * XSTRIDE + xq0 * EL;
   const int x_eoff0 = ((xq0 / TW) * a.e.w_ + (xq0 % TW)) * xcs, x_estep = (XPIX_STEP / TW) * a.e.w_ * xcs;
 
@@ -146,6 +156,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
     if (x0 >= a.e.w_) { x0 = 0; y0 += TH; if (y0 >= a.e.h) { y0 = 0; ++n0; } }
   };
   Raw8<T> rg[DI], ry[DI], rx[XI];
+  Raw8<T> rp[POOL ? DI : 1];                                                  // pooled gradient of the item's window
+  uint2 ra[POOL ? DI : 1];                                                    // arg-max bytes of the window (8 channels)
+  const int hp = a.e.h >> 1, wpool = a.e.w_ >> 1;
   unsigned valid = 0;
   auto issue_loads = [&](int n0, int y0, int x0) -> unsigned {
     unsigned vm = 0;
@@ -165,6 +178,24 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
       ry[j] = gload8<T>(yb + off);
     }
     return vm;
+  };
+  // the pooled gradient and the arg-max bytes of every halo item's window (small, L2-friendly tensors): requested late -- after the
+  // MFMA phases -- so that their 6 registers per item are not live beside the accumulators and fragments
+  auto issue_pool = [&](int n0, int y0, int x0) {
+    if constexpr (POOL) {
+      const int ylo = 1 - y0, yhi = a.e.h - y0 + 1, xlo = 1 - x0, xhi = a.e.w_ - x0 + 1;
+      const size_t pb = (size_t)(n0 * hp + (y0 >> 1)) * wpool + (x0 >> 1);
+#pragma unroll
+      for (int j = 0; j < DI; ++j) {
+        const int pk_ = d_item(j), L = pk_ >> 6, c = pk_ & 63;
+        const bool ok = pk_ != 0x3ff && L >= ylo && L < yhi && c >= xlo && c < xhi;
+        // the window of halo pixel (L - 1, c - 1) relative to the tile's first window; outside items read that first window
+        int po = ok ? __mul24((L - 1) >> 1, wpool) + ((c - 1) >> 1) : 0;
+        asm volatile("" : "+v"(po));
+        rp[j] = gload8<T>(reinterpret_cast<const T*>(a.dp) + (pb + po) * a.lddp + gy_lane);
+        ra[j] = *reinterpret_cast<const uint2*>(a.amax + (pb + po) * COUT + gy_lane);
+      }
+    }
   };
   auto issue_x = [&](int n0, int y0, int x0) {
     const size_t bp = (size_t)(n0 * a.e.h + y0) * a.e.w_ + x0;
@@ -195,12 +226,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
   }
 
   // (not in the one-wave-per-SIMD instantiation: its 120 registers of prefetched tile leave no room for 16 more accumulators)
-  constexpr bool BST = WPS != 1;
+  constexpr bool BST = !NODG && (WPS != 1 || POOL);      // (not in the dense one-wave-per-SIMD form; the pooled one has the room)
   float bs1[8], bs2[8];                                                       // fused sums of the layer below: this thread's 8 channels, all its tiles
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; }
   int n0, y0, x0;
-  if (t_lo < t_hi) { tile_origin(t_lo, n0, y0, x0); valid = issue_loads(n0, y0, x0); issue_x(n0, y0, x0); }
+  if (t_lo < t_hi) { tile_origin(t_lo, n0, y0, x0); valid = issue_loads(n0, y0, x0); issue_x(n0, y0, x0); issue_pool(n0, y0, x0); }
   __syncthreads();                                                            // weights and tables are in LDS
   for (int t = t_lo; t < t_hi; ++t) {
     // ---- registers -> LDS: dy from (g, y) with the BatchNorm-backward coefficients, zero outside the image; x with its BatchNorm + ReLU
@@ -218,6 +249,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
         float gv[8], yv[8];
         unpack8<T>(rg[j], gv);
         unpack8<T>(ry[j], yv);
+        if constexpr (POOL) {
+          float pv[8];
+          unpack8<T>(rp[j], pv);
+          const int pk2 = d_item(j);
+          const unsigned sub = ((((pk2 >> 6) + 1) & 1) << 1) | (((pk2 & 63) + 1) & 1);      // position of halo pixel (L - 1, c - 1) in its 2 x 2 window
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const unsigned am = ((e < 4 ? ra[j].x : ra[j].y) >> (8 * (e & 3))) & 0xffu;
+            gv[e] += am == sub ? pv[e] : 0.f;
+          }
+        }
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -294,6 +336,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
     }
     // (the next tile's x items are requested here rather than with g and y: 16 registers less through the weight-gradient phase)
     if (t + 1 < t_hi) issue_x(n0, y0, x0);
+    if (POOL && NODG && t + 1 < t_hi) issue_pool(n0, y0, x0);
+    if constexpr (!NODG) {
     // ---- data gradient (after the weight gradient: its accumulators are then live only from here to the epilogue): 9 taps x COUT / 16 k-steps on the dy halo image (conv_igemm_ws.hip's loop with dy as the input)
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -326,6 +370,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
           for (int n = 0; n < NT; ++n) mma32<T>(acc[m][n], af[st & 1][m], bf[st & 1][n]);
       }
     }
+    if (POOL && t + 1 < t_hi) issue_pool(n0, y0, x0);
     __syncthreads();                                                          // every wave is past its last fragment read: the tile region is free
     {
       // dx tile: accumulators -> bf16 -> LDS [pixel][CIN + 8] -> 16-byte row stores (the shared igemm_epilogue's interior path without
@@ -363,6 +408,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
         }
       }
     }
+    }
     __syncthreads();                                                          // staged output read out before the next tile is written
   }
   // ---- this workgroup's partial weight gradient: ws[block][tap][ci][co]
@@ -389,8 +435,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
       const int vq = tid >> 3, e = tid & 7;                                   // channel tid = vq * 8 + e; its contributors: threads t with t % VPR == vq
       double t1 = 0.0, t2 = 0.0;
       for (int k = 0; k < NPER; ++k) { t1 += (double)red[e * NTHREADS + k * VPR + vq]; t2 += (double)red[(8 + e) * NTHREADS + k * VPR + vq]; }
-      const double sc = (double)a.in_scale[tid], sh = (double)a.in_shift[tid], mu = (double)a.bst_mean[tid], rs = (double)a.bst_rstd[tid];
-      const double s2 = sc != 0.0 ? (t2 - (sh + sc * mu) * t1) * (rs / sc) : 0.0;
+      double s2 = t2;                                                         // activated form: the finalize converts
+      if (!a.bst_act_form) {
+        const double sc = (double)a.in_scale[tid], sh = (double)a.in_shift[tid], mu = (double)a.bst_mean[tid], rs = (double)a.bst_rstd[tid];
+        s2 = sc != 0.0 ? (t2 - (sh + sc * mu) * t1) * (rs / sc) : 0.0;
+      }
       satcv_stat_t* rowp = a.bst_sums + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.bst_ld;
       atomicAdd(rowp + tid, (satcv_stat_t)t1);
       atomicAdd(rowp + a.bst_ld + tid, (satcv_stat_t)s2);
@@ -399,13 +448,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
 }
 
 // ------------------------------------------------------------------ host side
-template <int CIN, int COUT, int NW>
+template <int CIN, int COUT, int NW, bool NODG = false>
 struct BwdfGeom {
   static constexpr int SD = COUT / 8, SX = CIN / 8;
   static constexpr size_t R0 = ((size_t)(SD * (10 * 34 * 8) + SX * (256 * 8 + 32)) * 2 + 127) / 128 * 128;
   static constexpr size_t O_BYTES = (size_t)256 * (CIN + 8) * 2;
   static constexpr bool O_ALIAS = O_BYTES <= (size_t)SD * (10 * 34 * 8) * 2;
-  static constexpr size_t BASE = R0 + (size_t)9 * SD * CIN * 16 + (size_t)(SD * 32 + SX * 16) * 4;
+  static constexpr size_t BASE = R0 + (NODG ? 0 : (size_t)9 * SD * CIN * 16) + (size_t)(SD * 32 + SX * 16) * 4;
   static constexpr size_t LDS0 = O_ALIAS ? BASE : (BASE + 127) / 128 * 128 + O_BYTES;
   static constexpr size_t RED = (size_t)16 * NW * 64 * 4;                      // end-of-kernel reduction scratch of the fused sums
   static constexpr size_t LDS = LDS0 > RED ? LDS0 : RED;
@@ -429,20 +478,28 @@ static int bwdf_grid(size_t lds, int waves, int wps, long long total) {
 
 static bool bwdf_shape_ok(const satcv_bwdf_desc* d, int& cin_s) {
   cin_s = d->c0 + d->c1;
-  if (d->bst_sums && cin_s == 64 && d->cout == 64) return false;    // (that instantiation does not carry the fused sums)
   if (d->dtype != SATCV_BF16 || d->kh != 3 || d->kw != 3 || d->dil != 1) return false;
-  if (!((cin_s == 32 && d->cout == 32) || (cin_s == 64 && d->cout == 32) || (cin_s == 64 && d->cout == 64))) return false;
-  if (d->cin != cin_s) return false;                                // real == stored input channels (the slab has no padding rows)
   if (d->x1 && d->c0 % 8 != 0) return false;
   if (d->h % 8 != 0 || d->w_ % 32 != 0) return false;               // whole 8 x 32 tiles
-  if (d->ldg % 8 != 0 || d->lddx % 8 != 0 || ((uintptr_t)d->dx % 16) != 0 || ((uintptr_t)d->g % 16) != 0 || ((uintptr_t)d->yraw % 16) != 0) return false;
+  if (d->ldg % 8 != 0 || ((uintptr_t)d->g % 16) != 0 || ((uintptr_t)d->yraw % 16) != 0) return false;
+  if (d->dx && (d->lddx % 8 != 0 || ((uintptr_t)d->dx % 16) != 0)) return false;
   if ((long long)d->w_ * d->ldg >= (1 << 23)) return false;         // 24-bit multiplies of the halo offsets
+  if (d->dpool) {
+    // encoder blocks: 32 -> 64 channels with a data gradient, or the first block (16 stored channels -> 32) without one
+    if (!d->amax || d->lddp % 8 != 0 || ((uintptr_t)d->dpool % 16) != 0 || ((uintptr_t)d->amax % 8) != 0 || d->x1) return false;
+    if (d->dx) return cin_s == 32 && d->cin == 32 && d->cout == 64;
+    return cin_s == 16 && d->cin <= 16 && d->cout == 32 && !d->bst_sums;
+  }
+  if (!d->dx) return false;
+  if (d->bst_sums && cin_s == 64 && d->cout == 64) return false;    // (that instantiation does not carry the fused sums)
+  if (!((cin_s == 32 && d->cout == 32) || (cin_s == 64 && d->cout == 32) || (cin_s == 64 && d->cout == 64))) return false;
+  if (d->cin != cin_s) return false;                                // real == stored input channels (the slab has no padding rows)
   return true;
 }
 
-template <int CIN, int COUT, int NW, int WPS>
+template <int CIN, int COUT, int NW, int WPS, bool POOL = false, bool NODG = false, int CINS = CIN>
 static int bwdf_launch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int64_t* ws_bytes) {
-  using G = BwdfGeom<CIN, COUT, NW>;
+  using G = BwdfGeom<CIN, COUT, NW, NODG>;
   static_assert(G::LDS <= 160 * 1024, "tile + weights exceed the LDS");
   const long long total = (long long)d->n * (d->h / 8) * (d->w_ / 32);
   const int grid = bwdf_grid(G::LDS, NW, WPS, total);
@@ -458,10 +515,11 @@ static int bwdf_launch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int
   a.bn_scale = d->bn_scale; a.bn_shift = d->bn_shift; a.bn_mean = d->bn_mean; a.bn_rstd = d->bn_rstd; a.bn_coef = d->bn_coef; a.bn_c = d->cout; a.linear = d->linear;
   a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_relu = d->in_relu;
   a.w = d->w_dgrad; a.ws = d->workspace; a.tiles_x = d->w_ / 32; a.tiles_y = d->h / 8;
-  a.bst_sums = d->bst_sums; a.bst_ld = d->bst_sums_ld; a.bst_mean = d->bst_mean; a.bst_rstd = d->bst_rstd;
-  auto kern = bwd_fused_kernel<CIN, COUT, NW, WPS>;
+  a.bst_sums = d->bst_sums; a.bst_ld = d->bst_sums_ld; a.bst_mean = d->bst_mean; a.bst_rstd = d->bst_rstd; a.bst_act_form = d->bst_act_form;
+  a.dp = d->dpool; a.lddp = d->lddp; a.amax = reinterpret_cast<const unsigned char*>(d->amax);
+  auto kern = bwd_fused_kernel<CIN, COUT, NW, WPS, POOL, NODG, CINS>;
   { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS); if (rc) return rc; }
-  const double flops = 4.0 * d->n * d->h * d->w_ * (double)CIN * COUT * 9;          // data gradient + weight gradient
+  const double flops = (NODG ? 2.0 : 4.0) * d->n * d->h * d->w_ * (double)CINS * COUT * 9;          // (data gradient +) weight gradient
   satcv_prof_begin(3, flops, st);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), G::LDS, st, a, (int)total);
   satcv_prof_end(3, st);
@@ -473,6 +531,11 @@ static int bwdf_launch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int
 static int bwdf_dispatch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int64_t* ws_bytes) {
   int cin_s;
   if (!bwdf_shape_ok(d, cin_s)) return SATCV_ERR_UNSUPPORTED;
+  if (d->dpool) {
+    // (32 -> 64 with the pooled gradient: 92 registers of prefetched items -- the 8-wave form needs 172 bytes of scratch; one wave per SIMD fits)
+    if (d->dx) return bwdf_launch<32, 64, 4, 1, true, false>(d, st, query, ws_bytes);
+    return bwdf_launch<32, 32, 8, 2, true, true, 16>(d, st, query, ws_bytes);
+  }
   // (32 -> 32: 8 waves x 1 workgroup per CU measured equal to 4 waves x 2 workgroups and leaves registers for the fused sums)
   if (cin_s == 32) return bwdf_launch<32, 32, 8, 2>(d, st, query, ws_bytes);
   if (d->cout == 32) return bwdf_launch<64, 32, 8, 2>(d, st, query, ws_bytes);
@@ -486,11 +549,12 @@ extern "C" int64_t satcv_conv2d_bwd_fused_workspace(const satcv_bwdf_desc* d) {
 }
 
 extern "C" int satcv_conv2d_bwd_fused(const satcv_bwdf_desc* d, void* stream) {
-  SATCV_CHECK(d && d->g && d->yraw && d->x0 && d->w_dgrad && d->dx && d->dw && d->workspace, "bwd_fused: null pointer");
+  SATCV_CHECK(d && d->g && d->yraw && d->x0 && d->dw && d->workspace && (d->dx == nullptr || d->w_dgrad), "bwd_fused: null pointer");
   SATCV_CHECK(d->bn_scale && d->bn_shift && d->bn_mean && d->bn_rstd && d->bn_coef, "bwd_fused: BatchNorm coefficients missing");
   SATCV_CHECK((d->c1 == 0) == (d->x1 == nullptr) && d->n > 0 && d->h > 0 && d->w_ > 0, "bwd_fused: bad dims");
-  SATCV_CHECK(!d->bst_sums || (d->in_scale && d->in_shift && d->in_relu && d->bst_mean && d->bst_rstd && d->bst_sums_ld >= d->c0 + d->c1),
-              "bwd_fused: the fused sums need the input's BatchNorm (in_scale / in_shift with ReLU, bst_mean / bst_rstd)");
+  SATCV_CHECK(!d->bst_sums || (d->bst_sums_ld >= d->c0 + d->c1 && (d->bst_act_form ? d->in_scale == nullptr
+                               : (d->in_scale && d->in_shift && d->in_relu && d->bst_mean && d->bst_rstd))),
+              "bwd_fused: the fused sums need the input's BatchNorm (in_scale / in_shift with ReLU, bst_mean / bst_rstd), or an activated input with bst_act_form");
   const int rc = bwdf_dispatch(d, reinterpret_cast<hipStream_t>(stream), false, nullptr);
   if (rc == SATCV_ERR_UNSUPPORTED) satcv_set_error("bwd_fused: shape outside the kernel's limits (ask satcv_conv2d_bwd_fused_workspace first)");
   return rc;

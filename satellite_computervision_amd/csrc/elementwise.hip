@@ -299,10 +299,13 @@ __device__ __forceinline__ void block_channel_reduce(float* lds, const float (&a
 }
 
 // ------------------------------------------------------------- BN + ReLU + maxpool
-template <typename T>
+// AMAX: also the index (i * f + j, first maximum in row-major window order -- the rule of bn_bwd_kernel) of every pooling window's maximum,
+// one byte per pooled pixel and channel: the fused pooled backward (conv_bwd_fused.hip) routes the pooled gradient with it instead of
+// re-reading the window
+template <typename T, bool AMAX = false>
 __global__ void bn_relu_pool_kernel(const T* __restrict__ yraw, const float* __restrict__ scale, const float* __restrict__ shift,
                                     T* __restrict__ act, T* __restrict__ pooled, satcv_stat_t* stats, int stats_ld,
-                                    int n, int h, int w, int c, int f, int act_ld) {
+                                    int n, int h, int w, int c, int f, int act_ld, unsigned char* __restrict__ amax = nullptr) {
   extern __shared__ float lds[];
   const int G = c / 8;
   const int hp = h / f, wp = w / f;               // 'valid' pooling
@@ -324,8 +327,9 @@ __global__ void bn_relu_pool_kernel(const T* __restrict__ yraw, const float* __r
       const int py = (int)(wdw % (unsigned)hw_);
       const int img = (int)(wdw / (unsigned)hw_);
       float mx[8];
+      unsigned char am[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
+      for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; am[e] = 0; }
       for (int i = 0; i < f; ++i) {
         const int y = py * f + i; if (y >= h) break;
         for (int j = 0; j < f; ++j) {
@@ -337,12 +341,17 @@ __global__ void bn_relu_pool_kernel(const T* __restrict__ yraw, const float* __r
           for (int e = 0; e < 8; ++e) {
             float a = fmaxf(v[e] * sc[e] + sh[e], 0.f);
             a = round_to<T>(a);
-            v[e] = a; mx[e] = fmaxf(mx[e], a); s1[e] += a; s2[e] += a * a;
+            v[e] = a; s1[e] += a; s2[e] += a * a;
+            if (AMAX) { if (a > mx[e]) { mx[e] = a; am[e] = (unsigned char)(i * f + j); } }
+            else mx[e] = fmaxf(mx[e], a);
           }
           if (act) store8<T>(act + ((size_t)(img * h + y) * w + x) * act_ld + g * 8, v);
         }
       }
-      if (pooled && py < hp && px < wp) store8<T>(pooled + ((size_t)(img * hp + py) * wp + px) * c + g * 8, mx);
+      if (pooled && py < hp && px < wp) {
+        store8<T>(pooled + ((size_t)(img * hp + py) * wp + px) * c + g * 8, mx);
+        if (AMAX) *reinterpret_cast<uint2*>(amax + ((size_t)(img * hp + py) * wp + px) * c + g * 8) = *reinterpret_cast<const uint2*>(am);
+      }
     }
   }
   if (stats) block_channel_reduce(lds, s1, s2, g, active, c, stats, stats_ld);
@@ -355,6 +364,18 @@ extern "C" int satcv_bn_relu_pool(const void* yraw, const float* scale, const fl
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_pool_kernel<T>, dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 1) * 16 * sizeof(float) : 0, (hipStream_t)stream,
                                        (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld));
   LAUNCH_OK("bn_relu_pool");
+  return SATCV_OK;
+}
+extern "C" int satcv_bn_relu_pool_amax(const void* yraw, const float* scale, const float* shift, void* act, int32_t act_ld, void* pooled, void* amax,
+                                       satcv_stat_t* stats, int32_t stats_ld, int32_t n, int32_t h, int32_t w_, int32_t c, int32_t f, int32_t dtype, void* stream) {
+  if (act_ld <= 0) act_ld = c;
+  SATCV_CHECK(yraw && scale && shift && pooled && amax && n > 0 && h > 0 && w_ > 0 && c > 0 && c % 8 == 0 && c <= 2048 && f >= 1 && f * f <= 255,
+              "bn_relu_pool_amax: bad args");
+  const long long items = (long long)n * cdiv(h, f) * cdiv(w_, f) * (c / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_pool_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 1) * 16 * sizeof(float) : 0,
+                                       (hipStream_t)stream, (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld,
+                                       (unsigned char*)amax));
+  LAUNCH_OK("bn_relu_pool_amax");
   return SATCV_OK;
 }
 

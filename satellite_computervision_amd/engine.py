@@ -262,6 +262,7 @@ class Plan:
         self.step_count = 0
         self.outputs = {}
         self.sync_bn = bool(training and getattr(rt.model, 'sync_bn', False) and parallel.active())
+        self.amax_of = {}                     # encoder output tensor id -> arg-max bytes of its 2 x 2 pooling windows (training)
         self._build()
 
     # -- helpers
@@ -342,6 +343,16 @@ class Plan:
             st_ptr, ld = _fp(sink[0], sink[1]), sink[2]
         a = r.affine
         dt = self.rt.dtype
+        if (self.training and pooled is not None and f == 2 and dt == BF16 and getattr(self.rt.model, 'fuse_pool_bwd', True)
+                and hh % 8 == 0 and ww % 32 == 0 and c in (32, 64)):
+            # training: also the arg-max byte of every window -- the fused pooled backward (satcv_conv2d_bwd_fused with dpool) routes
+            # MaxPooling2D's gradient with it
+            amax = self._z(self.n, hh // 2, ww // 2, c, dtype=torch.uint8)
+            self.amax_of[t.id] = amax
+            self.fwd.append(lambda st: check(lib.satcv_bn_relu_pool_amax(
+                y.data_ptr(), _fp(a['scale']), _fp(a['shift']), act_ptr, act_ld, pooled.data_ptr(), amax.data_ptr(),
+                st_ptr, ld, self.n, hh, ww, c, f, dt, st)))
+            return TRef([(act, c)], self.n, hh, ww) if actslot is None else None
         self.fwd.append(lambda st: check(lib.satcv_bn_relu_pool(
             y.data_ptr(), _fp(a['scale']), _fp(a['shift']), act_ptr, act_ld, pooled.data_ptr() if pooled is not None else None,
             st_ptr, ld, self.n, hh, ww, c, f, dt, st)))
@@ -700,6 +711,7 @@ class Plan:
             app = lambda st: check(lib.satcv_bn_bwd_apply(C.byref(d), st))
             app.label = f"bn_bwd_apply n{n} {hh}x{ww} c{c} f{f}"
             app.work = dict(kind='bn_bwd_apply', px=n * hh * ww, c=c, esize=es)
+            app.coef = coef
             if frozen:
                 # inference-mode BatchNormalization: dy = scale * g * mask, no batch-statistics terms (coef stays 0), no dgamma / dbeta
                 def fin_frozen(st):
@@ -1044,6 +1056,51 @@ class Plan:
                                              rt.gptr(lay.bn_name + '/gamma'), rt.gptr(lay.bn_name + '/beta'), accum,
                                              linear=0 if node.attrs.get('relu', True) else 1, frozen=lay.bn_name in self.frozen,
                                              act=act_sums.get(tout.id) if (act_sums.get(tout.id) or {}).get('parts') else None)
+                # ---- encoder blocks of the full- / half-resolution levels: the pooled BatchNorm apply + weight gradient (+ data gradient)
+                # in ONE launch (satcv_conv2d_bwd_fused with dpool / amax): no dy tensor, no separate weight-gradient launch
+                fzp = None
+                amax = self.amax_of.get(tout.id)
+                if (amax is not None and getattr(rt.model, 'fuse_pool_bwd', True) and dt == ops.BF16 and da is not None and dp is not None
+                        and gpool_f.get(tout.id, 1) == 2 and not graws and not BIAS_NOISE and cx['k'] == 3 and cx['dil'] == 1 and da[2] == ldy
+                        and dp[1] == 0 and lay.bn_name not in self.frozen and gact.get(tin.id) is None and lay.name not in shared_layers):
+                    pkp = rt.packed[lay.name]
+                    sa = self._src_args(r)
+                    want_dx = tin.node.op != 'input'
+                    cinp = r.c
+                    ginp = self._z(n, hh, ww, cinp) if want_dx else None
+                    fzp = ops.make_bwdf_desc(g=da_ptr, yraw=y.data_ptr() + yoff * es, ldg=ldy, bn_scale=_fp(aff['scale'], aoff), bn_shift=_fp(aff['shift'], aoff),
+                                             bn_mean=_fp(aff['mean'], aoff), bn_rstd=_fp(aff['rstd'], aoff), bn_coef=_fp(app.coef), linear=0,
+                                             w_dgrad=pkp['dgrad'].data_ptr() if want_dx else None, dx=ginp.data_ptr() if want_dx else None,
+                                             lddx=cinp if want_dx else 0, dw=rt.gptr(lay.name + '/kernel'), cin=pkp['cin'], cout=cout, n=n, h=hh, w_=ww,
+                                             dtype=dt, accumulate=accum, dpool=dp[0].data_ptr(), lddp=dp[2], amax=amax.data_ptr(), **sa)
+                    # its input is the max-pooled output of the block below: the pooled part of THAT block's sums, activated form
+                    ent = None
+                    if (want_dx and POOL_SUMS and tin.node.op == 'pool' and len(consumers[tin.id]) == 1 and sa['in_scale'] is None
+                            and len(vals[tin.id].srcs) == 1 and tin.node.inputs[0].channels == cinp):
+                        ent = act_sums_for(tin.node.inputs[0])
+                    if ent is not None:
+                        fzp.bst_sums, fzp.bst_sums_ld, fzp.bst_act_form = _fp(ent['buf']), cinp, 1
+                    nbp = lib.satcv_conv2d_bwd_fused_workspace(C.byref(fzp))
+                    if nbp < 0:
+                        fzp = None
+                    elif ent is not None:
+                        ent['parts'].add('pool')
+                if fzp is not None:
+                    fused_ws_need = max(fused_ws_need, nbp)
+                    fdescs.append(fzp)
+                    self.keep.append(fzp)
+                    self.bwd += [fin] if (pre is not None or red is None) else [red, fin]
+                    fstep = lambda st, fzp=fzp: check(lib.satcv_conv2d_bwd_fused(C.byref(fzp), st))
+                    fstep.label = f"bwd_fused k3 n{n} {hh}x{ww} {sa['c0']}+{sa['c1']}->{cout} pooled{'' if want_dx else ' nodx'}{' +poolsums' if fzp.bst_sums else ''}"
+                    fstep.work = dict(kind='bwd_fused', taps=9, px=n * hh * ww, cin=pkp['cin'], cout=cout, esize=es, nodx=not want_dx, pooled=True)
+                    self.bwd.append(fstep)
+                    if want_dx:
+                        gact[tin.id] = (ginp, 0, cinp)
+                        self.dbg['dx:' + lay.name] = ginp
+                    self.dbg['dyparts:' + lay.name] = dict(g=da, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout, coef=app.coef, linear=0,
+                                                           dp=dp, amax=amax)
+                    self.dbg['_ctx:' + lay.name] = dict(da=da, dp=dp, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout)
+                    continue
                 self.bwd += [fin, app] if (pre is not None or red is None) else [red, fin, app]
                 for gr in graws:            # consumers of the un-normalised output add their gradient to dy (and to the bias gradient)
                     if gr[1] != 0 or gr[2] != cout:

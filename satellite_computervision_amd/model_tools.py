@@ -735,6 +735,7 @@ class Model:
         self.fuse_dgrad_bn_bwd = os.environ.get('SATCV_FUSE_DGRAD_BN_BWD', '1') != '0'  # data-gradient epilogues do the reduce pass of the BN below them
         self.wgrad_side_stream = os.environ.get('SATCV_WGRAD_STREAM', '1') != '0'      # weight gradients on a second HIP stream
         self.fuse_pool_bn_sums = os.environ.get('SATCV_FUSE_POOL_BN_SUMS', '1') != '0'  # encoder BN-backward sums formed by the producers of its gradients
+        self.fuse_pool_bwd = os.environ.get('SATCV_FUSE_POOL_BWD', '1') != '0'         # encoder blocks: pooled BN apply + weight (+ data) gradient in one launch
         self.fuse_thin_bwd = os.environ.get('SATCV_FUSE_THIN_BWD', '1') != '0'         # thin layers: BN-backward apply + data + weight gradient in one launch
         self.sync_bn = os.environ.get('SATCV_SYNC_BN', '0') == '1'      # data parallel: BatchNorm statistics over ALL replicas (parallel.py)
         self._rt = None

@@ -289,6 +289,13 @@ def test_full_unet_training_step_matches_oracle(mt, dtype):
             gq = gt.double().reshape(-1, gld)[:, goff:goff + pz['cout']].reshape(n, 256 if False else cx['r'].h, cx['r'].w, pz['cout'])
             yq = pz['y'].double().reshape(-1, pz['ldy'])[:, pz['yoff']:pz['yoff'] + pz['cout']].reshape(gq.shape)
             af = {k_: pz['aff'][k_].double()[pz['aoff']:pz['aoff'] + pz['cout']] for k_ in ('scale', 'shift', 'mean', 'rstd')}
+            if 'dp' in pz:                  # encoder blocks: + MaxPooling2D's gradient routed to the first maximum of every 2 x 2 window
+                dpt, _, dpld = pz['dp']
+                dpq = dpt.double().reshape(gq.shape[0], gq.shape[1] // 2, gq.shape[2] // 2, dpld)[..., :pz['cout']]
+                am = pz['amax'].long()
+                gq = gq.clone()
+                for sub in range(4):
+                    gq[:, sub // 2::2, sub % 2::2, :] += torch.where(am == sub, dpq, torch.zeros_like(dpq))
             c1, c2 = pz['coef'].double()[0], pz['coef'].double()[1]
             gm = gq if pz['linear'] else torch.where(yq * af['scale'] + af['shift'] > 0, gq, torch.zeros_like(gq))
             dy = (af['scale'] * (gm - c1 - (yq - af['mean']) * af['rstd'] * c2)).to(td).double().cpu().numpy()
@@ -330,7 +337,7 @@ def test_fused_backward_launches_agree_with_the_separate_ones(mt):
         mt.reset_uids(); mt.set_seed(3)
         m = mt.get_unet_model(2, 4, filters=[32, 64, 128], factors=[2, 2, 2])
         m.compute_dtype = 'bfloat16'
-        m.fuse_thin_bwd = m.fuse_pool_bn_sums = m.fuse_dgrad_bn_bwd = m.fuse_head_bn_bwd = fuse
+        m.fuse_thin_bwd = m.fuse_pool_bwd = m.fuse_pool_bn_sums = m.fuse_dgrad_bn_bwd = m.fuse_head_bn_bwd = fuse
         m.compile(optimizer=mt.Adam(1e-3), loss=lambda a, b: mt.weighted_categorical_crossentropy(a, b, [1.0, 3.0]))
         plan = m.train_step_device(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
         torch.cuda.synchronize()
@@ -341,7 +348,7 @@ def test_fused_backward_launches_agree_with_the_separate_ones(mt):
     g0, lab0 = run(False)
     g1, lab1 = run(True)
     assert not any('fused' in l or 'sums' in l or 'bnred' in l for l in lab0)
-    assert sum('bwd_fused' in l for l in lab1) == 3 and sum('+poolsums' in l for l in lab1) >= 2 and sum('+skipsums' in l for l in lab1) >= 2
+    assert sum('bwd_fused' in l for l in lab1) == 5 and sum('pooled' in l for l in lab1) == 2 and sum('+poolsums' in l for l in lab1) >= 2 and sum('+skipsums' in l for l in lab1) >= 2
     assert sum('bn_bwd_reduce' in l for l in lab1) < sum('bn_bwd_reduce' in l for l in lab0) - 5
     for k in g0:
         a, b = g0[k], g1[k]

@@ -616,6 +616,70 @@ def test_fused_thin_layer_backward(ops, case):
                               to_dev(xr[:, :6, :, :c0], td), wd, cin, cout, x1=to_dev(xr[:, :6, :, c0:], td) if c1 else None) is None
 
 
+@pytest.mark.parametrize('case', [
+    # n, h, w, stored cin, real cin, cout, data gradient
+    (2, 16, 64, 32, 32, 64, True),          # encoder_block 2 of get_unet_model (32 -> 64 channels)
+    (3, 24, 32, 16, 4, 32, False),          # the first block: 4 bands stored as 16 channels -> 32, fed by the model input (no dx)
+])
+def test_fused_pooled_encoder_backward(ops, case):
+    """The pooled form of satcv_conv2d_bwd_fused (encoder_block, utils/model_tools.py:262-286: the block's output is a skip AND is
+    max-pooled): g = da + MaxPooling2D's gradient routed by the arg-max bytes of satcv_bn_relu_pool_amax.  Against the float64 oracle
+    (first maximum in row-major window order) and the arg-max bytes themselves against NumPy."""
+    n, h, w, cs, cin, cout, want_dx = case
+    td = torch.bfloat16
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    xr = rnd(rng, (n, h, w, cs), td)
+    xr[..., cin:] = 0
+    da = rnd(rng, (n, h, w, cout), td)
+    dp = rnd(rng, (n, h // 2, w // 2, cout), td)
+    v = rnd(rng, (n, h, w, cout), td) * 1.5 + 0.25
+    v = torch.tensor(v, dtype=torch.float32).to(td).double().numpy()
+    kern = rnd(rng, (3, 3, cin, cout), td, 0.2)
+    sc, sh = (0.5 + rng.random(cout)).astype(np.float32) * rng.choice([-1, 1], cout), rng.standard_normal(cout).astype(np.float32) * 0.5
+    mu, rs = rng.standard_normal(cout).astype(np.float32) * 0.3, (0.5 + rng.random(cout)).astype(np.float32)
+    coef = (rng.standard_normal((2, cout)) * 0.1).astype(np.float32)
+    f64 = lambda t: t.astype(np.float64)
+    # forward: activation (rounded to bf16 as stored), pooled maximum and its first position
+    act_d, pooled_d, amax_d = ops.bn_relu_pool_amax(to_dev(v, td), f32dev(sc), f32dev(sh), 2)
+    act = torch.tensor(np.maximum(v * f64(sc) + f64(sh), 0), dtype=torch.float32)
+    act = (torch.tensor(v, dtype=torch.float32) * torch.tensor(sc) + torch.tensor(sh)).clamp_min(0).to(td).double().numpy()     # fp32 affine, as the kernel
+    win = act.reshape(n, h // 2, 2, w // 2, 2, cout).transpose(0, 1, 3, 5, 2, 4).reshape(n, h // 2, w // 2, cout, 4)
+    am_ref = win.argmax(-1)                                                  # first maximum
+    np.testing.assert_array_equal(back(act_d), act)
+    np.testing.assert_array_equal(amax_d.cpu().numpy(), am_ref)
+    np.testing.assert_array_equal(back(pooled_d), win.max(-1))
+    # backward reference
+    route = np.zeros((n, h // 2, w // 2, cout, 4))
+    np.put_along_axis(route, am_ref[..., None], dp[..., None], -1)
+    g = da + route.reshape(n, h // 2, w // 2, cout, 2, 2).transpose(0, 1, 4, 2, 5, 3).reshape(n, h, w, cout)
+    mask = v * f64(sc) + f64(sh) > 0
+    dy = f64(sc) * (np.where(mask, g, 0.0) - f64(coef[0]) - (v - f64(mu)) * f64(rs) * f64(coef[1]))
+    dy = torch.tensor(dy, dtype=torch.float32).to(td).double().numpy()
+    dx_ref, dk_ref, _ = K.conv2d_same_bwd(xr[..., :cin], kern, dy, 1)
+    _, wd = ops.pack_weights(f32dev(kern), cs, ops.DTYPE_CODE[td])
+    out = ops.conv_bwd_fused(to_dev(da, td), to_dev(v, td), f32dev(sc), f32dev(sh), f32dev(mu), f32dev(rs), f32dev(coef), to_dev(xr, td), wd, cin, cout,
+                             dpool=to_dev(dp, td), amax=amax_d, want_dx=want_dx)
+    assert out is not None, 'shape must be served by the pooled fused kernel'
+    dx, dw = out
+    close(back(dw), dk_ref, td, f'pooled fused dw {case}', k=1.5)
+    if want_dx:
+        close(back(dx)[..., :cin], dx_ref, td, f'pooled fused dx {case}', k=1.5)
+        # the pooled part of the sums of the block below, in the activated form (its pooled output is this block's input x): sum dx [x > 0], sum dx x
+        stats = ops.new_stats(cs, dev())
+        xa = np.abs(xr)                                                       # an activation: non-negative, with exact zeros
+        xa[xa < 0.3] = 0
+        out2 = ops.conv_bwd_fused(to_dev(da, td), to_dev(v, td), f32dev(sc), f32dev(sh), f32dev(mu), f32dev(rs), f32dev(coef), to_dev(xa, td), wd, cin, cout,
+                                  dpool=to_dev(dp, td), amax=amax_d, bst=dict(sums=stats, act_form=1))
+        assert out2 is not None
+        gst = back(out2[0])
+        got = stats.sum(0).double().cpu().numpy()
+        tol = 2e-4 * np.sqrt(n * h * w) * max(1.0, float(np.abs(gst).max()))
+        np.testing.assert_allclose(got[0], np.where(xa > 0, gst, 0.0).sum((0, 1, 2)), rtol=1e-4, atol=tol)
+        np.testing.assert_allclose(got[1], (gst * xa).sum((0, 1, 2)), rtol=1e-4, atol=tol * float(xa.max()))
+    else:
+        assert dx is None
+
+
 def test_fused_bn_backward_sums_are_refused_on_partial_tiles(ops):
     """a map that is not a whole number of tiles keeps the separate reduce launch: the query says so and conv2d raises"""
     td = torch.bfloat16
