@@ -19,6 +19,13 @@
 #include <cstdlib>
 #include <cstring>
 
+// compile-time ablation for profiling builds (python -m satellite_computervision_amd.build -DBWDF_ABL=bits; SATCV_LIB selects the variant):
+// 1 skip the MFMAs, 2 skip the dy arithmetic, 4 skip the dx stores, 8 skip the MFMA phases altogether (no fragment reads), 32 no global loads
+#ifndef BWDF_ABL
+#define BWDF_ABL 0
+#endif
+#define FABL(bit) ((BWDF_ABL & (bit)) != 0)
+
 int wgrad_reduce_slabs(const float* ws, float* dw, int nslab, int taps, int kpad, int npad, int cin, int nvalid, int accumulate, hipStream_t st);   // conv_wgrad.hip
 void satcv_prof_begin(int kind, double flops, hipStream_t st);
 void satcv_prof_end(int kind, hipStream_t st);
@@ -64,7 +71,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
   constexpr int XPIX_STEP = NTHREADS / SXR;                       // interior pixels between two x items of a thread (a multiple of 32: same column)
   static_assert(XPIX_STEP % 32 == 0, "x items of a thread must share a column");
   constexpr int MT = 8 / NW, NT = CIN / 32;                      // data gradient: wave tile (MT x 32 pixels) x CIN
-  constexpr int NTILE = (CIN / 32) * (COUT / 32) * 9, WT = (NTILE + NW - 1) / NW;   // weight gradient: (ci-tile, co-tile, tap) products per wave
+  // weight gradient: NTILE (ci-tile, co-tile, tap) products of 16 k-steps each.  Every wave runs FULL whole products; the REM left over are
+  // cut along K -- each over WPP waves, KPW k-steps per wave, summed through LDS once per workgroup after the tile loop -- so that all waves
+  // carry the same number of MFMAs per tile (with 9 products on 8 waves, wave 0 ran two and held the tile's barrier for the other seven)
+#ifdef BWDF_NOBAL                                                              // (A/B build: whole products only, the surplus ones on the first waves)
+  constexpr int NTILE = (CIN / 32) * (COUT / 32) * 9, FULL = (NTILE + NW - 1) / NW, REM = 0, WT = FULL;
+#else
+  constexpr int NTILE = (CIN / 32) * (COUT / 32) * 9, FULL = NTILE / NW, REM = NTILE % NW, WT = FULL + (REM ? 1 : 0);
+#endif
+  constexpr bool GUARD = FULL * NW > NTILE;
+  constexpr int WPP = REM ? NW / REM : 1, KPW = REM ? 16 / WPP : 0;
+  static_assert(REM == 0 || (NW % REM == 0 && 16 % WPP == 0 && KPW % 2 == 0), "left-over products must split evenly along K");
   constexpr int W_ITEMS = NODG ? 0 : 9 * SD * CIN;
   constexpr size_t R0_BYTES = ((size_t)(SD * DSTRIDE + SX * XSTRIDE) * sizeof(T) + 127) / 128 * 128;
   constexpr size_t W_BYTES = (size_t)W_ITEMS * EL * sizeof(T);
@@ -174,8 +191,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
       vm |= (ok ? 1u : 0u) << j;
       unsigned off = ok ? (unsigned)(__mul24(L, g_rowstride) + __mul24(c, a.ldg)) + gy_lane : centre;   // (outside: a valid pixel, zeroed at the LDS store)
       asm volatile("" : "+v"(off));
-      rg[j] = gload8<T>(gb + off);
-      ry[j] = gload8<T>(yb + off);
+      if (!FABL(32)) { rg[j] = gload8<T>(gb + off); ry[j] = gload8<T>(yb + off); }
+      else { rg[j] = zero8<T>(); ry[j] = zero8<T>(); rg[j].q[0].x = off; }
     }
     return vm;
   };
@@ -201,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
     const size_t bp = (size_t)(n0 * a.e.h + y0) * a.e.w_ + x0;
     const T* xb = xsrc + bp * xcs + x_eoff0;
 #pragma unroll
-    for (int j = 0; j < XI; ++j) rx[j] = gload8<T>(xb + (size_t)j * x_estep);
+    for (int j = 0; j < XI; ++j) { if (!FABL(32)) rx[j] = gload8<T>(xb + (size_t)j * x_estep); else { rx[j] = zero8<T>(); rx[j].q[0].x = (unsigned)(size_t)xb; } }
   };
 
   // ---- XCD-aware contiguous tile ranges (conv_igemm_ws.hip)
@@ -218,11 +235,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
   for (int t = 0; t < WT; ++t) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) wacc[t][i] = 0.f;
-    const int id = __builtin_amdgcn_readfirstlane(wave) + t * NW;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int id = t < FULL ? wv + t * NW : FULL * NW + wv / WPP;
     const int tap = id % 9, pair = id / 9;
     const int ci_t = pair % (CIN / 32), co_t = pair / (CIN / 32);
     w_xo[t] = ci_t * 4 * XSTRIDE;
     w_do[t] = co_t * 4 * DSTRIDE + ((2 - tap / 3) * PITCH + (2 - tap % 3)) * EL;      // dy[q + 1 - tap] in halo coordinates: q + 2 - tap
+    if (t >= FULL) {                                                          // this wave's K range of the shared product: k-steps k0 ... k0 + KPW - 1 (k0 even)
+      const int k0 = (wv % WPP) * KPW;
+      w_xo[t] += k0 * 16 * EL;
+      w_do[t] += (k0 >> 1) * PITCH * EL;
+    }
   }
 
   // (not in the one-wave-per-SIMD instantiation: its 120 registers of prefetched tile leave no room for 16 more accumulators)
@@ -260,15 +283,18 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
             gv[e] += am == sub ? pv[e] : 0.f;
           }
         }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float act = yv[e] * prm[e] + prm[8 + e];
-          const float gm = act > lin_lo ? gv[e] : 0.f;
-          o[e] = (bf16)(prm[e] * gm + (prm[16 + e] * yv[e] + prm[24 + e]));
-        }
         Raw8<T> v;
-        v.q[0] = __builtin_bit_cast(uint4, o);
+        if constexpr (FABL(2)) { v = rg[j]; v.q[0].x ^= ry[j].q[0].x; }
+        else {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float act = yv[e] * prm[e] + prm[8 + e];
+            const float gm = act > lin_lo ? gv[e] : 0.f;
+            o[e] = (bf16)(prm[e] * gm + (prm[16 + e] * yv[e] + prm[24 + e]));
+          }
+          v.q[0] = __builtin_bit_cast(uint4, o);
+        }
         v = select8<T>((valid >> j) & 1u, v);
         const int pk_ = d_item(j);
         if (pk_ != 0x3ff) lstore8<T>(ldsD + slot_d * DSTRIDE + __mul24((pk_ >> 6) * CL + (pk_ & 63), EL), v);
@@ -302,8 +328,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
     //  the fragment reads of step k + 1 are issued before the MFMA of step k and pinned there, so the LDS latency is exposed once per
     //  product, not once per step; a wave's products are id = wave + tt * NW, only the last of which can fall beyond NTILE)
 #pragma unroll
-    for (int tt = 0; tt < WT; ++tt) {
-      if (tt < WT - 1 || __builtin_amdgcn_readfirstlane(wave) + (WT - 1) * NW < NTILE) {
+    for (int tt = 0; tt < FULL; ++tt) {
+      if (!FABL(8) && (!GUARD || tt < FULL - 1 || __builtin_amdgcn_readfirstlane(wave) + (FULL - 1) * NW < NTILE)) {
         const T* xa = ldsX + w_xo[tt] + tr_x;
         const T* da = ldsD + w_do[tt] + tr_d;
         // (a real loop over groups of four k-steps = two tile rows, the prefetched fragments carried across its iterations: fully unrolled,
@@ -329,8 +355,33 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 afr = __builtin_shufflevector(fa[u & 1][0], fa[u & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
             const bf16x8 bfr = __builtin_shufflevector(fb[u & 1][0], fb[u & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
-            wacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, wacc[tt], 0, 0, 0);
+            if constexpr (!FABL(1)) wacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, wacc[tt], 0, 0, 0);
+            else asm volatile("" :: "v"(afr), "v"(bfr));
           }
+        }
+      }
+    }
+    if constexpr (REM > 0) {
+      if (!FABL(8)) {
+        // this wave's share of a left-over product: KPW k-steps from its K offset (folded into w_xo / w_do), same one-step-ahead reads
+        const T* xa = ldsX + w_xo[FULL] + tr_x;
+        const T* da = ldsD + w_do[FULL] + tr_d;
+        bf16x4 fa[2][2], fb[2][2];
+        auto read_k = [&](int u, int buf) {
+          const int xq = u * 16 * EL, dq = ((u >> 1) * PITCH + (u & 1) * 16) * EL;
+          fa[buf][0] = tr_read4(xa + xq); fa[buf][1] = tr_read4(xa + xq + 4 * EL);
+          fb[buf][0] = tr_read4(da + dq); fb[buf][1] = tr_read4(da + dq + 4 * EL);
+        };
+        read_k(0, 0);
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) {
+          asm volatile("" ::: "memory");
+          if (u + 1 < KPW) read_k(u + 1, (u + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 afr = __builtin_shufflevector(fa[u & 1][0], fa[u & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 bfr = __builtin_shufflevector(fb[u & 1][0], fb[u & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          if constexpr (!FABL(1)) wacc[FULL] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, wacc[FULL], 0, 0, 0);
+          else asm volatile("" :: "v"(afr), "v"(bfr));
         }
       }
     }
@@ -358,6 +409,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
 #pragma unroll
         for (int n = 0; n < NT; ++n) bf[buf][n] = lds_frag<T>(ldsW + ((tap * SD + slot) * CIN + n * 32 + r) * EL);
       };
+      if constexpr (!FABL(8)) {
       read_step(0, 0);
 #pragma unroll
       for (int st = 0; st < STEPS; ++st) {
@@ -367,7 +419,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) mma32<T>(acc[m][n], af[st & 1][m], bf[st & 1][n]);
+          for (int n = 0; n < NT; ++n) {
+            if constexpr (!FABL(1)) mma32<T>(acc[m][n], af[st & 1][m], bf[st & 1][n]);
+            else asm volatile("" :: "v"(af[st & 1][m].v), "v"(bf[st & 1][n].v));
+          }
+      }
       }
     }
     if (POOL && t + 1 < t_hi) issue_pool(n0, y0, x0);
@@ -393,7 +449,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
       for (int it = tid; it < BM * VPR; it += NTHREADS) {
         const int q = it / VPR;
         const uint4 dv = *reinterpret_cast<const uint4*>(ldsO + q * OPITCH + vq * 8);
-        *reinterpret_cast<uint4*>(yp + (size_t)((q / TW) * row_pitch + (q % TW) * (unsigned)a.e.ldy)) = dv;
+        if constexpr (!FABL(4)) *reinterpret_cast<uint4*>(yp + (size_t)((q / TW) * row_pitch + (q % TW) * (unsigned)a.e.ldy)) = dv;
+        else asm volatile("" :: "v"(dv.x));
         if (BST && a.bst_sums) {
           // sums of the BatchNorm backward below from the STORED gradient and the staged activation a = relu(sc * v + sh):
           // gm = dx * [a > 0];  sum gm * xhat = (sum dx * a - (sh + sc * mean) * sum gm) * rstd / sc   (a = 0 where the mask is 0)
@@ -412,10 +469,24 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
     __syncthreads();                                                          // staged output read out before the next tile is written
   }
   // ---- this workgroup's partial weight gradient: ws[block][tap][ci][co]
+  if constexpr (REM > 0) {
+    // the K slices of a left-over product: summed in wave order by the first wave of its group (the tile region is free: the loop ends with a barrier)
+    float* red = reinterpret_cast<float*>(smem_raw);                          // [NW][16][64]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = wacc[FULL][i];
+    __syncthreads();
+    if (wave % WPP == 0) {
+#pragma unroll 1
+      for (int k = 1; k < WPP; ++k)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wacc[FULL][i] += red[((wave + k) * 16 + i) * 64 + lane];
+    }
+  }
 #pragma unroll
   for (int tt = 0; tt < WT; ++tt) {
-    const int id = __builtin_amdgcn_readfirstlane(wave) + tt * NW;
-    if (id < NTILE) {
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int id = tt < FULL ? wv + tt * NW : FULL * NW + wv / WPP;
+    if ((tt < FULL && (!GUARD || id < NTILE)) || (tt >= FULL && wv % WPP == 0)) {
       const int tap = id % 9, pair = id / 9;
       const int ci_t = pair % (CIN / 32), co_t = pair / (CIN / 32);
       float* dst = a.ws + ((size_t)(blockIdx.x * 9 + tap) * CIN + ci_t * 32) * COUT + co_t * 32 + r;

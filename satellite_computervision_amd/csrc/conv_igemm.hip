@@ -368,7 +368,8 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   satcv_prof_begin(d->kh * d->kw > 1 ? 0 : 1, flops, st);
   rc = SATCV_ERR_UNSUPPORTED;
   if (!igemm_force_generic()) {
-    rc = igemm_ws_launch(a, d->dtype, st, false);            // thin 3x3 layers: persistent weights-stationary kernel
+    rc = convt_thin_launch(a, d->dtype, st);                 // thin transposed convolutions: streaming kernel
+    if (rc == SATCV_ERR_UNSUPPORTED) rc = igemm_ws_launch(a, d->dtype, st, false);            // thin 3x3 layers: persistent weights-stationary kernel
     if (rc == SATCV_ERR_UNSUPPORTED) rc = igemm_fast_launch(a, d->dtype, st);
   }
   if (rc != SATCV_ERR_UNSUPPORTED) { /* launched (or failed hard) */ }

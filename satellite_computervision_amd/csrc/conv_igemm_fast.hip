@@ -21,7 +21,8 @@
 extern int g_opt_igemm_db, g_opt_igemm_thin, g_opt_igemm_sched;      // api.hip: satcv_set_option
 
 // compile-time ablation switches for profiling builds (-DSATCV_ABLATE=bits): 1 skip global stores, 2 skip MFMA,
-// 4 skip activation loads, 8 skip weight loads, 16 skip the LDS fragment reads, 32 skip the whole epilogue, 64 skip the LDS stores
+// 4 skip activation loads, 8 skip weight loads, 16 skip the LDS fragment reads, 32 skip the whole epilogue, 64 skip the LDS stores,
+// 128 every chunk loads the weights of chunk 0 (cache-resident: what is left is the cost of issuing them), 256 likewise the activations
 #ifndef SATCV_ABLATE
 #define SATCV_ABLATE 0
 #endif
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
   constexpr int KC = KS * 2 * SUB * EL;                          // channels per chunk (16 per K-step; 64 for scaled fp8)
   constexpr int SLOTS = KC / EL;
   // staged A items per thread: halo tile of a 3x3 / dilation-1 conv incl. the several-images-per-tile case
-  constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+  constexpr int XMAXPIX = TAPS == 1 ? BM : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);      // (single-tap forms stage no halo)
   constexpr int AI = (XMAXPIX * SLOTS + NTHREADS - 1) / NTHREADS;
   constexpr int BI = (TAPS * SLOTS * BN + NTHREADS - 1) / NTHREADS;  // staged B items per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -188,11 +189,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
   };
   auto load_a = [&](const ChunkSrc& c, int j) {
     const int p = a_p[j] < 0 ? 0 : a_p[j];
-    if (!ABL(4)) ra[j] = gload8<T>(c.src + (size_t)(p + c.sadd) * c.cs + c.coff + slot_t * EL);
+    if (!ABL(4)) ra[j] = gload8<T>(c.src + (size_t)(p + c.sadd) * c.cs + (ABL(256) ? 0 : c.coff) + slot_t * EL);
     else ra[j] = zero8<T>();
   };
   auto load_b = [&](const ChunkSrc& c, int j) {
-    if (!ABL(8)) rb[j] = gload8<T>(wp + ((size_t)b_g[j] + c.cadd) * EL);
+    if (!ABL(8)) rb[j] = gload8<T>(wp + ((size_t)b_g[j] + (ABL(128) ? 0 : c.cadd)) * EL);
     else rb[j] = zero8<T>();
   };
   auto load_p = [&](const ChunkSrc& c) {
@@ -489,14 +490,14 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   if (a.pool_y && (TH % a.pool_f != 0 || TW % a.pool_f != 0 || a.rpi % a.pool_f != 0)) return SATCV_ERR_UNSUPPORTED;    // pooling windows inside one tile
   if (a.cout_pad < a.n_tiles * BN) return SATCV_ERR_UNSUPPORTED;
   {
-    constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+    constexpr int XMAXPIX = TAPS == 1 ? BM : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
     constexpr int AI = (XMAXPIX * (KC / EL) + NTHREADS - 1) / NTHREADS;
     if (a.rl * a.cl * (KC / EL) > AI * NTHREADS) return SATCV_ERR_UNSUPPORTED;     // register-staged items per thread
   }
   if (a.ldy % (16 / (int)sizeof(T)) != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;
   if (a.mode_out == 0 && a.cout % (16 / (int)sizeof(T)) != 0 && a.cout < a.ldy) { /* tail handled by scalar stores */ }
   const size_t lds_stage = (((size_t)KC * a.rl * a.pitch + (size_t)TAPS * KC * BN) * sizeof(T) + (size_t)(KC / EL) * 128) * (DB ? 2 : 1);      // + slot padding (< 128 B per plane)
-  if (DB && (TL || a.mode_in != 0)) return SATCV_ERR_UNSUPPORTED;
+  if (DB && (TL || (a.mode_in != 0 && TAPS != 1))) return SATCV_ERR_UNSUPPORTED;
   size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
   if (a.bst_y) {
     // fused BatchNorm-backward reduce: only the epilogue's interior-tile path does it, so EVERY tile must be one; a second staging
@@ -578,6 +579,12 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
         // deep 1x1 / transposed convolutions (K = Cin >= 512; at 256 it measured slower): 64-channel chunks -- with 32 a chunk is 8 MFMAs per wave between two
         // barrier pairs; SATCV_DB=0 keeps the 32-channel form
         const bool ks4 = g_opt_igemm_db != 0 && (cin % 64 == 0) && cin >= 512 && (!a.x1 || a.c0 % 64 == 0) && (a.mode_in != 1 || a.c0 % 64 == 0);
+        // ... and on the double-buffered 256-pixel x 128-channel tile, one barrier per chunk (SATCV_DB1X1=0: the single-buffered tile)
+        static const bool db1 = !(getenv("SATCV_DB1X1") && atoi(getenv("SATCV_DB1X1")) == 0);
+        if (ks4 && db1 && nspace >= 128 && nspace % 128 == 0 && (long long)cdiv(a.n * a.h * a.w_, 256) * (nspace / 128) >= 192) {
+          const int rc = fast_cfg<T, TW, 4, 2, 2, 2, 4, TAPS, false, true>(a, st, dry);
+          if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+        }
         if (ks4 && nspace >= 128 && nspace % 128 == 0) {
           const int rc = fast_cfg<T, TW, 2, 2, 2, 2, 4, TAPS, false, false, 2>(a, st, dry);
           if (rc != SATCV_ERR_UNSUPPORTED) return rc;

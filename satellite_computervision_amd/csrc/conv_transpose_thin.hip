@@ -1,0 +1,262 @@
+// Thin transposed convolutions (Conv2DTranspose, kernel == stride == 2, of the full- and half-resolution decoder levels:
+// utils/model_tools.py:306) as a streaming kernel.
+//
+// These layers are HBM-bound by a wide margin (64 -> 4 x 32 channels at 128 x 128: 402 MB of tensors, 17 GFLOP) and ran at 0.3-0.36 of
+// their HBM roofline on the tiled implicit-GEMM kernel, whose tile pays a gather-table set-up, two barriers per chunk and an LDS-staged
+// epilogue for 4-8 MFMAs per wave.  Here a WAVE is the unit of work and nothing in the loop synchronises:
+//   * a wave owns strips of 32 consecutive input pixels (one row segment).  Its activation fragments come straight from global memory
+//     in MFMA operand layout (lane = pixel, 8 consecutive channels: one 16-byte load per k-step), get the producing layer's
+//     BatchNorm + ReLU in registers and are never staged in LDS;
+//   * the whole weight tensor (16-64 KB) is resident in LDS in fragment layout;
+//   * every product is formed in BOTH orientations from the same two fragments: W^T x X^T leaves the output with the pixel on the
+//     lane and the channels in the registers -- after the bias and bf16 packing, v_permlane32_swap pairs give each lane 8 consecutive
+//     channels, i.e. 16-byte stores straight to the depth-to-space position, no LDS transpose --, and X x W leaves the channel on the
+//     lane, which makes the BatchNorm sum / sum-of-squares of the stored values an in-lane accumulation (two registers per channel
+//     tile instead of a cross-lane reduction per strip).  The second product costs MFMA time the layer does not use anyway (the
+//     matrix pipe is < 25 % busy at the HBM rate) and no bytes;
+//   * the next strip's loads are in flight while the current one is multiplied and stored.
+#include "igemm_common.hpp"
+#include <cstdlib>
+
+struct ConvtArgs {
+  const void* x; const float* in_scale; const float* in_shift; int in_relu;
+  const void* w; const float* bias;
+  void* y; int ldy;
+  satcv_stat_t* stats; int stats_ld;
+  int h, w_;                  // input map
+  int total_strips;           // n * h * w_ / 32
+};
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v;
+  v[0] = (bf16)a; v[1] = (bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+template <int CIN, int COUT, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArgs a) {
+  typedef bf16 T;
+  constexpr int KS = CIN / 16, NCOL = 4 * COUT, NT = NCOL / 32, NTHREADS = NW * 64;
+  constexpr size_t W_BYTES = (size_t)CIN * NCOL * sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* ldsW = reinterpret_cast<T*>(smem_raw);                                   // [CIN / 8][NCOL][8]: the packed forward image as it is
+  float* tab = reinterpret_cast<float*>(smem_raw + W_BYTES);                  // scale[CIN], shift[CIN], bias[COUT]; later the statistics
+  // wave-private output staging: 32 input pixels x 128 bytes (a pair of channel tiles), rows padded to 144 bytes so that the 16-byte
+  // stores of 8 neighbouring pixels fall on distinct banks.  No barrier: only this wave touches its region, and a wave's LDS operations
+  // execute in order.
+  constexpr int OPITCH = 144, TAB_FLOATS = (2 * CIN + COUT > 2 * NW * COUT ? 2 * CIN + COUT : 2 * NW * COUT);
+  // (the loads stay fragment-shaped -- 32-byte pieces of 32 lines per instruction: whole-line loads redistributed through these rows
+  //  measured the same, 89.4 vs 90.6 and 48.5 vs 48.1 us)
+  unsigned char* ldsO = smem_raw + W_BYTES + (size_t)TAB_FLOATS * sizeof(float) + (size_t)(threadIdx.x >> 6) * (32 * OPITCH);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+
+  {
+    const T* wp = reinterpret_cast<const T*>(a.w);
+    for (int it = tid; it < (CIN / 8) * NCOL; it += NTHREADS) lstore8<T>(ldsW + (size_t)it * 8, gload8<T>(wp + (size_t)it * 8));
+    for (int ch = tid; ch < CIN; ch += NTHREADS) {
+      tab[ch] = a.in_scale ? a.in_scale[ch] : 1.f;
+      tab[CIN + ch] = a.in_scale ? a.in_shift[ch] : 0.f;
+    }
+    for (int ch = tid; ch < COUT; ch += NTHREADS) tab[2 * CIN + ch] = a.bias ? a.bias[ch] : 0.f;
+  }
+  __syncthreads();
+  const bool xaff = a.in_scale != nullptr;
+  const unsigned relu_lim = a.in_relu != 0 ? 0u : 0x80008000u;
+  const bool want_stats = a.stats != nullptr;
+
+  // ---- this wave's strips: XCD-aware contiguous ranges (blocks b and b + 8 share an XCD)
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, nx = G >> 3, remx = G & 7;
+  const int bid = (xcd < remx ? xcd * (nx + 1) : remx * (nx + 1) + (xcd - remx) * nx) + (blockIdx.x >> 3);
+  const int gw = __builtin_amdgcn_readfirstlane(bid * NW + wave), GW = G * NW;
+  const int per = a.total_strips / GW, extra = a.total_strips % GW;
+  const int t_lo = gw * per + (gw < extra ? gw : extra), t_hi = t_lo + per + (gw < extra ? 1 : 0);
+
+  const T* xlane = reinterpret_cast<const T*>(a.x) + (size_t)r * CIN + hh * 8;      // + strip * 32 * CIN + ks * 16
+  const T* wlane = ldsW + (size_t)(hh * NCOL + r) * 8;                               // + (ks * 2 * NCOL + nt * 32) * 8
+  const int wo = 2 * a.w_;
+  float st1[NT], st2[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { st1[n] = 0.f; st2[n] = 0.f; }
+
+  constexpr int XSTEP = 16;
+  Raw8<T> xr[KS];
+  if (t_lo < t_hi) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xr[ks] = gload8<T>(xlane + (size_t)t_lo * 32 * CIN + ks * XSTEP);
+  }
+  for (int t = t_lo; t < t_hi; ++t) {
+    // ---- the strip's fragments: BatchNorm + ReLU of the producing layer on the loaded registers
+    bf16x8 xf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      Raw8<T> v = xr[ks];
+      if (xaff) {
+        int toff = ks * 16 + hh * 8;
+        asm volatile("" : "+v"(toff));                                        // (read per strip: hoisted, the 16 KS values would stay live)
+        const float4* sp = reinterpret_cast<const float4*>(tab + toff);
+        const float4* hp = reinterpret_cast<const float4*>(tab + CIN + toff);
+        const float4 s0 = sp[0], s1 = sp[1], h0 = hp[0], h1 = hp[1];
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        v = affine8_lim(v, sc, sh, relu_lim);
+      }
+      xf[ks] = __builtin_bit_cast(bf16x8, v.q[0]);
+    }
+    // ---- the next strip's loads
+    if (t + 1 < t_hi) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xr[ks] = gload8<T>(xlane + (size_t)(t + 1) * 32 * CIN + ks * XSTEP);
+    }
+    // strip origin: pixel 32 t = (n, y, x0) of the input map; output rows 2 y, 2 y + 1
+    const int p0 = t * 32;
+    const int row = p0 / a.w_, x0 = p0 - row * a.w_;                          // row = n * h + y (the output has 2 h rows per image: 2 row is right)
+    // channel tiles in pairs: the pair's four 32-byte pieces complete whole 128-byte lines of the output (two neighbouring pixels of
+    // 32 channels, or one pixel of 64), and all four stores are issued together -- issued a tile apart, the pieces reached the L2
+    // microseconds apart under load and part of the lines were evicted half written (3.1 instead of 3.5-4.2 TB/s)
+#pragma unroll
+    for (int np = 0; np < NT / 2; ++np) {
+      f32x16 accT[2], accD[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accT[u][i] = 0.f; accD[u][i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wlane + (size_t)(ks * 2 * NCOL + (2 * np + u) * 32) * 8);
+          accT[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[ks], accT[u], 0, 0, 0);       // [channel][pixel]: stores
+          if (want_stats) accD[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks], wf, accD[u], 0, 0, 0);      // [pixel][channel]: statistics
+        }
+      }
+      // ---- stores: rows of accT are channels cb + 8 g + 4 hh + e (register 4 g + e), the column is this lane's pixel.  After the bias
+      // and the bf16 packing a half exchange (v_permlane32_swap) gives every lane 8 consecutive channels of its pixel; the pair's 128 bytes
+      // per pixel go through the wave's staging rows and leave as whole lines: a store instruction writes 8 pixels x 128 contiguous bytes
+      // (32-byte pieces straight from the registers ran the L2 write path at a quarter of its width: 3.4 TB/s)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int cb = ((2 * np + u) * 32) % COUT;
+        uint2 o2[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4*>(tab + 2 * CIN + cb + 8 * g + 4 * hh);
+          o2[g].x = pk_bf16(accT[u][4 * g] + b4.x, accT[u][4 * g + 1] + b4.y);
+          o2[g].y = pk_bf16(accT[u][4 * g + 2] + b4.z, accT[u][4 * g + 3] + b4.w);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k += 2) {
+          // afterwards lanes 0-31 hold channels 8 k ... 8 k + 7 of their pixel, lanes 32-63 channels 8 k + 8 ... 8 k + 15
+          const uint2 lo = o2[k], hi = o2[k + 1];
+          auto sx = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+          auto sy = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+          *reinterpret_cast<uint4*>(ldsO + r * OPITCH + u * 64 + k * 16 + hh * 16) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+      }
+      {
+        // the pair's position: channel tiles 2 np, 2 np + 1 are the two horizontal positions (j = 0, 1) of one output row for COUT = 32,
+        // the two channel halves of one position for COUT = 64
+        const int ij = (2 * np * 32) / COUT;
+        T* yrow = reinterpret_cast<T*>(a.y) + ((size_t)(2 * row + (ij >> 1)) * wo + 2 * x0 + (COUT == 32 ? 0 : (ij & 1))) * a.ldy;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int c = lane + 64 * m, q = c >> 3, piece = c & 7;              // 16-byte piece of input pixel q
+          const uint4 v = *reinterpret_cast<const uint4*>(ldsO + q * OPITCH + piece * 16);
+          const int eoff = COUT == 32 ? (2 * q + (piece >> 2)) * a.ldy + (piece & 3) * 8 : 2 * q * a.ldy + piece * 8;
+          *reinterpret_cast<uint4*>(yrow + eoff) = v;
+        }
+      }
+      // ---- statistics of the stored values: column of accD = channel cb + r, its 16 registers are pixels
+      if (want_stats) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int cb = ((2 * np + u) * 32) % COUT;
+          const float bv = tab[2 * CIN + cb + r];
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float fv = (float)(T)(accD[u][i] + bv);
+            s1 += fv; s2 += fv * fv;
+          }
+          st1[2 * np + u] += s1; st2[2 * np + u] += s2;
+        }
+      }
+    }
+  }
+  // ---- statistics: lane halves, channel tiles of one channel and the waves of the workgroup summed in a fixed order; one pair of
+  //      atomics per channel and workgroup
+  if (want_stats) {
+    float c1[COUT / 32], c2[COUT / 32];
+#pragma unroll
+    for (int u = 0; u < COUT / 32; ++u) { c1[u] = 0.f; c2[u] = 0.f; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { c1[nt % (COUT / 32)] += st1[nt]; c2[nt % (COUT / 32)] += st2[nt]; }
+    __syncthreads();                                                          // (the tables are dead: every wave is past its last strip)
+    float* red = tab;                                                         // [NW][2][COUT]
+#pragma unroll
+    for (int u = 0; u < COUT / 32; ++u) {
+      const float s1 = c1[u] + __shfl_xor(c1[u], 32, 64), s2 = c2[u] + __shfl_xor(c2[u], 32, 64);
+      if (hh == 0) { red[(wave * 2 + 0) * COUT + u * 32 + r] = s1; red[(wave * 2 + 1) * COUT + u * 32 + r] = s2; }
+    }
+    __syncthreads();
+    if (tid < COUT) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { t1 += red[(w * 2 + 0) * COUT + tid]; t2 += red[(w * 2 + 1) * COUT + tid]; }
+      satcv_stat_t* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
+      atomicAdd(rowp + tid, (satcv_stat_t)t1);
+      atomicAdd(rowp + a.stats_ld + tid, (satcv_stat_t)t2);
+    }
+  }
+}
+
+template <int CIN, int COUT, int NW, int WPS>
+static int convt_thin_cfg(const ConvtArgs& ca, hipStream_t st) {
+  constexpr size_t lds = (size_t)CIN * 4 * COUT * sizeof(bf16) + (size_t)(2 * CIN + COUT > 2 * NW * COUT ? 2 * CIN + COUT : 2 * NW * COUT) * sizeof(float) + (size_t)NW * 32 * 144;
+  auto kern = convt_thin_kernel<CIN, COUT, NW, WPS>;
+  { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
+  static const int cus = [] {
+    int dev = 0, v = 256;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) v = p.multiProcessorCount;
+    return v;
+  }();
+  int per_cu = WPS * 4 / NW;                                                  // resident workgroups: WPS waves per SIMD
+  while (per_cu > 1 && (size_t)per_cu * lds > 150 * 1024) --per_cu;
+  if (per_cu < 1) per_cu = 1;
+  long long grid = (long long)cus * per_cu;
+  const long long need = (ca.total_strips + NW - 1) / NW;                      // a wave should see at least one strip
+  if (grid > need) grid = need;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, ca);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { satcv_set_error("convt_thin launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  return SATCV_OK;
+}
+
+// SATCV_ERR_UNSUPPORTED outside the kernel's limits (the caller falls back to the tiled kernels)
+int convt_thin_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
+  static const bool on = [] { const char* e = getenv("SATCV_CONVT_THIN"); return !e || atoi(e) != 0; }();
+  if (!on || dtype != SATCV_BF16) return SATCV_ERR_UNSUPPORTED;
+  if (a.kh != 1 || a.kw != 1 || a.mode_out != 1 || a.mode_in != 0 || a.f != 2 || a.x1 || a.stride != 1) return SATCV_ERR_UNSUPPORTED;
+  if (a.out_scale || a.pool_y || a.accumulate || a.out_relu || a.bst_y) return SATCV_ERR_UNSUPPORTED;
+  const int cin = a.c0, cout_t = a.cstat;
+  if (a.cout != 4 * cout_t || a.cout_pad != 4 * cout_t) return SATCV_ERR_UNSUPPORTED;
+  if (a.w_ % 32 != 0 || a.ldy % 8 != 0 || a.ldy < cout_t || ((uintptr_t)a.y % 16) != 0 || ((uintptr_t)a.x0 % 16) != 0 || ((uintptr_t)a.w % 16) != 0) return SATCV_ERR_UNSUPPORTED;
+  const long long strips = (long long)a.n * a.h * a.w_ / 32;
+  if (strips < 8 || strips > 0x3fffffff) return SATCV_ERR_UNSUPPORTED;
+  if (a.stats && a.stats_ld < cout_t) return SATCV_ERR_UNSUPPORTED;
+  ConvtArgs ca;
+  ca.x = a.x0; ca.in_scale = a.in_scale; ca.in_shift = a.in_shift; ca.in_relu = a.in_relu;
+  ca.w = a.w; ca.bias = a.bias; ca.y = a.y; ca.ldy = a.ldy; ca.stats = a.stats; ca.stats_ld = a.stats_ld;
+  ca.h = a.h; ca.w_ = a.w_; ca.total_strips = (int)strips;
+  static const int wps = [] { const char* e = getenv("SATCV_CONVT_WPS"); return e ? atoi(e) : 3; }();
+  if (cin == 64 && cout_t == 32) {
+    if (wps == 2) return convt_thin_cfg<64, 32, 4, 2>(ca, st);
+    return convt_thin_cfg<64, 32, 4, 3>(ca, st);
+  }
+  if (cin == 128 && cout_t == 64) return convt_thin_cfg<128, 64, 8, 2>(ca, st);
+  return SATCV_ERR_UNSUPPORTED;
+}

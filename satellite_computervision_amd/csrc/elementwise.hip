@@ -302,11 +302,14 @@ __device__ __forceinline__ void block_channel_reduce(float* lds, const float (&a
 // AMAX: also the index (i * f + j, first maximum in row-major window order -- the rule of bn_bwd_kernel) of every pooling window's maximum,
 // one byte per pooled pixel and channel: the fused pooled backward (conv_bwd_fused.hip) routes the pooled gradient with it instead of
 // re-reading the window
-template <typename T, bool AMAX = false>
+// FC: the pooling factor at compile time (0: the run-time argument) -- the window loops unroll and a window's loads are issued together
+// instead of one dependent round trip per pixel
+template <typename T, bool AMAX = false, int FC = 0>
 __global__ void bn_relu_pool_kernel(const T* __restrict__ yraw, const float* __restrict__ scale, const float* __restrict__ shift,
                                     T* __restrict__ act, T* __restrict__ pooled, satcv_stat_t* stats, int stats_ld,
-                                    int n, int h, int w, int c, int f, int act_ld, unsigned char* __restrict__ amax = nullptr) {
+                                    int n, int h, int w, int c, int f_, int act_ld, unsigned char* __restrict__ amax = nullptr) {
   extern __shared__ float lds[];
+  const int f = FC ? FC : f_;
   const int G = c / 8;
   const int hp = h / f, wp = w / f;               // 'valid' pooling
   const int hw_ = cdiv(h, f), ww = cdiv(w, f);    // windows incl. partial ones (act must cover every pixel)
@@ -330,6 +333,25 @@ __global__ void bn_relu_pool_kernel(const T* __restrict__ yraw, const float* __r
       unsigned char am[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; am[e] = 0; }
+      if constexpr (FC != 0) {
+        // whole windows only (the launcher checks h % FC == 0 && w % FC == 0): all FC * FC loads first
+        float v[FC * FC][8];
+        const size_t off0 = ((size_t)(img * h + py * FC) * w + px * FC) * c + g * 8;
+#pragma unroll
+        for (int k = 0; k < FC * FC; ++k) load8<T>(yraw + off0 + ((size_t)(k / FC) * w + (k % FC)) * c, v[k]);
+#pragma unroll
+        for (int k = 0; k < FC * FC; ++k) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float a = fmaxf(v[k][e] * sc[e] + sh[e], 0.f);
+            a = round_to<T>(a);
+            v[k][e] = a; s1[e] += a; s2[e] += a * a;
+            if (AMAX) { if (a > mx[e]) { mx[e] = a; am[e] = (unsigned char)k; } }
+            else mx[e] = fmaxf(mx[e], a);
+          }
+          if (act) store8<T>(act + ((size_t)(img * h + py * FC + k / FC) * w + px * FC + k % FC) * act_ld + g * 8, v[k]);
+        }
+      } else
       for (int i = 0; i < f; ++i) {
         const int y = py * f + i; if (y >= h) break;
         for (int j = 0; j < f; ++j) {
@@ -361,8 +383,13 @@ extern "C" int satcv_bn_relu_pool(const void* yraw, const float* scale, const fl
   if (act_ld <= 0) act_ld = c;
   SATCV_CHECK(yraw && scale && shift && n > 0 && h > 0 && w_ > 0 && c > 0 && c % 8 == 0 && c <= 2048 && f >= 1, "bn_relu_pool: bad args");
   const long long items = (long long)n * cdiv(h, f) * cdiv(w_, f) * (c / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_pool_kernel<T>, dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 1) * 16 * sizeof(float) : 0, (hipStream_t)stream,
-                                       (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld));
+  if (f == 2 && h % 2 == 0 && w_ % 2 == 0) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_pool_kernel<T, false, 2>), dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 1) * 16 * sizeof(float) : 0,
+                                         (hipStream_t)stream, (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_pool_kernel<T>, dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 1) * 16 * sizeof(float) : 0, (hipStream_t)stream,
+                                         (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld));
+  }
   LAUNCH_OK("bn_relu_pool");
   return SATCV_OK;
 }
@@ -372,9 +399,15 @@ extern "C" int satcv_bn_relu_pool_amax(const void* yraw, const float* scale, con
   SATCV_CHECK(yraw && scale && shift && pooled && amax && n > 0 && h > 0 && w_ > 0 && c > 0 && c % 8 == 0 && c <= 2048 && f >= 1 && f * f <= 255,
               "bn_relu_pool_amax: bad args");
   const long long items = (long long)n * cdiv(h, f) * cdiv(w_, f) * (c / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_pool_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 1) * 16 * sizeof(float) : 0,
-                                       (hipStream_t)stream, (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld,
-                                       (unsigned char*)amax));
+  if (f == 2 && h % 2 == 0 && w_ % 2 == 0) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_pool_kernel<T, true, 2>), dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 1) * 16 * sizeof(float) : 0,
+                                         (hipStream_t)stream, (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld,
+                                         (unsigned char*)amax));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_pool_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 1) * 16 * sizeof(float) : 0,
+                                         (hipStream_t)stream, (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld,
+                                         (unsigned char*)amax));
+  }
   LAUNCH_OK("bn_relu_pool_amax");
   return SATCV_OK;
 }

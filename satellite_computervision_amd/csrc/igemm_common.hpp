@@ -430,3 +430,5 @@ static inline int igemm_pick_tw(int w) {
 int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run = false);
 // persistent weights-stationary kernel of the thin 3x3 layers (conv_igemm_ws.hip); SATCV_ERR_UNSUPPORTED outside its limits
 int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run);
+// streaming kernel of the thin transposed convolutions (conv_transpose_thin.hip); SATCV_ERR_UNSUPPORTED outside its limits
+int convt_thin_launch(const IgemmArgs& a, int dtype, hipStream_t st);

@@ -407,6 +407,39 @@ def test_conv2d_transpose(ops, td, case):
     close(back(dk), dk_ref, td, f'convT wgrad {case}', k=(5.0 if td == torch.float32 else 0.5))
 
 
+@pytest.mark.parametrize('case', [(2, 32, 32, 64, 32), (1, 16, 64, 128, 64), (3, 8, 96, 64, 32), (1, 64, 64, 64, 32)])
+def test_conv2d_transpose_streaming_kernel_with_input_batchnorm(ops, case):
+    """The thin transposed convolutions (64 -> 32, 128 -> 64 channels, maps a multiple of 32 wide) run on the streaming kernel
+    (conv_transpose_thin.hip): fused input BatchNorm + ReLU, bias, depth-to-space stores, statistics of the stored values, and the
+    same result as the tiled kernel (SATCV_CONVT_THIN=0 is read once per process, so the tiled result comes from a narrower twin map)."""
+    td = torch.bfloat16
+    n, h, w, cin, cout = case
+    rng = np.random.default_rng(sum(case))
+    x = rnd(rng, (n, h, w, cin), td)
+    kt = rnd(rng, (2, 2, cout, cin), td, 0.2)
+    b = rng.standard_normal(cout)
+    sc, sh = (rng.standard_normal(cin) * 0.5 + 1).astype(np.float32), rng.standard_normal(cin).astype(np.float32)
+    a = np.maximum(x * sc.astype(np.float64) + sh.astype(np.float64), 0)
+    a = torch.tensor(a, dtype=torch.float32).to(td).double().numpy()
+    ref = K.conv2d_transpose_ks(a, kt, b)
+    wf, _ = ops.pack_weights(f32dev(kt), cin, ops.DTYPE_CODE[td], transposed=True)
+    for relu in (True, False):
+        stats = ops.new_stats(cout, dev())
+        y = ops.conv2d_transpose(to_dev(x, td), wf, cout, 2, bias=f32dev(b), in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=relu, stats=stats)
+        got = back(y, cout)
+        if relu:
+            close(got, ref, td, f'convT streaming fwd {case}')
+        else:
+            al = torch.tensor(x * sc.astype(np.float64) + sh.astype(np.float64), dtype=torch.float32).to(td).double().numpy()
+            close(got, K.conv2d_transpose_ks(al, kt, b), td, f'convT streaming fwd, linear input {case}')
+        s = stats.sum(0).double().cpu().numpy()
+        np.testing.assert_allclose(s[0], got.sum((0, 1, 2)), rtol=2e-4, atol=2e-3 * np.sqrt(got.size / cout))
+        np.testing.assert_allclose(s[1], (got ** 2).sum((0, 1, 2)), rtol=2e-4, atol=1e-2)
+    # without statistics / bias / input transform
+    y2 = ops.conv2d_transpose(to_dev(x, td), wf, cout, 2)
+    close(back(y2, cout), K.conv2d_transpose_ks(x, kt, np.zeros(cout)), td, f'convT streaming fwd plain {case}')
+
+
 # ------------------------------------------------------------------------ batch norm
 @pytest.mark.parametrize('td', DT)
 @pytest.mark.parametrize('f', [2, 3])
