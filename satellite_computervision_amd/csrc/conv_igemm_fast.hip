@@ -497,7 +497,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   if (a.ldy % (16 / (int)sizeof(T)) != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;
   if (a.mode_out == 0 && a.cout % (16 / (int)sizeof(T)) != 0 && a.cout < a.ldy) { /* tail handled by scalar stores */ }
   const size_t lds_stage = (((size_t)KC * a.rl * a.pitch + (size_t)TAPS * KC * BN) * sizeof(T) + (size_t)(KC / EL) * 128) * (DB ? 2 : 1);      // + slot padding (< 128 B per plane)
-  if (DB && (TL || (a.mode_in != 0 && TAPS != 1))) return SATCV_ERR_UNSUPPORTED;
+  if (DB && (TL || a.mode_in != 0)) return SATCV_ERR_UNSUPPORTED;
   size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
   if (a.bst_y) {
     // fused BatchNorm-backward reduce: only the epilogue's interior-tile path does it, so EVERY tile must be one; a second staging
@@ -581,7 +581,8 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
         const bool ks4 = g_opt_igemm_db != 0 && (cin % 64 == 0) && cin >= 512 && (!a.x1 || a.c0 % 64 == 0) && (a.mode_in != 1 || a.c0 % 64 == 0);
         // ... and on the double-buffered 256-pixel x 128-channel tile, one barrier per chunk (SATCV_DB1X1=0: the single-buffered tile)
         static const bool db1 = !(getenv("SATCV_DB1X1") && atoi(getenv("SATCV_DB1X1")) == 0);
-        if (ks4 && db1 && nspace >= 128 && nspace % 128 == 0 && (long long)cdiv(a.n * a.h * a.w_, 256) * (nspace / 128) >= 192) {
+        // (forward transposed convs: 48.5 -> 40.2 and 50.3 -> 42.8 us at 8 x 8 and 16 x 16; their space-to-depth data gradients measured slower on it)
+        if (ks4 && db1 && a.mode_in == 0 && nspace >= 128 && nspace % 128 == 0 && (long long)cdiv(a.n * a.h * a.w_, 256) * (nspace / 128) >= 192) {
           const int rc = fast_cfg<T, TW, 4, 2, 2, 2, 4, TAPS, false, true>(a, st, dry);
           if (rc != SATCV_ERR_UNSUPPORTED) return rc;
         }

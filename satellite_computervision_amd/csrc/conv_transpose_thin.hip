@@ -236,6 +236,235 @@ static int convt_thin_cfg(const ConvtArgs& ca, hipStream_t st) {
   return SATCV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Data gradient of the same layers: dx[q][ci] = sum over the 2 x 2 positions and co of dy[2 q + (i, j)][co] w[i][j][ci][co], K = 4 COUT.
+// Same structure: a wave owns strips of 32 input-resolution pixels, the dy fragments come straight from global memory (lane = pixel,
+// 8 consecutive channels of one position), the data-gradient weight image is resident in LDS, the product is formed with the pixel on
+// the lane, packed, exchanged between the lane halves and sent through the wave's staging rows so that every store instruction
+// writes whole lines of dx.  The fused BatchNorm-backward sums of the layer below (bst_*, satcv.h) are formed from the staged row
+// pieces: a lane reads back 8 consecutive channels of a pixel -- always the same 8 channels --, loads that layer's raw output at the same
+// address and accumulates sum g [a > 0] and sum g xhat in registers; lanes, waves and workgroups are combined once at the end.
+struct ConvtDgradArgs {
+  const void* dy; int lddy;            // [n][2 h][2 w_][lddy], COUT channels used
+  const void* w;                       // data-gradient image [4 COUT / 8][CIN][8]
+  void* dx; int lddx;
+  satcv_stat_t* stats; int stats_ld;
+  const void* bst_y; int bst_ld;
+  const float* bst_scale; const float* bst_shift; const float* bst_mean; const float* bst_rstd; int bst_relu;
+  int h, w_, total_strips;
+};
+
+template <int CIN, int COUT, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void convt_thin_dgrad_kernel(const ConvtDgradArgs a) {
+  typedef bf16 T;
+  constexpr int K = 4 * COUT, KS = K / 16, NT = CIN / 32, NP = NT / 2, NTHREADS = NW * 64, KPP = COUT / 16;      // KPP: k-steps per position
+  constexpr size_t W_BYTES = (size_t)K * CIN * sizeof(T);
+  constexpr int OPITCH = 144, TAB_FLOATS = (4 * CIN > 2 * NW * CIN ? 4 * CIN : 2 * NW * CIN);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* ldsW = reinterpret_cast<T*>(smem_raw);                                   // [K / 8][CIN][8]
+  float* tab = reinterpret_cast<float*>(smem_raw + W_BYTES);                  // scale, shift of the layer below [2][CIN]; later the sums
+  unsigned char* ldsO = smem_raw + W_BYTES + (size_t)TAB_FLOATS * sizeof(float) + (size_t)(threadIdx.x >> 6) * (32 * OPITCH);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const bool bst = a.bst_y != nullptr;
+  {
+    const T* wp = reinterpret_cast<const T*>(a.w);
+    for (int it = tid; it < (K / 8) * CIN; it += NTHREADS) lstore8<T>(ldsW + (size_t)it * 8, gload8<T>(wp + (size_t)it * 8));
+    if (bst) {
+      for (int ch = tid; ch < CIN; ch += NTHREADS) {
+        tab[ch] = a.bst_scale[ch]; tab[CIN + ch] = a.bst_shift[ch];
+      }
+    }
+  }
+  __syncthreads();
+  const float lin_lo = a.bst_relu == 0 ? -INFINITY : 0.f;
+
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, nx = G >> 3, remx = G & 7;
+  const int bid = (xcd < remx ? xcd * (nx + 1) : remx * (nx + 1) + (xcd - remx) * nx) + (blockIdx.x >> 3);
+  const int gw = __builtin_amdgcn_readfirstlane(bid * NW + wave), GW = G * NW;
+  const int per = a.total_strips / GW, extra = a.total_strips % GW;
+  const int t_lo = gw * per + (gw < extra ? gw : extra), t_hi = t_lo + per + (gw < extra ? 1 : 0);
+
+  const int wo = 2 * a.w_;
+  const T* wlane = ldsW + (size_t)(hh * CIN + r) * 8;                         // + (ks * 2 * CIN + nt * 32) * 8
+  // this lane's dy item of k-step ks: position ij = ks / KPP, channels (ks % KPP) * 16 + hh * 8 of output pixel (2 y + i, 2 (x0 + r) + j)
+  const unsigned dy_lane = (unsigned)(2 * r) * a.lddy + hh * 8;
+  auto issue = [&](Raw8<T> (&dst)[KS], int t) {
+    const int p0 = t * 32;
+    const int row = p0 / a.w_, x0 = p0 - row * a.w_;
+    const T* base = reinterpret_cast<const T*>(a.dy) + ((size_t)(2 * row) * wo + 2 * x0) * a.lddy + dy_lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int ij = ks / KPP, cq = (ks % KPP) * 16;
+      dst[ks] = gload8<T>(base + ((size_t)(ij >> 1) * wo + (ij & 1)) * a.lddy + cq);
+    }
+  };
+  float bs1[NP][8], bs2[NP][8];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bs1[p][e] = 0.f; bs2[p][e] = 0.f; }
+
+  Raw8<T> dr[KS];
+  if (t_lo < t_hi) issue(dr, t_lo);
+  for (int t = t_lo; t < t_hi; ++t) {
+    // one register set for dy: a k-step's item is re-requested for the next strip as soon as its MFMAs have read it
+    const bool more = t + 1 < t_hi;
+    const int p1 = (more ? t + 1 : t) * 32;
+    const int row1 = p1 / a.w_, x1 = p1 - row1 * a.w_;
+    const T* base1 = reinterpret_cast<const T*>(a.dy) + ((size_t)(2 * row1) * wo + 2 * x1) * a.lddy + dy_lane;
+    const size_t pix0 = (size_t)t * 32;
+    const int piece = lane & 7;
+    // the raw outputs of the layer below at the pieces this lane will store: requested BEFORE the next strip's dy (the in-order load
+    // counter would otherwise make their use wait for that whole strip)
+    uint4 vv[NP][4];
+    if (bst) {
+      const T* vrow = reinterpret_cast<const T*>(a.bst_y) + pix0 * a.bst_ld + piece * 8;
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) vv[p][m] = *reinterpret_cast<const uint4*>(vrow + (size_t)((lane >> 3) + 8 * m) * a.bst_ld + p * 64);
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 df = __builtin_bit_cast(bf16x8, dr[ks].q[0]);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wlane + (size_t)(ks * 2 * CIN + n * 32) * 8);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, df, acc[n], 0, 0, 0);       // [ci][pixel]
+      }
+      if (more) {
+        const int ij = ks / KPP, cq = (ks % KPP) * 16;
+        dr[ks] = gload8<T>(base1 + ((size_t)(ij >> 1) * wo + (ij & 1)) * a.lddy + cq);
+      }
+    }
+#pragma unroll
+    for (int np = 0; np < NP; ++np) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        uint2 o2[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          o2[g].x = pk_bf16(acc[2 * np + u][4 * g], acc[2 * np + u][4 * g + 1]);
+          o2[g].y = pk_bf16(acc[2 * np + u][4 * g + 2], acc[2 * np + u][4 * g + 3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k += 2) {
+          const uint2 lo = o2[k], hi = o2[k + 1];
+          auto sx = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+          auto sy = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+          *reinterpret_cast<uint4*>(ldsO + r * OPITCH + u * 64 + k * 16 + hh * 16) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+      }
+      // the pair's 64 channels of the strip: 8 pixels x 128 bytes per store instruction
+      T* xrow = reinterpret_cast<T*>(a.dx) + pix0 * a.lddx + np * 64;
+      float sc[8], sh[8];
+      if (bst) {
+        int toff = np * 64 + piece * 8;
+        asm volatile("" : "+v"(toff));
+        const float4* tp = reinterpret_cast<const float4*>(tab + toff);
+        const float4 a0 = tp[0], a1 = tp[1], b0 = tp[CIN / 4], b1 = tp[CIN / 4 + 1];
+        sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+        sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int q = (lane >> 3) + 8 * m;                                    // 16-byte piece `piece` of pixel q
+        const uint4 v = *reinterpret_cast<const uint4*>(ldsO + q * OPITCH + piece * 16);
+        *reinterpret_cast<uint4*>(xrow + (size_t)q * a.lddx + piece * 8) = v;
+        if (bst) {
+          const bf16x8 g8 = __builtin_bit_cast(bf16x8, v), y8 = __builtin_bit_cast(bf16x8, vv[np][m]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float fv = (float)g8[e], yv = (float)y8[e];
+            const float gg = yv * sc[e] + sh[e] > lin_lo ? fv : 0.f;
+            bs1[np][e] += gg; bs2[np][e] += gg * yv;            // sum g y: turned into sum g xhat = rstd (sum g y - mean sum g) at the end
+          }
+        }
+      }
+    }
+  }
+  // ---- fused sums: the lanes holding one channel group (lane % 8), then the waves, in a fixed order; one pair of atomics per channel
+  if (bst) {
+    __syncthreads();
+    float* red = tab;                                                         // [NW][2][CIN]
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float s1 = bs1[p][e], s2 = bs2[p][e];
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (lane < 8) { red[(wave * 2 + 0) * CIN + p * 64 + lane * 8 + e] = s1; red[(wave * 2 + 1) * CIN + p * 64 + lane * 8 + e] = s2; }
+      }
+    __syncthreads();
+    if (tid < CIN) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { t1 += red[(w * 2 + 0) * CIN + tid]; t2 += red[(w * 2 + 1) * CIN + tid]; }
+      satcv_stat_t* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
+      atomicAdd(rowp + tid, (satcv_stat_t)t1);
+      atomicAdd(rowp + a.stats_ld + tid, (satcv_stat_t)(((double)t2 - (double)a.bst_mean[tid] * (double)t1) * (double)a.bst_rstd[tid]));
+    }
+  }
+}
+
+template <int CIN, int COUT, int NW, int WPS>
+static int convt_thin_dgrad_cfg(const ConvtDgradArgs& ca, hipStream_t st) {
+  constexpr size_t lds = (size_t)4 * COUT * CIN * sizeof(bf16) + (size_t)(4 * CIN > 2 * NW * CIN ? 4 * CIN : 2 * NW * CIN) * sizeof(float) + (size_t)NW * 32 * 144;
+  auto kern = convt_thin_dgrad_kernel<CIN, COUT, NW, WPS>;
+  { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
+  static const int cus = [] {
+    int dev = 0, v = 256;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) v = p.multiProcessorCount;
+    return v;
+  }();
+  int per_cu = WPS * 4 / NW;
+  while (per_cu > 1 && (size_t)per_cu * lds > 150 * 1024) --per_cu;
+  if (per_cu < 1) per_cu = 1;
+  long long grid = (long long)cus * per_cu;
+  const long long need = (ca.total_strips + NW - 1) / NW;
+  if (grid > need) grid = need;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, ca);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { satcv_set_error("convt_thin_dgrad launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  return SATCV_OK;
+}
+
+// the space-to-depth launch of satcv_conv2d_igemm (mode_in == 1): x0 = dy with c0 = COUT channels, cout = CIN
+int convt_thin_dgrad_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
+  static const bool on = [] { const char* e = getenv("SATCV_CONVT_THIN"); return !e || atoi(e) != 0; }();
+  if (!on || dtype != SATCV_BF16) return SATCV_ERR_UNSUPPORTED;
+  if (a.kh != 1 || a.kw != 1 || a.mode_in != 1 || a.mode_out != 0 || a.f != 2 || a.x1 || a.stride != 1) return SATCV_ERR_UNSUPPORTED;
+  if (a.out_scale || a.pool_y || a.accumulate || a.out_relu || a.in_scale || a.bias || a.bst_y1) return SATCV_ERR_UNSUPPORTED;
+  if ((a.stats != nullptr) != (a.bst_y != nullptr)) return SATCV_ERR_UNSUPPORTED;      // (plain output statistics are not formed here)
+  const int cout_t = a.c0, cin = a.cout;
+  if (a.cout_pad != cin || a.w_ % 32 != 0 || a.ldy % 8 != 0 || a.ldy < cin) return SATCV_ERR_UNSUPPORTED;
+  if (((uintptr_t)a.y % 16) != 0 || ((uintptr_t)a.x0 % 16) != 0 || ((uintptr_t)a.w % 16) != 0) return SATCV_ERR_UNSUPPORTED;
+  if (a.bst_y && (a.bst_ld % 8 != 0 || a.bst_ld < cin || ((uintptr_t)a.bst_y % 16) != 0 || a.stats_ld < cin || a.cstat != cin)) return SATCV_ERR_UNSUPPORTED;
+  const long long strips = (long long)a.n * a.h * a.w_ / 32;
+  if (strips < 8 || strips > 0x3fffffff) return SATCV_ERR_UNSUPPORTED;
+  ConvtDgradArgs ca;
+  ca.dy = a.x0; ca.lddy = a.c0; ca.w = a.w; ca.dx = a.y; ca.lddx = a.ldy; ca.stats = a.stats; ca.stats_ld = a.stats_ld;
+  ca.bst_y = a.bst_y; ca.bst_ld = a.bst_ld; ca.bst_scale = a.bst_scale; ca.bst_shift = a.bst_shift; ca.bst_mean = a.bst_mean; ca.bst_rstd = a.bst_rstd;
+  ca.bst_relu = a.bst_relu;
+  ca.h = a.h; ca.w_ = a.w_; ca.total_strips = (int)strips;
+  // (64 <- 4 x 32 channels at 128 x 128 moves 536 MB -- dy, the raw outputs for the fused sums, dx -- and the tiled kernel already does it at
+  //  5.0 TB/s, 107 us; this kernel measured 113-120 us there.  SATCV_CONVT_THIN=2 runs it anyway.)
+  static const bool all = [] { const char* e = getenv("SATCV_CONVT_THIN"); return e && atoi(e) >= 2; }();
+  if (cin == 64 && cout_t == 32 && all) return convt_thin_dgrad_cfg<64, 32, 4, 3>(ca, st);
+  if (cin == 128 && cout_t == 64) return convt_thin_dgrad_cfg<128, 64, 8, 2>(ca, st);
+  return SATCV_ERR_UNSUPPORTED;
+}
+
 // SATCV_ERR_UNSUPPORTED outside the kernel's limits (the caller falls back to the tiled kernels)
 int convt_thin_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
   static const bool on = [] { const char* e = getenv("SATCV_CONVT_THIN"); return !e || atoi(e) != 0; }();

@@ -432,3 +432,4 @@ int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run = fa
 int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run);
 // streaming kernel of the thin transposed convolutions (conv_transpose_thin.hip); SATCV_ERR_UNSUPPORTED outside its limits
 int convt_thin_launch(const IgemmArgs& a, int dtype, hipStream_t st);
+int convt_thin_dgrad_launch(const IgemmArgs& a, int dtype, hipStream_t st);

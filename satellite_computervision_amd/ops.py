@@ -150,15 +150,18 @@ def conv2d_dgrad(dy, w_dgrad, cin, *, kh=3, kw=3, dil=1, out=None, accumulate=Fa
     return dx
 
 
-def conv2d_transpose_dgrad(dy, w_dgrad, cin, cout, f, *, out=None):
-    """Data gradient of Conv2DTranspose(k==s): space-to-depth gather of dy, 1x1 GEMM."""
+def conv2d_transpose_dgrad(dy, w_dgrad, cin, cout, f, *, out=None, stats=None, bst=None):
+    """Data gradient of Conv2DTranspose(k==s): space-to-depth gather of dy, 1x1 GEMM.  bst (with stats): the fused BatchNorm-backward
+    sums of the layer whose activation gradient this launch writes (satcv.h: bst_*)."""
     n, hf, wf, cy = dy.shape
     h, w_ = hf // f, wf // f
     dtype = DTYPE_CODE[dy.dtype]
     assert cy == cout, 'dy channel stride must equal cout'
     dx = out if out is not None else torch.empty(n, h, w_, rup(cin, 16), dtype=dy.dtype, device=dy.device)
     d = make_conv_desc(x0=_p(dy), c0=cy, w=_p(w_dgrad), y=_p(dx), ldy=dx.shape[-1], n=n, h=h, w_=w_, cout=cin,
-                       cout_pad=rup(cin, 32), dtype=dtype, kh=1, kw=1, dil=1, mode_in=1, f=f)
+                       cout_pad=rup(cin, 32), dtype=dtype, kh=1, kw=1, dil=1, mode_in=1, f=f,
+                       stats=_p(stats), stats_ld=stats.shape[-1] if stats is not None else 0,
+                       bst={k: (_p(v) if torch.is_tensor(v) else v) for k, v in bst.items()} if bst else None)
     check(lib.satcv_conv2d_igemm(C.byref(d), stream_ptr()))
     return dx
 

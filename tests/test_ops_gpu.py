@@ -440,6 +440,39 @@ def test_conv2d_transpose_streaming_kernel_with_input_batchnorm(ops, case):
     close(back(y2, cout), K.conv2d_transpose_ks(x, kt, np.zeros(cout)), td, f'convT streaming fwd plain {case}')
 
 
+@pytest.mark.parametrize('case', [(2, 32, 32, 64, 32), (1, 16, 64, 128, 64), (3, 8, 96, 64, 32), (1, 64, 64, 64, 32), (2, 32, 64, 128, 64)])
+def test_conv2d_transpose_streaming_data_gradient_with_fused_bn_sums(ops, case):
+    """Data gradient of the thin transposed convolutions on the streaming kernel (maps a multiple of 32 wide), with and without the fused
+    BatchNorm-backward sums of the layer below: the stored gradient is the same either way, the sums are those of the STORED gradient."""
+    td = torch.bfloat16
+    n, h, w, cin, cout = case
+    rng = np.random.default_rng(sum(case) + 1)
+    x = rnd(rng, (n, h, w, cin), td)
+    kt = rnd(rng, (2, 2, cout, cin), td, 0.2)
+    dy = rnd(rng, (n, 2 * h, 2 * w, cout), td)
+    dx_ref, _, _ = K.conv2d_transpose_ks_bwd(x, kt, dy)
+    _, wd = ops.pack_weights(f32dev(kt), cin, ops.DTYPE_CODE[td], transposed=True)
+    plain = ops.conv2d_transpose_dgrad(to_dev(dy, td), wd, cin, cout, 2)
+    close(back(plain, cin), dx_ref, td, f'convT streaming dgrad {case}')
+    v = rnd(rng, (n, h, w, cin), td) * 1.5 + 0.25
+    v = torch.tensor(v, dtype=torch.float32).to(td).double().numpy()
+    sc, sh = rng.standard_normal(cin).astype(np.float32), rng.standard_normal(cin).astype(np.float32) * 0.5
+    mu, rs = rng.standard_normal(cin).astype(np.float32) * 0.3, (0.5 + rng.random(cin)).astype(np.float32)
+    for relu in (1, 0):
+        stats = ops.new_stats(cin, dev())
+        got = ops.conv2d_transpose_dgrad(to_dev(dy, td), wd, cin, cout, 2, stats=stats,
+                                         bst=dict(y=to_dev(v, td), ld=cin, scale=f32dev(sc), shift=f32dev(sh), mean=f32dev(mu), rstd=f32dev(rs), relu=relu))
+        assert torch.equal(got, plain), 'the fused sums must not change the stored gradient'
+        g = back(got, cin)
+        mask = (v * sc.astype(np.float64) + sh.astype(np.float64) > 0) if relu else np.ones_like(v, bool)
+        gg = np.where(mask, g, 0.0)
+        xh = (v - mu.astype(np.float64)) * rs.astype(np.float64)
+        s = stats.sum(0).double().cpu().numpy()
+        tol = 2e-4 * np.sqrt(n * h * w) * max(1.0, float(np.abs(g).max()))
+        np.testing.assert_allclose(s[0], gg.sum((0, 1, 2)), rtol=1e-4, atol=tol, err_msg=f'sum g {case} relu={relu}')
+        np.testing.assert_allclose(s[1], (gg * xh).sum((0, 1, 2)), rtol=1e-4, atol=tol * float(np.abs(xh).max()), err_msg=f'sum g xhat {case} relu={relu}')
+
+
 # ------------------------------------------------------------------------ batch norm
 @pytest.mark.parametrize('td', DT)
 @pytest.mark.parametrize('f', [2, 3])
