@@ -194,6 +194,10 @@ typedef struct satcv_bwdf_desc {
    * wrote: the launch uses g + (amax == position in the window ? dpool : 0).  Limits: 32 -> 64 channels; or 16 stored channels -> 32
    * with dx == NULL (the first block: fed by the model input, no data gradient). */
   const void* dpool; int32_t lddp; const void* amax;
+  /* optional, the block under the 1 x 1 head (utils/model_tools.py:405): g is not read -- it is formed in the loader as
+   * g[p][c] = bf16(dlogits[p][0] w[c][0] + dlogits[p][1] w[c][1]), what satcv_head_bwd would have stored as dx (pass dx = NULL there).
+   * hg_dlogits (npix, 2) fp32, hg_w the head's Keras kernel (cout, 2) fp32, hg_ncls == 2; 32 -> 32 channels only. */
+  const float* hg_dlogits; const float* hg_w; int32_t hg_ncls;
 } satcv_bwdf_desc;
 int64_t satcv_conv2d_bwd_fused_workspace(const satcv_bwdf_desc* d);
 int satcv_conv2d_bwd_fused(const satcv_bwdf_desc* d, void* stream);

@@ -66,7 +66,8 @@ class BwdfDesc(C.Structure):
                 ('n', c_i32), ('h', c_i32), ('w_', c_i32), ('kh', c_i32), ('kw', c_i32), ('dil', c_i32),
                 ('workspace', c_vp), ('workspace_bytes', c_i64), ('dtype', c_i32), ('accumulate', c_i32),
                 ('bst_sums', c_vp), ('bst_sums_ld', c_i32), ('bst_mean', c_vp), ('bst_rstd', c_vp), ('bst_act_form', c_i32),
-                ('dpool', c_vp), ('lddp', c_i32), ('amax', c_vp)]
+                ('dpool', c_vp), ('lddp', c_i32), ('amax', c_vp),
+                ('hg_dlogits', c_vp), ('hg_w', c_vp), ('hg_ncls', c_i32)]
 
 
 class BnBwdDesc(C.Structure):

@@ -45,6 +45,9 @@ struct BwdfArgs {
   int bst_act_form;                              // 1: leave the sums in the activated form (sum dx [x > 0], sum dx x): satcv_bn_bwd_finalize2 converts
   // POOL: the block's output was also max-pooled 2 x 2 -- g = da + (amax == position in the window ? dpool : 0)
   const void* dp; int lddp; const unsigned char* amax;
+  // HG: the block feeds the 1 x 1 head directly -- g[p][c] = sum_k dlogits[p][k] w_head[c][k] is formed here from the 2 logit gradients of
+  // a pixel (8 bytes) instead of being written by the head's backward kernel and read back (2 x 64 bytes per pixel)
+  const float* hg_dl; const float* hg_w;
 };
 
 __device__ __forceinline__ bf16x4 tr_read4(const bf16* p) {
@@ -57,8 +60,9 @@ __device__ __forceinline__ bf16x4 tr_read4(const bf16* p) {
 // POOL: encoder blocks -- the gradient of the activated output is da (skip) + the 2 x 2 max-pool's gradient routed by the arg-max bytes
 // the forward pooling kernel wrote.  NODG: no data gradient (the block is fed by the model input).  CINS: stored input channels when
 // fewer than the 32 rows of an MFMA tile (16 for the first block: the upper x planes are zero)
-template <int CIN, int COUT, int NW, int WPS, bool POOL = false, bool NODG = false, int CINS = CIN>
+template <int CIN, int COUT, int NW, int WPS, bool POOL = false, bool NODG = false, int CINS = CIN, bool HG = false>
 __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs a, const int total_tiles) {
+  static_assert(!HG || !POOL, "the head feeds a decoder block");
   typedef bf16 T;
   constexpr int TW = 32, TH = 8, BM = 256, RL = TH + 2, CL = TW + 2, PITCH = CL, EL = 8, NTHREADS = NW * 64;
   constexpr int SD = COUT / 8, SX = CIN / 8, SXR = CINS / 8;     // 16-byte channel slots of dy / x (SXR of them real)
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
   // read the activated x beside the staged dx), else a region of its own behind the tables
   constexpr size_t O_BYTES = (size_t)BM * (CIN + 8) * sizeof(T);
   constexpr bool O_ALIAS = O_BYTES <= (size_t)SD * DSTRIDE * sizeof(T);
-  constexpr size_t TAB_BYTES = (size_t)(SD * 32 + SX * 16) * sizeof(float);
+  constexpr size_t TAB_BYTES = (size_t)(SD * 32 + SX * 16 + (HG ? 2 * COUT : 0)) * sizeof(float);
   static_assert(!NODG || O_ALIAS || true, "");
   constexpr size_t O_OFF = O_ALIAS ? 0 : (R0_BYTES + W_BYTES + TAB_BYTES + 127) / 128 * 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
   T* ldsW = reinterpret_cast<T*>(smem_raw + R0_BYTES);                        // [tap][SD][CIN][8], resident
   float* tabD = reinterpret_cast<float*>(smem_raw + R0_BYTES + W_BYTES);      // [SD][4][8]: scale, shift, B, C of the BatchNorm backward
   float* tabX = tabD + SD * 32;                                               // [SX][2][8]: scale, shift of the input's BatchNorm
+  float* tabH = tabX + SX * 16;                                               // HG: [SD][2][8]: the head's kernel, class 0 / class 1 of 8 channels
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -113,6 +118,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
     const float sc = a.bn_scale[ch], sh = a.bn_shift[ch], mu = a.bn_mean[ch], rs = a.bn_rstd[ch], c1 = a.bn_coef[ch], c2 = a.bn_coef[a.bn_c + ch];
     float* t = tabD + (ch >> 3) * 32 + (ch & 7);
     t[0] = sc; t[8] = sh; t[16] = -sc * c2 * rs; t[24] = sc * (c2 * rs * mu - c1);
+  }
+  if constexpr (HG) {
+    for (int ch = tid; ch < COUT; ch += NTHREADS) {
+      float* t = tabH + (ch >> 3) * 16 + (ch & 7);
+      t[0] = a.hg_w[ch * 2]; t[8] = a.hg_w[ch * 2 + 1];                       // Keras (1, 1, cin, ncls) kernel: w[c][k]
+    }
   }
   for (int ch = tid; ch < CINS; ch += NTHREADS) {
     float* t = tabX + (ch >> 3) * 16 + (ch & 7);
@@ -172,7 +183,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
     x0 += TW;
     if (x0 >= a.e.w_) { x0 = 0; y0 += TH; if (y0 >= a.e.h) { y0 = 0; ++n0; } }
   };
-  Raw8<T> rg[DI], ry[DI], rx[XI];
+  Raw8<T> rg[HG ? 1 : DI], ry[DI], rx[XI];
+  float2 rdl[HG ? DI : 1];                                                    // HG: the pixel's two logit gradients
   Raw8<T> rp[POOL ? DI : 1];                                                  // pooled gradient of the item's window
   uint2 ra[POOL ? DI : 1];                                                    // arg-max bytes of the window (8 channels)
   const int hp = a.e.h >> 1, wpool = a.e.w_ >> 1;
@@ -180,7 +192,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
   auto issue_loads = [&](int n0, int y0, int x0) -> unsigned {
     unsigned vm = 0;
     const int ylo = 1 - y0, yhi = a.e.h - y0 + 1, xlo = 1 - x0, xhi = a.e.w_ - x0 + 1;      // limits of the halo row / column inside the image
-    const long long bp = ((long long)(n0 * a.e.h + y0 - 1) * a.e.w_ + (x0 - 1)) * a.ldg;       // halo origin (may lie before the tensor: never dereferenced)
+    const long long pb = (long long)(n0 * a.e.h + y0 - 1) * a.e.w_ + (x0 - 1);                  // halo origin in pixels
+    const long long bp = pb * a.ldg;                                                             // (may lie before the tensor: never dereferenced)
     const T* gb = reinterpret_cast<const T*>(a.g) + bp;
     const T* yb = reinterpret_cast<const T*>(a.yraw) + bp;
     const unsigned centre = (unsigned)(g_rowstride + a.ldg) + gy_lane;                         // the tile's first pixel: always inside
@@ -191,7 +204,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
       vm |= (ok ? 1u : 0u) << j;
       unsigned off = ok ? (unsigned)(__mul24(L, g_rowstride) + __mul24(c, a.ldg)) + gy_lane : centre;   // (outside: a valid pixel, zeroed at the LDS store)
       asm volatile("" : "+v"(off));
-      if (!FABL(32)) { rg[j] = gload8<T>(gb + off); ry[j] = gload8<T>(yb + off); }
+      if constexpr (HG) {
+        int poff = ok ? __mul24(L, a.e.w_) + c : a.e.w_ + 1;
+        asm volatile("" : "+v"(poff));
+        rdl[j] = reinterpret_cast<const float2*>(a.hg_dl)[pb + poff];
+        ry[j] = gload8<T>(yb + off);
+      } else if (!FABL(32)) { rg[j] = gload8<T>(gb + off); ry[j] = gload8<T>(yb + off); }
       else { rg[j] = zero8<T>(); ry[j] = zero8<T>(); rg[j].q[0].x = off; }
     }
     return vm;
@@ -270,7 +288,19 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
 #pragma unroll
       for (int j = 0; j < DI; ++j) {
         float gv[8], yv[8];
-        unpack8<T>(rg[j], gv);
+        if constexpr (HG) {
+          // the head's data gradient as satcv_head_bwd would have stored it: dl0 w[c][0] + dl1 w[c][1] in that order, rounded to bf16
+          int hoff = slot_d * 16;
+          asm volatile("" : "+v"(hoff));
+          const float4* hp = reinterpret_cast<const float4*>(tabH + hoff);
+          const float4 w00 = hp[0], w01 = hp[1], w10 = hp[2], w11 = hp[3];
+          const float w0[8] = {w00.x, w00.y, w00.z, w00.w, w01.x, w01.y, w01.z, w01.w};
+          const float w1[8] = {w10.x, w10.y, w10.z, w10.w, w11.x, w11.y, w11.z, w11.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gv[e] = (float)(T)fmaf(rdl[j].y, w1[e], rdl[j].x * w0[e]);
+        } else {
+          unpack8<T>(rg[j], gv);
+        }
         unpack8<T>(ry[j], yv);
         if constexpr (POOL) {
           float pv[8];
@@ -284,7 +314,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void bwd_fused_kernel(const BwdfArgs 
           }
         }
         Raw8<T> v;
-        if constexpr (FABL(2)) { v = rg[j]; v.q[0].x ^= ry[j].q[0].x; }
+        if constexpr (FABL(2) && !HG) { v = rg[j]; v.q[0].x ^= ry[j].q[0].x; }
         else {
           bf16x8 o;
 #pragma unroll
@@ -525,7 +555,7 @@ struct BwdfGeom {
   static constexpr size_t R0 = ((size_t)(SD * (10 * 34 * 8) + SX * (256 * 8 + 32)) * 2 + 127) / 128 * 128;
   static constexpr size_t O_BYTES = (size_t)256 * (CIN + 8) * 2;
   static constexpr bool O_ALIAS = O_BYTES <= (size_t)SD * (10 * 34 * 8) * 2;
-  static constexpr size_t BASE = R0 + (NODG ? 0 : (size_t)9 * SD * CIN * 16) + (size_t)(SD * 32 + SX * 16) * 4;
+  static constexpr size_t BASE = R0 + (NODG ? 0 : (size_t)9 * SD * CIN * 16) + (size_t)(SD * 32 + SX * 16 + 2 * COUT) * 4;
   static constexpr size_t LDS0 = O_ALIAS ? BASE : (BASE + 127) / 128 * 128 + O_BYTES;
   static constexpr size_t RED = (size_t)16 * NW * 64 * 4;                      // end-of-kernel reduction scratch of the fused sums
   static constexpr size_t LDS = LDS0 > RED ? LDS0 : RED;
@@ -553,6 +583,7 @@ static bool bwdf_shape_ok(const satcv_bwdf_desc* d, int& cin_s) {
   if (d->x1 && d->c0 % 8 != 0) return false;
   if (d->h % 8 != 0 || d->w_ % 32 != 0) return false;               // whole 8 x 32 tiles
   if (d->ldg % 8 != 0 || ((uintptr_t)d->g % 16) != 0 || ((uintptr_t)d->yraw % 16) != 0) return false;
+  if (d->hg_dlogits && (!d->hg_w || d->hg_ncls != 2 || d->dpool || ((uintptr_t)d->hg_dlogits % 8) != 0)) return false;
   if (d->dx && (d->lddx % 8 != 0 || ((uintptr_t)d->dx % 16) != 0)) return false;
   if ((long long)d->w_ * d->ldg >= (1 << 23)) return false;         // 24-bit multiplies of the halo offsets
   if (d->dpool) {
@@ -568,7 +599,7 @@ static bool bwdf_shape_ok(const satcv_bwdf_desc* d, int& cin_s) {
   return true;
 }
 
-template <int CIN, int COUT, int NW, int WPS, bool POOL = false, bool NODG = false, int CINS = CIN>
+template <int CIN, int COUT, int NW, int WPS, bool POOL = false, bool NODG = false, int CINS = CIN, bool HG = false>
 static int bwdf_launch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int64_t* ws_bytes) {
   using G = BwdfGeom<CIN, COUT, NW, NODG>;
   static_assert(G::LDS <= 160 * 1024, "tile + weights exceed the LDS");
@@ -588,7 +619,8 @@ static int bwdf_launch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int
   a.w = d->w_dgrad; a.ws = d->workspace; a.tiles_x = d->w_ / 32; a.tiles_y = d->h / 8;
   a.bst_sums = d->bst_sums; a.bst_ld = d->bst_sums_ld; a.bst_mean = d->bst_mean; a.bst_rstd = d->bst_rstd; a.bst_act_form = d->bst_act_form;
   a.dp = d->dpool; a.lddp = d->lddp; a.amax = reinterpret_cast<const unsigned char*>(d->amax);
-  auto kern = bwd_fused_kernel<CIN, COUT, NW, WPS, POOL, NODG, CINS>;
+  a.hg_dl = d->hg_dlogits; a.hg_w = d->hg_w;
+  auto kern = bwd_fused_kernel<CIN, COUT, NW, WPS, POOL, NODG, CINS, HG>;
   { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS); if (rc) return rc; }
   const double flops = (NODG ? 2.0 : 4.0) * d->n * d->h * d->w_ * (double)CINS * COUT * 9;          // (data gradient +) weight gradient
   satcv_prof_begin(3, flops, st);
@@ -608,6 +640,8 @@ static int bwdf_dispatch(const satcv_bwdf_desc* d, hipStream_t st, bool query, i
     return bwdf_launch<32, 32, 8, 2, true, true, 16>(d, st, query, ws_bytes);
   }
   // (32 -> 32: 8 waves x 1 workgroup per CU measured equal to 4 waves x 2 workgroups and leaves registers for the fused sums)
+  if (cin_s == 32 && d->hg_dlogits) return bwdf_launch<32, 32, 8, 2, false, false, 32, true>(d, st, query, ws_bytes);
+  if (d->hg_dlogits) return SATCV_ERR_UNSUPPORTED;
   if (cin_s == 32) return bwdf_launch<32, 32, 8, 2>(d, st, query, ws_bytes);
   if (d->cout == 32) return bwdf_launch<64, 32, 8, 2>(d, st, query, ws_bytes);
   return bwdf_launch<64, 64, 4, 1>(d, st, query, ws_bytes);
@@ -620,7 +654,7 @@ extern "C" int64_t satcv_conv2d_bwd_fused_workspace(const satcv_bwdf_desc* d) {
 }
 
 extern "C" int satcv_conv2d_bwd_fused(const satcv_bwdf_desc* d, void* stream) {
-  SATCV_CHECK(d && d->g && d->yraw && d->x0 && d->dw && d->workspace && (d->dx == nullptr || d->w_dgrad), "bwd_fused: null pointer");
+  SATCV_CHECK(d && (d->g || d->hg_dlogits) && d->yraw && d->x0 && d->dw && d->workspace && (d->dx == nullptr || d->w_dgrad), "bwd_fused: null pointer");
   SATCV_CHECK(d->bn_scale && d->bn_shift && d->bn_mean && d->bn_rstd && d->bn_coef, "bwd_fused: BatchNorm coefficients missing");
   SATCV_CHECK((d->c1 == 0) == (d->x1 == nullptr) && d->n > 0 && d->h > 0 && d->w_ > 0, "bwd_fused: bad dims");
   SATCV_CHECK(!d->bst_sums || (d->bst_sums_ld >= d->c0 + d->c1 && (d->bst_act_form ? d->in_scale == nullptr

@@ -1006,7 +1006,7 @@ __global__ void head_bwd_kernel(const satcv_head_desc d) {
 }
 extern "C" int satcv_head_bwd(const satcv_head_desc* d, void* stream) {
   SATCV_CHECK(d && d->x && d->w && d->dlogits, "head_bwd: null pointer");
-  SATCV_CHECK(!d->bnr_sums || (d->bnr_mean && d->bnr_rstd && d->in_scale && d->dx && d->bnr_sums_ld >= d->cin), "head_bwd: incomplete bnr_* fields");
+  SATCV_CHECK(!d->bnr_sums || (d->bnr_mean && d->bnr_rstd && d->in_scale && d->bnr_sums_ld >= d->cin), "head_bwd: incomplete bnr_* fields");
   SATCV_CHECK(d->cin > 0 && d->cin % 8 == 0 && d->ncls >= 1 && d->ncls <= HEAD_NCMAX && d->npix > 0, "head_bwd: bad dims");
   SATCV_CHECK(!d->partials || satcv_head_bwd_workspace(d) > 0, "head_bwd: partial rows only with the register-resident kernel");
   const size_t lds = (size_t)(2 * d->cin * d->ncls + d->ncls + 2 * d->cin) * sizeof(float);

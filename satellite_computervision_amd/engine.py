@@ -258,6 +258,7 @@ class Plan:
         self.dropouts = []                    # dropout masks (regenerated every training step)
         self.x_inputs = []                    # fp32 staging tensor of every model input
         self.x_by_tid = {}
+        self.x_src = {}                       # tensor id -> device pointer of a caller's batch read in place (Model._stage_x), else the staging tensor
         self.side = torch.cuda.Stream() if (training and rt.model.wgrad_side_stream) else None
         self.step_count = 0
         self.outputs = {}
@@ -422,7 +423,8 @@ class Plan:
                 self.x_by_tid[t.id] = xin
                 npix = n * self.h * self.w
                 cc = t.channels
-                self.fwd.append(lambda st, xin=xin, x=x, npix=npix, cc=cc, cp=cp: check(lib.satcv_ingest_nhwc(xin.data_ptr(), x.data_ptr(), npix, cc, cp, dt, st)))
+                self.fwd.append(lambda st, xin=xin, x=x, npix=npix, cc=cc, cp=cp, tid=t.id: check(lib.satcv_ingest_nhwc(
+                    self.x_src.get(tid) or xin.data_ptr(), x.data_ptr(), npix, cc, cp, dt, st)))
                 vals[t.id] = TRef([(x, cp)], n, self.h, self.w)
             elif op == 'cba':
                 tin, tout = node.inputs[0], node.outputs[0]
@@ -885,6 +887,7 @@ class Plan:
                     sync.ready_above(rt.gflat, lo, self.side)
             self.bwd.append(ckpt)
 
+        head_feed = {}                                 # tensor id -> the head launch that writes its gradient
         prev_node = None
         for node in reversed(m.nodes):
             if prev_node is not None:
@@ -916,6 +919,9 @@ class Plan:
                     hd.partials = part.data_ptr()
                     self.bwd.append(lambda st, hd=hd: check(lib.satcv_head_bwd_finalize(C.byref(hd), st)))
                 gact[node.inputs[0].id] = (dx, 0, c)
+                # (the block under the head may form this gradient itself from the logit gradients: see the fused launch below)
+                head_feed[node.inputs[0].id] = dict(hd=hd, ncls=cx['ncls'], c=c, w=rt.pptr(lay.name + '/kernel'), wname=lay.name + '/kernel',
+                                                    fused_reduce=ft is not None)
             elif op == 'add_relu':
                 # out = ReLU(BN(conv) + shortcut): the masked gradient g * (out > 0) belongs to BOTH addends.  It is formed in place
                 # and handed to the branch's (linear) BN backward and to the shortcut; a tensor that already holds a gradient
@@ -1002,6 +1008,16 @@ class Plan:
                     if bt is not None and bt[1] == cinp and bt[0].get('relu', 0) == 1:
                         sums_below = self._z(STAT_ROWS, 2, cinp, dtype=torch.float64)
                         fz.bst_sums, fz.bst_sums_ld, fz.bst_mean, fz.bst_rstd = _fp(sums_below), cinp, bt[0]['mean'], bt[0]['rstd']
+                    # ... and, for the block under the 1 x 1 head, the gradient g itself: two logit gradients per pixel instead of the
+                    # head's dx tensor written and read back (2 x 64 bytes per pixel)
+                    hf = head_feed.get(tout.id)
+                    if (hf is not None and getattr(rt.model, 'fuse_head_grad', True) and hf['ncls'] == 2 and hf['c'] == cout == 32 and cinp == 32
+                            and hf['fused_reduce'] and pre is not None and len(consumers.get(tout.id, [])) == 1):
+                        fz.hg_dlogits, fz.hg_w, fz.hg_ncls = self.dlogits.data_ptr(), hf['w'], 2
+                        if lib.satcv_conv2d_bwd_fused_workspace(C.byref(fz)) < 0:
+                            fz.hg_dlogits, fz.hg_w, fz.hg_ncls = None, None, 0
+                        else:
+                            hf['hd'].dx = None                      # satcv_head_bwd keeps its dW / db and the fused sums, stores no dx
                     nbf = lib.satcv_conv2d_bwd_fused_workspace(C.byref(fz))
                     if nbf < 0 and sums_below is not None:              # (the 64 -> 64 form does not carry the sums)
                         fz.bst_sums, fz.bst_sums_ld, fz.bst_mean, fz.bst_rstd = None, 0, None, None
@@ -1041,12 +1057,14 @@ class Plan:
                             fin = fin0
                     self.bwd.append(fin)
                     fstep = lambda st, fz=fz: check(lib.satcv_conv2d_bwd_fused(C.byref(fz), st))
-                    fstep.label = f"bwd_fused k3 n{n} {hh}x{ww} {sa['c0']}+{sa['c1']}->{cout}{' +bnred' if fz.bst_sums else ''}"
+                    fstep.label = f"bwd_fused k3 n{n} {hh}x{ww} {sa['c0']}+{sa['c1']}->{cout}{' +bnred' if fz.bst_sums else ''}{' +headgrad' if fz.hg_dlogits else ''}"
                     fstep.work = dict(kind='bwd_fused', taps=9, px=n * hh * ww, cin=pk['cin'], cout=cout, esize=es)
                     self.bwd.append(fstep)
                     gact[tin.id] = (gin, 0, cinp)
                     self.dbg['dx:' + lay.name] = gin
                     self.dbg['dyparts:' + lay.name] = dict(g=da, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout, coef=coef, linear=fz.linear)
+                    if fz.hg_dlogits:
+                        self.dbg['dyparts:' + lay.name]['head'] = (self.dlogits, head_feed[tout.id]['wname'])
                     self.dbg['_ctx:' + lay.name] = dict(da=da, dp=dp, y=y, yoff=yoff, ldy=ldy, aff=aff, aoff=aoff, cout=cout)
                     continue
                 dy = self._z(n, hh, ww, cout)

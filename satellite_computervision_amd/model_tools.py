@@ -527,6 +527,17 @@ class _LossArg:
         self.what = what
 
 
+def _resident_f32(x, like):
+    """True when a caller's batch tensor can be read in place of the plan's staging tensor: float32, contiguous, same shape and device."""
+    return (x.dtype == torch.float32 and x.is_contiguous() and x.device == like.device and tuple(x.shape) == tuple(like.shape)
+            and x.data_ptr() % 16 == 0)
+
+
+def _y_ptr(plan):
+    y = getattr(plan, 'y_src', None)
+    return y.data_ptr() if y is not None else plan.y_true.data_ptr()
+
+
 def _eager_loss(kind, y_true, y_pred, weights, activation='softmax', eps=1e-6):
     dev = torch.device('cuda')
     p = torch.as_tensor(np.asarray(y_pred, np.float32)).to(dev).contiguous()
@@ -735,6 +746,7 @@ class Model:
         self.fuse_dgrad_bn_bwd = os.environ.get('SATCV_FUSE_DGRAD_BN_BWD', '1') != '0'  # data-gradient epilogues do the reduce pass of the BN below them
         self.wgrad_side_stream = os.environ.get('SATCV_WGRAD_STREAM', '1') != '0'      # weight gradients on a second HIP stream
         self.fuse_pool_bn_sums = os.environ.get('SATCV_FUSE_POOL_BN_SUMS', '1') != '0'  # encoder BN-backward sums formed by the producers of its gradients
+        self.fuse_head_grad = os.environ.get('SATCV_FUSE_HEAD_GRAD', '1') != '0'      # the block under the head forms the head's data gradient in its loader
         self.fuse_pool_bwd = os.environ.get('SATCV_FUSE_POOL_BWD', '1') != '0'         # encoder blocks: pooled BN apply + weight (+ data) gradient in one launch
         self.fuse_thin_bwd = os.environ.get('SATCV_FUSE_THIN_BWD', '1') != '0'         # thin layers: BN-backward apply + data + weight gradient in one launch
         self.sync_bn = os.environ.get('SATCV_SYNC_BN', '0') == '1'      # data parallel: BatchNorm statistics over ALL replicas (parallel.py)
@@ -985,10 +997,20 @@ class Model:
         xs = list(xb) if isinstance(xb, (list, tuple)) else [xb]
         if len(xs) != len(self.inputs):
             raise ValueError(f'model expects {len(self.inputs)} input array(s), got {len(xs)}')
+        src = getattr(plan, 'x_src', None)
         for t, x in zip(self.inputs, xs):
             dst = plan.x_by_tid[t.id]
+            if src is not None:
+                src.pop(t.id, None)
             if isinstance(x, torch.Tensor):
-                dst.copy_(x.to(torch.float32), non_blocking=True)
+                if src is not None and _resident_f32(x, dst):
+                    # a float32 batch already resident on this device is read in place by the ingest kernel (no staging copy);
+                    # the reference is held until the next batch is staged
+                    src[t.id] = x.data_ptr()
+                    plan._x_hold = getattr(plan, '_x_hold', {})
+                    plan._x_hold[t.id] = x
+                else:
+                    dst.copy_(x.to(torch.float32), non_blocking=True)
             else:
                 dst.copy_(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)), non_blocking=True)
 
@@ -1085,20 +1107,24 @@ class Model:
         if kind >= 2:
             if not hasattr(plan, 'loss_ws'):
                 plan.loss_ws = torch.zeros(plan.n * 3 * h['ncls'], dtype=torch.float32, device=rt.dev)
-            check(lib.satcv_loss_global_fwd_bwd(kind, h['probs'].data_ptr(), plan.y_true.data_ptr(),
+            check(lib.satcv_loss_global_fwd_bwd(kind, h['probs'].data_ptr(), _y_ptr(plan),
                                                 self._loss_w.data_ptr() if self._loss_w is not None else None, h['ncls'], h['act'], plan.n,
                                                 h['r'].h * h['r'].w, self._loss.eps, grad_scale, plan.loss_ws.data_ptr(),
                                                 plan.loss_buf.data_ptr(), plan.dlogits.data_ptr(), st))
             return
-        check(lib.satcv_loss_fwd_bwd(kind, h['probs'].data_ptr(), plan.y_true.data_ptr(), self._loss_w.data_ptr(), h['ncls'], h['act'],
+        check(lib.satcv_loss_fwd_bwd(kind, h['probs'].data_ptr(), _y_ptr(plan), self._loss_w.data_ptr(), h['ncls'], h['act'],
                                      plan.n * h['r'].h * h['r'].w, grad_scale, plan.loss_buf.data_ptr(), plan.dlogits.data_ptr(), st))
 
     def _stage_y(self, plan, yb):
         if not hasattr(plan, 'y_true'):
             h = plan.head
             plan.y_true = torch.zeros(plan.n, h['r'].h, h['r'].w, h['ncls'], dtype=torch.float32, device=self.runtime.dev)
+        plan.y_src = None
         if isinstance(yb, torch.Tensor):
-            plan.y_true.copy_(yb.to(torch.float32), non_blocking=True)
+            if _resident_f32(yb, plan.y_true):
+                plan.y_src = yb                  # read in place by the loss / confusion kernels
+            else:
+                plan.y_true.copy_(yb.to(torch.float32), non_blocking=True)
         else:
             plan.y_true.copy_(torch.from_numpy(np.ascontiguousarray(yb, dtype=np.float32)), non_blocking=True)
 
@@ -1179,7 +1205,7 @@ class Model:
             if self._metrics and hd['act'] == 0:
                 if conf is None:
                     conf = torch.zeros(hd['ncls'], hd['ncls'], dtype=torch.int64, device=rt.dev)
-                check(lib.satcv_confusion(hd['classes'].data_ptr(), plan.y_true.data_ptr(), hd['ncls'], hd['classes'].numel(),
+                check(lib.satcv_confusion(hd['classes'].data_ptr(), _y_ptr(plan), hd['ncls'], hd['classes'].numel(),
                                           conf.data_ptr(), ops.stream_ptr()))
             cnt += plan.n
         loss = float(loss_sum.item()) / max(cnt, 1)

@@ -181,7 +181,8 @@ def make_wgrad_desc(*, x0, c0, dy, lddy, dw, cin, cout, n, h, w_, dtype, x1=None
 
 def make_bwdf_desc(*, g, yraw, ldg, bn_scale, bn_shift, bn_mean, bn_rstd, bn_coef, x0, c0, w_dgrad, dx, lddx, dw, cin, cout, n, h, w_, dtype,
                    linear=0, x1=None, c1=0, in_scale=None, in_shift=None, in_relu=0, kh=3, kw=3, dil=1, workspace=None, workspace_bytes=0,
-                   accumulate=0, bst_sums=None, bst_sums_ld=0, bst_mean=None, bst_rstd=None, bst_act_form=0, dpool=None, lddp=0, amax=None):
+                   accumulate=0, bst_sums=None, bst_sums_ld=0, bst_mean=None, bst_rstd=None, bst_act_form=0, dpool=None, lddp=0, amax=None,
+                   hg_dlogits=None, hg_w=None, hg_ncls=0):
     from ._lib import BwdfDesc
     d = BwdfDesc()
     d.g, d.yraw, d.ldg = g, yraw, ldg
@@ -193,23 +194,25 @@ def make_bwdf_desc(*, g, yraw, ldg, bn_scale, bn_shift, bn_mean, bn_rstd, bn_coe
     d.workspace, d.workspace_bytes, d.dtype, d.accumulate = workspace, workspace_bytes, dtype, int(accumulate)
     d.bst_sums, d.bst_sums_ld, d.bst_mean, d.bst_rstd, d.bst_act_form = bst_sums, bst_sums_ld, bst_mean, bst_rstd, int(bst_act_form)
     d.dpool, d.lddp, d.amax = dpool, lddp, amax
+    d.hg_dlogits, d.hg_w, d.hg_ncls = hg_dlogits, hg_w, int(hg_ncls)
     return d
 
 
 def conv_bwd_fused(g, yraw, scale, shift, mean, rstd, coef, x, w_dgrad, cin, cout, *, x1=None, in_scale=None, in_shift=None, in_relu=False,
-                   linear=False, accumulate_into=None, bst=None, dpool=None, amax=None, want_dx=True):
+                   linear=False, accumulate_into=None, bst=None, dpool=None, amax=None, want_dx=True, head=None):
     """BatchNorm-backward apply + data gradient + weight gradient of a thin conv -> BN -> ReLU block in one launch
-    (satcv_conv2d_bwd_fused).  dpool / amax: the pooled form (encoder blocks).  Returns (dx, dw) -- dx None with want_dx=False --, or None
-    when the shape is outside the kernel's limits."""
+    (satcv_conv2d_bwd_fused).  dpool / amax: the pooled form (encoder blocks).  head=(dlogits (npix, 2) fp32, w (cout, 2) fp32) with g=None:
+    the block under the 1 x 1 head, g formed in the loader.  Returns (dx, dw) -- dx None with want_dx=False --, or None when the shape is
+    outside the kernel's limits."""
     n, h, w_, c0 = x.shape
     c1 = x1.shape[-1] if x1 is not None else 0
     dx = torch.empty(n, h, w_, c0 + c1, dtype=x.dtype, device=x.device) if want_dx else None
     dw = accumulate_into if accumulate_into is not None else torch.empty(3, 3, cin, cout, dtype=torch.float32, device=x.device)
-    d = make_bwdf_desc(g=_p(g), yraw=_p(yraw), ldg=g.shape[-1], bn_scale=_p(scale), bn_shift=_p(shift), bn_mean=_p(mean), bn_rstd=_p(rstd),
+    d = make_bwdf_desc(g=_p(g), yraw=_p(yraw), ldg=g.shape[-1] if g is not None else yraw.shape[-1], bn_scale=_p(scale), bn_shift=_p(shift), bn_mean=_p(mean), bn_rstd=_p(rstd),
                        bn_coef=_p(coef), x0=_p(x), c0=c0, x1=_p(x1), c1=c1, in_scale=_p(in_scale), in_shift=_p(in_shift), in_relu=in_relu,
                        w_dgrad=_p(w_dgrad), dx=_p(dx), lddx=c0 + c1, dw=_p(dw), cin=cin, cout=cout, n=n, h=h, w_=w_, dtype=DTYPE_CODE[x.dtype],
                        linear=linear, accumulate=accumulate_into is not None, dpool=_p(dpool), lddp=dpool.shape[-1] if dpool is not None else 0,
-                       amax=_p(amax),
+                       amax=_p(amax), **(dict(hg_dlogits=_p(head[0]), hg_w=_p(head[1]), hg_ncls=head[0].shape[-1]) if head else {}),
                        **(dict(bst_sums=_p(bst['sums']), bst_sums_ld=bst['sums'].shape[-1], bst_mean=_p(bst.get('mean')), bst_rstd=_p(bst.get('rstd')),
                                bst_act_form=bst.get('act_form', 0)) if bst else {}))
     nb = lib.satcv_conv2d_bwd_fused_workspace(C.byref(d))

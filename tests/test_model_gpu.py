@@ -287,6 +287,10 @@ def test_full_unet_training_step_matches_oracle(mt, dtype):
             pz = plan.dbg['dyparts:' + lay.name]
             gt, goff, gld = pz['g']
             gq = gt.double().reshape(-1, gld)[:, goff:goff + pz['cout']].reshape(n, 256 if False else cx['r'].h, cx['r'].w, pz['cout'])
+            if 'head' in pz:                # the block under the head: g was never stored, the launch formed it from the logit gradients
+                dl, wname = pz['head']
+                wh = rt.get_param(wname).reshape(pz['cout'], -1)
+                gq = (dl.reshape(-1, wh.shape[1]) @ wh.t()).to(td).double().reshape(gq.shape)
             yq = pz['y'].double().reshape(-1, pz['ldy'])[:, pz['yoff']:pz['yoff'] + pz['cout']].reshape(gq.shape)
             af = {k_: pz['aff'][k_].double()[pz['aoff']:pz['aoff'] + pz['cout']] for k_ in ('scale', 'shift', 'mean', 'rstd')}
             if 'dp' in pz:                  # encoder blocks: + MaxPooling2D's gradient routed to the first maximum of every 2 x 2 window
@@ -1312,6 +1316,35 @@ def test_training_is_bit_reproducible(mt):
     assert not diff, diff
     assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
     assert all(np.all(w0[k] == 0) for k in w0 if k.endswith('/bias') and not k.startswith('probs'))      # exact zero gradient: never moved
+
+
+def test_resident_float32_batches_are_read_in_place(mt):
+    """A float32 batch that already lives on the device is read in place by the ingest and loss kernels (no staging copy); a host array, or a
+    tensor of another dtype, goes through the staging tensors.  Either way the step is the same step: bit-identical weights."""
+    rng = np.random.default_rng(31)
+    xs = [rng.random((4, 64, 64, 4)).astype(np.float32) for _ in range(2)]
+    ys = [np.eye(2, dtype=np.float32)[(x[..., 1] + x[..., 2] > 1.0).astype(int)] for x in xs]
+    runs = []
+    for mode in ('host', 'device', 'device-f64'):
+        mt.reset_uids(); mt.set_seed(9)
+        m = mt.get_unet_model(2, 4, filters=[32, 64], factors=[2, 2])
+        m.compile(optimizer=mt.Adam(2e-3), loss=lambda t, p: mt.weighted_categorical_crossentropy(t, p, [1.0, 3.0]))
+        losses = []
+        for step in range(4):
+            x, y = xs[step % 2], ys[step % 2]
+            if mode == 'device':
+                x, y = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+            elif mode == 'device-f64':
+                x, y = torch.from_numpy(x).cuda().double(), torch.from_numpy(y).cuda().double()
+            losses.append(m.train_on_batch(x, y))
+            plan = m._head_plan(4, 64, 64, True)
+            assert bool(plan.x_src) == (mode == 'device') and (plan.y_src is not None) == (mode == 'device')
+        ev = m.evaluate(xs[0], ys[0], batch_size=4, verbose=0)
+        runs.append((losses, m.get_weights_dict(), ev))
+    for other in runs[1:]:
+        assert np.allclose(other[0], runs[0][0], rtol=1e-6, atol=0)           # (the scalar loss is summed with float atomics: last-bit noise)
+        assert not [k for k in runs[0][1] if not np.array_equal(runs[0][1][k], other[1][k])]
+        assert np.allclose(np.asarray(other[2], dtype=np.float64), np.asarray(runs[0][2], dtype=np.float64), rtol=1e-6, atol=0)
 
 
 def test_frozen_layers_run_batchnorm_in_inference_mode(mt):

@@ -682,6 +682,35 @@ def test_fused_thin_layer_backward(ops, case):
                               to_dev(xr[:, :6, :, :c0], td), wd, cin, cout, x1=to_dev(xr[:, :6, :, c0:], td) if c1 else None) is None
 
 
+@pytest.mark.parametrize('case', [(2, 16, 64, True), (3, 24, 32, False)])
+def test_fused_backward_forms_the_head_gradient_in_its_loader(ops, case):
+    """The block under the 1 x 1 head (utils/model_tools.py:405): with hg_dlogits / hg_w the fused launch forms g = bf16(dlogits w^T) itself
+    instead of reading the tensor satcv_head_bwd would have stored; same gradients as the launch fed with that tensor."""
+    n, h, w, affine = case
+    td = torch.bfloat16
+    cin = cout = 32
+    rng = np.random.default_rng(n * 100 + h)
+    x = to_dev(rnd(rng, (n, h, w, cin), td), td)
+    v = to_dev(rnd(rng, (n, h, w, cout), td) * 1.5 + 0.25, td)
+    kern = rnd(rng, (3, 3, cin, cout), td, 0.2)
+    _, wd = ops.pack_weights(f32dev(kern), cin, ops.DTYPE_CODE[td])
+    dl = f32dev(rng.standard_normal((n * h * w, 2)) * 0.1)
+    wh = f32dev(rng.standard_normal((cout, 2)))
+    g = (dl.double() @ wh.double().t()).float().to(td).reshape(n, h, w, cout).contiguous()      # what satcv_head_bwd stores (up to the last fp32 bit before rounding)
+    one = lambda c, s_=1.0: f32dev((rng.random(c) + 0.5) * s_)
+    sc, sh, mu, rs = one(cout), one(cout, 0.1), one(cout, 0.1), one(cout)
+    coef = f32dev(rng.standard_normal((2, cout)) * 0.1)
+    isc, ish = (one(cin), one(cin, 0.1)) if affine else (None, None)
+    ref = ops.conv_bwd_fused(g, v, sc, sh, mu, rs, coef, x, wd, cin, cout, in_scale=isc, in_shift=ish, in_relu=affine)
+    got = ops.conv_bwd_fused(None, v, sc, sh, mu, rs, coef, x, wd, cin, cout, in_scale=isc, in_shift=ish, in_relu=affine, head=(dl, wh))
+    assert ref is not None and got is not None
+    # (a product sum that lands within an fp32 ulp of a bf16 rounding boundary may round the other way: a handful of elements of g differ by
+    #  one bf16 ulp, nothing else does)
+    assert float((got[0].float() - ref[0].float()).abs().max()) <= 2e-2 * float(ref[0].float().abs().max())
+    assert float((got[0].float() - ref[0].float()).abs().mean()) <= 1e-4 * float(ref[0].float().abs().mean())
+    assert float((got[1] - ref[1]).abs().max()) <= 2e-3 * float(ref[1].abs().max())
+
+
 @pytest.mark.parametrize('case', [
     # n, h, w, stored cin, real cin, cout, data gradient
     (2, 16, 64, 32, 32, 64, True),          # encoder_block 2 of get_unet_model (32 -> 64 channels)
