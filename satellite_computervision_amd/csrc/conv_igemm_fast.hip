@@ -552,6 +552,14 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
         if (rc != SATCV_ERR_UNSUPPORTED) return rc;
       }
     }
+    // 64 output channels with deep K (64 + 64 -> 64 at 128 x 128): a 512-pixel x 64-channel tile, 8 waves of 64 x 64 -- the 9-tap weight slab
+    // (18 KB per 16-channel chunk) is fetched once per 512 pixels instead of once per 128 (SATCV_DB64=0: the 128 x 64 tile)
+    static const int db64 = [] { const char* e = getenv("SATCV_DB64"); return e ? atoi(e) : 1; }();
+    if (db_mode && db64 && a.dil == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && nspace % 64 == 0 && (nspace == 64 || db64 >= 2) && (cin >= 128 || db64 >= 3) &&
+        (long long)cdiv(a.n * a.h * a.w_, 512) * (nspace / 64) >= 192) {
+      const int rc = fast_cfg<T, TW, 8, 1, 2, 2, 1, TAPS, false, true>(a, st, dry);
+      if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+    }
     // (a 256-pixel x 64-channel form of the same loop for the 64-channel layers measured equal to the 128 x 64 tile: not kept)
   }
   // 32-channel chunks only for 1x1 taps (the 9-tap weight slab of a 32-channel chunk would not leave
