@@ -64,7 +64,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
   constexpr int KC = KS * 2 * SUB * EL;                          // channels per chunk (16 per K-step; 64 for scaled fp8)
   constexpr int SLOTS = KC / EL;
   // staged A items per thread: halo tile of a 3x3 / dilation-1 conv incl. the several-images-per-tile case
-  constexpr int XMAXPIX = TAPS == 1 ? BM : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);      // (single-tap forms stage no halo)
+  constexpr int XMAXPIX = (TAPS == 1 && DB) ? BM : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);      // (the double-buffered single-tap tile stages no halo; the older single-tap forms keep their budget: sized exactly, their 16-channel forms needed 24 bytes of scratch)
   constexpr int AI = (XMAXPIX * SLOTS + NTHREADS - 1) / NTHREADS;
   constexpr int BI = (TAPS * SLOTS * BN + NTHREADS - 1) / NTHREADS;  // staged B items per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -490,7 +490,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   if (a.pool_y && (TH % a.pool_f != 0 || TW % a.pool_f != 0 || a.rpi % a.pool_f != 0)) return SATCV_ERR_UNSUPPORTED;    // pooling windows inside one tile
   if (a.cout_pad < a.n_tiles * BN) return SATCV_ERR_UNSUPPORTED;
   {
-    constexpr int XMAXPIX = TAPS == 1 ? BM : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+    constexpr int XMAXPIX = (TAPS == 1 && DB) ? BM : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
     constexpr int AI = (XMAXPIX * (KC / EL) + NTHREADS - 1) / NTHREADS;
     if (a.rl * a.cl * (KC / EL) > AI * NTHREADS) return SATCV_ERR_UNSUPPORTED;     // register-staged items per thread
   }
