@@ -21,6 +21,7 @@
 struct ConvtArgs {
   const void* x; const float* in_scale; const float* in_shift; int in_relu;
   const void* w; const float* bias;
+  const float* out_scale; int out_relu;      // folded inference graph: y = relu(acc * out_scale + bias)
   void* y; int ldy;
   satcv_stat_t* stats; int stats_ld;
   int h, w_;                  // input map
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArg
   // wave-private output staging: 32 input pixels x 128 bytes (a pair of channel tiles), rows padded to 144 bytes so that the 16-byte
   // stores of 8 neighbouring pixels fall on distinct banks.  No barrier: only this wave touches its region, and a wave's LDS operations
   // execute in order.
-  constexpr int OPITCH = 144, TAB_FLOATS = (2 * CIN + COUT > 2 * NW * COUT ? 2 * CIN + COUT : 2 * NW * COUT);
+  constexpr int OPITCH = 144, TAB_FLOATS = (2 * CIN + 2 * COUT > 2 * NW * COUT ? 2 * CIN + 2 * COUT : 2 * NW * COUT);
   // (the loads stay fragment-shaped -- 32-byte pieces of 32 lines per instruction: whole-line loads redistributed through these rows
   //  measured the same, 89.4 vs 90.6 and 48.5 vs 48.1 us)
   unsigned char* ldsO = smem_raw + W_BYTES + (size_t)TAB_FLOATS * sizeof(float) + (size_t)(threadIdx.x >> 6) * (32 * OPITCH);
@@ -59,11 +60,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArg
       tab[ch] = a.in_scale ? a.in_scale[ch] : 1.f;
       tab[CIN + ch] = a.in_scale ? a.in_shift[ch] : 0.f;
     }
-    for (int ch = tid; ch < COUT; ch += NTHREADS) tab[2 * CIN + ch] = a.bias ? a.bias[ch] : 0.f;
+    for (int ch = tid; ch < COUT; ch += NTHREADS) { tab[2 * CIN + ch] = a.bias ? a.bias[ch] : 0.f; tab[2 * CIN + COUT + ch] = a.out_scale ? a.out_scale[ch] : 1.f; }
   }
   __syncthreads();
   const bool xaff = a.in_scale != nullptr;
   const unsigned relu_lim = a.in_relu != 0 ? 0u : 0x80008000u;
+  const unsigned orelu_lim = a.out_relu != 0 ? 0u : 0x80008000u;
   const bool want_stats = a.stats != nullptr;
 
   // ---- this wave's strips: XCD-aware contiguous ranges (blocks b and b + 8 share an XCD)
@@ -143,8 +145,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArg
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 b4 = *reinterpret_cast<const float4*>(tab + 2 * CIN + cb + 8 * g + 4 * hh);
-          o2[g].x = pk_bf16(accT[u][4 * g] + b4.x, accT[u][4 * g + 1] + b4.y);
-          o2[g].y = pk_bf16(accT[u][4 * g + 2] + b4.z, accT[u][4 * g + 3] + b4.w);
+          const float4 m4 = *reinterpret_cast<const float4*>(tab + 2 * CIN + COUT + cb + 8 * g + 4 * hh);      // (1 without out_scale: acc * 1 + b == acc + b)
+          o2[g].x = relu_pk_bf16(pk_bf16(fmaf(accT[u][4 * g], m4.x, b4.x), fmaf(accT[u][4 * g + 1], m4.y, b4.y)), orelu_lim);
+          o2[g].y = relu_pk_bf16(pk_bf16(fmaf(accT[u][4 * g + 2], m4.z, b4.z), fmaf(accT[u][4 * g + 3], m4.w, b4.w)), orelu_lim);
         }
 #pragma unroll
         for (int k = 0; k < 4; k += 2) {
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArg
 
 template <int CIN, int COUT, int NW, int WPS>
 static int convt_thin_cfg(const ConvtArgs& ca, hipStream_t st) {
-  constexpr size_t lds = (size_t)CIN * 4 * COUT * sizeof(bf16) + (size_t)(2 * CIN + COUT > 2 * NW * COUT ? 2 * CIN + COUT : 2 * NW * COUT) * sizeof(float) + (size_t)NW * 32 * 144;
+  constexpr size_t lds = (size_t)CIN * 4 * COUT * sizeof(bf16) + (size_t)(2 * CIN + 2 * COUT > 2 * NW * COUT ? 2 * CIN + 2 * COUT : 2 * NW * COUT) * sizeof(float) + (size_t)NW * 32 * 144;
   auto kern = convt_thin_kernel<CIN, COUT, NW, WPS>;
   { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
   static const int cus = [] {
@@ -470,7 +473,7 @@ int convt_thin_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
   static const bool on = [] { const char* e = getenv("SATCV_CONVT_THIN"); return !e || atoi(e) != 0; }();
   if (!on || dtype != SATCV_BF16) return SATCV_ERR_UNSUPPORTED;
   if (a.kh != 1 || a.kw != 1 || a.mode_out != 1 || a.mode_in != 0 || a.f != 2 || a.x1 || a.stride != 1) return SATCV_ERR_UNSUPPORTED;
-  if (a.out_scale || a.pool_y || a.accumulate || a.out_relu || a.bst_y) return SATCV_ERR_UNSUPPORTED;
+  if (a.pool_y || a.accumulate || a.bst_y || ((a.out_scale || a.out_relu) && a.stats)) return SATCV_ERR_UNSUPPORTED;      // (statistics are of the plain training output)
   const int cin = a.c0, cout_t = a.cstat;
   if (a.cout != 4 * cout_t || a.cout_pad != 4 * cout_t) return SATCV_ERR_UNSUPPORTED;
   if (a.w_ % 32 != 0 || a.ldy % 8 != 0 || a.ldy < cout_t || ((uintptr_t)a.y % 16) != 0 || ((uintptr_t)a.x0 % 16) != 0 || ((uintptr_t)a.w % 16) != 0) return SATCV_ERR_UNSUPPORTED;
@@ -479,7 +482,7 @@ int convt_thin_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
   if (a.stats && a.stats_ld < cout_t) return SATCV_ERR_UNSUPPORTED;
   ConvtArgs ca;
   ca.x = a.x0; ca.in_scale = a.in_scale; ca.in_shift = a.in_shift; ca.in_relu = a.in_relu;
-  ca.w = a.w; ca.bias = a.bias; ca.y = a.y; ca.ldy = a.ldy; ca.stats = a.stats; ca.stats_ld = a.stats_ld;
+  ca.w = a.w; ca.bias = a.bias; ca.out_scale = a.out_scale; ca.out_relu = a.out_relu; ca.y = a.y; ca.ldy = a.ldy; ca.stats = a.stats; ca.stats_ld = a.stats_ld;
   ca.h = a.h; ca.w_ = a.w_; ca.total_strips = (int)strips;
   static const int wps = [] { const char* e = getenv("SATCV_CONVT_WPS"); return e ? atoi(e) : 3; }();
   if (cin == 64 && cout_t == 32) {

@@ -126,7 +126,8 @@ def conv2d(x, w_packed, cout, *, kh=3, kw=3, dil=1, bias=None, x1=None, in_scale
     return y
 
 
-def conv2d_transpose(x, w_packed, cout, f, *, bias=None, in_scale=None, in_shift=None, in_relu=False, stats=None, out=None):
+def conv2d_transpose(x, w_packed, cout, f, *, bias=None, in_scale=None, in_shift=None, in_relu=False, stats=None, out=None,
+                     out_scale=None, out_relu=False):
     """layers.Conv2DTranspose(cout, f, strides=f, padding='same') (utils/model_tools.py:306)."""
     n, h, w_, c0 = x.shape
     dtype = DTYPE_CODE[x.dtype]
@@ -134,7 +135,7 @@ def conv2d_transpose(x, w_packed, cout, f, *, bias=None, in_scale=None, in_shift
     d = make_conv_desc(x0=_p(x), c0=c0, w=_p(w_packed), y=_p(y), ldy=y.shape[-1], n=n, h=h, w_=w_, cout=f * f * cout,
                        cout_pad=rup(f * f * cout, 32), dtype=dtype, in_scale=_p(in_scale), in_shift=_p(in_shift),
                        in_relu=in_relu, bias=_p(bias), stats=_p(stats), stats_ld=stats.shape[-1] if stats is not None else 0,
-                       kh=1, kw=1, dil=1, mode_out=1, f=f, cstat=cout)
+                       kh=1, kw=1, dil=1, mode_out=1, f=f, cstat=cout, out_scale=_p(out_scale), out_relu=out_relu)
     check(lib.satcv_conv2d_igemm(C.byref(d), stream_ptr()))
     return y
 

@@ -502,6 +502,11 @@ def test_conv2d_transpose_streaming_kernel_with_input_batchnorm(ops, case):
     # without statistics / bias / input transform
     y2 = ops.conv2d_transpose(to_dev(x, td), wf, cout, 2)
     close(back(y2, cout), K.conv2d_transpose_ks(x, kt, np.zeros(cout)), td, f'convT streaming fwd plain {case}')
+    # the folded inference form: per-channel multiplier on the accumulator, bias, ReLU in the epilogue
+    osc = (rng.standard_normal(cout) * 0.5).astype(np.float32)
+    y3 = ops.conv2d_transpose(to_dev(x, td), wf, cout, 2, bias=f32dev(b), out_scale=f32dev(osc), out_relu=True)
+    ref3 = np.maximum(K.conv2d_transpose_ks(x, kt, np.zeros(cout)) * osc.astype(np.float64) + b, 0)
+    close(back(y3, cout), ref3, td, f'convT streaming fwd, folded epilogue {case}')
 
 
 @pytest.mark.parametrize('case', [(2, 32, 32, 64, 32), (1, 16, 64, 128, 64), (3, 8, 96, 64, 32), (1, 64, 64, 64, 32), (2, 32, 64, 128, 64)])
