@@ -639,7 +639,8 @@ static int bwdf_dispatch(const satcv_bwdf_desc* d, hipStream_t st, bool query, i
     if (d->dx) return bwdf_launch<32, 64, 4, 1, true, false>(d, st, query, ws_bytes);
     return bwdf_launch<32, 32, 8, 2, true, true, 16>(d, st, query, ws_bytes);
   }
-  // (32 -> 32: 8 waves x 1 workgroup per CU measured equal to 4 waves x 2 workgroups and leaves registers for the fused sums)
+  // (32 -> 32: 8 waves x 1 workgroup per CU measured equal to 4 waves x 2 workgroups and leaves registers for the fused sums; with the
+  //  weight-gradient products balanced over the waves the 4-wave form -- 256 registers, 32 bytes of scratch -- measured 365 vs 346 us)
   if (cin_s == 32 && d->hg_dlogits) return bwdf_launch<32, 32, 8, 2, false, false, 32, true>(d, st, query, ws_bytes);
   if (d->hg_dlogits) return SATCV_ERR_UNSUPPORTED;
   if (cin_s == 32) return bwdf_launch<32, 32, 8, 2>(d, st, query, ws_bytes);
