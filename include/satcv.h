@@ -293,7 +293,7 @@ int satcv_add_act(const void* y, const float* y_scale, const float* y_shift, con
                   const float* res_scale, const float* res_shift, int32_t relu, void* out, int64_t npix,
                   int32_t c, int32_t dtype, void* stream);
 /* out = Q(relu?(scale[c]*x + shift[c])) channel-wise between two NHWC tensors with their own channel strides; dtype_out is
- * dtype or SATCV_FP8.  Uses in the folded fp8 inference path: the skip half of concat([skip, up]) -> BN -> ReLU with the
+ * dtype or SATCV_FP8 (or SATCV_BF16 from SATCV_FP8: where the hybrid fp8 graph hands a tensor to its bf16 levels).  Uses in the folded fp8 inference path: the skip half of concat([skip, up]) -> BN -> ReLU with the
  * requantisation q_skip/q_cat folded into scale/shift (utils/model_tools.py:307-309), and BN+ReLU+quantisation of the
  * first conv block, which is computed in bf16 because the e4m3 rounding of the INPUT bands costs the most accuracy. */
 int satcv_affine_requant(const void* x, int32_t ldx, const float* scale, const float* shift, int32_t relu, void* out, int32_t ldo,

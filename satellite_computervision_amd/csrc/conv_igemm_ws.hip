@@ -31,20 +31,21 @@ extern "C" int satcv_debug_read_stamps_ws(unsigned long long* out) { return hipM
 
 // WN = 2 (64 -> 64 channels): 8 waves, each pair of waves shares its 64 pixels and splits the 64 output channels -- the 74 KB weight
 // tensor and the 44 KB tile leave ONE workgroup per CU, and 8 waves keep the two waves per SIMD of the other forms
-template <int CIN, int NT, int WPS, int WN = 1>
+// T: bf16, or fp8 (e4m3 storage, 8-byte items, v_mfma_f32_32x32x16_fp8_fp8: the folded fp8 inference graph's thin layers -- same MFMA rate,
+// half the bytes of these HBM-bound layers)
+template <typename T, int CIN, int NT, int WPS, int WN = 1>
 __global__ __launch_bounds__(256 * WN, WPS) void igemm_ws_kernel(const IgemmArgs a, const int total_tiles) {
-  typedef bf16 T;
   constexpr int TW = 32, TH = 8, WM = 4, MT = 2, BM = 256, BN = WN * NT * 32, NTHREADS = 256 * WN, EL = 8;
   constexpr int SLOTS = CIN / EL, CL = TW + 2, PITCH = CL, RL = TH + 2;
   constexpr int PLANE = RL * PITCH * EL;                                   // elements of one slot plane
   // 8 consecutive lanes store 8 / SLOTS pixels x SLOTS slots with one ds_write_b128 (serviced in groups of 8 lanes over 32 banks):
   // the plane stride must be 128 / SLOTS bytes modulo 128 for the eight 16-byte stores to fall on distinct banks
-  constexpr int WANT = (SLOTS >= 8 ? 16 : 128 / SLOTS) / (int)sizeof(T);
-  constexpr int SPAD = ((WANT - PLANE % 64) % 64 + 64) % 64;
+  constexpr int WANT = (SLOTS >= 8 ? 16 : 128 / SLOTS) / (int)sizeof(T), BANKSPAN = 128 / (int)sizeof(T);      // (elements)
+  constexpr int SPAD = ((WANT - PLANE % BANKSPAN) % BANKSPAN + BANKSPAN) % BANKSPAN;
   constexpr int SLOT_STRIDE = PLANE + SPAD;
   constexpr int A_ITEMS = RL * CL * SLOTS, AI = (A_ITEMS + NTHREADS - 1) / NTHREADS;
   constexpr int W_ITEMS = 9 * SLOTS * BN;
-  constexpr int OPITCH = BN + 8;
+  constexpr int OPITCH = BN + 16 / (int)sizeof(T);
   constexpr size_t A_BYTES = (size_t)SLOTS * SLOT_STRIDE * sizeof(T);
   constexpr size_t O_BYTES = (size_t)BM * OPITCH * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
   constexpr size_t R0_BYTES = ((A_BYTES > O_BYTES ? A_BYTES : O_BYTES) + 127) / 128 * 128;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256 * WN, WPS) void igemm_ws_kernel(const IgemmArgs
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
       Raw8<T> v = ra[j];
-      if (aff) v = affine8_lim(v, sc, sh, relu_lim);
+      if (aff) { if constexpr (std::is_same<T, bf16>::value) v = affine8_lim(v, sc, sh, relu_lim); else v = affine8<T>(v, sc, sh, a.in_relu); }
       v = select8<T>((valid >> j) & 1u, v);
       if (a_l[j] >= 0) lstore8<T>(ldsA + a_l[j], v);
     }
@@ -226,16 +227,17 @@ __global__ __launch_bounds__(256 * WN, WPS) void igemm_ws_kernel(const IgemmArgs
 }
 
 // ------------------------------------------------------------------ host side
-template <int CIN, int NT, int WPS, int WN = 1>
+template <typename T, int CIN, int NT, int WPS, int WN = 1>
 static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   constexpr int TW = 32, TH = 8, BN = WN * NT * 32, SLOTS = CIN / 8, RL = TH + 2, PITCH = TW + 2;
+  constexpr int ES = (int)sizeof(T);
   constexpr int PLANE = RL * PITCH * 8;
-  constexpr int WANT = (SLOTS >= 8 ? 16 : 128 / SLOTS) / 2;
-  constexpr int SPAD = ((WANT - PLANE % 64) % 64 + 64) % 64;
-  constexpr size_t A_BYTES = (size_t)SLOTS * (PLANE + SPAD) * 2;
-  constexpr size_t O_BYTES = (size_t)256 * (BN + 8) * 2 + (size_t)5 * 2 * BN * 4;
+  constexpr int WANT = (SLOTS >= 8 ? 16 : 128 / SLOTS) / ES, BANKSPAN = 128 / ES;
+  constexpr int SPAD = ((WANT - PLANE % BANKSPAN) % BANKSPAN + BANKSPAN) % BANKSPAN;
+  constexpr size_t A_BYTES = (size_t)SLOTS * (PLANE + SPAD) * ES;
+  constexpr size_t O_BYTES = (size_t)256 * (BN + 16 / ES) * ES + (size_t)5 * 2 * BN * 4;
   constexpr size_t R0 = ((A_BYTES > O_BYTES ? A_BYTES : O_BYTES) + 127) / 128 * 128;
-  constexpr size_t LDS = R0 + (size_t)9 * SLOTS * BN * 16;
+  constexpr size_t LDS = R0 + (size_t)9 * SLOTS * BN * 8 * ES;
   static_assert(LDS <= 160 * 1024, "weights + tile exceed the LDS");
   // tiling fields the shared epilogue reads
   a.halh = a.halw = 1;
@@ -244,7 +246,7 @@ static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   const long long total = (long long)a.n * a.tiles_y * a.tiles_x;
   if (total <= 0 || total > 0x7fffffffLL) return SATCV_ERR_UNSUPPORTED;
   if (dry) return SATCV_OK;
-  auto kern = igemm_ws_kernel<CIN, NT, WPS, WN>;
+  auto kern = igemm_ws_kernel<T, CIN, NT, WPS, WN>;
   { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS); if (rc) return rc; }
   static int ncu = 0;
   if (!ncu) {
@@ -267,24 +269,31 @@ static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
 
 // returns SATCV_ERR_UNSUPPORTED when the shape is outside this kernel's limits (the caller falls back to conv_igemm_fast.hip)
 int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
-  if (!g_opt_igemm_thin || dtype != SATCV_BF16) return SATCV_ERR_UNSUPPORTED;
+  if (!g_opt_igemm_thin || (dtype != SATCV_BF16 && dtype != SATCV_FP8)) return SATCV_ERR_UNSUPPORTED;
   const int cin = a.c0 + a.c1;
   if (a.kh != 3 || a.kw != 3 || a.dil != 1 || a.stride != 1 || a.mode_in || a.mode_out || a.accumulate || a.bst_y) return SATCV_ERR_UNSUPPORTED;
   if (a.pool_y && (8 % a.pool_f != 0 || 32 % a.pool_f != 0)) return SATCV_ERR_UNSUPPORTED;      // pooling windows inside one 8 x 32 tile
   if (!(cin == 16 || cin == 32 || cin == 64) || !(a.cout == 32 || a.cout == 64) || a.cout_pad != a.cout || a.cstat != a.cout) return SATCV_ERR_UNSUPPORTED;
   if (a.x1 && (a.c0 % 8 != 0)) return SATCV_ERR_UNSUPPORTED;
-  if (a.h % 8 != 0 || a.w_ % 32 != 0 || a.ldy % 8 != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;      // whole 8 x 32 tiles: the kernel compiles the interior-tile epilogue only
+  const int epv = dtype == SATCV_FP8 ? 16 : 8;
+  if (a.h % 8 != 0 || a.w_ % 32 != 0 || a.ldy % epv != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;      // whole 8 x 32 tiles: the kernel compiles the interior-tile epilogue only
+  if (dtype == SATCV_FP8) {
+    // e4m3 storage (folded fp8 inference graph): the 32- and 64-channel inputs; no statistics (inference only)
+    if (a.stats || cin == 16 || (a.pool_y && a.pool_ld % 16 != 0)) return SATCV_ERR_UNSUPPORTED;
+    if (a.cout == 32) return cin == 32 ? ws_cfg<fp8, 32, 1, 3>(a, st, dry) : ws_cfg<fp8, 64, 1, 2>(a, st, dry);
+    return cin == 32 ? ws_cfg<fp8, 32, 2, 2>(a, st, dry) : ws_cfg<fp8, 64, 1, 1, 2>(a, st, dry);
+  }
   // (no tile-count threshold: the kernel choice must not depend on the batch size -- inference is bit-identical across batch splits,
   //  tests/test_model_gpu.py::test_full_size_batch_invariance_property, and the two kernels sum K in different orders)
   if (a.cout == 32) {
     // three workgroups per CU where the registers allow (<= 168): 16 -> 32 at 256 x 256 132 -> 116 us, 32 -> 32 equal or better
-    if (cin == 16) return ws_cfg<16, 1, 3>(a, st, dry);
-    if (cin == 32) return ws_cfg<32, 1, 3>(a, st, dry);
-    return ws_cfg<64, 1, 2>(a, st, dry);
+    if (cin == 16) return ws_cfg<bf16, 16, 1, 3>(a, st, dry);
+    if (cin == 32) return ws_cfg<bf16, 32, 1, 3>(a, st, dry);
+    return ws_cfg<bf16, 64, 1, 2>(a, st, dry);
   }
-  if (cin == 16) return ws_cfg<16, 2, 2>(a, st, dry);
-  if (cin == 32) return ws_cfg<32, 2, 2>(a, st, dry);
+  if (cin == 16) return ws_cfg<bf16, 16, 2, 2>(a, st, dry);
+  if (cin == 32) return ws_cfg<bf16, 32, 2, 2>(a, st, dry);
   // 64 -> 64: weights (74 KB) + tile leave one workgroup per CU, so it has 8 waves (128 x 128 at batch 64: 154 -> 120 us with the fused
   // input BatchNorm; at batch 8, two tiles per workgroup, 23.4 -> 24.7 us)
-  return ws_cfg<64, 1, 1, 2>(a, st, dry);
+  return ws_cfg<bf16, 64, 1, 1, 2>(a, st, dry);
 }

@@ -1105,8 +1105,12 @@ __global__ void affine_requant_kernel(const T* __restrict__ x, int ldx, const fl
 extern "C" int satcv_affine_requant(const void* x, int32_t ldx, const float* scale, const float* shift, int32_t relu, void* out, int32_t ldo,
                                     int64_t npix, int32_t c, int32_t dtype, int32_t dtype_out, void* stream) {
   SATCV_CHECK(x && scale && shift && out && npix > 0 && c > 0 && c % 8 == 0 && ldx >= c && ldo >= c, "affine_requant: bad args");
-  SATCV_CHECK(dtype_out == dtype || dtype_out == SATCV_FP8, "affine_requant: output dtype must equal the input dtype or be fp8");
-  if (dtype_out == dtype) {
+  SATCV_CHECK(dtype_out == dtype || dtype_out == SATCV_FP8 || (dtype == SATCV_FP8 && dtype_out == SATCV_BF16),
+              "affine_requant: output dtype must equal the input dtype, be fp8, or be bf16 from fp8");
+  if (dtype == SATCV_FP8 && dtype_out == SATCV_BF16) {       // de-quantisation where the hybrid inference graph leaves its fp8 levels
+    hipLaunchKernelGGL((affine_requant_kernel<fp8, bf16>), dim3(ew_grid(npix * (c / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const fp8*)x, ldx,
+                       scale, shift, relu, (bf16*)out, ldo, (long long)npix, c);
+  } else if (dtype_out == dtype) {
     DISPATCH_T8(dtype, hipLaunchKernelGGL((affine_requant_kernel<T, T>), dim3(ew_grid(npix * (c / 8))), dim3(EW_BLOCK), 0, (hipStream_t)stream, (const T*)x, ldx,
                                           scale, shift, relu, (T*)out, ldo, (long long)npix, c));
   } else {

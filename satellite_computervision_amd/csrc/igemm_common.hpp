@@ -104,8 +104,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
   // accumulation -- no validity masks, no per-element selects, no divisions in the store loop.  The general path below cost ~4,700
   // cycles per 256 x 32 tile (19 % of a thin-layer tile) of which most was mask and address bookkeeping.
   if (FAST && (!GENERAL || (a.imgs == 1 && !a.accumulate && !a.pool_y && !a.out_relu && n0 < a.n && y0 + BM / TW <= a.h && x0 + TW <= a.w_ &&
-      nbase + BN <= a.cout && (a.mode_out == 0 || a.cstat % 8 == 0))) && !SKIP_STORES && sizeof(T) == 2) {
-    constexpr int VPR = BN / 8;                   // 16-byte vectors per tile row
+      nbase + BN <= a.cout && (a.mode_out == 0 || a.cstat % 8 == 0))) && !SKIP_STORES && (sizeof(T) == 2 || (!GENERAL && sizeof(T) == 1))) {
+    constexpr int EPV = 16 / (int)sizeof(T);      // elements per 16-byte vector (8, or 16 for the fp8 form of the thin-layer kernel)
+    constexpr int VPR = BN / EPV;                 // 16-byte vectors per tile row
     static_assert(NTHREADS % VPR == 0, "column group of a thread must be loop-invariant");
     const int vq = tid % VPR;                     // this thread's 16-byte column group (fixed: NTHREADS is a multiple of VPR)
     // ---- fused BatchNorm-backward reduce (bst_*, satcv.h): this launch writes dL/d act of a conv -> BN -> ReLU layer; the sums that
@@ -226,19 +227,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     T* yp; size_t row_pitch, col_pitch;
     if (a.mode_out == 1) {
       // depth-to-space (transposed conv): the column group belongs to ONE sub-pixel position (iy, ix) of cstat channels
-      const int cn0 = nbase + vq * 8, ij = cn0 / a.cstat, cb = cn0 - ij * a.cstat;
+      const int cn0 = nbase + vq * EPV, ij = cn0 / a.cstat, cb = cn0 - ij * a.cstat;
       const int f = a.f, wo = a.w_ * f;
       yp = reinterpret_cast<T*>(a.y) + ((size_t)(n0 * a.h * f + y0 * f + ij / f) * wo + (size_t)x0 * f + ij % f) * a.ldy + cb;
       row_pitch = (size_t)f * wo * a.ldy; col_pitch = (size_t)f * a.ldy;
     } else {
-      yp = reinterpret_cast<T*>(a.y) + ((size_t)(n0 * a.h + y0) * a.w_ + x0) * a.ldy + nbase + vq * 8;
+      yp = reinterpret_cast<T*>(a.y) + ((size_t)(n0 * a.h + y0) * a.w_ + x0) * a.ldy + nbase + vq * EPV;
       row_pitch = (size_t)a.w_ * a.ldy; col_pitch = (size_t)a.ldy;
     }
 #pragma unroll
     for (int it = tid; it < BM * VPR; it += NTHREADS) {
       const int q = it / VPR;                     // (compile-time divisors)
       const int t = q / TW, cx = q % TW;
-      *reinterpret_cast<uint4*>(yp + (size_t)t * row_pitch + (size_t)cx * col_pitch) = *reinterpret_cast<const uint4*>(ldsO + q * OPITCH + vq * 8);
+      *reinterpret_cast<uint4*>(yp + (size_t)t * row_pitch + (size_t)cx * col_pitch) = *reinterpret_cast<const uint4*>(ldsO + q * OPITCH + vq * EPV);
     }
     if constexpr (!GENERAL) {
       // fused max-pool of the tile just stored (folded inference encoder blocks; the interior-tile-only instantiations take these
@@ -246,22 +247,22 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
       if (a.pool_y) {
         const int f = a.pool_f, pw = TW / f, ph = (BM / TW) / f;
         const int hp = a.h / f, wp = a.w_ / f;
-        T* pp = reinterpret_cast<T*>(a.pool_y) + nbase + vq * 8;
+        T* pp = reinterpret_cast<T*>(a.pool_y) + nbase + vq * EPV;
         for (int it = tid; it < ph * pw * VPR; it += NTHREADS) {
           const int pq = it / VPR;
           const int t0 = (pq / pw) * f, c0 = (pq % pw) * f;
-          float mx[8];
+          float mx[EPV];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
+          for (int e = 0; e < EPV; ++e) mx[e] = -INFINITY;
           for (int i = 0; i < f; ++i)
             for (int j = 0; j < f; ++j) {
-              const T* sp = ldsO + ((t0 + i) * TW + c0 + j) * OPITCH + vq * 8;
+              const T* sp = ldsO + ((t0 + i) * TW + c0 + j) * OPITCH + vq * EPV;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], (float)sp[e]);
+              for (int e = 0; e < EPV; ++e) mx[e] = fmaxf(mx[e], (float)sp[e]);
             }
-          T o[8];
+          T o[EPV];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (T)mx[e];
+          for (int e = 0; e < EPV; ++e) o[e] = (T)mx[e];
           *reinterpret_cast<uint4*>(pp + ((size_t)(n0 * hp + (y0 + t0) / f) * wp + (x0 + c0) / f) * a.pool_ld) = *reinterpret_cast<const uint4*>(o);
         }
       }

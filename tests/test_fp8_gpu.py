@@ -52,6 +52,44 @@ def test_fp8_conv_bit_exact(env, cin, cout, k, dil, scaled):
     assert torch.equal(got, ref.view(torch.uint8)), (got.view(torch.float8_e4m3fn).float() - ref.float()).abs().max()
 
 
+@pytest.mark.parametrize('cin,cout,c1,affine', [(32, 32, 0, False), (64, 32, 32, True), (32, 64, 0, True), (64, 64, 0, False), (64, 64, 32, True)])
+def test_fp8_thin_layer_kernel_bit_exact(env, cin, cout, c1, affine):
+    """The persistent weights-stationary kernel in e4m3 storage (conv_igemm_ws.hip, T = fp8: the thin layers of the folded fp8 graph): whole
+    8 x 32 tiles, optional second source and input affine + ReLU (the skip half of a decoder concatenation), folded epilogue.  Exactly
+    representable data: bit-exact against float64."""
+    ops, lib, check, FP8 = env['ops'], env['lib'], env['check'], env['FP8']
+    import ctypes
+    rng = np.random.default_rng(cin * 11 + cout + c1)
+    n, h, w = 3, 24, 64
+    c0 = cin - c1
+    x = torch.tensor(rng.integers(-3, 4, (n, h, w, cin)), dtype=torch.float32)
+    kern = torch.tensor(rng.integers(-2, 3, (3, 3, cin, cout)), dtype=torch.float32)
+    osc = torch.tensor(2.0 ** rng.integers(-7, -4, cout), dtype=torch.float32)
+    bias = torch.tensor(rng.integers(-4, 5, cout), dtype=torch.float32)
+    isc = torch.tensor(2.0 ** rng.integers(-1, 2, cin), dtype=torch.float32)
+    ish = torch.tensor(rng.integers(-2, 3, cin), dtype=torch.float32)
+    a = (x * isc + ish).clamp_min(0) if affine else x              # (small integers: exact in e4m3)
+    assert torch.equal(_to_f8(a).float(), a)
+    acc = torch.nn.functional.conv2d(a.permute(0, 3, 1, 2).double(), kern.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
+    ref = _to_f8((acc * osc.double() + bias.double()).clamp_min(0).clamp_max(448).float())
+    x0 = _to_f8(x[..., :c0].contiguous()).cuda()
+    x1 = _to_f8(x[..., c0:].contiguous()).cuda() if c1 else None
+    w8, _ = ops.pack_weights(kern.cuda(), cin, FP8, want_dgrad=False)
+    y = torch.zeros(n, h, w, cout, dtype=torch.uint8, device='cuda')
+    oscd, bd, iscd, ishd = osc.cuda(), bias.cuda(), isc.cuda(), ish.cuda()
+    before = ctypes.c_int32()
+    check(lib.satcv_get_option(b'igemm_thin_launches', ctypes.byref(before)))
+    d = ops.make_conv_desc(x0=x0.data_ptr(), c0=c0, x1=x1.data_ptr() if c1 else None, c1=c1, w=w8.data_ptr(), bias=bd.data_ptr(), out_scale=oscd.data_ptr(),
+                           y=y.data_ptr(), ldy=cout, n=n, h=h, w_=w, cout=cout, cout_pad=ops.rup(cout, 32), kh=3, kw=3, dil=1, dtype=FP8, out_relu=1,
+                           in_scale=iscd.data_ptr() if affine else None, in_shift=ishd.data_ptr() if affine else None, in_relu=1 if affine else 0)
+    check(lib.satcv_conv2d_igemm(C.byref(d), ops.stream_ptr()))
+    after = ctypes.c_int32()
+    check(lib.satcv_get_option(b'igemm_thin_launches', ctypes.byref(after)))
+    assert after.value - before.value == 1, 'served by the thin-layer kernel'
+    got = y.cpu()
+    assert torch.equal(got, ref.view(torch.uint8)), (got.view(torch.float8_e4m3fn).float() - ref.float()).abs().max()
+
+
 def test_fp8_transposed_conv_into_concat_slice_and_requant(env):
     ops, lib, check, FP8 = env['ops'], env['lib'], env['check'], env['FP8']
     rng = np.random.default_rng(3)
