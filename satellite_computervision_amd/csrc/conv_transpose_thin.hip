@@ -454,7 +454,7 @@ int convt_thin_dgrad_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
   if (((uintptr_t)a.y % 16) != 0 || ((uintptr_t)a.x0 % 16) != 0 || ((uintptr_t)a.w % 16) != 0) return SATCV_ERR_UNSUPPORTED;
   if (a.bst_y && (a.bst_ld % 8 != 0 || a.bst_ld < cin || ((uintptr_t)a.bst_y % 16) != 0 || a.stats_ld < cin || a.cstat != cin)) return SATCV_ERR_UNSUPPORTED;
   const long long strips = (long long)a.n * a.h * a.w_ / 32;
-  if (strips < 8 || strips > 0x3fffffff) return SATCV_ERR_UNSUPPORTED;
+  if (strips < 8 || strips > 0x3ffffff) return SATCV_ERR_UNSUPPORTED;      // (pixel indices of a strip stay in 31 bits)
   ConvtDgradArgs ca;
   ca.dy = a.x0; ca.lddy = a.c0; ca.w = a.w; ca.dx = a.y; ca.lddx = a.ldy; ca.stats = a.stats; ca.stats_ld = a.stats_ld;
   ca.bst_y = a.bst_y; ca.bst_ld = a.bst_ld; ca.bst_scale = a.bst_scale; ca.bst_shift = a.bst_shift; ca.bst_mean = a.bst_mean; ca.bst_rstd = a.bst_rstd;
@@ -478,7 +478,7 @@ int convt_thin_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
   if (a.cout != 4 * cout_t || a.cout_pad != 4 * cout_t) return SATCV_ERR_UNSUPPORTED;
   if (a.w_ % 32 != 0 || a.ldy % 8 != 0 || a.ldy < cout_t || ((uintptr_t)a.y % 16) != 0 || ((uintptr_t)a.x0 % 16) != 0 || ((uintptr_t)a.w % 16) != 0) return SATCV_ERR_UNSUPPORTED;
   const long long strips = (long long)a.n * a.h * a.w_ / 32;
-  if (strips < 8 || strips > 0x3fffffff) return SATCV_ERR_UNSUPPORTED;
+  if (strips < 8 || strips > 0x3ffffff) return SATCV_ERR_UNSUPPORTED;      // (pixel indices of a strip stay in 31 bits)
   if (a.stats && a.stats_ld < cout_t) return SATCV_ERR_UNSUPPORTED;
   ConvtArgs ca;
   ca.x = a.x0; ca.in_scale = a.in_scale; ca.in_shift = a.in_shift; ca.in_relu = a.in_relu;
