@@ -35,13 +35,16 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-template <int CIN, int COUT, int NW, int WPS>
+// NSPLIT > 1: the 4 COUT output columns are cut into NSPLIT blocks, one per workgroup of a group of NSPLIT (256 -> 4 x 128 channels: 256 KB of
+// weights, 64 KB per workgroup = one position; the input strip is read by the group's four workgroups, three times out of four from L2)
+template <int CIN, int COUT, int NW, int WPS, int NSPLIT = 1>
 __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArgs a) {
   typedef bf16 T;
-  constexpr int KS = CIN / 16, NCOL = 4 * COUT, NT = NCOL / 32, NTHREADS = NW * 64;
-  constexpr size_t W_BYTES = (size_t)CIN * NCOL * sizeof(T);
+  constexpr int KS = CIN / 16, NCOL = 4 * COUT, NTW = NCOL / 32 / NSPLIT, NT = NTW, NCOLW = NTW * 32, NTHREADS = NW * 64;
+  static_assert(NTW % 2 == 0 && (NTW * 32) % 64 == 0 && (NSPLIT == 1 || (NTW * 32) % COUT == 0 || COUT % (NTW * 32) == 0), "column blocks of whole 64-channel pairs");
+  constexpr size_t W_BYTES = (size_t)CIN * NCOLW * sizeof(T);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* ldsW = reinterpret_cast<T*>(smem_raw);                                   // [CIN / 8][NCOL][8]: the packed forward image as it is
+  T* ldsW = reinterpret_cast<T*>(smem_raw);                                   // [CIN / 8][NCOLW][8]: this workgroup's columns of the packed forward image
   float* tab = reinterpret_cast<float*>(smem_raw + W_BYTES);                  // scale[CIN], shift[CIN], bias[COUT]; later the statistics
   // wave-private output staging: 32 input pixels x 128 bytes (a pair of channel tiles), rows padded to 144 bytes so that the 16-byte
   // stores of 8 neighbouring pixels fall on distinct banks.  No barrier: only this wave touches its region, and a wave's LDS operations
@@ -55,7 +58,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArg
 
   {
     const T* wp = reinterpret_cast<const T*>(a.w);
-    for (int it = tid; it < (CIN / 8) * NCOL; it += NTHREADS) lstore8<T>(ldsW + (size_t)it * 8, gload8<T>(wp + (size_t)it * 8));
+    const int col0 = (int)((blockIdx.x >> 3) % NSPLIT) * NCOLW;
+    for (int it = tid; it < (CIN / 8) * NCOLW; it += NTHREADS) lstore8<T>(ldsW + (size_t)it * 8, gload8<T>(wp + ((size_t)(it / NCOLW) * NCOL + col0 + it % NCOLW) * 8));
     for (int ch = tid; ch < CIN; ch += NTHREADS) {
       tab[ch] = a.in_scale ? a.in_scale[ch] : 1.f;
       tab[CIN + ch] = a.in_scale ? a.in_shift[ch] : 0.f;
@@ -69,15 +73,19 @@ __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArg
   const bool want_stats = a.stats != nullptr;
 
   // ---- this wave's strips: XCD-aware contiguous ranges (blocks b and b + 8 share an XCD)
-  const int G = gridDim.x;
-  const int xcd = blockIdx.x & 7, nx = G >> 3, remx = G & 7;
-  const int bid = (xcd < remx ? xcd * (nx + 1) : remx * (nx + 1) + (xcd - remx) * nx) + (blockIdx.x >> 3);
+  // (NSPLIT > 1: the workgroups of a group are neighbours in the launch order -- they read the same strips at about the same time)
+  // (NSPLIT > 1: the launch has a multiple of 8 NSPLIT workgroups; a group's members are blocks b, b + 8, ... -- one XCD, one L2)
+  const int G = gridDim.x / NSPLIT;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, by = jx % NSPLIT, gj = jx / NSPLIT;
+  const int gnt0 = __builtin_amdgcn_readfirstlane(by * NTW);                  // first global channel tile of this workgroup
+  const int nx = G >> 3, remx = G & 7;
+  const int bid = (xcd < remx ? xcd * (nx + 1) : remx * (nx + 1) + (xcd - remx) * nx) + gj;
   const int gw = __builtin_amdgcn_readfirstlane(bid * NW + wave), GW = G * NW;
   const int per = a.total_strips / GW, extra = a.total_strips % GW;
   const int t_lo = gw * per + (gw < extra ? gw : extra), t_hi = t_lo + per + (gw < extra ? 1 : 0);
 
   const T* xlane = reinterpret_cast<const T*>(a.x) + (size_t)r * CIN + hh * 8;      // + strip * 32 * CIN + ks * 16
-  const T* wlane = ldsW + (size_t)(hh * NCOL + r) * 8;                               // + (ks * 2 * NCOL + nt * 32) * 8
+  const T* wlane = ldsW + (size_t)(hh * NCOLW + r) * 8;                              // + (ks * 2 * NCOLW + nt * 32) * 8
   const int wo = 2 * a.w_;
   float st1[NT], st2[NT];
 #pragma unroll
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArg
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wlane + (size_t)(ks * 2 * NCOL + (2 * np + u) * 32) * 8);
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wlane + (size_t)(ks * 2 * NCOLW + (2 * np + u) * 32) * 8);
           accT[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[ks], accT[u], 0, 0, 0);       // [channel][pixel]: stores
           if (want_stats) accD[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ks], wf, accD[u], 0, 0, 0);      // [pixel][channel]: statistics
         }
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArg
       // (32-byte pieces straight from the registers ran the L2 write path at a quarter of its width: 3.4 TB/s)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int cb = ((2 * np + u) * 32) % COUT;
+        const int cb = ((gnt0 + 2 * np + u) * 32) % COUT;
         uint2 o2[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -161,8 +169,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArg
       {
         // the pair's position: channel tiles 2 np, 2 np + 1 are the two horizontal positions (j = 0, 1) of one output row for COUT = 32,
         // the two channel halves of one position for COUT = 64
-        const int ij = (2 * np * 32) / COUT;
-        T* yrow = reinterpret_cast<T*>(a.y) + ((size_t)(2 * row + (ij >> 1)) * wo + 2 * x0 + (COUT == 32 ? 0 : (ij & 1))) * a.ldy;
+        const int ij = ((gnt0 + 2 * np) * 32) / COUT, cbp = ((gnt0 + 2 * np) * 32) % COUT;      // (cbp: 0 unless a position has more than 64 channels)
+        T* yrow = reinterpret_cast<T*>(a.y) + ((size_t)(2 * row + (ij >> 1)) * wo + 2 * x0 + (COUT == 32 ? 0 : (ij & 1))) * a.ldy + (COUT == 32 ? 0 : cbp);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int c = lane + 64 * m, q = c >> 3, piece = c & 7;              // 16-byte piece of input pixel q
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArg
       if (want_stats) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int cb = ((2 * np + u) * 32) % COUT;
+          const int cb = ((gnt0 + 2 * np + u) * 32) % COUT;
           const float bv = tab[2 * CIN + cb + r];
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -195,7 +203,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArg
 #pragma unroll
     for (int u = 0; u < COUT / 32; ++u) { c1[u] = 0.f; c2[u] = 0.f; }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { c1[nt % (COUT / 32)] += st1[nt]; c2[nt % (COUT / 32)] += st2[nt]; }
+    for (int nt = 0; nt < NT; ++nt) {
+      const int grp = (gnt0 + nt) % (COUT / 32);
+#pragma unroll
+      for (int u = 0; u < COUT / 32; ++u) { c1[u] += u == grp ? st1[nt] : 0.f; c2[u] += u == grp ? st2[nt] : 0.f; }
+    }
     __syncthreads();                                                          // (the tables are dead: every wave is past its last strip)
     float* red = tab;                                                         // [NW][2][COUT]
 #pragma unroll
@@ -215,10 +227,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void convt_thin_kernel(const ConvtArg
   }
 }
 
-template <int CIN, int COUT, int NW, int WPS>
+template <int CIN, int COUT, int NW, int WPS, int NSPLIT = 1>
 static int convt_thin_cfg(const ConvtArgs& ca, hipStream_t st) {
-  constexpr size_t lds = (size_t)CIN * 4 * COUT * sizeof(bf16) + (size_t)(2 * CIN + 2 * COUT > 2 * NW * COUT ? 2 * CIN + 2 * COUT : 2 * NW * COUT) * sizeof(float) + (size_t)NW * 32 * 144;
-  auto kern = convt_thin_kernel<CIN, COUT, NW, WPS>;
+  constexpr size_t lds = (size_t)CIN * 4 * COUT / NSPLIT * sizeof(bf16) + (size_t)(2 * CIN + 2 * COUT > 2 * NW * COUT ? 2 * CIN + 2 * COUT : 2 * NW * COUT) * sizeof(float) + (size_t)NW * 32 * 144;
+  auto kern = convt_thin_kernel<CIN, COUT, NW, WPS, NSPLIT>;
   { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
   static const int cus = [] {
     int dev = 0, v = 256;
@@ -230,8 +242,9 @@ static int convt_thin_cfg(const ConvtArgs& ca, hipStream_t st) {
   while (per_cu > 1 && (size_t)per_cu * lds > 150 * 1024) --per_cu;
   if (per_cu < 1) per_cu = 1;
   long long grid = (long long)cus * per_cu;
-  const long long need = (ca.total_strips + NW - 1) / NW;                      // a wave should see at least one strip
+  const long long need = (ca.total_strips + NW - 1) / NW * NSPLIT;             // a wave should see at least one strip
   if (grid > need) grid = need;
+  if (NSPLIT > 1) { grid -= grid % (8 * NSPLIT); if (grid < 8 * NSPLIT) grid = 8 * NSPLIT; }      // whole groups on every XCD
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, st, ca);
   hipError_t e = hipGetLastError();
@@ -490,5 +503,7 @@ int convt_thin_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     return convt_thin_cfg<64, 32, 4, 3>(ca, st);
   }
   if (cin == 128 && cout_t == 64) return convt_thin_cfg<128, 64, 8, 2>(ca, st);
+  static const bool mid = [] { const char* e = getenv("SATCV_CONVT_MID"); return !e || atoi(e) != 0; }();
+  if (cin == 256 && cout_t == 128 && mid) return convt_thin_cfg<256, 128, 8, 2, 4>(ca, st);      // one position (64 KB of weights) per workgroup
   return SATCV_ERR_UNSUPPORTED;
 }

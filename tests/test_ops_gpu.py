@@ -471,7 +471,7 @@ def test_conv2d_transpose(ops, td, case):
     close(back(dk), dk_ref, td, f'convT wgrad {case}', k=(5.0 if td == torch.float32 else 0.5))
 
 
-@pytest.mark.parametrize('case', [(2, 32, 32, 64, 32), (1, 16, 64, 128, 64), (3, 8, 96, 64, 32), (1, 64, 64, 64, 32)])
+@pytest.mark.parametrize('case', [(2, 32, 32, 64, 32), (1, 16, 64, 128, 64), (3, 8, 96, 64, 32), (1, 64, 64, 64, 32), (2, 32, 32, 256, 128), (1, 8, 32, 256, 128), (5, 16, 64, 256, 128)])
 def test_conv2d_transpose_streaming_kernel_with_input_batchnorm(ops, case):
     """The thin transposed convolutions (64 -> 32, 128 -> 64 channels, maps a multiple of 32 wide) run on the streaming kernel
     (conv_transpose_thin.hip): fused input BatchNorm + ReLU, bias, depth-to-space stores, statistics of the stored values, and the
