@@ -566,7 +566,8 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   // room for 2-3 workgroups per CU)
   if constexpr (KTraits<T>::SUB == 2) {
     // scaled fp8: a chunk is 64 channels, so the 9-tap weight slab of a 128-wide N tile (74 KB) would leave one workgroup per CU
-    // (a 256x64 tile was measured 10-30 % slower than 128x64 here)
+    // (a 256x64 tile was measured 10-30 % slower than 128x64 here; the double-buffered loop on a 256 x 64 tile of 8 waves needs ~300 bytes of
+    //  scratch at its 256-register cap: the K = 64 fragments are 8 registers each)
     if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 1, TAPS>(a, st, dry);
     return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS>(a, st, dry);
   }
