@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3_stream_kernel(const Conv3s
       const int x = x0 - 1 + it_px[j];
       const bool ok = it_src[j] != -1 && x >= 0 && x < a.w_;
       const T* p = it_second[j] ? xp1 + pix * a.c1 : xp0 + pix * a.c0;
-      dst[j] = gload8<T>(p + (ok ? it_src[j] : (it_second[j] ? 0 : 0)));       // (outside: the strip's first pixel, zeroed below)
+      dst[j] = gload8<T>(p + (ok ? it_src[j] : 0));       // (outside: the strip's first pixel, zeroed when the row is written)
     }
   };
   auto write_row = [&](const Raw8<T> (&src)[RJ], int yy, int x0) {
