@@ -138,6 +138,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 
   const T* wp = reinterpret_cast<const T*>(a.w);
   Raw8<T> ra[AI], rb[BI];
+  float* ldsT = reinterpret_cast<float*>(ldsA + (DB ? 2 : 1) * stage_elems);  // [2][cin] scale, shift (behind the stage(s))
+  if (a.in_scale) {
+    for (int i = tid; i < cin; i += NTHREADS) { ldsT[i] = a.in_scale[i]; ldsT[cin + i] = a.in_shift[i]; }      // (visible after the barrier that ends the prologue)
+  }
 
   auto tile_origin = [&](int v, int& n0, int& y0, int& x0) {
     int mt = v / a.n_tiles;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
   // spread them over the tap steps of the chunk being multiplied (one LDS store + one global load between two groups of MFMAs):
   // issued back to back, the 11 loads of a chunk kept every wave in its issue phase for 1,400-3,000 cycles per chunk while the
   // vector-memory pipe took them in, with the matrix pipe idle (s_memtime stamps: tools/stamp_probe.py)
-  struct ChunkSrc { const T* src; int cs, coff, sadd; size_t cadd; const float* scp; const float* shp; };
+  struct ChunkSrc { const T* src; int cs, coff, sadd, cg0s; size_t cadd; const float* scp; const float* shp; };
   auto chunk_src = [&](int chunk_) {
     ChunkSrc c;
     const int tap = TL ? chunk_ / a.cpt : 0;
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
     }
     c.cadd = ((size_t)chunk * SLOTS + (TL ? (size_t)tap * (cin / EL) : 0)) * a.cout_pad;
     // (a pointer select, not a branch: without an input transform the values are loaded from the weight image and never used)
+    c.cg0s = cg0 + slot_t * EL;
     c.scp = a.in_scale ? a.in_scale + cg0 + slot_t * EL : reinterpret_cast<const float*>(a.w);
     c.shp = a.in_scale ? a.in_shift + cg0 + slot_t * EL : reinterpret_cast<const float*>(a.w);
     return c;
@@ -196,10 +201,22 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
     if (!ABL(8)) rb[j] = gload8<T>(wp + ((size_t)b_g[j] + (ABL(128) ? 0 : c.cadd)) * EL);
     else rb[j] = zero8<T>();
   };
-  auto load_p = [&](const ChunkSrc& c) {
+  // from_lds (double-buffered loop, after its first barrier): the scale / shift vectors sit in an LDS table behind the two stages.  As
+  // global loads these 4 x 16 bytes per thread and chunk were 32 of the 88 one-KB wave-loads a chunk pushes through the CU's
+  // vector-memory path -- the path whose instruction rate, not whose bytes, bounds the loop -- and launches
+  // without an input transform (the data gradients) issued them too, as dummy loads of the weight image
+  auto load_p = [&](const ChunkSrc& c, bool from_lds = false) {
     if constexpr (KTraits<T>::EL == 8) {
-      rs[0] = reinterpret_cast<const float4*>(c.scp)[0]; rs[1] = reinterpret_cast<const float4*>(c.scp)[1];
-      rs[2] = reinterpret_cast<const float4*>(c.shp)[0]; rs[3] = reinterpret_cast<const float4*>(c.shp)[1];
+      if (from_lds) {
+        if (a.in_scale) {
+          const float4* tp = reinterpret_cast<const float4*>(ldsT + c.cg0s);
+          const float4* hp = reinterpret_cast<const float4*>(ldsT + cin + c.cg0s);
+          rs[0] = tp[0]; rs[1] = tp[1]; rs[2] = hp[0]; rs[3] = hp[1];
+        }
+      } else {
+        rs[0] = reinterpret_cast<const float4*>(c.scp)[0]; rs[1] = reinterpret_cast<const float4*>(c.scp)[1];
+        rs[2] = reinterpret_cast<const float4*>(c.shp)[0]; rs[3] = reinterpret_cast<const float4*>(c.shp)[1];
+      }
     }
   };
   auto store_a = [&](int chunk_, int boff, int j) {
@@ -272,7 +289,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
       for (int j = 0; j < AI; ++j) {
         if (a_l[j] >= 0) {
           Raw8<T> v = ra[j];
-          if (a.in_scale && a_p[j] >= 0) v = affine8<T>(v, a.in_scale + cg0, a.in_shift + cg0, a.in_relu);
+          if (a.in_scale && a_p[j] >= 0) {
+#ifdef SATCV_RS_GLOBAL
+            v = affine8<T>(v, a.in_scale + cg0, a.in_shift + cg0, a.in_relu);
+#else
+            // (from the LDS table once it is visible -- every chunk but the first, which is stored before the kernel's first barrier: as
+            //  global loads inside the store phase their latency sat between the two barriers of every chunk)
+            if (chunk_ > 0) v = affine8<T>(v, ldsT + cg0, ldsT + cin + cg0, a.in_relu);
+            else v = affine8<T>(v, a.in_scale + cg0, a.in_shift + cg0, a.in_relu);
+#endif
+          }
           if (ABL(64)) { keep8<T>(v); continue; }
           lstore8<T>(ldsA + boff + a_l[j], v);
         }
@@ -376,7 +402,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
           for (int u = 0; u < NUNITS; ++u) {
             if ((u < STEPS_ ? u : STEPS_ - 1) != st) continue;
             if (u < AI) { if (do_store) store_a(chunk + 1, oth, u); load_a(cs_, u); }
-            else if (u == AI) load_p(cs_);
+#ifdef SATCV_RS_GLOBAL                                  // (A/B build: the scale / shift values by global loads, as before)
+            else if (u == AI) load_p(cs_, false);
+#else
+            else if (u == AI) load_p(cs_, true);
+#endif
             else { if (do_store) store_b(oth, u - AI - 1); load_b(cs_, u - AI - 1); }
           }
         };
@@ -509,7 +539,8 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
       return SATCV_ERR_UNSUPPORTED;
     lds_out += (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T);
   }
-  const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
+  const size_t lds_tab = a.in_scale ? (size_t)2 * cin * sizeof(float) : 0;         // scale / shift table behind the stage(s)
+  const size_t lds = lds_stage + lds_tab > lds_out ? lds_stage + lds_tab : lds_out;
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
   if (dry) return SATCV_OK;
   const bool dyn = TAPS == 9 && a.dil != 1;
