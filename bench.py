@@ -55,7 +55,7 @@ def unet_layers(batch, tile=TILE, cin0=CH, filters=(32, 64, 128, 256, 512), ncls
     return L
 
 
-def alg_work(batch, esize=2):
+def alg_work(batch, esize=2, cin0=CH):
     """algorithmic FLOPs / unfused HBM bytes (input once, output once, weights once) of the launches of one training step,
     per class, and the per-layer roofline time sum(max(flops / MFMA peak, bytes / HBM peak))."""
     out = {'conv3_fwd_dgrad': [0.0, 0.0, 0.0, 0], 'all': [0.0, 0.0, 0.0, 0]}
@@ -66,7 +66,7 @@ def alg_work(batch, esize=2):
             if k in out:
                 out[k][0] += fl; out[k][1] += by; out[k][2] += t; out[k][3] += 1
     first = True
-    for kind, px, ci, co, taps in unet_layers(batch):
+    for kind, px, ci, co, taps in unet_layers(batch, cin0=cin0):
         fl = 2.0 * px * ci * co * taps
         by = px * (ci + co) * esize + taps * ci * co * esize
         key = 'conv3_fwd_dgrad' if kind == 'conv3' else 'other'
@@ -78,9 +78,10 @@ def alg_work(batch, esize=2):
     return {k: dict(flops=v[0], bytes=v[1], roof_s=v[2], launches=v[3]) for k, v in out.items()}
 
 
-def synth_batch(rng, n):
-    """Sentinel-2-like reflectance /10000 (gamma-ish) and ~5 % positive rectangular masks."""
-    x = rng.beta(2, 5, (n, TILE, TILE, CH)).astype(np.float32)
+def synth_batch(rng, n, ch=CH):
+    """Sentinel-2-like reflectance /10000 (gamma-ish; ch = 4 NAIP-like bands or all 13 Sentinel-2 bands, utils/ee_tools.py:100)
+    and ~5 % positive rectangular masks."""
+    x = rng.beta(2, 5, (n, TILE, TILE, ch)).astype(np.float32)
     lab = np.zeros((n, TILE, TILE), np.int64)
     for i in range(n):
         for _ in range(3):
@@ -135,7 +136,7 @@ def _cpu_model():
     return 'unknown'
 
 
-def _tf_cpu_baseline(seconds_budget):
+def _tf_cpu_baseline(seconds_budget, CH=CH):
     """when TensorFlow is importable, time the Keras graph of the reference's builder semantics on the
     host cores (GPUs hidden).  The graph is rebuilt here from tf.keras layers following utils/model_tools.py:174-415 as
     coded (one conv per block) -- none of the reference's files travel to the GPU box."""
@@ -160,28 +161,28 @@ def _tf_cpu_baseline(seconds_budget):
     rng = np.random.default_rng(0)
     res = {}
     for bs in (1, 16):
-        xb, _ = synth_batch(rng, bs)
+        xb, _ = synth_batch(rng, bs, CH)
         m.predict(xb, verbose=0)
         t0, n = time.perf_counter(), 0
         while time.perf_counter() - t0 < seconds_budget / 4 or n < 1:
             m.predict(xb, batch_size=bs, verbose=0); n += 1
         res[f'predict_b{bs}_tiles_per_s'] = round(bs * n / (time.perf_counter() - t0), 3)
-    xb, yb = synth_batch(rng, 1)
+    xb, yb = synth_batch(rng, 1, CH)
     m.train_on_batch(xb, yb)
     t0, n = time.perf_counter(), 0
     while time.perf_counter() - t0 < seconds_budget / 2 or n < 1:
         m.train_on_batch(xb, yb); n += 1
     return dict(value=round(n / (time.perf_counter() - t0), 3), unit='tiles/s', cores=os.cpu_count(), kind='reference',
-                sample=f'{n} tf.keras train_on_batch steps of batch 1 (256x256x4, fp32, TensorFlow {tf.__version__} CPU)', **res)
+                sample=f'{n} tf.keras train_on_batch steps of batch 1 (256x256x{CH}, fp32, TensorFlow {tf.__version__} CPU)', **res)
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=20.0, CH=CH):
     """The reference's CPU path timed on this host (rank 0, N = 1 only, bounded sample): TensorFlow's Keras graph when
     TensorFlow can be imported (kind "reference"), else the PyTorch-CPU (oneDNN) restatement of the identical graph
     (oracle/torch_unet.py, kind "port"): one training step of batch 1 plus inference at batch 1 and 16
     (utils/prediction_tools.py:152 predicts chip by chip at batch 1)."""
     try:
-        out = _tf_cpu_baseline(seconds_budget)
+        out = _tf_cpu_baseline(seconds_budget, CH)
         out['cpu_model'] = _cpu_model()
         return out
     except ImportError:
@@ -197,7 +198,7 @@ def cpu_baseline(seconds_budget=20.0):
     v = {k: torch.zeros_like(p[k]) for k in train}
     rng = np.random.default_rng(0)
     bs = 1
-    x, y = synth_batch(rng, bs)
+    x, y = synth_batch(rng, bs, CH)
     xt, yt = torch.from_numpy(x), torch.from_numpy(y)
     filters, factors = [32, 64, 128, 256, 512], [2, 2, 2, 2, 2]
 
@@ -218,7 +219,7 @@ def cpu_baseline(seconds_budget=20.0):
     res = {}
     with torch.no_grad():
         for b in (1, 16):
-            xb = torch.from_numpy(synth_batch(rng, b)[0])
+            xb = torch.from_numpy(synth_batch(rng, b, CH)[0])
             TU.unet_forward(p, xb, filters, factors, training=False)
             t1, n = time.perf_counter(), 0
             while (time.perf_counter() - t1 < seconds_budget * 0.2 and n < 50) or n < 1:
@@ -227,7 +228,7 @@ def cpu_baseline(seconds_budget=20.0):
             res[f'predict_b{b}_tiles_per_s'] = round(b * n / (time.perf_counter() - t1), 3)
     return dict(value=round(bs * nsteps / dt, 3), unit='tiles/s', cores=cores, kind='port', cpu_model=_cpu_model(),
                 threads=f'torch.set_num_threads({cores}); os.cpu_count()={os.cpu_count()}',
-                sample=f'{nsteps} training steps of batch {bs} (256x256x4, fp32, torch-CPU/oneDNN stand-in: TensorFlow absent), '
+                sample=f'{nsteps} training steps of batch {bs} (256x256x{CH}, fp32, torch-CPU/oneDNN stand-in: TensorFlow absent), '
                        f'predict at batch 1 and 16 beside it', **res)
 
 
@@ -238,6 +239,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--dtype', default='bfloat16')
+    ap.add_argument('--channels', type=int, default=CH, choices=(4, 13),
+                    help='input bands: 4 (BASELINE configs[1], the default line) or 13 = all Sentinel-2 bands (BASELINE configs[3])')
+    ap.add_argument('--repeats', type=int, default=5,
+                    help='the timed region of exactly --steps steps is run this many times (same work each); value = the MEDIAN region')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--infer', action='store_true', help='(default) also time bf16 / fp8 inference and the config-5 chip rate, reported under "extra"')
     ap.add_argument('--no-infer', action='store_true', help='skip the inference timings')
@@ -268,7 +273,8 @@ def main():
     mt.reset_uids()
     mt.set_seed(0)                                     # identical initial weights on every rank
     mt.set_compute_dtype(args.dtype)
-    model = mt.get_unet_model(NCLS, CH)
+    CHN = args.channels
+    model = mt.get_unet_model(NCLS, CHN)
     model.compile(optimizer=mt.Adam(9e-4), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 20.0]))
     sync = parallel.make_grad_sync(model) if dist is not None else None
 
@@ -276,7 +282,7 @@ def main():
     B = args.batch
     pool = []
     for _ in range(2):
-        x, y = synth_batch(rng, B)
+        x, y = synth_batch(rng, B, CHN)
         pool.append((torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()))
 
     def barrier():
@@ -290,19 +296,28 @@ def main():
         xb, yb = pool[i % len(pool)]
         model.train_step_device(xb, yb, sync)
     barrier()
+    # the timed region: EXACTLY --steps steps between barrier + synchronize pairs, max over ranks.  Boxes of the pool differ by several
+    # percent and a 0.17-s region is short, so the region is repeated (identical work) and the MEDIAN region is the reported one; the
+    # spread goes to extra.region_ms_per_step
     check(lib.satcv_prof_enable(0b1111))
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        xb, yb = pool[i % len(pool)]
-        plan = model.train_step_device(xb, yb, sync)
-    barrier()
-    dt = time.perf_counter() - t0
+    regions = []
+    for rep in range(max(args.repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            xb, yb = pool[i % len(pool)]
+            plan = model.train_step_device(xb, yb, sync)
+        barrier()
+        dtr = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dtr], device='cuda')
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dtr = float(tmax.item())
+        regions.append(dtr)
     check(lib.satcv_prof_enable(0))
     loss = float(plan.loss_buf.item())
-    if dist is not None:
-        tmax = torch.tensor([dt], device='cuda')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = float(np.median(regions))
+    nprof = args.steps * len(regions)               # steps the HIP-event sums cover
 
     prof = {}
     for kind, name in ((0, 'conv3x3_igemm_fwd_dgrad'), (1, 'conv1x1_convT_gemm'), (2, 'conv_wgrad'), (3, 'conv3x3_fused_dgrad_wgrad')):
@@ -310,7 +325,9 @@ def main():
         check(lib.satcv_prof_collect(kind, C.byref(ms), C.byref(cnt), C.byref(fl)))
         prof[name] = dict(ms=ms.value, launches=cnt.value, flops=fl.value)
 
-    extra = {'loss_last': loss, 'kernel_ms_per_step': {k: round(v['ms'] / args.steps, 3) for k, v in prof.items()},
+    extra = {'loss_last': loss, 'kernel_ms_per_step': {k: round(v['ms'] / nprof, 3) for k, v in prof.items()},
+             'region_ms_per_step': {'median': round(1000 * dt / args.steps, 3), 'min': round(1000 * min(regions) / args.steps, 3),
+                                    'max': round(1000 * max(regions) / args.steps, 3), 'repeats': len(regions)},
              'kernel_tflops': {k: round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 1) for k, v in prof.items()}}
     if dist is not None:
         extra['grad_exchange'] = {'via': 'satcv_allreduce_grads (C ABI, RCCL)' if parallel.cabi_comm() is not None else f'torch.distributed {dist.get_backend()}',
@@ -327,7 +344,7 @@ def main():
         extra['infer_tiles_per_s'] = round(world * B * 10 / (time.perf_counter() - t1), 1)
         # BASELINE configs[4]: sliding-window inference on 1024^2 scenes = 9 chips of 384^2 per scene (buff 128, kernel 256,
         # utils/prediction_tools.py:87-156), bf16 plan vs folded fp8 (e4m3) plan; output "kernel tiles" = 256^2 centres kept
-        chips = torch.from_numpy(np.random.default_rng(5).beta(2, 5, (36, 384, 384, CH)).astype(np.float32)).cuda()      # 4 scenes
+        chips = torch.from_numpy(np.random.default_rng(5).beta(2, 5, (36, 384, 384, CHN)).astype(np.float32)).cuda()      # 4 scenes
         for tag in ('bf16', 'fp8'):
             if tag == 'fp8':
                 model.enable_fp8_inference(chips[:8])
@@ -368,7 +385,7 @@ def main():
         value = tiles / dt
         d, d3 = prof['conv3x3_igemm_fwd_dgrad'], prof['conv3x3_fused_dgrad_wgrad']
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bfloat16' else 157.3
-        aw = alg_work(B, 2 if args.dtype == 'bfloat16' else 4)
+        aw = alg_work(B, 2 if args.dtype == 'bfloat16' else 4, CHN)
         a3 = aw['conv3_fwd_dgrad']
         # achieved = ALGORITHMIC FLOPs of the 3x3 implicit-GEMM launches of the timed steps (forward + data gradient; true Cin: 4 for the
         # first layer although 16 channels are stored) / their summed HIP-event durations on the launch stream.  The data gradients of the
@@ -381,21 +398,24 @@ def main():
                           + (w['px'] // 4 * w['cout'] * (w['esize'] + 1) if w.get('pooled') else 0) for w in fused)
         fused_dgrad_bytes = sum(w['px'] * (w['cin'] + w['cout']) * w['esize'] + 9 * w['cin'] * w['cout'] * w['esize'] for w in fused if not w.get('nodx'))
         n_fused_dgrad = sum(1 for w in fused if not w.get('nodx'))
-        ach = (a3['flops'] - fused_dgrad_flops) * args.steps / max(d['ms'], 1e-9) / 1e9
-        extra['fused_backward'] = {'launches_per_step': len(fused), 'ms_per_step': round(d3['ms'] / args.steps, 3),
+        ach = (a3['flops'] - fused_dgrad_flops) * nprof / max(d['ms'], 1e-9) / 1e9
+        # like-for-like with rounds 1-2 (every 3x3 forward + data-gradient FLOP of the step over the time of every launch that executes
+        # one of them, the fused thin-layer launches with their WHOLE duration: a lower bound)
+        ach_all = a3['flops'] * nprof / max(d['ms'] + d3['ms'], 1e-9) / 1e9
+        extra['fused_backward'] = {'launches_per_step': len(fused), 'ms_per_step': round(d3['ms'] / nprof, 3),
                                    'algorithmic_MB_per_step': round(fused_bytes / 1e6, 1), 'bound': 'hbm',
-                                   'achieved_TBps': round(fused_bytes * args.steps / max(d3['ms'], 1e-9) / 1e9, 3), 'peak_TBps': PEAK_HBM_TBPS,
-                                   'frac': round(fused_bytes * args.steps / max(d3['ms'], 1e-9) / 1e9 / PEAK_HBM_TBPS, 4),
+                                   'achieved_TBps': round(fused_bytes * nprof / max(d3['ms'], 1e-9) / 1e9, 3), 'peak_TBps': PEAK_HBM_TBPS,
+                                   'frac': round(fused_bytes * nprof / max(d3['ms'], 1e-9) / 1e9 / PEAK_HBM_TBPS, 4),
                                    'tflops': round(d3['flops'] / max(d3['ms'], 1e-9) / 1e9, 1),
                                    'data_gradient_gflop_per_step_inside': round(fused_dgrad_flops / 1e9, 1)}
-        launches_per_step = max(d['launches'] / args.steps, 1)
+        launches_per_step = max(d['launches'] / nprof, 1)
         traffic, traffic_src = pmc_traffic_per_launch()
         out = {
-            'metric': 'tiles/sec (train) 256x256x4 U-Net', 'value': round(value, 2), 'unit': 'tiles/s',
+            'metric': f'tiles/sec (train) 256x256x{CHN} U-Net', 'value': round(value, 2), 'unit': 'tiles/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16' if args.dtype == 'bfloat16' else 'f32', 'data': 'synthetic',
-            'config': {'workload': f'U-Net 256x256x4 {args.dtype} training, batch {B} per GPU (BASELINE configs[1])',
+            'config': {'workload': f'U-Net 256x256x{CHN} {args.dtype} training, batch {B} per GPU (BASELINE configs[{1 if CHN == 4 else 3}])',
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'loss': 'weighted_categorical_crossentropy',
                        'optimizer': 'adam(9e-4)'},
             'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
@@ -410,12 +430,13 @@ def main():
                          'step_roofline_ms': round(1000 * aw['all']['roof_s'], 3),
                          'step_frac': round(1000 * aw['all']['roof_s'] / (1000 * dt / args.steps), 4),
                          'stack_roofline_ms': round(1000 * a3['roof_s'], 3),
-                         'stack_roofline_frac': round(1000 * a3['roof_s'] / max((d['ms'] + d3['ms']) / args.steps, 1e-9), 4)},
-            'model_tflops': round(value * TRAIN_GFLOP_PER_TILE / 1000, 2),
+                         'stack_roofline_frac': round(1000 * a3['roof_s'] / max((d['ms'] + d3['ms']) / nprof, 1e-9), 4),
+                         'frac_like_for_like_r02': round(ach_all / peak, 4)},
+            'model_tflops': round(value * (TRAIN_GFLOP_PER_TILE + (2 * 2 * 9 * 32 * (CHN - CH) * TILE * TILE / 1e9 if CHN != CH else 0.0)) / 1000, 2),
             'extra': extra,
         }
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(CH=CHN)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier(**BARRIER_KW)

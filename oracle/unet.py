@@ -15,12 +15,29 @@ Follows /root/reference/utils/model_tools.py:
   DilatedSpatialPyramidPooling :533-574 (ASPP, image-pooling branch disabled)
 Adam follows the Keras formulation (epsilon outside the bias correction,
 SURVEY.md Appendix A).
+
+store_dtype='bfloat16' (tests only): the same float64 arithmetic, but every tensor the
+device path keeps in bf16 storage is rounded to bf16 (round-to-nearest-even) at the point
+where the device stores it: the input tile, the MFMA weight images,
+every raw conv / transposed-conv output (BatchNorm statistics are then those of the STORED
+values), every activated tensor a consumer stages, every gradient tensor (head dx, dy,
+dx, dskip, du).  Accumulations stay exact.  This separates "the kernels compute what the
+reference computes on the values they are given" (tight) from the accumulated storage
+rounding of a 30-BatchNorm chain (reported, loose).
 """
 import numpy as np
 from . import keras_ops as K
 
 BN_EPS = 1e-3
 BN_MOMENTUM = 0.99
+
+
+def round_bf16(x):
+    """round-to-nearest-even to bfloat16, returned in x's dtype (finite values)"""
+    x = np.asarray(x)
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return r.astype(x.dtype)
 
 
 def _glorot(rng, shape, fan_in, fan_out, dtype):
@@ -68,7 +85,9 @@ def unet_param_specs(nclasses, nchannels, filters, factors):
 class UNetOracle:
     def __init__(self, nclasses, nchannels, filters=(32, 64, 128, 256, 512),
                  factors=(2, 2, 2, 2, 2), bias=None, dtype=np.float64, seed=0,
-                 bessel=True):
+                 bessel=True, store_dtype=None):
+        assert store_dtype in (None, 'bfloat16')
+        self.q = round_bf16 if store_dtype == 'bfloat16' else (lambda v: v)
         self.nclasses, self.nchannels = nclasses, nchannels
         self.filters, self.factors = list(filters), list(factors)
         self.dtype, self.bessel = dtype, bessel
@@ -111,20 +130,24 @@ class UNetOracle:
         return y, (mean, var)
 
     def _cba_fwd(self, name, bnname, x, training, c, dilation=1, updates=1):
-        p = self.params
-        y = K.conv2d_same(x, p[f'{name}.kernel'], p[f'{name}.bias'], dilation)
+        p, q = self.params, self.q
+        y = q(K.conv2d_same(x, q(p[f'{name}.kernel']), p[f'{name}.bias'], dilation))
         z, st = self._bn_fwd(bnname, y, training, updates)
-        a = K.relu(z)
+        a_exact = K.relu(z)
+        a = q(a_exact)                    # what a consumer's loader stages (the 1x1 head reads the fp32 value: c[name + ':exact'])
         c[name] = (x, y, st, a, dilation)
+        c[name + ':exact'] = a_exact
         return a
 
     def _cba_bwd(self, name, bnname, da, c, g):
-        p = self.params
+        p, q = self.params, self.q
         x, y, (mean, var), a, dilation = c[name]
-        dz = K.relu_bwd(a, da)
+        dz = K.relu_bwd(c[name + ':exact'], da)
         dy, g[f'{bnname}.gamma'], g[f'{bnname}.beta'] = K.batchnorm_train_bwd(
             y, p[f'{bnname}.gamma'], mean, var, dz, BN_EPS)
-        dx, g[f'{name}.kernel'], g[f'{name}.bias'] = K.conv2d_same_bwd(x, p[f'{name}.kernel'], dy, dilation)
+        dy = q(dy)
+        dx, g[f'{name}.kernel'], g[f'{name}.bias'] = K.conv2d_same_bwd(x, q(p[f'{name}.kernel']), dy, dilation)
+        dx = q(dx)
         self.dbg[f'dy:{name}'], self.dbg[f'dx:{name}'] = dy, dx
         return dx
 
@@ -136,8 +159,8 @@ class UNetOracle:
         'pool0' SpatialDropout2D after the level-0 pool (:350-351), 'center' Dropout (:362-363),
         'dec0' SpatialDropout2D inside the last decoder block (:310-311, :375), 'final'
         SpatialDropout2D in front of the head (:401-402)."""
-        x = np.asarray(x, self.dtype)
-        p, c = self.params, {}
+        x = self.q(np.asarray(x, self.dtype))
+        p, c, q = self.params, {}, self.q
         masks = masks or {}
         c['masks'] = masks
         L = len(self.filters)
@@ -149,22 +172,25 @@ class UNetOracle:
             c[f'enc{i}'] = a
             h = K.maxpool(a, self.factors[i])
             if i == 0 and 'pool0' in masks:
-                h = h * masks['pool0']
+                h = q(h * masks['pool0'])
         h = self._cba_fwd('center.conv', 'center.bn', h, training, c, updates=2)
         if 'center' in masks:
-            h = h * masks['center']
+            h = q(h * masks['center'])
         for j in range(L - 1, -1, -1):
-            up = K.conv2d_transpose_ks(h, p[f'dec{j}.up.kernel'], p[f'dec{j}.up.bias'])
+            up = q(K.conv2d_transpose_ks(h, q(p[f'dec{j}.up.kernel']), p[f'dec{j}.up.bias']))
             cat = np.concatenate([c[f'enc{j}'], up], axis=-1)        # skip first (:307)
             z, st = self._bn_fwd(f'dec{j}.bn0', cat, training, 1)
-            a0 = K.relu(z)
-            c[f'dec{j}.up'] = (h, cat, st, a0)
+            a0_exact = K.relu(z)
+            a0 = q(a0_exact)
+            c[f'dec{j}.up'] = (h, cat, st, a0_exact)
             if j == 0 and 'dec0' in masks:
-                a0 = a0 * masks['dec0']
+                a0 = q(a0_exact * masks['dec0'])
             a1 = self._cba_fwd(f'dec{j}.conv1', f'dec{j}.bn1', a0, training, c)
             h = self._cba_fwd(f'dec{j}.conv2', f'dec{j}.bn2', a1, training, c)
         if 'final' in masks:
-            h = h * masks['final']
+            h = q(h * masks['final'])
+        else:
+            h = c['dec0.conv2:exact']         # the head applies the BatchNorm + ReLU in fp32 registers: nothing is rounded in between
         logits = K.conv2d_same(h, p['probs.kernel'], p['probs.bias'])
         probs = K.softmax(logits)
         c['head'] = (h, probs)
@@ -180,6 +206,8 @@ class UNetOracle:
         h, probs = c['head']
         dlogits = K.softmax_bwd(probs, np.asarray(dprobs, self.dtype))
         dh, g['probs.kernel'], g['probs.bias'] = K.conv2d_same_bwd(h, p['probs.kernel'], dlogits)
+        q = self.q
+        dh = q(dh)
         masks = c.get('masks', {})
         if 'final' in masks:
             dh = dh * masks['final']
@@ -193,11 +221,13 @@ class UNetOracle:
             dz = K.relu_bwd(a0, da0)
             dcat, g[f'dec{j}.bn0.gamma'], g[f'dec{j}.bn0.beta'] = K.batchnorm_train_bwd(
                 cat, p[f'dec{j}.bn0.gamma'], mean, var, dz, BN_EPS)
+            dcat = q(dcat)
             f = self.filters[j]
             dskip[j] = dcat[..., :f]
             self.dbg[f'dskip:dec{j}.bn0'], self.dbg[f'du:dec{j}.bn0'] = dcat[..., :f], dcat[..., f:]
             dh, g[f'dec{j}.up.kernel'], g[f'dec{j}.up.bias'] = K.conv2d_transpose_ks_bwd(
-                hin, p[f'dec{j}.up.kernel'], dcat[..., f:])
+                hin, q(p[f'dec{j}.up.kernel']), dcat[..., f:])
+            dh = q(dh)
             self.dbg[f'dx:dec{j}.up'] = dh
         if 'center' in masks:
             dh = dh * masks['center']

@@ -9,13 +9,14 @@ import hashlib
 import os
 import subprocess
 import sys
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libsatcv.so')
 OBJDIR = os.path.join(HERE, 'csrc', '_obj')
-SOURCES = ['api.hip', 'comm.hip', 'conv_igemm.hip', 'conv_igemm_fast.hip', 'conv_igemm_ws.hip', 'conv_transpose_thin.hip', 'conv3_stream.hip', 'conv_bwd_fused.hip', 'conv_wgrad.hip', 'elementwise.hip', 'input_pipeline.hip']
+SOURCES = ['api.hip', 'comm.hip', 'conv_igemm.hip', 'conv_igemm_fast.hip', 'conv_igemm_ws.hip', 'conv_transpose_thin.hip', 'conv_bwd_fused.hip', 'conv_wgrad.hip', 'elementwise.hip', 'input_pipeline.hip']
 EXTRA = []
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-Wno-unused-variable', '-Wno-pass-failed']
@@ -84,6 +85,7 @@ if __name__ == '__main__':
     ab = [a for a in sys.argv[1:] if a.startswith('-D')]
     if ab:      # profiling variant: python -m ...build -DSATCV_ABLATE=2 -> libsatcv_<tag>.so
         tag = ''.join(c for c in '_'.join(ab) if c.isalnum() or c == '_')
-        print(build(force=True, extra_flags=ab, out=os.path.join(HERE, f'libsatcv{tag}.so'), objdir=os.path.join(CSRC, '_obj' + tag)))
+        print(build(force=True, extra_flags=ab, out=os.path.join(HERE, f'libsatcv{tag}.so'), 
+                    objdir=os.path.join(tempfile.gettempdir(), 'satcv_obj' + tag)))      # (objects of a variant build stay OUT of the tree: everything in-tree ships to every GPU lease)
     else:
         print(build(force='--force' in sys.argv))

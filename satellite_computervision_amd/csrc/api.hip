@@ -135,12 +135,10 @@ int g_opt_igemm_db = env_int("SATCV_DB", 1);
 int g_opt_wgrad_db = env_int("SATCV_WGRAD_DB", 1);
 int g_opt_igemm_sched = env_int("SATCV_IGEMM_SCHED", 0);
 int g_opt_igemm_thin = env_int("SATCV_THIN", 1);      // 0 off, 1 / 2 on wherever the shape limits allow (independent of the batch size)
-int g_opt_conv3_stream = env_int("SATCV_CONV3_STREAM", 0);      // the streaming form of the thin 3x3 forward convs (conv3_stream.hip): off, see there
 static int* opt_slot(const char* key) {
   if (!key) return nullptr;
   if (!strcmp(key, "igemm_db")) return &g_opt_igemm_db;
   if (!strcmp(key, "igemm_thin")) return &g_opt_igemm_thin;
-  if (!strcmp(key, "conv3_stream")) return &g_opt_conv3_stream;
   if (!strcmp(key, "wgrad_db")) return &g_opt_wgrad_db;
   if (!strcmp(key, "igemm_sched")) return &g_opt_igemm_sched;
   return nullptr;
@@ -152,10 +150,8 @@ extern "C" int satcv_set_option(const char* key, int32_t value) {
   return SATCV_OK;
 }
 extern int g_ws_launches;          // conv_igemm_ws.hip
-extern int g_conv3s_launches;      // conv3_stream.hip
 extern "C" int satcv_get_option(const char* key, int32_t* value) {
   if (key && value && !strcmp(key, "igemm_thin_launches")) { *value = g_ws_launches; return SATCV_OK; }
-  if (key && value && !strcmp(key, "conv3_stream_launches")) { *value = g_conv3s_launches; return SATCV_OK; }
   int* p = opt_slot(key);
   SATCV_CHECK(p && value, "get_option: unknown key '%s'", key ? key : "(null)");
   *value = *p;

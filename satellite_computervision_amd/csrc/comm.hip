@@ -10,7 +10,20 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
-#include <rccl/rccl.h>          // types and enums only: the entry points below are resolved with dlsym
+// types and enums only: the entry points below are resolved with dlsym.  A ROCm install without the RCCL development headers still
+// builds the library: the handful of ABI-stable declarations this file needs are restated (values as in nccl.h 2.x / rccl.h).
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7,
+               ncclFloat64 = 8, ncclBfloat16 = 9 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+}
+#endif
 
 namespace {
 struct Rccl {

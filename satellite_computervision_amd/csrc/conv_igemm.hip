@@ -370,7 +370,6 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   if (!igemm_force_generic()) {
     rc = convt_thin_launch(a, d->dtype, st);                 // thin transposed convolutions: streaming kernel
     if (rc == SATCV_ERR_UNSUPPORTED) rc = convt_thin_dgrad_launch(a, d->dtype, st);      // ... and their data gradients
-    if (rc == SATCV_ERR_UNSUPPORTED) rc = conv3_stream_launch(a, d->dtype, st);              // thin 3x3 layers, training-style forward: streaming kernel
     if (rc == SATCV_ERR_UNSUPPORTED) rc = igemm_ws_launch(a, d->dtype, st, false);            // thin 3x3 layers: persistent weights-stationary kernel
     if (rc == SATCV_ERR_UNSUPPORTED) rc = igemm_fast_launch(a, d->dtype, st);
   }

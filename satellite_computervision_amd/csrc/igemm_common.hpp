@@ -434,5 +434,3 @@ int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run);
 // streaming kernel of the thin transposed convolutions (conv_transpose_thin.hip); SATCV_ERR_UNSUPPORTED outside its limits
 int convt_thin_launch(const IgemmArgs& a, int dtype, hipStream_t st);
 int convt_thin_dgrad_launch(const IgemmArgs& a, int dtype, hipStream_t st);
-// streaming kernel of the thin 3x3 forward convolutions (conv3_stream.hip)
-int conv3_stream_launch(const IgemmArgs& a, int dtype, hipStream_t st);

@@ -991,7 +991,8 @@ class Plan:
                 # the data gradient AND the weight gradient (csrc/conv_bwd_fused.hip): 4 tensor passes instead of 7, no dy tensor
                 fz = None
                 if (getattr(rt.model, 'fuse_thin_bwd', True) and dt == ops.BF16 and da is not None and dp is None and not graws and not BIAS_NOISE
-                        and tin.node.op != 'input' and gact.get(tin.id) is None and cx['k'] == 3 and cx['dil'] == 1 and da[2] == ldy):
+                        and tin.node.op != 'input' and gact.get(tin.id) is None and cx['k'] == 3 and cx['dil'] == 1 and da[2] == ldy
+                        and lay.name not in shared_layers):      # (a shared layer's other visit may have its weight gradient in flight on the side stream)
                     pk = rt.packed[lay.name]
                     cinp = r.c
                     sa = self._src_args(r)

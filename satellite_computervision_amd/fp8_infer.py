@@ -55,7 +55,11 @@ def calibrate(model, x):
     for node in model.nodes:
         cx = plan.node_ctx.get(id(node))
         if node.op == 'input':
-            put(node.outputs[0].id, float(plan.x_by_tid[node.outputs[0].id].abs().amax()))
+            # (a resident float32 batch is read in place by the ingest kernel -- Model._stage_x sets plan.x_src and holds the tensor --
+            #  so the staging tensor then holds zeros or an older batch: take the maximum of the tensor that was actually ingested)
+            tid = node.outputs[0].id
+            held = getattr(plan, '_x_hold', {}).get(tid) if plan.x_src.get(tid) else None
+            put(tid, float((held if held is not None else plan.x_by_tid[tid]).abs().amax()))
         elif node.op == 'cba':
             y, aff, c = cx['y'], cx['aff'], cx['cout']
             if cx['yoff'] != 0 or cx['ldy'] != c:

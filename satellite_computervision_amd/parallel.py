@@ -39,35 +39,56 @@ def init_from_env(backend=None):
 FORCE = os.environ.get('SATCV_FORCE_COLLECTIVES', '0') == '1'
 
 
-# ---- the C-ABI communicator (include/satcv.h: satcv_comm_*): with the RCCL backend the gradient exchange and the SyncBN means go
+# ---- the C-ABI communicator (include/satcv.h: satcv_comm_*): with the RCCL backend the gradient exchange and the SyncBN means CAN go
 # through libsatcv's own ncclAllReduce wrapper -- what a caller binding the C ABI from the reference side would use -- on a
 # communicator bootstrapped over the default process group.  torch.distributed stays the rendezvous (and the whole path for gloo,
-# i.e. the CPU tests).  SATCV_CABI_COMM=0 keeps everything on torch.distributed.
-CABI_COMM = os.environ.get('SATCV_CABI_COMM', '1') != '0'
+# i.e. the CPU tests).  OPT-IN (SATCV_CABI_COMM=1) until a world >= 2 run on real hardware has been recorded: the path has only ever
+# executed on a one-rank communicator (tests/test_dp_gpu.py), the default exchange is torch.distributed's ProcessGroupNCCL.
+CABI_COMM = os.environ.get('SATCV_CABI_COMM', '0') == '1'
 _comm = {'handle': None, 'tried': False, 'calls': 0}
 
 
+def _all_ok(flag):
+    """collective AND of a per-rank success flag over the default group (every rank gets the same answer)"""
+    if dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def cabi_comm():
-    """opaque satcv_comm* (an int) for the default group on RCCL, created collectively on first use; None otherwise."""
+    """opaque satcv_comm* (an int) for the default group on RCCL, created collectively on first use; None otherwise.
+
+    Every step is agreed on by ALL ranks before the next one starts, so that no rank enters ncclCommInitRank while a peer has
+    already given up (it would block there forever): (1) every rank proves it can bind RCCL through the library (a throw-away
+    unique id), all-reduce(MIN) of the flags; (2) rank 0's id is broadcast; (3) satcv_comm_init, all-reduce(MIN) of the results --
+    if any rank failed, the ranks that succeeded destroy their communicator and EVERY rank stays on torch.distributed."""
     if _comm['tried'] or not (CABI_COMM and dist.is_initialized() and dist.get_backend() == 'nccl' and torch.cuda.is_available()):
         return _comm['handle']
     import ctypes as C
+    import warnings
     from ._lib import lib
     _comm['tried'] = True
     rank, world = dist.get_rank(), dist.get_world_size()
     ident = (C.c_ubyte * 128)()
-    ok = 1
-    if rank == 0:
-        ok = 1 if lib.satcv_comm_unique_id(ident) == 0 else 0
-    box = [bytes(ident) if ok else None]
+    can_bind = lib.satcv_comm_unique_id(ident) == 0          # (binds RCCL in this process; only rank 0's id is used)
+    if not _all_ok(can_bind):
+        warnings.warn('satcv C-ABI communicator: RCCL could not be bound on every rank (' + lib.satcv_last_error().decode() +
+                      '); the exchange stays on torch.distributed')
+        return None
+    box = [bytes(ident)]
     if world > 1:
         dist.broadcast_object_list(box, src=0)
-    if box[0] is None:            # RCCL could not be bound by the library on rank 0: every rank stays on torch.distributed
-        return None
     buf = (C.c_ubyte * 128).from_buffer_copy(box[0])
     h = C.c_void_p()
-    if lib.satcv_comm_init(C.byref(h), rank, world, buf) != 0:
-        raise RuntimeError('satcv_comm_init: ' + lib.satcv_last_error().decode())
+    ok = lib.satcv_comm_init(C.byref(h), rank, world, buf) == 0
+    err = '' if ok else lib.satcv_last_error().decode()
+    if not _all_ok(ok):
+        if ok:
+            lib.satcv_comm_destroy(h.value)
+        warnings.warn(f'satcv C-ABI communicator: satcv_comm_init failed on a rank ({err or "a peer"}); the exchange stays on torch.distributed')
+        return None
     _comm['handle'] = h.value
     return _comm['handle']
 
@@ -125,6 +146,7 @@ class GradSync:
         # wire format of the gradient: fp32 (74.1 MB for get_unet_model(2, 4)) or bf16 (37 MB: rounded, summed in bf16, widened
         # back; C-ABI communicator only).  SATCV_GRAD_PAYLOAD=bf16 selects it for every GradSync of the process.
         self.payload = payload or os.environ.get('SATCV_GRAD_PAYLOAD', 'fp32')
+        self._warned_payload = False
         self._scratch = None
         self._side_ev = None
         self.bounds = []
@@ -178,7 +200,13 @@ class GradSync:
                 self._next -= 1
 
     def _comm(self, flat):
-        return cabi_comm() if (self.group is None and flat.is_cuda and flat.dtype == torch.float32) else None
+        comm = cabi_comm() if (self.group is None and flat.is_cuda and flat.dtype == torch.float32) else None
+        if comm is None and self.payload == 'bf16' and not self._warned_payload:
+            import warnings
+            self._warned_payload = True          # (only satcv_allreduce_grads implements the 37 MB wire format)
+            warnings.warn("GradSync(payload='bf16') needs the C-ABI communicator (SATCV_CABI_COMM=1, RCCL backend, default group): "
+                          'the exchange runs over torch.distributed in fp32')
+        return comm
 
     def _exchange_stream(self, device):
         if getattr(self, '_xs', None) is None:

@@ -20,9 +20,9 @@ def mt():
     return model_tools
 
 
-def build_pair(mt, dtype, nclasses, nchannels, filters, factors, seed=3, perturb=True):
+def build_pair(mt, dtype, nclasses, nchannels, filters, factors, seed=3, perturb=True, store_dtype=None):
     """same weights in the oracle (float64) and in the device model."""
-    o = UNetOracle(nclasses, nchannels, filters, factors, dtype=np.float64, seed=seed)
+    o = UNetOracle(nclasses, nchannels, filters, factors, dtype=np.float64, seed=seed, store_dtype=store_dtype)
     rng = np.random.default_rng(seed + 1)
     if perturb:
         for n, _, kind in o.specs:
@@ -206,33 +206,19 @@ def test_trained_model_bf16_iou_within_1e3(mt):
     assert abs(iou(c_bf, labt) - iou_ref) < 1e-3, (iou(c_bf, labt), iou_ref)
 
 
-@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
-def test_full_unet_training_step_matches_oracle(mt, dtype):
-    """One training step of the BENCHMARKED network -- get_unet_model(2, 4) with its default filters [32 .. 512] + 1024-channel
-    centre (utils/model_tools.py:394-415), 256x256x4 tiles -- against the float64 oracle: loss and EVERY gradient, so the deep
-    (256..1024-channel) data- and weight-gradient instantiations that bench.py times are under parity, not only the thin ones.
-    Criteria: fp32 relative L2 < 1e-2 per tensor (bulk exact; isolated ReLU-mask flips); bf16 cosine > 0.98
-    on the kernels that carry 99.9 % of the gradient norm and > 0.9 everywhere."""
-    f32 = dtype == 'float32'
-    o, m, names = build_pair(mt, dtype, 2, 4, [32, 64, 128, 256, 512], [2, 2, 2, 2, 2], seed=17, perturb=False)
-    rng = np.random.default_rng(4)
-    n = 2
-    x = rng.beta(2, 5, (n, 256, 256, 4)).astype(np.float32)
+def _synthetic_step_batch(n, ch, seed=4):
+    rng = np.random.default_rng(seed)
+    x = rng.beta(2, 5, (n, 256, 256, ch)).astype(np.float32)
     lab = np.zeros((n, 256, 256), np.int64)
     for i in range(n):
         for _ in range(6):
             hh, ww = rng.integers(16, 96, 2)
             y0, x0 = rng.integers(0, 256 - hh), rng.integers(0, 256 - ww)
             lab[i, y0:y0 + hh, x0:x0 + ww] = 1
-    t = np.eye(2, dtype=np.float32)[lab]
-    m.compile(optimizer=mt.Adam(0.0), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 20.0]))
-    pr, _ = o.forward(x, training=True)
-    loss_ref, dprobs, _ = OL.weighted_categorical_crossentropy(t.astype(np.float64), pr, [1.0, 20.0])
-    g_ref = o.backward(dprobs)
-    loss = m.train_on_batch(x, t)
-    np.testing.assert_allclose(loss, loss_ref, rtol=2e-5 if f32 else 2e-2)
-    rt = m.runtime
-    torch.cuda.synchronize()
+    return x, np.eye(2, dtype=np.float32)[lab]
+
+
+def _grad_report(o, rt, names, g_ref):
     tot = np.sqrt(sum(np.linalg.norm(g_ref[k]) ** 2 for k in o.trainable if not (k.endswith('.bias') and not k.startswith('probs'))))
     report = []
     for k in o.trainable:
@@ -247,18 +233,50 @@ def test_full_unet_training_step_matches_oracle(mt, dtype):
     if os.environ.get('SATCV_TEST_VERBOSE'):
         for k, l2, cos, share in report:
             print(f'   {k:28s} relL2 {l2:.3e} cos {cos:.5f} share {share:.4f}')
+    return report
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_full_unet_training_step_matches_oracle(mt, dtype):
+    """One training step of the BENCHMARKED network -- get_unet_model(2, 4) with its default filters [32 .. 512] + 1024-channel
+    centre (utils/model_tools.py:394-415), 256x256x4 tiles -- against the float64 oracle: loss and EVERY gradient, so the deep
+    (256..1024-channel) data- and weight-gradient instantiations that bench.py times are under parity, not only the thin ones.
+    Criteria: fp32 relative L2 < 1e-2 per tensor (bulk exact; isolated ReLU-mask flips).  bf16: against the float64
+    oracle that rounds every STORED tensor to bf16 where the device stores it (oracle/unet.py store_dtype: same values in, exact sums)
+    every gradient tensor must agree to cosine >= 0.99; the drift against the unrounded float64 chain (accumulated storage rounding
+    through 30 BatchNorm backward passes at batch 2) is reported, not asserted."""
+    f32 = dtype == 'float32'
+    o, m, names = build_pair(mt, dtype, 2, 4, [32, 64, 128, 256, 512], [2, 2, 2, 2, 2], seed=17, perturb=False,
+                             store_dtype=None if f32 else 'bfloat16')
+    n = 2
+    x, t = _synthetic_step_batch(n, 4)
+    m.compile(optimizer=mt.Adam(0.0), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 20.0]))
+    pr, _ = o.forward(x, training=True)
+    loss_ref, dprobs, _ = OL.weighted_categorical_crossentropy(t.astype(np.float64), pr, [1.0, 20.0])
+    g_ref = o.backward(dprobs)
+    loss = m.train_on_batch(x, t)
+    np.testing.assert_allclose(loss, loss_ref, rtol=2e-5 if f32 else 2e-3)
+    rt = m.runtime
+    torch.cuda.synchronize()
+    report = _grad_report(o, rt, names, g_ref)
     for k, l2, cos, share in report:
         if f32:
             assert l2 < 1e-2, f'grad {k}: relL2 {l2:.3e} cos {cos:.6f}'
         else:
-            # bf16 storage of every gradient tensor: on a random-initialised net (batch 2, so only 128 pixels feed the deepest
-            # BatchNorm) the agreement with the float64 chain decays smoothly from the head (cos 1.0000) through dec0 (0.99) to
-            # the deepest / encoder layers (~0.78): accumulated storage rounding, amplified by every BatchNorm's mean removal
-            # (DESIGN section 4).  A wrong kernel would show as a break at ITS layer: the layer-local check below is the
-            # kernel criterion, this one bounds the end-to-end drift.
-            assert cos > 0.6, f'grad {k}: cos {cos:.4f} relL2 {l2:.3e}'
-            if k.startswith(('probs', 'dec0.bn2', 'dec0.conv2', 'dec0.bn1', 'dec0.conv1')):
-                assert cos > 0.98, f'grad {k}: cos {cos:.4f}'
+            # same stored values on both sides: what is left is the summation order (fp32 MFMA chains vs float64), isolated ReLU-mask
+            # flips and one-ulp rounding flips of stored elements
+            assert cos >= 0.99, f'grad {k}: cos {cos:.4f} relL2 {l2:.3e} vs the bf16-storage oracle'
+    if not f32:
+        # reported drift against the UNROUNDED float64 chain (DESIGN section 4)
+        o2 = UNetOracle(2, 4, [32, 64, 128, 256, 512], [2, 2, 2, 2, 2], dtype=np.float64, seed=17)
+        o2.params = {k: v.copy() for k, v in o.params.items()}
+        pr2, _ = o2.forward(x, training=True)
+        _, dp2, _ = OL.weighted_categorical_crossentropy(t.astype(np.float64), pr2, [1.0, 20.0])
+        rep2 = _grad_report(o2, rt, names, o2.backward(dp2))
+        wk, _, wcos, _ = min(rep2, key=lambda r_: r_[2])
+        print(f'bf16 step vs the unrounded float64 chain: lowest cosine {wcos:.3f} ({wk}); vs the bf16-storage oracle: '
+              f'{min(r_[2] for r_ in report):.4f}')
+        assert wcos > 0.5
     worst = sorted(report, key=lambda r: -r[1])[:4]
     print(f'full-size {dtype} step: loss {loss:.6f} (oracle {loss_ref:.6f}); worst relL2 ' + ', '.join(f'{k} {l2:.2e}' for k, l2, _, _ in worst))
     if f32:
@@ -612,6 +630,49 @@ def test_config4_13_band_tiles_and_config5_1024_scene(mt):
     ref = OT.predict_chips(scene, idx, np.zeros(scene.shape[:2]), lambda chip: o4.forward(chip, training=False)[0], kernel=256, buff=128)
     np.testing.assert_allclose(got, ref, atol=5e-5)
     assert not got[:64].any() and not got[832:].any() and not got[:, :64].any() and not got[:, 832:].any()
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_config4_13_band_five_level_training_step(mt, dtype):
+    """BASELINE configs[3]: get_unet_model(2, 13) (utils/model_tools.py:394-415 with nchannels = 13: all Sentinel-2 bands,
+    utils/ee_tools.py:100), the five-level graph bench.py --channels 13 times, 256 x 256 tiles, ONE training step against the float64
+    oracle: loss and every gradient -- in particular enc0.conv.kernel, whose 13 real input channels live in 16 stored ones (the
+    padded channels must neither feed the forward sum nor appear in the gradient).  bf16: the storage-rounding oracle, cosine >= 0.99
+    per tensor, plus the forward mask's IoU against the oracle's."""
+    f32 = dtype == 'float32'
+    o, m, names = build_pair(mt, dtype, 2, 13, [32, 64, 128, 256, 512], [2, 2, 2, 2, 2], seed=23, perturb=False,
+                             store_dtype=None if f32 else 'bfloat16')
+    n = 2
+    x, t = _synthetic_step_batch(n, 13, seed=9)
+    m.compile(optimizer=mt.Adam(0.0), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 20.0]))
+    pr, _ = o.forward(x, training=True)
+    loss_ref, dprobs, _ = OL.weighted_categorical_crossentropy(t.astype(np.float64), pr, [1.0, 20.0])
+    g_ref = o.backward(dprobs)
+    loss = m.train_on_batch(x, t)
+    np.testing.assert_allclose(loss, loss_ref, rtol=2e-5 if f32 else 2e-3)
+    rt = m.runtime
+    torch.cuda.synchronize()
+    gk = rt.get_grad(names['enc0.conv.kernel']).cpu().numpy()
+    assert gk.shape == (3, 3, 13, 32) and np.abs(gk).max() > 0
+    for k, l2, cos, share in _grad_report(o, rt, names, g_ref):
+        if f32:
+            assert l2 < 1e-2, f'grad {k}: relL2 {l2:.3e} cos {cos:.6f}'
+        else:
+            assert cos >= 0.99, f'grad {k}: cos {cos:.4f} relL2 {l2:.3e}'
+    # forward of the trained-mode statistics' moving averages: inference mask against the oracle (bit-exact beyond the margin)
+    balance_head(o, x)
+    m.set_weights_dict({names['probs.bias']: o.params['probs.bias']})
+    for k in o.params:                      # the training step above moved the BatchNorm moving statistics on both sides
+        if k.endswith(('moving_mean', 'moving_var')):
+            m.set_weights_dict({names[k]: o.params[k]})
+    p_ref, c_ref = o.forward(x, training=False)
+    probs, classes = m.predict(x, batch_size=2)
+    ok = np.abs(p_ref[..., 0] - p_ref[..., 1]) > (1e-3 if f32 else 0.1)
+    assert np.array_equal(classes[ok], c_ref[ok])
+    if f32:
+        np.testing.assert_allclose(probs, p_ref, atol=5e-5)
+    else:
+        assert (classes == c_ref).mean() > 0.97 and abs(iou(classes, c_ref) - 1.0) < 0.05
 
 
 @pytest.mark.parametrize('dtype,size,batch', [('float32', 64, 2), ('bfloat16', 128, 2), ('bfloat16', 512, 1)])

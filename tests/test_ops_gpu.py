@@ -298,70 +298,6 @@ def ws_launches():
     return v.value
 
 
-@pytest.fixture
-def force_stream(ops):
-    from satellite_computervision_amd._lib import lib, check
-    import ctypes
-    old = ctypes.c_int32()
-    check(lib.satcv_get_option(b'conv3_stream', ctypes.byref(old)))
-    check(lib.satcv_set_option(b'conv3_stream', 1))
-    yield
-    check(lib.satcv_set_option(b'conv3_stream', old.value))
-
-
-def stream_launches():
-    from satellite_computervision_amd._lib import lib, check
-    import ctypes
-    v = ctypes.c_int32()
-    check(lib.satcv_get_option(b'conv3_stream_launches', ctypes.byref(v)))
-    return v.value
-
-
-@pytest.mark.parametrize('case', WS_CASES + [(2, 40, 64, 32, 32, 32), (1, 24, 96, 32, 32, 32), (2, 17, 32, 32, 32, 64), (2, 8, 64, 16, 48, 32)])
-def test_conv2d_streaming_thin_kernel(ops, case, force_stream):
-    """The thin 3x3 forward convolutions on the streaming kernel (conv3_stream.hip; an option, off by default): maps a multiple of 32 wide and ANY height, fused input
-    BatchNorm + ReLU, second source (decoder concatenation), bias, statistics of the stored values; runs that start in the middle of a column,
-    more row strips than waves and fewer."""
-    td = torch.bfloat16
-    n, h, w, cin, cout = case[:5]
-    c1 = case[5] if len(case) > 5 else 0
-    rng = np.random.default_rng(hash(case) % 2**31)
-    cpad = rup(cin, 16)
-    xa = rnd(rng, (n, h, w, cin), td)
-    xb = rnd(rng, (n, h, w, c1), td) if c1 else None
-    ct = cpad + c1
-    kern = rnd(rng, (3, 3, cin + c1, cout), td, 0.2)
-    b = rng.standard_normal(cout)
-    sc, sh = (rng.standard_normal(ct) * 0.5 + 1).astype(np.float32), rng.standard_normal(ct).astype(np.float32) * 0.5
-    served = w % 32 == 0 and ct in (16, 32, 64) and cout in (32, 64)
-    xcat = np.concatenate([xa, xb], -1) if c1 else xa
-    scr = np.concatenate([sc[:cin], sc[cpad:]]) if c1 else sc[:cin]
-    shr = np.concatenate([sh[:cin], sh[cpad:]]) if c1 else sh[:cin]
-    if c1:
-        kfull = np.zeros((3, 3, ct, cout)); kfull[:, :, :cin] = kern[:, :, :cin]; kfull[:, :, cpad:] = kern[:, :, cin:]
-    else:
-        kfull = kern
-    wf, _ = ops.pack_weights(f32dev(kfull), ct if c1 else cpad, ops.DTYPE_CODE[td], want_dgrad=False)
-    for affine, relu in ((True, True), (True, False), (False, False)):
-        if affine:
-            a = xcat * scr.astype(np.float64) + shr.astype(np.float64)
-            a = np.maximum(a, 0) if relu else a
-            a = torch.tensor(a, dtype=torch.float32).to(td).double().numpy()
-        else:
-            a = xcat
-        ref = K.conv2d_same(a, kern, b, 1)
-        stats = ops.new_stats(cout, dev())
-        before = stream_launches()
-        y = ops.conv2d(to_dev(xa, td, cpad), wf, cout, bias=f32dev(b), stats=stats, x1=to_dev(xb, td) if c1 else None,
-                       in_scale=f32dev(sc) if affine else None, in_shift=f32dev(sh) if affine else None, in_relu=relu)
-        assert stream_launches() - before == (1 if served else 0), 'path taken'
-        got = back(y, cout)
-        close(got, ref, td, f'streaming conv {case} affine={affine} relu={relu}')
-        s = stats.sum(0).double().cpu().numpy()
-        np.testing.assert_allclose(s[0, :cout], got.sum((0, 1, 2)), rtol=2e-4, atol=2e-3 * np.sqrt(n * h * w))
-        np.testing.assert_allclose(s[1, :cout], (got ** 2).sum((0, 1, 2)), rtol=2e-4)
-
-
 @pytest.mark.parametrize('case', WS_CASES)
 def test_conv2d_weights_stationary_thin_kernel(ops, case, force_thin):
     """forward (bias + BN statistics) and data gradient through conv_igemm_ws.hip"""
