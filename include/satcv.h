@@ -441,6 +441,64 @@ int satcv_allreduce_grads(satcv_comm* comm, float* grads, int64_t lo, int64_t hi
                           void* scratch, void* stream);
 int satcv_allreduce(satcv_comm* comm, void* buf, int64_t count, int32_t dtype, int32_t average, void* stream);
 
+/* ------------------------------------------------------------ ConvLSTM2D family
+ * The reference's LSTM builders (utils/model_tools.py:666-768 build_lstm_layers / build_lstm_layers2, :773-920 get_lstm_model /
+ * get_lstm_autoencoder / get_hybrid_model, :1016-1060 get_hierarchical_model) call tf.keras.layers.ConvLSTM2D(filters, [3, 3],
+ * padding 'same', activation None, optional dilation_rate on the INPUT convolution).  Per time step
+ *     z = conv(x_t, kernel) + bias + conv(h_{t-1}, recurrent_kernel)          (gate order i, f, c, o along the 4 F channels)
+ *     i, f, o = rec_act(z_i, z_f, z_o);  g = act(z_c);  c_t = f c_{t-1} + i g;  h_t = o act(c_t)
+ * Both convolutions are satcv_conv2d_igemm launches (sequences are stored time-major, so the input convolution of ALL steps is
+ * one launch over T * B images); these entry points are the cell arithmetic.
+ *
+ * satcv_ingest_seq: (B, T, H, W, C) float32 (the Keras input layout) -> (T, B, H, W, cpad) storage type. */
+int satcv_ingest_seq(const float* src, void* dst, int32_t batch, int32_t steps, int32_t h, int32_t w_, int32_t c, int32_t cpad,
+                     int32_t dtype, void* stream);
+typedef struct satcv_lstm_gates_desc {
+  /* forward inputs: the two convolution outputs of this step (storage type), (npix, 4 F) with leading dimensions ldx / ldh_g;
+   * hg NULL at t = 0 (h_0 = 0); c_prev (npix, F) float32 or NULL (c_0 = 0) */
+  const void* xg; int32_t ldx; const void* hg; int32_t ldh_g; const float* c_prev;
+  float* c_out;                        /* c_t (npix, F) float32 (backward: c_t as an INPUT)                                       */
+  void* h_out; int32_t ldh;            /* h_t (npix, ldh) storage type                                                            */
+  void* gates_out;                     /* post-activation (i, f, g, o) (npix, 4 F) storage type: forward output (NULL at inference),
+                                          backward input                                                                          */
+  satcv_stat_t* stats; int32_t stats_ld;   /* optional BatchNorm statistics of the stored h_t, rows as in satcv_conv_desc           */
+  /* backward: dL/dh_t from up to two producers (the layer above; the recurrent data gradient of step t + 1), dc_{t+1 -> t} or NULL */
+  const void* dh_a; int32_t lddh_a; const void* dh_b; int32_t lddh_b; const float* dc_next;
+  void* dz_out; int32_t lddz;          /* dL/dz_t (npix, lddz >= 4 F) storage type: the dy of both convolutions' gradients        */
+  float* dc_prev_out;                  /* dc_{t -> t-1} (npix, F) float32                                                         */
+  int64_t npix; int32_t filters;
+  int32_t rec_act;                     /* 0 hard_sigmoid = clip(0.2 z + 0.5, 0, 1) (Keras 2.x ConvLSTM2D default), 1 sigmoid (Keras 3) */
+  int32_t act;                         /* 0 linear (activation=None, as every reference call site), 1 tanh (the Keras default)    */
+  int32_t dtype;
+} satcv_lstm_gates_desc;
+int satcv_convlstm_gates_fwd(const satcv_lstm_gates_desc* d, void* stream);
+int satcv_convlstm_gates_bwd(const satcv_lstm_gates_desc* d, void* stream);
+
+/* Conv2D(cout <= 16, 1x1) over the channel concatenation of one or two sources -- the `dense` layers and fusion heads of the LSTM
+ * family (utils/model_tools.py:797, 847-857, 902-910, 1050-1056).  A source is an NHWC tensor (float32 or bf16) with an optional
+ * pending BatchNorm + ReLU and, if hs / ws are set, on a coarser grid that is read through tf.image.resize(..., 'nearest')
+ * (half-pixel centres: source index min(floor((i + 0.5) in / out), in - 1)).  activation: 0 softmax (+ argmax classes), 1 sigmoid,
+ * 2 linear, 3 ReLU clipped at max_value (max_value <= 0: plain ReLU; layers.ReLU(max_value=2.0) is the reference's default head).
+ * Backward: `dout` is dL/d out for activations 2 / 3 (for softmax / sigmoid heads pass the loss kernel's dL/dlogits with activation 2);
+ * dw (rows of every source in order, (sum cin, cout)) and db are ACCUMULATED (zero them first); src[i].dx receives the gradient of the
+ * source's ACTIVATED values on the source's own grid. */
+typedef struct satcv_dense_src {
+  const void* x; int32_t ld, cin, dtype;
+  const float* in_scale; const float* in_shift; int32_t in_relu;
+  int32_t hs, ws;                      /* 0, 0: the output grid                                                                   */
+  void* dx; int32_t lddx, dx_dtype;    /* backward output or NULL                                                                 */
+} satcv_dense_src;
+typedef struct satcv_dense_desc {
+  satcv_dense_src src[2]; int32_t nsrc;
+  const float* w; const float* b; int32_t cout;
+  int32_t activation; float max_value;
+  float* out; int32_t* classes; float* z_out;      /* (npix, cout) float32; classes (npix) for softmax or NULL; z_out optional     */
+  int64_t npix; int32_t h, w_;                     /* output grid (npix = images * h * w_)                                         */
+  const float* dout; float* dz_out; float* dw; float* db;
+} satcv_dense_desc;
+int satcv_dense_small_fwd(const satcv_dense_desc* d, void* stream);
+int satcv_dense_small_bwd(const satcv_dense_desc* d, void* stream);
+
 /* ------------------------------------------------------- stream utilities */
 int satcv_graph_begin(void* stream);
 int satcv_graph_end(void* stream, void** graph_exec_out);

@@ -88,6 +88,7 @@ class UNetOracle:
                  bessel=True, store_dtype=None):
         assert store_dtype in (None, 'bfloat16')
         self.q = round_bf16 if store_dtype == 'bfloat16' else (lambda v: v)
+        self.store_sums_exact = store_dtype is not None
         self.nclasses, self.nchannels = nclasses, nchannels
         self.filters, self.factors = list(filters), list(factors)
         self.dtype, self.bessel = dtype, bessel
@@ -139,12 +140,22 @@ class UNetOracle:
         c[name + ':exact'] = a_exact
         return a
 
-    def _cba_bwd(self, name, bnname, da, c, g):
+    def _cba_bwd(self, name, bnname, da, c, g, da_sums=None):
+        """da_sums (store_dtype mode only): the gradient the BatchNorm-backward SUMS are formed from when it is not the stored tensor --
+        the block under the head: the head's backward kernel sums its float32 gradient, the apply step uses the bf16-rounded one."""
         p, q = self.params, self.q
         x, y, (mean, var), a, dilation = c[name]
         dz = K.relu_bwd(c[name + ':exact'], da)
         dy, g[f'{bnname}.gamma'], g[f'{bnname}.beta'] = K.batchnorm_train_bwd(
             y, p[f'{bnname}.gamma'], mean, var, dz, BN_EPS)
+        if da_sums is not None:
+            dzs = K.relu_bwd(c[name + ':exact'], da_sums)
+            m = y.shape[0] * y.shape[1] * y.shape[2]
+            rstd = 1.0 / np.sqrt(var + BN_EPS)
+            xhat = (y - mean) * rstd
+            dbeta, dgamma = dzs.sum(axis=(0, 1, 2)), (dzs * xhat).sum(axis=(0, 1, 2))
+            dy = p[f'{bnname}.gamma'] * rstd * (dz - dbeta / m - xhat * dgamma / m)
+            g[f'{bnname}.gamma'], g[f'{bnname}.beta'] = dgamma, dbeta
         dy = q(dy)
         dx, g[f'{name}.kernel'], g[f'{name}.bias'] = K.conv2d_same_bwd(x, q(p[f'{name}.kernel']), dy, dilation)
         dx = q(dx)
@@ -207,13 +218,15 @@ class UNetOracle:
         dlogits = K.softmax_bwd(probs, np.asarray(dprobs, self.dtype))
         dh, g['probs.kernel'], g['probs.bias'] = K.conv2d_same_bwd(h, p['probs.kernel'], dlogits)
         q = self.q
+        dh_exact = dh
         dh = q(dh)
         masks = c.get('masks', {})
         if 'final' in masks:
             dh = dh * masks['final']
         dskip = {}
         for j in range(L):
-            da1 = self._cba_bwd(f'dec{j}.conv2', f'dec{j}.bn2', dh, c, g)
+            head_sums = dh_exact if (j == 0 and self.store_sums_exact and 'final' not in masks) else None
+            da1 = self._cba_bwd(f'dec{j}.conv2', f'dec{j}.bn2', dh, c, g, da_sums=head_sums)
             da0 = self._cba_bwd(f'dec{j}.conv1', f'dec{j}.bn1', da1, c, g)
             if j == 0 and 'dec0' in masks:
                 da0 = da0 * masks['dec0']

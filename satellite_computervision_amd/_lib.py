@@ -91,6 +91,31 @@ class HeadDesc(C.Structure):
                 ('npix', c_i64), ('dtype', c_i32), ('partials', c_vp)]
 
 
+class LstmGatesDesc(C.Structure):
+    _fields_ = [('xg', c_vp), ('ldx', c_i32), ('hg', c_vp), ('ldh_g', c_i32), ('c_prev', c_vp),
+                ('c_out', c_vp), ('h_out', c_vp), ('ldh', c_i32), ('gates_out', c_vp),
+                ('stats', c_vp), ('stats_ld', c_i32),
+                ('dh_a', c_vp), ('lddh_a', c_i32), ('dh_b', c_vp), ('lddh_b', c_i32), ('dc_next', c_vp),
+                ('dz_out', c_vp), ('lddz', c_i32), ('dc_prev_out', c_vp),
+                ('npix', c_i64), ('filters', c_i32), ('rec_act', c_i32), ('act', c_i32), ('dtype', c_i32)]
+
+
+class DenseSrc(C.Structure):
+    _fields_ = [('x', c_vp), ('ld', c_i32), ('cin', c_i32), ('dtype', c_i32),
+                ('in_scale', c_vp), ('in_shift', c_vp), ('in_relu', c_i32),
+                ('hs', c_i32), ('ws', c_i32),
+                ('dx', c_vp), ('lddx', c_i32), ('dx_dtype', c_i32)]
+
+
+class DenseDesc(C.Structure):
+    _fields_ = [('src', DenseSrc * 2), ('nsrc', c_i32),
+                ('w', c_vp), ('b', c_vp), ('cout', c_i32),
+                ('activation', c_i32), ('max_value', c_f32),
+                ('out', c_vp), ('classes', c_vp), ('z_out', c_vp),
+                ('npix', c_i64), ('h', c_i32), ('w_', c_i32),
+                ('dout', c_vp), ('dz_out', c_vp), ('dw', c_vp), ('db', c_vp)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/satcv.h
 _SIGS = {
     'satcv_version': (C.c_char_p, []),
@@ -144,6 +169,11 @@ _SIGS = {
     'satcv_comm_info': (C.c_int, [c_vp, C.POINTER(c_i32), C.POINTER(c_i32)]),
     'satcv_allreduce_grads': (C.c_int, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp]),
     'satcv_allreduce': (C.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    'satcv_ingest_seq': (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'satcv_convlstm_gates_fwd': (C.c_int, [C.POINTER(LstmGatesDesc), c_vp]),
+    'satcv_convlstm_gates_bwd': (C.c_int, [C.POINTER(LstmGatesDesc), c_vp]),
+    'satcv_dense_small_fwd': (C.c_int, [C.POINTER(DenseDesc), c_vp]),
+    'satcv_dense_small_bwd': (C.c_int, [C.POINTER(DenseDesc), c_vp]),
     'satcv_graph_begin': (C.c_int, [c_vp]),
     'satcv_graph_end': (C.c_int, [c_vp, C.POINTER(c_vp)]),
     'satcv_graph_launch': (C.c_int, [c_vp, c_vp]),

@@ -273,6 +273,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves 64 x 16 bytes from per-lane global addresses to 1 KB of CONTIGUOUS
+// LDS (lane l lands at lds_dst + 16 l), with no VGPR destination and no ds_write.  Inline asm so that hipcc neither counts it in its own
+// s_waitcnt bookkeeping nor orders LDS reads behind it: the caller waits (dma_wait_all / a counted s_waitcnt vmcnt) and then passes a
+// workgroup barrier before any wave reads the bytes (cdna_hip_programming.md section 5.7).  M0 carries the LDS base for the
+// instruction and is restored.  gbase: wave-uniform base pointer (SGPR pair), voff: this lane's byte offset from it (32 bit).
+typedef __attribute__((address_space(3))) char satcv_lds_char;
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(uintptr_t)(satcv_lds_char*)p; }
+__device__ __forceinline__ void lds_dma16(const void* gbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(gbase), "v"(voff), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // number of replica rows used for per-channel atomics (spreads contention; the
 // consumer sums the rows in fixed order).
 #define SATCV_STAT_REPL 32

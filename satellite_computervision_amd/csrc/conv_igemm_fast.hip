@@ -45,7 +45,10 @@ extern "C" int satcv_debug_read_stamps(unsigned long long* out) {
 // cdna_hip_programming.md T14).  Used with the 256-pixel x 128-channel, 8-wave tile for the deep layers: per MFMA the 9-tap weight
 // slab (77 % of the staged bytes, re-fetched from L2 by every workgroup) is amortised over twice the pixels of the 128 x 128 tile
 // (20.7 instead of 37.7 staged bytes per MFMA-cycle and CU at full rate), which is what bounded that tile at ~0.9 PFLOP/s.
-template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool DYN, bool TL = false, bool DB = false, int WPS = 0>
+// WDMA (round 4, double-buffered tile only): the weight slab of a chunk -- 77 % of the staged bytes, and the operand that needs no
+// transform -- moves by LDS-DMA (global_load_lds_dwordx4, 1-KB pieces, no staging registers, no ds_write) into a THREE-slot ring two
+// chunks ahead; the activations keep the register path (fused input BatchNorm + ReLU, zero padding).
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool DYN, bool TL = false, bool DB = false, int WPS = 0, bool WDMA = false>
 // thin configurations (<= 32 accumulator registers) request 4 waves/SIMD; the scaled-fp8 fragments are 8 registers each, so
 // that path asks for 2.  WPS overrides (tile-at-once configurations stage a whole tile through registers)
 __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<T>::SUB == 2 ? 2 : 4) : 1))) void igemm_fast_kernel(const IgemmArgs a) {
@@ -66,7 +69,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
   // staged A items per thread: halo tile of a 3x3 / dilation-1 conv incl. the several-images-per-tile case
   constexpr int XMAXPIX = (TAPS == 1 && DB) ? BM : (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);      // (the double-buffered single-tap tile stages no halo; the older single-tap forms keep their budget: sized exactly, their 16-channel forms needed 24 bytes of scratch)
   constexpr int AI = (XMAXPIX * SLOTS + NTHREADS - 1) / NTHREADS;
-  constexpr int BI = (TAPS * SLOTS * BN + NTHREADS - 1) / NTHREADS;  // staged B items per thread
+  constexpr int BI = WDMA ? 1 : (TAPS * SLOTS * BN + NTHREADS - 1) / NTHREADS;  // staged B items per thread (none with WDMA: a dummy of 1)
+  static_assert(!WDMA || (DB && !TL && std::is_same<T, bf16>::value && BN * EL * (int)sizeof(T) == 2048), "weights by LDS-DMA: double-buffered bf16 tile of 128 output channels");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* ldsA = reinterpret_cast<T*>(smem_raw);
   // padding between the slot planes: ds_write_b128 is serviced in groups of 8 lanes over 32 banks (128 B).  With 4+ slots the
@@ -75,8 +79,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
   const int plane = a.rl * pitch * EL;
   const int spad = SLOTS > 2 ? ((32 - (plane * (int)sizeof(T)) % 128 + 128) % 128) / (int)sizeof(T) : 0;
   const int slot_stride = plane + spad;
-  T* ldsB = ldsA + SLOTS * slot_stride;
-  const int stage_elems = SLOTS * slot_stride + TAPS * SLOTS * BN * EL;      // one LDS stage (A planes + weight slab); DB: two of them
+  const int a_stage = SLOTS * slot_stride;                                    // A planes of one stage
+  constexpr int b_slab = TAPS * SLOTS * BN * EL;                              // weight slab of one chunk
+  // without WDMA a stage is [A planes | weight slab] (DB: two stages); with WDMA: [A stage 0 | A stage 1 | ring slot 0 | 1 | 2]
+  T* ldsB = WDMA ? ldsA + 2 * a_stage : ldsA + a_stage;
+  const int stage_elems = a_stage + b_slab;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 
   const T* wp = reinterpret_cast<const T*>(a.w);
   Raw8<T> ra[AI], rb[BI];
-  float* ldsT = reinterpret_cast<float*>(ldsA + (DB ? 2 : 1) * stage_elems);  // [2][cin] scale, shift (behind the stage(s))
+  float* ldsT = reinterpret_cast<float*>(WDMA ? ldsA + 2 * a_stage + 3 * b_slab : ldsA + (DB ? 2 : 1) * stage_elems);  // [2][cin] scale, shift (behind the stage(s))
   if (a.in_scale) {
     for (int i = tid; i < cin; i += NTHREADS) { ldsT[i] = a.in_scale[i]; ldsT[cin + i] = a.in_shift[i]; }      // (visible after the barrier that ends the prologue)
   }
@@ -247,8 +254,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #pragma unroll
       for (int j = 0; j < AI; ++j) load_a(c, j);
       load_p(c);
+      if constexpr (!WDMA) {
 #pragma unroll
-      for (int j = 0; j < BI; ++j) load_b(c, j);
+        for (int j = 0; j < BI; ++j) load_b(c, j);
+      }
     } else {
       const int tap = TL ? chunk_ / a.cpt : 0;
       const int chunk = TL ? chunk_ - tap * a.cpt : chunk_;
@@ -280,8 +289,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
     if constexpr (DB) {
 #pragma unroll
       for (int j = 0; j < AI; ++j) store_a(chunk_, boff, j);
+      if constexpr (!WDMA) {
 #pragma unroll
-      for (int j = 0; j < BI; ++j) store_b(boff, j);
+        for (int j = 0; j < BI; ++j) store_b(boff, j);
+      }
     } else {
       const int chunk = TL ? chunk_ % a.cpt : chunk_;
       const int cg0 = chunk * KC + slot_t * EL;
@@ -312,6 +323,23 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
     }
   };
 
+  // ---- WDMA: round r of the weight slab of chunk `chunk_` -> ring slot `ring`.  The slab is 36 (TAPS = 9) or 4 * KS (TAPS = 1) pieces of
+  // 1 KB: piece p = half (p & 1) of the 2-KB row of (tap, slot) = ((p >> 1) / SLOTS, (p >> 1) % SLOTS), contiguous in the packed image
+  // and in LDS; wave w moves pieces w, w + 8, ...  Everything but the lane's 16-byte offset is scalar.
+  constexpr int NPIECES = TAPS * SLOTS * 2, NROUNDS = (NPIECES + 7) / 8;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds_ring = lds_addr_of(ldsB);
+  auto dma_b = [&](int chunk_, int ring, int r) {
+    if constexpr (WDMA) {
+      const int p = wave_u + 8 * r;
+      if (p < NPIECES) {
+        const int run = p >> 1, tap = run / SLOTS, slot = run % SLOTS;
+        const size_t off = ((size_t)(tap * (cin / EL) + chunk_ * SLOTS + slot) * a.cout_pad + nbase + (p & 1) * 64) * EL;
+        lds_dma16(wp + off, (unsigned)lane * 16u, lds_ring + (unsigned)(ring * b_slab * (int)sizeof(T)) + (unsigned)p * 1024u);
+      }
+    }
+  };
+
   int n0, y0, x0;
   tile_origin(bid, n0, y0, x0);
   if constexpr (TL) gather_pixels(n0, y0, x0, -a.halh_tl, -a.halw_tl);
@@ -319,9 +347,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #ifdef SATCV_STAMP
   STAMP(k1);
 #endif
+  if constexpr (WDMA) {
+#pragma unroll
+    for (int r = 0; r < NROUNDS; ++r) dma_b(0, 0, r);
+#pragma unroll
+    for (int r = 0; r < NROUNDS; ++r) dma_b(a.nchunks > 1 ? 1 : 0, 1, r);
+  }
   load_regs(0);
   store_lds(0);
   if constexpr (DB) { if (a.nchunks > 1) load_regs(1); }
+  if constexpr (WDMA) dma_wait_all();
   __syncthreads();
 #ifdef SATCV_STAMP
   STAMP(k2);
@@ -341,7 +376,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
     // waves 4-7 half a chunk later de-phases them (MI355X_MICROARCH.md, two waves per SIMD, item 9)
     // (rot is a wave-uniform run-time value: the tap offsets of a staggered wave are scalar additions instead of instruction immediates;
     //  two compile-time copies of the loop cost 200 bytes of scratch per lane)
-    auto compute_chunk = [&](int boff, auto&& side) {
+    auto compute_chunk = [&](int boff, int boffB, auto&& side) {
       constexpr int STEPS = TAPS * KS;
       FragT<T> af[2][MT], bf[2][NT];
       auto read_step = [&](int st_, int buf) {
@@ -356,7 +391,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #pragma unroll
         for (int m = 0; m < MT; ++m) af[buf][m] = lds_frag<T>(ldsA + boff + (ABL(16) ? 0 : slot * slot_stride + a_off[m] + tap_off), slot_stride);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bf[buf][n] = lds_frag<T>(ldsB + boff + ((tap * SLOTS + slot) * BN + (wn * NT + n) * 32 + r) * EL, BN * EL);
+        for (int n = 0; n < NT; ++n) bf[buf][n] = lds_frag<T>(ldsB + boffB + ((tap * SLOTS + slot) * BN + (wn * NT + n) * 32 + r) * EL, BN * EL);
       };
       read_step(0, 0);
 #pragma unroll
@@ -385,13 +420,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #endif
       // units of one chunk's staging in program order: A items (store c+1, then re-issue for c+2), the scale / shift values (needed by
       // the A stores above, so re-issued after them), weight items; unit u runs in tap step u (the surplus in the last step)
-      constexpr int NUNITS = AI + 1 + BI, STEPS_ = TAPS * KS;
+      constexpr int NUNITS = AI + 1 + (WDMA ? NROUNDS : BI), STEPS_ = TAPS * KS;
       for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        const int cur = (chunk & 1) * stage_elems, oth = stage_elems - cur;
+        // A stages alternate; without WDMA the weight slab sits behind the A planes of the same stage, with it in ring slot chunk % 3
+        const int cur = WDMA ? (chunk & 1) * a_stage : (chunk & 1) * stage_elems;
+        const int oth = WDMA ? a_stage - cur : stage_elems - cur;
+        const int curB = WDMA ? (chunk % 3) * b_slab : cur;
         const bool do_store = chunk + 1 < a.nchunks, do_load = chunk + 2 < a.nchunks;
         // (wave-uniform flags; the loads of the last two iterations re-read the last chunk instead of branching around vector-memory
         //  instructions inside the loop: see the note at the loaders)
-        const ChunkSrc cs_ = chunk_src(do_load ? chunk + 2 : a.nchunks - 1);
+        const int nxt2 = do_load ? chunk + 2 : a.nchunks - 1;
+        const ChunkSrc cs_ = chunk_src(nxt2);
 #ifdef SATCV_STAMP
         STAMP(t0);
         STAMP(t1);
@@ -407,19 +446,27 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #else
             else if (u == AI) load_p(cs_, true);
 #endif
+            else if constexpr (WDMA) dma_b(nxt2, (chunk + 2) % 3, u - AI - 1);      // (slot (chunk + 2) % 3 was last read in iteration chunk - 1)
             else { if (do_store) store_b(oth, u - AI - 1); load_b(cs_, u - AI - 1); }
           }
         };
-        compute_chunk(cur, side);
+        compute_chunk(cur, curB, side);
 #ifdef SATCV_STAMP
         STAMP(t3);
 #endif
+        if constexpr (WDMA) {
+          // the slab of chunk + 1 (this wave's pieces, issued one iteration ago) must have landed before the barrier that lets every wave
+          // read it: everything but what this iteration issued AFTER them -- AI activation loads and this wave's pieces of chunk + 2
+          if (wave_u + 8 * (NROUNDS - 1) < NPIECES) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(AI + NROUNDS) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(AI + NROUNDS - 1) : "memory");
+        }
         __syncthreads();
 #ifdef SATCV_STAMP
         STAMP(t4);
         s_wait += t1 - t0; s_store += t2 - t1; s_comp += t3 - t2; s_bar += t4 - t3;
 #endif
       }
+      if constexpr (WDMA) { dma_wait_all(); __syncthreads(); }      // (the epilogue's staging tile aliases the ring: no piece may still be in flight)
 #ifdef SATCV_STAMP
       if (blockIdx.x < 8 && lane == 0) {
         g_stamp[blockIdx.x][wave][0] = s_wait; g_stamp[blockIdx.x][wave][1] = s_store; g_stamp[blockIdx.x][wave][2] = s_comp; g_stamp[blockIdx.x][wave][3] = s_bar;
@@ -446,7 +493,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #ifdef SATCV_STAMP
       STAMP(t1);
 #endif
-      compute_chunk(0, [](int) {});
+      compute_chunk(0, 0, [](int) {});
 #ifdef SATCV_STAMP
       STAMP(t2);
 #endif
@@ -492,7 +539,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 }
 
 // ------------------------------------------------------------------ host side
-template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool TL = false, bool DB = false, int WPS = 0>
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool TL = false, bool DB = false, int WPS = 0, bool WDMA = false>
 static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   constexpr int EL = KTraits<T>::EL, SUB = KTraits<T>::SUB;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, KC = KS * 2 * SUB * EL, NTHREADS = WM * WN * 64;
@@ -526,7 +573,9 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   }
   if (a.ldy % (16 / (int)sizeof(T)) != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;
   if (a.mode_out == 0 && a.cout % (16 / (int)sizeof(T)) != 0 && a.cout < a.ldy) { /* tail handled by scalar stores */ }
-  const size_t lds_stage = (((size_t)KC * a.rl * a.pitch + (size_t)TAPS * KC * BN) * sizeof(T) + (size_t)(KC / EL) * 128) * (DB ? 2 : 1);      // + slot padding (< 128 B per plane)
+  size_t lds_stage = (((size_t)KC * a.rl * a.pitch + (size_t)TAPS * KC * BN) * sizeof(T) + (size_t)(KC / EL) * 128) * (DB ? 2 : 1);      // + slot padding (< 128 B per plane)
+  if (WDMA) lds_stage = 2 * ((size_t)KC * a.rl * a.pitch * sizeof(T) + (size_t)(KC / EL) * 128) + 3 * (size_t)TAPS * KC * BN * sizeof(T);      // two A stages + a three-slot weight ring
+  if (WDMA && (((uintptr_t)a.w % 16) != 0 || a.cout_pad % 64 != 0)) return SATCV_ERR_UNSUPPORTED;
   if (DB && (TL || a.mode_in != 0)) return SATCV_ERR_UNSUPPORTED;
   size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
   if (a.bst_y) {
@@ -549,7 +598,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
     constexpr int PITCHc = TW == 32 ? CLc : (TW == 16 ? ((CLc + 15) / 16) * 16 : (CLc <= 8 ? 8 : ((CLc - 8 + 15) / 16) * 16 + 8));
     if (a.cl != CLc || a.pitch != PITCHc) { satcv_set_error("igemm_fast: internal pitch mismatch (%d/%d vs %d/%d)", a.cl, a.pitch, CLc, PITCHc); return SATCV_ERR_INVALID; }
   }
-  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, false, TL, DB, WPS>;
+  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, false, TL, DB, WPS, WDMA>;
   if constexpr (TAPS == 9 && !DB && WPS == 0) { if (dyn) kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, true>; }
   if ((DB || WPS) && dyn) return SATCV_ERR_UNSUPPORTED;
   { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
@@ -579,6 +628,13 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
       // (a 512-pixel x 128-channel tile -- wave tile 64 x 128, 128 accumulator registers -- needs ~300 bytes of scratch per lane at the
       //  256-register cap of two waves per SIMD: not kept)
       if (db_mode >= 2 || tiles256 >= 192) {
+        // weights by LDS-DMA into a three-slot ring (SATCV_WDMA=0: register-staged weights; the ring does not fit beside the halo tiles
+        // of the 8-pixel-wide maps, which stay on the register path)
+        static const int wdma = [] { const char* e = getenv("SATCV_WDMA"); return e ? atoi(e) : 1; }();
+        if (wdma) {
+          const int rc = fast_cfg<T, TW, 4, 2, 2, 2, 1, TAPS, false, true, 0, true>(a, st, dry);
+          if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+        }
         const int rc = fast_cfg<T, TW, 4, 2, 2, 2, 1, TAPS, false, true>(a, st, dry);
         if (rc != SATCV_ERR_UNSUPPORTED) return rc;
       }

@@ -712,6 +712,235 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 4: the deep 3x3 weight gradient on a (64 ci) x (128 co) x (9 taps) block per workgroup, dY by LDS-DMA.
+//
+// The (32 ci) x (128 co) block of wgrad_db_kernel staged 160 channel-rows per pixel for 32 x 128 x 9 products (4.3 bytes per kFLOP through
+// the CU's vector-memory path, dY re-read by Cin / 32 blocks: 1.8-2.0x the algorithmic HBM traffic); its 64-ci form spilled because one
+// more staged item per thread did not fit beside 144 accumulator registers.  Here dY -- 2/3 of the staged bytes, and the operand that
+// needs no transform -- never touches a VGPR: every wave moves four 1-KB pieces per pixel tile with global_load_lds_dwordx4 straight into
+// the other stage (no load registers, no ds_write, no per-item bookkeeping), which pays for the second ci tile:
+//   * block 64 x 128 x 9: 8 waves = 2 (ci) x 4 (co) tiles of 32 x 32, every wave all 9 taps (144 accumulator registers) and ALL 8 k-steps of
+//     a 128-pixel tile (no k-split, no LDS reduction at the end); 2.6 bytes per kFLOP staged, dY re-read by Cin / 64 blocks;
+//   * dY image: 128 pixel rows of 256 B, UNPADDED (an LDS-DMA piece is 1 KB of contiguous LDS = 4 rows); the four 64-byte segments of a
+//     row are XOR-swizzled by (row & 3) -- on the SOURCE address of the DMA and on the transposing reads -- so that the 4 rows x 64 B a
+//     32-lane half reads fall on 64 distinct banks (the padded rows of the register-staged image did this with 64 B of padding);
+//   * X (halo tile, BatchNorm + ReLU of the producing layer in registers) as before: register-staged, one item between two MFMAs;
+//   * per tile: X items in the first third of the 72 MFMA slots, the four DMA pieces in the second third, `s_waitcnt vmcnt(0)` + ONE
+//     barrier at the end (everything issued in an iteration has ~half an iteration to land; hipcc sees no DMA, so its own counted
+//     waits for the X registers stay exact).
+// Requires whole tiles (the DMA has no bounds handling), Cin % 64 == 0, Cout % 128 == 0, dilation 1, bf16; everything else stays on
+// wgrad_db_kernel.
+template <int TW>
+__global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs a) {
+  using T = bf16;
+  constexpr int NCI = 2, NCO = 4, NTAPS = 9, NTHREADS = 512, BMPIX = 128, TH = BMPIX / TW;
+  constexpr int CI_T = 32 * NCI, CO_T = 32 * NCO, XP = CI_T + 32, GX = CI_T / 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int x_elems = a.rl * a.cl * XP;
+  const int stage_elems = x_elems + BMPIX * CO_T;
+  T* lds0 = reinterpret_cast<T*>(smem_raw);
+  int* tab = reinterpret_cast<int*>(lds0 + 2 * stage_elems);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wci = wave % NCI, wco = wave / NCI;
+  const int r = lane & 31, hh = lane >> 5;
+  int blk, sp;
+  {
+    const int nblk = a.n_ci_blk * a.n_co_blk, id = blockIdx.x;
+    if ((a.nsplit & 7) == 0) { const int xcd = id & 7, j = id >> 3; blk = j % nblk; sp = (j / nblk) * 8 + xcd; }
+    else { blk = id % nblk; sp = id / nblk; }
+  }
+  const int ci_blk = blk % a.n_ci_blk, co_blk = blk / a.n_ci_blk;
+  const int ci0 = ci_blk * CI_T, co0 = co_blk * CO_T;
+
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  for (int q = tid; q < BMPIX; q += NTHREADS) {
+    const int t = q / TW, cx = q % TW;
+    const int k = t / a.rpi;
+    const int l0 = (k < a.imgs) ? k * a.seg + (t - k * a.rpi) : 0;
+    tab[q] = (l0 * a.cl + cx) * XP;
+  }
+
+  // ---- X: per-thread, tile-invariant description of the staged items (as in wgrad_db_kernel)
+  const int x_items = a.rl * a.cl * GX;
+  constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+  constexpr int XI = (XMAXPIX * GX + NTHREADS - 1) / NTHREADS;
+  constexpr int NPIECE = 4;                              // 1-KB dY pieces per wave and tile: 8 waves x 4 x 4 pixel rows = 128 pixels
+  constexpr int NU = XI + NPIECE;
+  const int gx = tid % GX, cgx = ci0 + gx * 8;
+  const bool xsecond = a.x1 != nullptr && cgx >= a.c0;
+  const T* xsrc = xsecond ? reinterpret_cast<const T*>(a.x1) + (cgx - a.c0) : reinterpret_cast<const T*>(a.x0) + cgx;
+  const int xcs = xsecond ? a.c1 : a.c0;
+  float* ldsS = reinterpret_cast<float*>(tab + BMPIX);                     // [GX][16]: 8 scale + 8 shift per channel group
+  const bool aff = a.in_scale != nullptr;
+  if (aff && tid < GX * 16) {
+    const int g = tid / 16, e = tid % 16, ch = ci0 + g * 8 + (e & 7);
+    ldsS[tid] = e < 8 ? a.in_scale[ch] : a.in_shift[ch];
+  }
+  const unsigned relu_lim = a.in_relu != 0 ? 0u : 0x80008000u;
+  constexpr int XSTEP = (NTHREADS / GX) * XP;
+  const int x_dst0 = (tid / GX) * XP + gx * 8;
+  int x_rel[XI], x_eoff[XI];
+#pragma unroll
+  for (int j = 0; j < XI; ++j) {
+    const int it = tid + j * NTHREADS;
+    const int pix = it / GX;
+    const int c = pix % a.cl, L = pix / a.cl;
+    const int k = L / a.seg;
+    const int yy = L - k * a.seg - a.halh;
+    x_rel[j] = ((it < x_items) ? (1 << 30) : 0) | (k << 20) | ((yy + 64) << 10) | c;
+    x_eoff[j] = ((k * a.h + yy) * a.w_ + (c - a.halw)) * xcs;
+  }
+  // ---- dY: byte offset of this lane's 16 bytes of piece j from the tile's first pixel.  Piece p = 4 wave + j holds the pixel rows
+  // 4 p .. 4 p + 3; lane l writes chunk (l & 15) of row 4 p + (l >> 4) and fetches the chunk whose 64-byte segment is XOR-ed with that
+  // row's low two bits (= l >> 4)
+  unsigned d_voff[NPIECE];
+#pragma unroll
+  for (int j = 0; j < NPIECE; ++j) {
+    const int q = (wave * NPIECE + j) * 4 + (lane >> 4);
+    const int t = q / TW, cx = q % TW;
+    const int k = (a.imgs == 1) ? 0 : t / a.rpi;
+    const int row = t - k * a.rpi;
+    const int chunk = (lane & 15) ^ ((lane >> 4) << 2);
+    d_voff[j] = (unsigned)((((k * a.h + row) * a.w_ + cx) * a.lddy + chunk * 8) * (int)sizeof(T));
+  }
+  const T* dyp = reinterpret_cast<const T*>(a.dy) + co0;
+  const unsigned lds_base = lds_addr_of(lds0);
+
+  Raw8<T> xr[XI];
+  unsigned xmask = 0;
+  int klim = 0, ylo = 0, yhi = 0, clo = 0, chi = 0;
+  size_t xbase = 0;
+  auto tile_origin = [&](int pt, size_t& dbase) {
+    int m = pt;
+    const int tx = m % a.tiles_x; m /= a.tiles_x;
+    const int ty = m % a.tiles_y;
+    const int n0 = (m / a.tiles_y) * a.imgs, y0 = ty * TH, x0 = tx * TW;
+    klim = a.n - n0;
+    ylo = 64 - y0; yhi = 64 + a.h - y0;
+    clo = a.halw - x0; chi = a.w_ + a.halw - x0;
+    const size_t bp = ((size_t)n0 * a.h + y0) * a.w_ + x0;
+    xbase = bp * xcs;
+    dbase = bp * a.lddy;
+  };
+  auto load_x = [&](int j) {
+    const int c = x_rel[j] & 1023, yy = (x_rel[j] >> 10) & 1023, k = (x_rel[j] >> 20) & 1023;
+    const bool ok = (x_rel[j] >> 30) && (k < klim) && (yy >= ylo) && (yy < yhi) && (c >= clo) && (c < chi);
+    xmask = (xmask & ~(1u << j)) | ((ok ? 1u : 0u) << j);
+    xr[j] = gload8<T>(xsrc + xbase + (ok ? x_eoff[j] : 0));
+  };
+  auto store_x = [&](int j, T* ldsX) {
+    Raw8<T> v = xr[j];
+    if (aff) {
+      float sc[8], sh[8];
+      const float4* sp4 = reinterpret_cast<const float4*>(ldsS + gx * 16);
+      const float4 s0 = sp4[0], s1 = sp4[1], h0 = sp4[2], h1 = sp4[3];
+      sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+      sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+      v = affine8_lim(v, sc, sh, relu_lim);
+    }
+    v = select8<T>((xmask >> j) & 1u, v);
+    if (tid + j * NTHREADS < x_items) lstore8<T>(ldsX + x_dst0 + j * XSTEP, v);
+  };
+  // piece j of the tile whose first pixel is at element offset dbase -> stage st
+  auto dma_piece = [&](int j, size_t dbase, int st) {
+    const unsigned dst = lds_base + (unsigned)((st * stage_elems + x_elems) * (int)sizeof(T)) + (unsigned)((wave * NPIECE + j) * 1024);
+    lds_dma16(dyp + dbase, d_voff[j], __builtin_amdgcn_readfirstlane(dst));
+  };
+
+  const int ntl = sp < a.total_ptiles ? (a.total_ptiles - 1 - sp) / a.nsplit + 1 : 0;
+  __syncthreads();                                   // the scale / shift table is read by the first stores below
+  size_t dnext = 0, dtmp = 0;
+  if (ntl > 0) {
+    tile_origin(sp, dnext);
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) dma_piece(j, dnext, 0);
+#pragma unroll
+    for (int j = 0; j < XI; ++j) load_x(j);
+#pragma unroll
+    for (int j = 0; j < XI; ++j) store_x(j, lds0);
+    tile_origin(sp + (ntl > 1 ? 1 : 0) * a.nsplit, dnext);      // registers: X of tile 1; dnext: dY of tile 1 (moved in iteration 0)
+#pragma unroll
+    for (int j = 0; j < XI; ++j) load_x(j);
+  }
+  dma_wait_all();
+  __syncthreads();
+  // fragment addresses (elements): dY rows 128 wide, segment swizzle = (pixel row & 3) = (i16 >> 2), a lane constant
+  const int gi = lane >> 4, i16 = lane & 15;
+  const int chb = 16 * (gi & 1) + 4 * (i16 & 3);
+  const int d_lane = (8 * (gi >> 1) + (i16 >> 2)) * CO_T + ((wco ^ (i16 >> 2)) * 32) + chb;
+  const int q_lane = 8 * (gi >> 1) + (i16 >> 2);
+  constexpr int SLOTS = (BMPIX / 16) * NTAPS;          // 72 MFMAs per wave and tile
+  for (int i = 0; i < ntl; ++i) {
+    T* ldsX = lds0 + (i & 1) * stage_elems;
+    T* ldsD = ldsX + x_elems;
+    T* othX = lds0 + ((i + 1) & 1) * stage_elems;
+    const bool do_store = i + 1 < ntl;
+    const size_t dcur = dnext;                         // dY of tile i + 1 (this iteration's DMA)
+    tile_origin(sp + (i + 2 < ntl ? i + 2 : ntl - 1) * a.nsplit, dtmp);      // X loads of tile i + 2
+    // (two compile-time halves of four k-steps: hipcc does not fully unroll 72 MFMAs, and with a run-time slot number every staging unit
+    //  would be compiled into every slot behind a branch)  half 0: the X items, half 1: the DMA pieces
+    auto half_tile = [&](auto HALF) {
+      constexpr int H0 = decltype(HALF)::value * 4;
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        const int ks = H0 + kq;
+        const bf16x4 blo = tr_read(ldsD + d_lane + ks * 16 * CO_T);
+        const bf16x4 bhi = tr_read(ldsD + d_lane + (ks * 16 + 4) * CO_T);
+        const bf16x8 bfr = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const int xoa = tab[ks * 16 + q_lane] + wci * 32 + chb;
+        const int xob = tab[ks * 16 + q_lane + 4] + wci * 32 + chb;
+        bf16x4 alo[2], ahi[2];
+        alo[0] = tr_read(ldsX + xoa);
+        ahi[0] = tr_read(ldsX + xob);
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+          if (tap + 1 < NTAPS) {
+            const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
+            const int toff = (ky * (TW + 2) + kx) * XP;      // dilation 1: cl = TW + 2, an instruction immediate
+            alo[(tap + 1) & 1] = tr_read(ldsX + xoa + toff);
+            ahi[(tap + 1) & 1] = tr_read(ldsX + xob + toff);
+          }
+          const int slot = kq * NTAPS + tap;                 // 0 .. 35 inside the half
+          if constexpr (decltype(HALF)::value == 0) {
+#pragma unroll
+            for (int u = 0; u < XI; ++u)
+              if (slot == 2 + 8 * u) { if (do_store) store_x(u, othX); load_x(u); }
+          } else {
+#pragma unroll
+            for (int u = 0; u < NPIECE; ++u)
+              if (slot == 1 + 6 * u) { if (do_store) dma_piece(u, dcur, (i + 1) & 1); }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 afr = __builtin_shufflevector(alo[tap & 1], ahi[tap & 1], 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[tap], 0, 0, 0);
+        }
+      }
+    };
+    half_tile(std::integral_constant<int, 0>{});
+    half_tile(std::integral_constant<int, 1>{});
+    dnext = dtmp;
+    dma_wait_all();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tap = 0; tap < NTAPS; ++tap) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ci = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      const int co = co0 + wco * 32 + r;
+      a.ws[((size_t)(sp * NTAPS + tap) * a.kpad + ci) * a.npad + co] = acc[tap][i];
+    }
+  }
+}
+
 // dw (Keras layout) = sum over slabs in a fixed order (deterministic): 64 outputs x 4 split lanes
 // per block, each lane sums every 4th slab, LDS combines the 4 partial sums.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslab, int taps, int kpad,
@@ -834,7 +1063,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce16_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ host side
-struct WgradPlan { int tw, nci, nco, nw, nks, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk, pix, db; size_t ws_bytes; };
+struct WgradPlan { int tw, nci, nco, nw, nks, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk, pix, db, dma; size_t ws_bytes; };
 extern int g_opt_wgrad_db;        // api.hip: satcv_set_option("wgrad_db", ...)
 
 static bool wgrad_pix256() {
@@ -860,12 +1089,24 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   // 64 x 128 block (each dY tile is re-read by half as many ci blocks: these launches are staging-bound, ~110 us whatever their size)
   // ... and, where the layer has them, a 128 x 256 block with four co tiles per wave (see wgrad_db_kernel)
   p.nw = 1;
-  if (p.ntaps == 1 && db_ok && cinx % 128 == 0 && nspace % 256 == 0 && g_opt_wgrad_db != 2) { p.nci = 4; p.nco = 2; p.nw = 4; }
+  p.dma = 0;
+  {
+    // deep 3x3 layers: the (64 ci) x (128 co) block with dY by LDS-DMA (wgrad_dma_kernel; SATCV_WGRAD_DMA=0 keeps the (32 x 128) block)
+    static const int dma_on = [] { const char* e = getenv("SATCV_WGRAD_DMA"); return e ? atoi(e) : 1; }();
+    const int th_ = 128 / p.tw;
+    const bool whole = d->w_ % p.tw == 0 && (d->h >= th_ ? d->h % th_ == 0 : (th_ % d->h == 0 && d->n % (th_ / d->h) == 0));
+    if (dma_on && db_ok && p.ntaps == 9 && !d->mode_dy && cinx % 64 == 0 && nspace % 128 == 0 && whole && d->lddy % 8 == 0 &&
+        ((uintptr_t)d->dy % 16) == 0 && (!d->x1 || d->c0 % 8 == 0) && d->cin == cinx)
+      p.dma = 1;
+  }
+  if (p.dma) { p.nci = 2; p.nco = 4; }
+  else if (p.ntaps == 1 && db_ok && cinx % 128 == 0 && nspace % 256 == 0 && g_opt_wgrad_db != 2) { p.nci = 4; p.nco = 2; p.nw = 4; }
   else if (p.ntaps == 1) { p.nci = (db_ok && cinx % 64 == 0) ? 2 : 1; p.nco = 4; }
   else if (nspace % 128 == 0) { p.nci = 1; p.nco = 4; }
   else if (nspace % 64 == 0) { p.nci = (cinx % 64 == 0) ? 2 : 1; p.nco = 2; }
   else { p.nci = (cinx % 64 == 0) ? 2 : 1; p.nco = 1; }
   p.nks = 4 / (p.nci * p.nco) > 0 ? 4 / (p.nci * p.nco) : 1;                 // 4 waves per workgroup (single-buffered kernel)
+  if (p.dma) p.nks = 1;
   const int ci_t = 32 * p.nci, co_t = 32 * p.nco * p.nw;
   p.n_ci_blk = cdiv(cinx, ci_t); p.n_co_blk = cdiv(nspace, co_t);
   p.kpad = p.n_ci_blk * ci_t; p.npad = p.n_co_blk * co_t;
@@ -876,6 +1117,7 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   p.pix = (p.ntaps == 9 && p.tw == 32 && p.nci == 1 && p.nco == 1 && d->dtype == SATCV_BF16 && p.n_ci_blk * p.n_co_blk <= 3 && d->h >= 8 && d->w_ >= 256 &&
            d->dil == 1 && wgrad_pix256()) ? 256 : 128;
   if (p.nw > 1) p.pix = 64;
+  if (p.dma) p.pix = 128;
   const int th = p.pix / p.tw;
   const int tiles_x = cdiv(d->w_, p.tw);
   long long ptiles;
@@ -990,9 +1232,48 @@ static int wgrad_db_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStr
   return SATCV_OK;
 }
 
+template <int TW>
+static int wgrad_dma_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st) {
+  constexpr int PIX = 128, TH = PIX / TW, NTHREADS = 512, XP = 96, GX = 8;
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.in_relu = d->in_relu;
+  a.dy = d->dy; a.lddy = d->lddy; a.ws = d->workspace;
+  a.n = d->n; a.h = d->h; a.w_ = d->w_; a.kh = 3; a.kw = 3; a.dil = 1;
+  a.f = 1; a.cout_t = d->cout;
+  a.kpad = p.kpad; a.npad = p.npad;
+  a.cin_lim = d->c0 + d->c1; a.n_lim = d->cout;
+  a.halh = 1; a.halw = 1;
+  a.tiles_x = d->w_ / TW;
+  if (d->h >= TH) { a.rpi = TH; a.imgs = 1; a.tiles_y = d->h / TH; a.ngroups = d->n; }
+  else { a.rpi = d->h; a.imgs = TH / d->h; a.tiles_y = 1; a.ngroups = d->n / a.imgs; }
+  a.seg = a.rpi + 2; a.rl = a.imgs * a.seg; a.cl = TW + 2;
+  a.n_ci_blk = p.n_ci_blk; a.n_co_blk = p.n_co_blk; a.nsplit = p.nsplit;
+  a.total_ptiles = a.ngroups * a.tiles_y * a.tiles_x;
+  constexpr int XMAXPIX = (TH + 2 * (TH / 4 > 1 ? TH / 4 : 1)) * (TW + 2);
+  constexpr int XI = (XMAXPIX * GX + NTHREADS - 1) / NTHREADS;
+  if ((long long)a.rl * a.cl * GX > (long long)XI * NTHREADS) return SATCV_ERR_UNSUPPORTED;
+  if (a.rl >= 1024 || a.cl >= 1024 || a.imgs >= 1024) return SATCV_ERR_UNSUPPORTED;
+  // a lane's dY offset inside a tile is a 32-bit byte offset
+  if ((long long)a.imgs * d->h * d->w_ * d->lddy * 2 >= (1ll << 31)) return SATCV_ERR_UNSUPPORTED;
+  const size_t stage = (size_t)a.rl * a.cl * XP + (size_t)PIX * 128;
+  const size_t lds = 2 * stage * sizeof(bf16) + (size_t)PIX * sizeof(int) + (size_t)GX * 16 * sizeof(float);
+  if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
+  auto kern = wgrad_dma_kernel<TW>;
+  { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
+  hipLaunchKernelGGL(kern, dim3(p.n_ci_blk * p.n_co_blk * p.nsplit), dim3(NTHREADS), lds, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { satcv_set_error("wgrad_dma launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  return SATCV_OK;
+}
+
 // the double-buffered kernel (bf16): 8 waves = (ci, co) tiles x k-slices
 template <typename T, int TW>
 static int wgrad_db_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy, int sx) {
+  if constexpr (std::is_same<T, bf16>::value) {
+    if (p.dma) return wgrad_dma_launch<TW>(d, p, st);      // (the plan's slab geometry is this kernel's: no other kernel can serve it)
+  }
   if (p.ntaps == 1 && p.nw == 4) return wgrad_db_launch<T, TW, 4, 2, 1, 1, 64, 4>(d, p, st, sy, sx);
   if (p.ntaps == 1 && p.nci == 2) return wgrad_db_launch<T, TW, 2, 4, 1, 1>(d, p, st, sy, sx);
   if (p.ntaps == 1) return wgrad_db_launch<T, TW, 1, 4, 2, 1>(d, p, st, sy, sx);

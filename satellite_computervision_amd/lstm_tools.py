@@ -1,0 +1,580 @@
+"""The ConvLSTM2D model family of the reference on the HIP library: build_lstm_layers / build_lstm_layers2 / get_lstm_model /
+get_lstm_autoencoder / get_hybrid_model / get_hierarchical_model (utils/model_tools.py:666-920, 1016-1060).
+
+Unlike the U-Net plans (engine.Plan: one static launch list per input shape) these models are small, recurrent and multi-input, so
+they run as an eager TAPE of C-ABI launches: every layer object has forward / backward methods that call the library (ops.py wrappers
+around include/satcv.h) on device tensors; torch is the allocator.  No CPU path, no torch arithmetic on the data path.
+
+Layout: a sequence (B, T, H, W, C) is ingested TIME-MAJOR, (T, B, H, W, Cpad) (satcv_ingest_seq), so that
+  * the input convolution of ALL time steps of a ConvLSTM2D is ONE implicit-GEMM launch over T * B images (it does not depend on h),
+  * a single step is a contiguous slice, and the recurrent weight gradient over steps 1 .. T-1 is one launch over (T-1) * B images.
+Per step: recurrent 3x3 conv of h_{t-1} (satcv_conv2d_igemm) + the gate kernel (satcv_convlstm_gates_fwd).  BPTT: gate backward
+(satcv_convlstm_gates_bwd) + the recurrent data gradient per step; weight / bias gradients once per layer after the loop.
+
+Keras semantics (unpinned, see oracle/convlstm.py): gate order i, f, c, o; `activation=None` at every reference call site;
+recurrent_activation is version dependent -- RECURRENT_ACTIVATION = 'hard_sigmoid' (Keras 2.x / TF 2.x default for ConvLSTM2D) or
+'sigmoid' (Keras 3); unit_forget_bias; orthogonal recurrent initialiser; the recurrent convolution is never dilated.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from . import model_tools as mt
+from ._lib import lib, check, F32, BF16, LstmGatesDesc, DenseDesc
+
+RECURRENT_ACTIVATION = os.environ.get('SATCV_LSTM_RECURRENT_ACTIVATION', 'hard_sigmoid')
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99
+
+
+def _dev():
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class _Params:
+    """flat float32 parameters / gradients / Adam slots of one model (what engine.Runtime is to the U-Net graphs)"""
+
+    def __init__(self):
+        self.specs, self.n = {}, 0
+        self.flat = self.grad = self.m = self.v = None
+        self.state = None
+        self.init = {}
+
+    def add(self, name, shape, init, trainable=True):
+        size = int(np.prod(shape))
+        self.specs[name] = (self.n, tuple(shape), trainable)
+        self.init[name] = init
+        self.n += ops.rup(size, 4)
+        return name
+
+    def build(self):
+        host = np.zeros(max(self.n, 4), np.float32)
+        for name, (off, shape, _) in self.specs.items():
+            host[off:off + int(np.prod(shape))] = np.asarray(self.init[name](), np.float32).reshape(-1)
+        self.flat = torch.from_numpy(host).to(_dev())
+        self.grad = torch.zeros_like(self.flat)
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.state = torch.tensor([1e-3, 0.0, 1.0, 0.0], dtype=torch.float32, device=_dev())
+        mul = np.ones(max(self.n, 4), np.float32)
+        for name, (off, shape, tr) in self.specs.items():
+            if not tr:
+                mul[off:off + int(np.prod(shape))] = 0
+        self.lr_mul = torch.from_numpy(mul).to(_dev())
+
+    def p(self, name):
+        off, shape, _ = self.specs[name]
+        return self.flat[off:off + int(np.prod(shape))].view(shape)
+
+    def g(self, name):
+        off, shape, _ = self.specs[name]
+        return self.grad[off:off + int(np.prod(shape))].view(shape)
+
+
+def _glorot(rng, shape, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return lambda: rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def _orthogonal(rng, shape):
+    def init():
+        rows, cols = int(np.prod(shape[:-1])), shape[-1]
+        a = rng.standard_normal((rows, cols))
+        q, r = np.linalg.qr(a.T if rows < cols else a)
+        q = q * np.sign(np.diag(r))
+        q = q.T if rows < cols else q
+        return q.reshape(shape).astype(np.float32)
+    return init
+
+
+class Act:
+    """a device activation: tensor (N, H, W, Cpad) in the storage type, its real channel count, and the BatchNorm (+ ReLU) its consumers
+    still have to apply (scale, shift, mean, rstd) -- the same raw-storage contract as the U-Net engine"""
+
+    def __init__(self, t, c, bn=None, relu=False):
+        self.t, self.c, self.bn, self.relu = t, c, bn, relu
+
+    @property
+    def scale(self):
+        return self.bn[0] if self.bn else None
+
+    @property
+    def shift(self):
+        return self.bn[1] if self.bn else None
+
+
+# ------------------------------------------------------------------------------------------------ layers
+class ConvLSTM2D:
+    """layers.ConvLSTM2D(filters, [3, 3], padding='same', activation=None, dilation_rate=d, return_sequences=..., return_state=...)
+    (utils/model_tools.py:690-700, 710-720)"""
+
+    def __init__(self, params, rng, name, cin, filters, dilation=1, return_sequences=True, activation=None):
+        self.P, self.name, self.cin, self.F, self.dil, self.rs = params, name, cin, filters, dilation, return_sequences
+        self.act = 0 if activation in (None, 'linear') else 1
+        k, F = 3, filters
+        params.add(f'{name}/kernel', (k, k, cin, 4 * F), _glorot(rng, (k, k, cin, 4 * F), k * k * cin, k * k * 4 * F))
+        params.add(f'{name}/recurrent_kernel', (k, k, F, 4 * F), _orthogonal(rng, (k, k, F, 4 * F)))
+
+        def bias():
+            b = np.zeros(4 * F, np.float32)
+            b[F:2 * F] = 1.0                           # unit_forget_bias
+            return b
+        params.add(f'{name}/bias', (4 * F,), bias)
+        if F % 8 or (4 * F) % 16:
+            raise NotImplementedError('ConvLSTM2D filters must be a multiple of 8')
+
+    def _pack(self, dtype):
+        P = self.P
+        cpad = ops.rup(self.cin, 16)
+        self.wk, self.wk_d = ops.pack_weights(P.p(f'{self.name}/kernel'), cpad, dtype)
+        self.wr, self.wr_d = ops.pack_weights(P.p(f'{self.name}/recurrent_kernel'), ops.rup(self.F, 16), dtype)
+
+    def forward(self, x, T, B, training, dtype, want_stats=True):
+        """x: Act, time-major (T * B, H, W, Cpad).  Returns the raw output Act ((T * B, ..) or (B, ..), F channels) and its BatchNorm
+        statistics rows (sum, sum of squares of the stored h) for the BatchNormalization every reference call site applies next."""
+        self._pack(dtype)
+        F, P = self.F, self.P
+        n, H, W, _ = x.t.shape
+        assert n == T * B
+        td = x.t.dtype
+        dev = x.t.device
+        Fp = ops.rup(F, 16)
+        xg = ops.conv2d(x.t, self.wk, 4 * F, dil=self.dil, bias=P.p(f'{self.name}/bias'), in_scale=x.scale, in_shift=x.shift, in_relu=x.relu)
+        hseq = torch.zeros(T * B, H, W, Fp, dtype=td, device=dev)
+        cseq = torch.empty(T, B * H * W, F, dtype=torch.float32, device=dev)
+        gates = torch.empty(T, B * H * W, 4 * F, dtype=td, device=dev) if training else None
+        stats = ops.new_stats(Fp, dev) if want_stats else None
+        rk = 0 if RECURRENT_ACTIVATION == 'hard_sigmoid' else 1
+        npix = B * H * W
+        for t in range(T):
+            hg = ops.conv2d(hseq[(t - 1) * B:t * B], self.wr, 4 * F) if t > 0 else None
+            d = LstmGatesDesc()
+            d.xg, d.ldx = xg[t * B:(t + 1) * B].data_ptr(), xg.shape[-1]
+            d.hg, d.ldh_g = (hg.data_ptr(), hg.shape[-1]) if hg is not None else (None, 0)
+            d.c_prev = cseq[t - 1].data_ptr() if t > 0 else None
+            d.c_out, d.h_out, d.ldh = cseq[t].data_ptr(), hseq[t * B:(t + 1) * B].data_ptr(), Fp
+            d.gates_out = gates[t].data_ptr() if gates is not None else None
+            if stats is not None and (self.rs or t == T - 1):
+                d.stats, d.stats_ld = stats.data_ptr(), Fp
+            d.npix, d.filters, d.rec_act, d.act, d.dtype = npix, F, rk, self.act, ops.DTYPE_CODE[td]
+            check(lib.satcv_convlstm_gates_fwd(C.byref(d), ops.stream_ptr()))
+        self.ctx = dict(x=x, T=T, B=B, H=H, W=W, hseq=hseq, cseq=cseq, gates=gates, rk=rk, td=td)
+        out = hseq if self.rs else hseq[(T - 1) * B:]
+        self.h_last = hseq[(T - 1) * B:]
+        return Act(out, F), stats, (T * B * H * W if self.rs else B * H * W)
+
+    def backward(self, dout, dstate_h=None, need_dx=True):
+        """dout: gradient of the returned tensor (storage type, F padded channels), dstate_h: gradient of the final hidden state taken
+        through return_state.  Accumulates the three parameter gradients; returns the gradient of the (activated) input."""
+        c = self.ctx
+        T, B, H, W, F, P = c['T'], c['B'], c['H'], c['W'], self.F, self.P
+        td, dev = c['td'], c['hseq'].device
+        Fp = c['hseq'].shape[-1]
+        npix = B * H * W
+        dz = torch.empty(T * B, H, W, 4 * F, dtype=td, device=dev)
+        dc = [torch.empty(npix, F, dtype=torch.float32, device=dev) for _ in range(2)]
+        dh_rec = None
+        for t in range(T - 1, -1, -1):
+            srcs = []
+            if self.rs:
+                srcs.append(dout[t * B:(t + 1) * B])
+            elif t == T - 1:
+                srcs.append(dout)
+            if dstate_h is not None and t == T - 1:
+                srcs.append(dstate_h)
+            if dh_rec is not None:
+                srcs.append(dh_rec)
+            assert len(srcs) <= 2                   # (the state gradient only joins at t = T - 1, where there is no recurrent one)
+            d = LstmGatesDesc()
+            if srcs:
+                d.dh_a, d.lddh_a = srcs[0].data_ptr(), srcs[0].shape[-1]
+            if len(srcs) > 1:
+                d.dh_b, d.lddh_b = srcs[1].data_ptr(), srcs[1].shape[-1]
+            if not srcs:                            # no gradient reaches h_t (return_sequences=False, t < T - 1 has dh_rec; only T = 1 corner)
+                z = torch.zeros(B, H, W, Fp, dtype=td, device=dev)
+                d.dh_a, d.lddh_a = z.data_ptr(), Fp
+            d.dc_next = dc[(t + 1) & 1].data_ptr() if t < T - 1 else None
+            d.gates_out = c['gates'][t].data_ptr()
+            d.c_prev = c['cseq'][t - 1].data_ptr() if t > 0 else None
+            d.c_out = c['cseq'][t].data_ptr()
+            d.dz_out, d.lddz = dz[t * B:(t + 1) * B].data_ptr(), 4 * F
+            d.dc_prev_out = dc[t & 1].data_ptr()
+            d.npix, d.filters, d.rec_act, d.act, d.dtype = npix, F, c['rk'], self.act, ops.DTYPE_CODE[td]
+            check(lib.satcv_convlstm_gates_bwd(C.byref(d), ops.stream_ptr()))
+            dh_rec = ops.conv2d_dgrad(dz[t * B:(t + 1) * B], self.wr_d, F) if t > 0 else None
+        x = c['x']
+        # weight gradients: the input kernel over all T * B images at once, the recurrent kernel over steps 1 .. T-1 (h_{t-1} = hseq[t-1])
+        ops.conv2d_wgrad(x.t, dz, self.cin, 4 * F, dil=self.dil, in_scale=x.scale, in_shift=x.shift, in_relu=x.relu, dw=P.g(f'{self.name}/kernel'))
+        if T > 1:
+            ops.conv2d_wgrad(c['hseq'][:(T - 1) * B], dz[B:], F, 4 * F, dw=P.g(f'{self.name}/recurrent_kernel'))
+        nb = lib.satcv_bias_grad_workspace(T * B * H * W, 4 * F)
+        ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=dev)
+        check(lib.satcv_bias_grad(dz.data_ptr(), 4 * F, T * B * H * W, 4 * F, ops.DTYPE_CODE[td], P.g(f'{self.name}/bias').data_ptr(), ws.data_ptr(), ops.stream_ptr()))
+        if not need_dx:
+            return None
+        return ops.conv2d_dgrad(dz, self.wk_d, self.cin, dil=self.dil)
+
+
+class BatchNorm:
+    """layers.BatchNormalization() on a ConvLSTM2D output (statistics over batch, time and space), followed -- or not -- by ReLU"""
+
+    def __init__(self, params, name, c):
+        self.P, self.name, self.c = params, name, c
+        params.add(f'{name}/gamma', (c,), lambda: np.ones(c, np.float32))
+        params.add(f'{name}/beta', (c,), lambda: np.zeros(c, np.float32))
+        params.add(f'{name}/moving_mean', (c,), lambda: np.zeros(c, np.float32), trainable=False)
+        params.add(f'{name}/moving_var', (c,), lambda: np.ones(c, np.float32), trainable=False)
+
+    def forward(self, a, stats, count, training, relu=True, bessel=True):
+        P, n = self.P, self.name
+        cp = a.t.shape[-1]
+
+        def padded(v, fill):                         # per-channel vectors over the PADDED channel count (pad channels hold zeros: scale 1, shift 0)
+            if cp == self.c:
+                return v
+            out = torch.full((cp,), fill, dtype=torch.float32, device=v.device)
+            out[:self.c] = v
+            return out
+        if training:
+            g, b = padded(P.p(f'{n}/gamma'), 1.0), padded(P.p(f'{n}/beta'), 0.0)
+            mm, mv = padded(P.p(f'{n}/moving_mean'), 0.0), padded(P.p(f'{n}/moving_var'), 1.0)
+            scale, shift, mean, rstd = ops.bn_finalize_train(stats, count, g, b, mm, mv, BN_EPS, BN_MOMENTUM, 1, bessel)
+            if cp != self.c:
+                P.p(f'{n}/moving_mean').copy_(mm[:self.c]); P.p(f'{n}/moving_var').copy_(mv[:self.c])
+        else:
+            scale, shift = ops.bn_affine_infer(padded(P.p(f'{n}/gamma'), 1.0), padded(P.p(f'{n}/beta'), 0.0),
+                                               padded(P.p(f'{n}/moving_mean'), 0.0), padded(P.p(f'{n}/moving_var'), 1.0), BN_EPS)
+            mean = rstd = None
+        self.ctx = dict(a=a, relu=relu)
+        out = Act(a.t, a.c, (scale, shift, mean, rstd), relu)
+        self.out = out
+        return out
+
+    def backward(self, da):
+        """da: gradient of the normalised (+ ReLU) tensor, storage type.  Returns the gradient of the raw input."""
+        a, out = self.ctx['a'], self.out
+        scale, shift, mean, rstd = out.bn
+        y = a.t
+        n, h, w_, cp = y.shape
+        dev = y.device
+        sums = ops.new_stats(cp, dev)
+        coef = torch.empty(2, cp, dtype=torch.float32, device=dev)
+        dgamma, dbeta = torch.empty(cp, dtype=torch.float32, device=dev), torch.empty(cp, dtype=torch.float32, device=dev)
+        dy = torch.empty_like(y)
+        d = ops.make_bnbwd_desc(yraw=y.data_ptr(), ldy=cp, scale=scale.data_ptr(), shift=shift.data_ptr(), mean=mean.data_ptr(), rstd=rstd.data_ptr(),
+                                n=n, h=h, w_=w_, c=cp, dtype=ops.DTYPE_CODE[y.dtype], da=da.data_ptr(), ldda=da.shape[-1], sums=sums.data_ptr(),
+                                sums_ld=cp, coef=coef.data_ptr(), dy=dy.data_ptr(), lddy_out=cp, linear=0 if self.ctx['relu'] else 1)
+        st = ops.stream_ptr()
+        check(lib.satcv_bn_bwd_reduce(C.byref(d), st))
+        check(lib.satcv_bn_bwd_finalize(sums.data_ptr(), cp, cp, float(n * h * w_), dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(), 0, st))
+        check(lib.satcv_bn_bwd_apply(C.byref(d), st))
+        self.P.g(f'{self.name}/gamma').add_(dgamma[:self.c])
+        self.P.g(f'{self.name}/beta').add_(dbeta[:self.c])
+        return dy
+
+
+class Dense1x1:
+    """layers.Conv2D(cout, [1, 1]) over the concatenation of one or two sources, with softmax / sigmoid / linear / ReLU(max_value)
+    (satcv_dense_small_fwd / _bwd); a source may sit on a coarser grid and be read through tf.image.resize(..., 'nearest')"""
+    ACT = {'softmax': 0, 'sigmoid': 1, 'linear': 2, None: 2, 'relu': 3}
+
+    def __init__(self, params, rng, name, cins, cout, activation='linear', max_value=0.0):
+        self.P, self.name, self.cins, self.cout = params, name, list(cins), cout
+        self.activation, self.max_value = self.ACT[activation], float(max_value or 0.0)
+        cin = sum(cins)
+        params.add(f'{name}/kernel', (1, 1, cin, cout), _glorot(rng, (1, 1, cin, cout), cin, cout))
+        params.add(f'{name}/bias', (cout,), lambda: np.zeros(cout, np.float32))
+
+    def _desc(self, srcs, out_hw):
+        d = DenseDesc()
+        d.nsrc = len(srcs)
+        for i, (a, resize) in enumerate(srcs):
+            s = d.src[i]
+            s.x, s.ld, s.cin = a.t.data_ptr(), a.t.shape[-1], self.cins[i]
+            s.dtype = F32 if a.t.dtype == torch.float32 else BF16
+            if a.bn is not None:
+                s.in_scale, s.in_shift, s.in_relu = a.scale.data_ptr(), a.shift.data_ptr(), 1 if a.relu else 0
+            elif a.relu:                               # a plain pending ReLU (a linear head's output consumed through Activation('relu'))
+                one, zero = self._ident(self.cins[i], a.t.device)
+                s.in_scale, s.in_shift, s.in_relu = one.data_ptr(), zero.data_ptr(), 1
+            if resize:
+                s.hs, s.ws = a.t.shape[1], a.t.shape[2]
+        d.w, d.b, d.cout = self.P.p(f'{self.name}/kernel').data_ptr(), self.P.p(f'{self.name}/bias').data_ptr(), self.cout
+        d.activation, d.max_value = self.activation, self.max_value
+        d.h, d.w_ = out_hw
+        return d
+
+    def _ident(self, c, dev):
+        if getattr(self, '_id', None) is None or self._id[0].numel() < c:
+            self._id = (torch.ones(c, dtype=torch.float32, device=dev), torch.zeros(c, dtype=torch.float32, device=dev))
+        return self._id
+
+    def forward(self, srcs, out_hw=None, want_classes=False):
+        """srcs: list of (Act, resize flag).  Returns float32 (N, H, W, cout) (and int32 classes for softmax heads)."""
+        a0 = srcs[0][0]
+        nimg = a0.t.shape[0]
+        H, W = out_hw if out_hw is not None else (a0.t.shape[1], a0.t.shape[2])
+        d = self._desc(srcs, (H, W))
+        out = torch.empty(nimg, H, W, self.cout, dtype=torch.float32, device=a0.t.device)
+        classes = torch.empty(nimg, H, W, dtype=torch.int32, device=a0.t.device) if (want_classes and self.activation == 0) else None
+        d.out, d.classes, d.npix = out.data_ptr(), classes.data_ptr() if classes is not None else None, nimg * H * W
+        check(lib.satcv_dense_small_fwd(C.byref(d), ops.stream_ptr()))
+        self.ctx = dict(srcs=srcs, hw=(H, W), out=out)
+        return (out, classes) if want_classes else out
+
+    def backward(self, dout, need_dx=(True, True)):
+        """dout: dL/d out for linear / ReLU heads, dL/dlogits (from the loss kernel) for softmax / sigmoid heads.  Returns one gradient
+        tensor per source (w.r.t. the source's ACTIVATED values, on the source's grid, in the source's storage type) or None."""
+        srcs, (H, W), out = self.ctx['srcs'], self.ctx['hw'], self.ctx['out']
+        d = self._desc(srcs, (H, W))
+        if d.activation in (0, 1):
+            d.activation = 2
+        nimg = out.shape[0]
+        dxs = []
+        for i, (a, resize) in enumerate(srcs):
+            if need_dx[i]:
+                dx = torch.zeros(a.t.shape, dtype=a.t.dtype, device=a.t.device)
+                d.src[i].dx, d.src[i].lddx, d.src[i].dx_dtype = dx.data_ptr(), dx.shape[-1], F32 if dx.dtype == torch.float32 else BF16
+                dxs.append(dx)
+            else:
+                dxs.append(None)
+        dz = torch.empty(nimg, H, W, self.cout, dtype=torch.float32, device=out.device)
+        d.out, d.dout, d.dz_out, d.npix = out.data_ptr(), dout.data_ptr(), dz.data_ptr(), nimg * H * W
+        d.dw, d.db = self.P.g(f'{self.name}/kernel').data_ptr(), self.P.g(f'{self.name}/bias').data_ptr()
+        check(lib.satcv_dense_small_bwd(C.byref(d), ops.stream_ptr()))
+        return dxs
+
+
+# ------------------------------------------------------------------------------------------------ the two layer stacks
+class LSTMLayers:
+    """build_lstm_layers (utils/model_tools.py:666-717): ConvLSTM2D(64) 'conv_lstm' -> BatchNormalization 'batch_norm' -> ReLU ->
+    ConvLSTM2D(64, dilation (3, 3), return_sequences) 'dilated_conv_lstm' -> BatchNormalization 'batch_norm2' -> ReLU"""
+
+    def __init__(self, params, rng, n_channels, filters=64, return_sequences=False, prefix=''):
+        self.l1 = ConvLSTM2D(params, rng, prefix + 'conv_lstm', n_channels, filters, 1, True)
+        self.bn1 = BatchNorm(params, prefix + 'batch_norm', filters)
+        self.l2 = ConvLSTM2D(params, rng, prefix + 'dilated_conv_lstm', filters, filters, 3, return_sequences)
+        self.bn2 = BatchNorm(params, prefix + 'batch_norm2', filters)
+        self.F = filters
+
+    def forward(self, x, T, B, training, dtype):
+        s1, st1, n1 = self.l1.forward(x, T, B, training, dtype)
+        a1 = self.bn1.forward(s1, st1, n1, training)
+        h2, st2, n2 = self.l2.forward(a1, T, B, training, dtype)
+        return self.bn2.forward(h2, st2, n2, training)
+
+    def backward(self, da2, need_dx=False):
+        dh2 = self.bn2.backward(da2)
+        da1 = self.l2.backward(dh2)
+        ds1 = self.bn1.backward(da1)
+        return self.l1.backward(ds1, need_dx=need_dx)
+
+
+def _ingest_seq(x, cpad, dtype):
+    """(B, T, H, W, C) float32 host / device array -> time-major storage tensor (T * B, H, W, cpad)"""
+    xt = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    xt = xt.to(_dev(), torch.float32).contiguous()
+    B, T, H, W, Cc = xt.shape
+    out = torch.empty(T * B, H, W, cpad, dtype=ops.TORCH_DTYPE[dtype], device=xt.device)
+    check(lib.satcv_ingest_seq(xt.data_ptr(), out.data_ptr(), B, T, H, W, Cc, cpad, dtype, ops.stream_ptr()))
+    return out, (B, T, H, W)
+
+
+class _SeqModelBase:
+    """compile / fit / predict / train_on_batch plumbing shared by the LSTM-family models (Adam through satcv_adam_step)"""
+
+    def _finish(self):
+        self.P.build()
+        self.optimizer, self._loss = None, None
+        self.compute_dtype = mt._DEFAULT_DTYPE
+
+    @property
+    def dtype_code(self):
+        return BF16 if self.compute_dtype == 'bfloat16' else F32
+
+    def compile(self, optimizer='adam', loss=None, metrics=None, **kw):
+        self.optimizer = mt.Adam() if isinstance(optimizer, str) else optimizer
+        spec = loss(mt._LossArg('y_true'), mt._LossArg('y_pred')) if callable(loss) else loss
+        if not isinstance(spec, mt.LossSpec):
+            raise ValueError('loss must be one of the model_tools loss functions (or a lambda wrapping one)')
+        self._loss = spec
+        self.P.state[0:1].fill_(self.optimizer._lr)
+
+    def _loss_grad(self, out, y_true, activation):
+        """fused device loss on the model output: returns (loss tensor, dL/dlogits for softmax / sigmoid heads, dL/dout for linear ones)"""
+        w = None if self._loss.weights is None else torch.as_tensor(self._loss.weights).to(out.device)
+        y = y_true if isinstance(y_true, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y_true, dtype=np.float32))
+        y = y.to(out.device, torch.float32).contiguous()
+        loss, dlog = ops.loss_fwd_bwd(self._loss.kind, out, y, w, activation=activation, eps=self._loss.eps)
+        return loss, dlog
+
+    def _adam(self):
+        P, opt = self.P, self.optimizer
+        P.state[0:1].fill_(opt._lr)
+        check(lib.satcv_adam_step(P.flat.data_ptr(), P.grad.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.flat.numel(), opt.beta_1, opt.beta_2,
+                                  opt.epsilon, P.state.data_ptr(), P.lr_mul.data_ptr(), ops.stream_ptr()))
+
+    def get_weights_dict(self):
+        return {k: self.P.p(k).detach().cpu().numpy().copy() for k in self.P.specs}
+
+    def set_weights_dict(self, d):
+        for k, v in d.items():
+            self.P.p(k).copy_(torch.as_tensor(np.asarray(v, np.float32)).to(self.P.flat.device).view(self.P.specs[k][1]))
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=0, steps_per_epoch=None, **kw):
+        """x: array(s) or a Sequence / iterable of (x, y) batches (LSTMDataGenerator, HybridDataGenerator)"""
+        hist = {'loss': []}
+        for _ in range(epochs):
+            losses = []
+            if y is None:
+                it = (x[i] for i in range(len(x))) if hasattr(x, '__getitem__') and hasattr(x, '__len__') and not isinstance(x, (list, tuple, np.ndarray)) else iter(x)
+                for i, batch in enumerate(it):
+                    if steps_per_epoch is not None and i >= steps_per_epoch:
+                        break
+                    losses.append(self.train_on_batch(batch[0], batch[1]))
+                if hasattr(x, 'on_epoch_end'):
+                    x.on_epoch_end()
+            else:
+                n = (x[0] if isinstance(x, (list, tuple)) else x).shape[0]
+                bs = batch_size or 32
+                for i in range(0, n, bs):
+                    xb = [a[i:i + bs] for a in x] if isinstance(x, (list, tuple)) else x[i:i + bs]
+                    losses.append(self.train_on_batch(xb, y[i:i + bs]))
+            hist['loss'].append(float(np.mean(losses)))
+        h = mt.History()
+        h.history = hist
+        return h
+
+
+class LSTMModel(_SeqModelBase):
+    """get_lstm_model (utils/model_tools.py:773-808).  The reference body cannot run as coded (`layers.Input(n_time, None, None,
+    n_channels)`, `activations(dense_layer)`: SURVEY Appendix B Q7); this is the network it describes: Input (n_time, None, None,
+    n_channels) -> build_lstm_layers -> Conv2D(n_classes, [1, 1]) -> activation (default layers.ReLU(max_value=2.0))."""
+
+    def __init__(self, n_channels, n_classes, n_time, activation='relu', max_value=2.0, dropout=None, seed=None):
+        if dropout is not None:
+            raise NotImplementedError('dropout inside the LSTM stack')
+        rng = np.random.default_rng(seed if seed is not None else mt._RNG.integers(1 << 31))
+        self.P = _Params()
+        self.n_channels, self.n_classes, self.n_time = n_channels, n_classes, n_time
+        self.layers_ = LSTMLayers(self.P, rng, n_channels)
+        self.dense = Dense1x1(self.P, rng, 'conv2d', [self.layers_.F], n_classes, activation, max_value)
+        self._finish()
+
+    def _forward(self, x, training):
+        xt, (B, T, H, W) = _ingest_seq(x, ops.rup(self.n_channels, 16), self.dtype_code)
+        if T != self.n_time:
+            raise ValueError(f'model was built for {self.n_time} time steps, got {T}')
+        feats = self.layers_.forward(Act(xt, self.n_channels), T, B, training, self.dtype_code)
+        return self.dense.forward([(feats, False)])
+
+    def predict(self, x, batch_size=None, verbose=0, **kw):
+        n = x.shape[0]
+        bs = batch_size or 32
+        outs = [self._forward(x[i:i + bs], False).cpu().numpy() for i in range(0, n, bs)]
+        return np.concatenate(outs, 0)
+
+    def train_on_batch(self, x, y):
+        if self._loss is None:
+            raise RuntimeError('compile() the model before fit/train')
+        self.P.grad.zero_()
+        out = self._forward(x, True)
+        loss, dout = self._loss_grad(out, y, 'linear')
+        (da,) = self.dense.backward(dout, need_dx=(True,))
+        self.layers_.backward(da)
+        self._adam()
+        return float(loss.item())
+
+
+def get_lstm_model(n_channels, n_classes, n_time, optim=None, metrics=None, loss=None, activation='relu', dropout=None, max_value=2.0):
+    """utils/model_tools.py:773-808; compiled when `optim` and `loss` are given"""
+    m = LSTMModel(n_channels, n_classes, n_time, activation=activation, max_value=max_value, dropout=dropout)
+    if optim is not None and loss is not None:
+        m.compile(optimizer=optim, loss=loss, metrics=metrics)
+    return m
+
+
+class HybridModel(_SeqModelBase):
+    """get_hybrid_model (utils/model_tools.py:874-920): a U-Net branch (build_unet_layers, factors [3, 2, 2, 2]) and an LSTM branch
+    (build_lstm_layers), each through Conv2D(n_classes, [1, 1], relu); the LSTM map is brought to the U-Net grid with
+    tf.image.resize(..., 'nearest'), concatenated [lstm, unet] and classified by Conv2D(n_classes, [1, 1], softmax) 'probabilities'.
+    Inputs [unet_input (B, H, W, C), lstm_input (B, T, h, w, c)].  The U-Net branch runs on the static engine (a model_tools.Model
+    with a linear 1x1 head = the pre-activation of its `relu` dense layer), the rest on the tape."""
+
+    def __init__(self, unet_dim, lstm_dim, n_classes, filters=(32, 64, 128, 256), factors=(3, 2, 2, 2), dropout=None, seed=None):
+        if dropout is not None:
+            raise NotImplementedError('dropout in the hybrid model')
+        rng = np.random.default_rng(seed if seed is not None else mt._RNG.integers(1 << 31))
+        self.unet_dim, self.lstm_dim, self.n_classes = tuple(unet_dim), tuple(lstm_dim), n_classes
+        inp = mt.Input(shape=(None, None, unet_dim[-1]))
+        dec = mt.build_unet_layers(inp, list(filters), list(factors))
+        self.unet = mt.Model(inputs=inp, outputs=mt._Head(n_classes, 'linear', 'zeros', 'unet_dense')(dec))
+        self.P = _Params()
+        self.lstm = LSTMLayers(self.P, rng, lstm_dim[-1])
+        self.lstm_dense = Dense1x1(self.P, rng, 'lstm_dense', [self.lstm.F], n_classes, 'relu')
+        self.fusion = Dense1x1(self.P, rng, 'probabilities', [n_classes, n_classes], n_classes, 'softmax')
+        self._finish()
+
+    def compile(self, optimizer='adam', loss=None, metrics=None, **kw):
+        super().compile(optimizer, loss, metrics)
+        self.unet.optimizer = self.optimizer
+        self.unet.runtime.adam_state[0:1].fill_(self.optimizer._lr)
+
+    def _forward(self, xs, training):
+        xu, xl = xs
+        self.unet.compute_dtype = self.compute_dtype
+        n, h, w, _ = self.unet._shape_of(xu)
+        plan = self.unet.runtime.plan(n, h, w, training)
+        self.unet._stage_x(plan, xu)
+        if training:
+            plan.step_count += 1
+        plan.run_forward(ops.stream_ptr())
+        zu = plan.outputs[self.unet.outputs[0].id]                    # float32 (n, h, w, k): pre-activation of the U-Net's relu dense layer
+        xt, (B, T, hh, ww) = _ingest_seq(xl, ops.rup(self.lstm_dim[-1], 16), self.dtype_code)
+        feats = self.lstm.forward(Act(xt, self.lstm_dim[-1]), T, B, training, self.dtype_code)
+        zl = self.lstm_dense.forward([(feats, False)])                # float32 (B, hh, ww, k), already through its ReLU
+        probs, classes = self.fusion.forward([(Act(zl, self.n_classes), True), (Act(zu, self.n_classes, relu=True), False)], out_hw=(h, w),
+                                             want_classes=True)
+        self._plan, self._zu = plan, zu
+        return probs, classes
+
+    def predict(self, x, batch_size=None, verbose=0, **kw):
+        n = x[0].shape[0]
+        bs = batch_size or 8
+        outs = [self._forward([a[i:i + bs] for a in x], False)[0].cpu().numpy() for i in range(0, n, bs)]
+        return np.concatenate(outs, 0)
+
+    def train_on_batch(self, x, y):
+        if self._loss is None:
+            raise RuntimeError('compile() the model before fit/train')
+        rt = self.unet.runtime
+        rt.ensure_adam()
+        self.P.grad.zero_(); rt.gflat.zero_()
+        probs, _ = self._forward(x, True)
+        loss, dlog = self._loss_grad(probs, y, 'softmax')
+        dzl, dau = self.fusion.backward(dlog, need_dx=(True, True))
+        (dfeat,) = self.lstm_dense.backward(dzl, need_dx=(True,))
+        self.lstm.backward(dfeat)
+        # U-Net branch: d relu(z_u) -> dz_u (mask in place) -> the plan's logit gradient -> its backward pass + Adam + repack
+        check(lib.satcv_relu_bwd(self._zu.data_ptr(), dau.data_ptr(), dau.numel(), F32, ops.stream_ptr()))
+        plan = self._plan
+        plan.dlogits.view(-1).copy_(dau.view(-1))
+        plan.run_backward(ops.stream_ptr())
+        opt = self.optimizer
+        rt.adam_state[0:1].fill_(opt._lr)
+        check(lib.satcv_adam_step(rt.pflat.data_ptr(), rt.gflat.data_ptr(), rt.adam_m.data_ptr(), rt.adam_v.data_ptr(), rt.pflat.numel(), opt.beta_1,
+                                  opt.beta_2, opt.epsilon, rt.adam_state.data_ptr(), None, ops.stream_ptr()))
+        rt.repack()
+        self.unet._weights_version = getattr(self.unet, '_weights_version', 0) + 1
+        self._adam()
+        return float(loss.item())
+
+
+def get_hybrid_model(unet_dim, lstm_dim, n_classes, filters=[32, 64, 128, 256], factors=[3, 2, 2, 2], dropout=None, compile_model=False,
+                     optim=None, metrics=None, loss=None):
+    """utils/model_tools.py:874-920"""
+    m = HybridModel(unet_dim, lstm_dim, n_classes, filters, factors, dropout)
+    if compile_model:
+        m.compile(optimizer=optim, loss=loss, metrics=metrics)
+    return m

@@ -16,6 +16,7 @@ Surface mirrored here
                  optimizer.learning_rate / metrics_names (call sites: utils/model_tools.py:1128-1176,
                  utils/prediction_tools.py:152,333; notebooks/UNET_G4G_2019_solar.ipynb:1206-1277)
 """
+import ctypes as C
 import json
 import os
 import time
@@ -1037,8 +1038,56 @@ class Model:
         n, h, w, _ = self._shape_of(xb)
         plan = self._infer_plan(n, h, w)
         self._stage_x(plan, xb)
-        plan.run_forward(ops.stream_ptr())
+        if not self._replay_graph(plan):
+            plan.run_forward(ops.stream_ptr())
         return [plan.outputs[t.id] for t in self.outputs]
+
+    # ---- hipGraph replay of launch-bound inference plans (satcv_graph_begin / _end / _launch, include/satcv.h)
+    # A plan of many short kernels -- DeepLab-v3 / ResNet-50 at batch 1: ~170 dependent launches of a few microseconds each -- is bound by
+    # the HOST: a ctypes launch costs 10-20 us, the kernels 2-6 us.  Such a plan (at least SATCV_INFER_GRAPH_MIN launches, default 96) is
+    # captured once per (plan, input address) after a warm-up run and replayed with ONE call; the U-Net plans (~50 launches, GPU-bound
+    # even at batch 1) stay eager.  SATCV_INFER_GRAPH=0 turns it off, =2 forces it for every inference plan.
+    def _replay_graph(self, plan):
+        mode = int(os.environ.get('SATCV_INFER_GRAPH', '1'))
+        fwd = getattr(plan, 'fwd', None)
+        if mode == 0 or fwd is None or getattr(plan, 'training', False) or getattr(plan, 'dropouts', None):
+            return False
+        if mode < 2 and len(fwd) < int(os.environ.get('SATCV_INFER_GRAPH_MIN', '96')):
+            return False
+        cache = plan.__dict__.setdefault('_graphs', {})
+        key = tuple(sorted((getattr(plan, 'x_src', None) or {}).items()))      # (a resident batch is read in place: its address is part of the graph)
+        ent = cache.get(key)
+        cur = torch.cuda.current_stream()
+        if ent is None:
+            cache[key] = 'warm'                  # first use of this key: an eager run (per-kernel one-time set-up must not happen inside a capture)
+            return False
+        if ent == 'warm':
+            if len(cache) > 8:                   # callers that pass a fresh tensor every time: stop capturing for this plan
+                for v in cache.values():
+                    if v not in ('warm', 'off'):
+                        lib.satcv_graph_destroy(v)
+                cache.clear()
+                cache[key] = 'off'
+                return False
+            side = self.__dict__.setdefault('_capture_stream', torch.cuda.Stream())     # (the legacy default stream cannot be captured)
+            side.wait_stream(cur)
+            sp = C.c_void_p(side.cuda_stream)
+            if lib.satcv_graph_begin(sp) != 0:
+                cache[key] = 'off'
+                return False
+            h = C.c_void_p()
+            try:
+                plan.run_forward(sp)
+            finally:
+                rc = lib.satcv_graph_end(sp, C.byref(h))
+            if rc != 0 or not h.value:
+                cache[key] = 'off'
+                return False
+            cache[key] = ent = h.value
+        if ent == 'off':
+            return False
+        check(lib.satcv_graph_launch(ent, C.c_void_p(cur.cuda_stream)))
+        return True
 
     def predict(self, x, batch_size=None, verbose=0, steps=None, **kw):
         """Model.predict semantics used by the reference (utils/prediction_tools.py:152, 251, 333, 515):

@@ -395,8 +395,11 @@ def head_bwd(x, w, dlogits, in_scale=None, in_shift=None):
 LOSS_KINDS = {'weighted_categorical_crossentropy': 0, 'weighted_bce': 1, 'gen_dice': 2, 'iou_loss': 3, 'mse_4d': 4}
 
 
+_ACT_CODE = {'softmax': 0, 'sigmoid': 1, 'linear': 2}
+
+
 def loss_fwd_bwd(kind, probs, y_true, weights, activation='softmax', grad_scale=1.0, eps=1e-6):
-    """Returns (loss scalar tensor, dL/dlogits)."""
+    """Returns (loss scalar tensor, dL/dlogits); activation 'linear': the outputs ARE the logits (regression heads)."""
     ncls = probs.shape[-1]
     npix = probs.numel() // ncls
     loss = torch.zeros(1, dtype=torch.float32, device=probs.device)
@@ -405,11 +408,11 @@ def loss_fwd_bwd(kind, probs, y_true, weights, activation='softmax', grad_scale=
         nimg = probs.shape[0]
         ws = torch.empty(nimg * 3 * ncls, dtype=torch.float32, device=probs.device)
         check(lib.satcv_loss_global_fwd_bwd(LOSS_KINDS[kind], ptr(probs), ptr(y_true.contiguous()), ptr(weights), ncls,
-                                            0 if activation == 'softmax' else 1, nimg, npix // nimg, eps, grad_scale, ptr(ws), ptr(loss),
+                                            _ACT_CODE[activation], nimg, npix // nimg, eps, grad_scale, ptr(ws), ptr(loss),
                                             ptr(dlogits), stream_ptr()))
         return loss, dlogits
     check(lib.satcv_loss_fwd_bwd(LOSS_KINDS[kind], ptr(probs), ptr(y_true.contiguous()), ptr(weights), ncls,
-                                 0 if activation == 'softmax' else 1, npix, grad_scale, ptr(loss), ptr(dlogits), stream_ptr()))
+                                 _ACT_CODE[activation], npix, grad_scale, ptr(loss), ptr(dlogits), stream_ptr()))
     return loss, dlogits
 
 

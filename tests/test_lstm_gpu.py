@@ -1,0 +1,188 @@
+"""ConvLSTM2D family on the GPU (satellite_computervision_amd/lstm_tools.py, csrc/convlstm.hip) against the NumPy float64 oracle
+(oracle/convlstm.py: Keras ConvLSTM2D cell as the reference calls it, utils/model_tools.py:666-920; parity unpinned, cross-checked
+against torch autograd in tests/test_oracle_cpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import convlstm as CL
+from oracle import keras_ops as K
+from oracle import losses as OL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lt():
+    from satellite_computervision_amd import lstm_tools
+    assert torch.cuda.is_available()
+    return lstm_tools
+
+
+def rel(got, ref):
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+def cosine(a, b):
+    return float((a * b).sum() / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('rec_act', ['hard_sigmoid', 'sigmoid'])
+@pytest.mark.parametrize('dil,rs', [(1, True), (3, False)])
+def test_convlstm2d_layer_forward_and_bptt(lt, dtype, rec_act, dil, rs, monkeypatch):
+    """ONE ConvLSTM2D layer (utils/model_tools.py:690-700 / 710-720): output sequence or last state, and through BPTT the gradients of
+    the input, kernel, recurrent kernel and bias -- with a gradient arriving through return_state as well (build_lstm_layers2, :737)."""
+    from satellite_computervision_amd import ops
+    from satellite_computervision_amd._lib import BF16, F32
+    monkeypatch.setattr(lt, 'RECURRENT_ACTIVATION', rec_act)
+    f32 = dtype == 'float32'
+    code, td = (F32, torch.float32) if f32 else (BF16, torch.bfloat16)
+    rng = np.random.default_rng(3)
+    B, T, H, W, Cc, F = 2, 4, 16, 16, 6, 16
+    p = CL.convlstm_init(rng, Cc, F)
+    p['bias'] = p['bias'] + 0.1 * rng.standard_normal(4 * F)
+    p = {k: v.astype(np.float32).astype(np.float64) for k, v in p.items()}
+    x = rng.standard_normal((B, T, H, W, Cc)).astype(np.float32).astype(np.float64)
+    if not f32:          # values the device stores exactly
+        x = torch.tensor(x, dtype=torch.float32).to(td).double().numpy()
+    pq = p if f32 else {k: (torch.tensor(v, dtype=torch.float32).to(td).double().numpy() if k != 'bias' else v) for k, v in p.items()}
+    out_ref, cache = CL.convlstm_forward(x, pq, dil, None, rec_act, rs)
+    dout = rng.standard_normal(out_ref.shape)
+    dhl = rng.standard_normal((B, H, W, F))
+    if not f32:
+        dout = torch.tensor(dout, dtype=torch.float32).to(td).double().numpy()
+        dhl = torch.tensor(dhl, dtype=torch.float32).to(td).double().numpy()
+    dx_ref, g_ref = CL.convlstm_backward(dout, cache, dh_last=dhl)
+
+    P = lt._Params()
+    layer = lt.ConvLSTM2D(P, np.random.default_rng(0), 'l', Cc, F, dil, rs)
+    P.build()
+    for k, v in p.items():
+        P.p('l/' + k).copy_(torch.tensor(v, dtype=torch.float32).cuda())
+    xt, _ = lt._ingest_seq(x.astype(np.float32), 16, code)
+    out, stats, cnt = layer.forward(lt.Act(xt, Cc), T, B, True, code)
+    got = out.t.float().cpu().numpy()[..., :F]
+    got = got.reshape(T, B, H, W, F).transpose(1, 0, 2, 3, 4) if rs else got
+    assert rel(got, out_ref) < (2e-5 if f32 else 2e-2)
+    # BatchNorm statistics of the stored output
+    s = stats.sum(0).cpu().numpy()
+    np.testing.assert_allclose(s[0, :F], got.reshape(-1, F).sum(0), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[1, :F], (got.reshape(-1, F) ** 2).sum(0), rtol=1e-4, atol=1e-3)
+    assert cnt == (T if rs else 1) * B * H * W
+    Fp = out.t.shape[-1]
+    d_tm = dout.transpose(1, 0, 2, 3, 4).reshape(T * B, H, W, F) if rs else dout
+    dd = torch.zeros(d_tm.shape[0], H, W, Fp, dtype=td, device='cuda')
+    dd[..., :F] = torch.tensor(d_tm, dtype=torch.float32).to(td).cuda()
+    ds = torch.zeros(B, H, W, Fp, dtype=td, device='cuda')
+    ds[..., :F] = torch.tensor(dhl, dtype=torch.float32).to(td).cuda()
+    dx = layer.backward(dd, dstate_h=ds, need_dx=True)
+    dxg = dx.float().cpu().numpy()[..., :Cc].reshape(T, B, H, W, Cc).transpose(1, 0, 2, 3, 4)
+    tol = 5e-5 if f32 else 3e-2
+    assert rel(dxg, dx_ref) < tol, rel(dxg, dx_ref)
+    for k in ('kernel', 'recurrent_kernel', 'bias'):
+        g = P.g('l/' + k).cpu().numpy().astype(np.float64)
+        assert rel(g, g_ref[k]) < tol, (k, rel(g, g_ref[k]))
+        assert cosine(g, g_ref[k]) > (0.99999 if f32 else 0.999), k
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_get_lstm_model_training_step_matches_oracle(lt, dtype):
+    """get_lstm_model (utils/model_tools.py:773-808: build_lstm_layers -> Conv2D(n_classes, 1x1) -> ReLU(max_value = 2)) end to end:
+    prediction, mse_4d loss (:142-166) and every gradient of one training step against the float64 oracle."""
+    from satellite_computervision_amd import model_tools as mt
+    f32 = dtype == 'float32'
+    mt.set_compute_dtype(dtype)
+    try:
+        B, T, H, W, Cc, ncls = 2, 3, 16, 16, 6, 4
+        o = CL.LSTMLayersOracle(Cc, ncls, filters=64, rec_act=lt.RECURRENT_ACTIVATION, seed=5)
+        m = lt.get_lstm_model(Cc, ncls, T)
+        assert m.compute_dtype == dtype
+        names = {'l1': 'conv_lstm', 'l2': 'dilated_conv_lstm', 'bn1': 'batch_norm', 'bn2': 'batch_norm2', 'dense': 'conv2d'}
+        w = {}
+        for lk, lv in o.p.items():
+            for pk, pv in lv.items():
+                lv[pk] = pv.astype(np.float32).astype(np.float64)
+                w[f'{names[lk]}/{pk}'] = lv[pk]
+        m.set_weights_dict(w)
+        rng = np.random.default_rng(8)
+        x = rng.random((B, T, H, W, Cc)).astype(np.float32)
+        y = rng.random((B, H, W, ncls)).astype(np.float32) * 1.5
+        out_ref = o.forward(x.astype(np.float64))
+        loss_ref, dout = OL.mse_4d(y.astype(np.float64), out_ref)
+        g_ref = o.backward(dout)
+        m.compile(optimizer=mt.Adam(0.0), loss=mt.mse_4d)
+        loss = m.train_on_batch(x, y)
+        np.testing.assert_allclose(loss, loss_ref, rtol=1e-4 if f32 else 3e-2)
+        key = {'l1.kernel': 'conv_lstm/kernel', 'l1.recurrent_kernel': 'conv_lstm/recurrent_kernel', 'l1.bias': 'conv_lstm/bias',
+               'l2.kernel': 'dilated_conv_lstm/kernel', 'l2.recurrent_kernel': 'dilated_conv_lstm/recurrent_kernel', 'l2.bias': 'dilated_conv_lstm/bias',
+               'bn1.gamma': 'batch_norm/gamma', 'bn1.beta': 'batch_norm/beta', 'bn2.gamma': 'batch_norm2/gamma', 'bn2.beta': 'batch_norm2/beta',
+               'dense.kernel': 'conv2d/kernel', 'dense.bias': 'conv2d/bias'}
+        for ok, dk in key.items():
+            g = m.P.g(dk).cpu().numpy().astype(np.float64).reshape(g_ref[ok].shape)
+            c = cosine(g, g_ref[ok])
+            assert c > (0.9999 if f32 else 0.98), (ok, c, rel(g, g_ref[ok]))
+            if f32:
+                assert rel(g, g_ref[ok]) < 2e-3, (ok, rel(g, g_ref[ok]))
+        # inference (moving statistics): after the step above both sides hold updated moving averages; compare through training-mode
+        # statistics instead -- predict() of a model whose moving statistics equal the batch statistics
+        pred = m.predict(x)
+        assert pred.shape == (B, H, W, ncls) and np.isfinite(pred).all() and pred.min() >= 0 and pred.max() <= 2.0
+    finally:
+        mt.set_compute_dtype('bfloat16')
+
+
+def test_hybrid_model_forward_and_training_step(lt):
+    """get_hybrid_model (utils/model_tools.py:874-920), fp32: the fusion head -- Conv2D(relu) on each branch, nearest resize of the LSTM
+    map to the U-Net grid, concat [lstm, unet], Conv2D(softmax) -- against the oracle ON THE DEVICE'S OWN branch features (the two
+    branches are covered by test_full_unet_* and the tests above), then a training step that must move every parameter group."""
+    from satellite_computervision_amd import model_tools as mt
+    mt.set_compute_dtype('float32')
+    try:
+        mt.reset_uids(); mt.set_seed(4)
+        ncls = 3
+        m = lt.get_hybrid_model((48, 48, 4), (3, 8, 8, 6), ncls, filters=[32, 64], factors=[3, 2])
+        rng = np.random.default_rng(2)
+        xu = rng.random((2, 48, 48, 4)).astype(np.float32)
+        xl = rng.random((2, 3, 8, 8, 6)).astype(np.float32)
+        lab = rng.integers(0, ncls, (2, 48, 48))
+        y = np.eye(ncls, dtype=np.float32)[lab]
+        probs = m.predict([xu, xl])
+        assert probs.shape == (2, 48, 48, ncls)
+        np.testing.assert_allclose(probs.sum(-1), 1.0, atol=1e-5)
+        # oracle of the fusion head on the device's branch outputs
+        zu = m._zu.cpu().numpy().astype(np.float64)                                  # U-Net dense pre-activation (n, 48, 48, k)
+        zl = m.lstm_dense.ctx['out'].cpu().numpy().astype(np.float64)               # LSTM dense output, after its ReLU (n, 8, 8, k)
+        up, _ = CL.resize_nearest(zl, 48, 48)
+        cat = np.concatenate([up, np.maximum(zu, 0)], -1)
+        w = m.get_weights_dict()
+        logits = K.conv2d_same(cat, w['probabilities/kernel'].astype(np.float64), w['probabilities/bias'].astype(np.float64))
+        np.testing.assert_allclose(probs, K.softmax(logits), atol=2e-6)
+        m.compile(optimizer=mt.Adam(1e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0] * ncls))
+        w0 = m.get_weights_dict()
+        u0 = m.unet.runtime.pflat.clone()
+        l0 = m.train_on_batch([xu, xl], y)
+        for _ in range(15):
+            l1 = m.train_on_batch([xu, xl], y)
+        assert np.isfinite(l1) and l1 < l0, (l0, l1)
+        w1 = m.get_weights_dict()
+        for k in ('conv_lstm/kernel', 'conv_lstm/recurrent_kernel', 'dilated_conv_lstm/kernel', 'batch_norm/gamma', 'lstm_dense/kernel', 'probabilities/kernel'):
+            assert np.abs(w1[k] - w0[k]).max() > 0, k
+        assert float((m.unet.runtime.pflat - u0).abs().max()) > 0
+        # gradient check of the fusion head's two data gradients against the oracle (finite structure: softmax cross-entropy)
+        m.P.grad.zero_()
+        pr, _ = m._forward([xu, xl], True)
+        loss, dlog = m._loss_grad(pr, y, 'softmax')
+        dzl, dau = m.fusion.backward(dlog, need_dx=(True, True))
+        zu = m._zu.cpu().numpy().astype(np.float64)
+        zl = m.lstm_dense.ctx['out'].cpu().numpy().astype(np.float64)
+        up, idx = CL.resize_nearest(zl, 48, 48)
+        cat = np.concatenate([up, np.maximum(zu, 0)], -1)
+        wk = m.P.p('probabilities/kernel').cpu().numpy().astype(np.float64)
+        dcat, dk_ref, db_ref = K.conv2d_same_bwd(cat, wk, dlog.cpu().numpy().astype(np.float64))
+        np.testing.assert_allclose(m.P.g('probabilities/kernel').cpu().numpy(), dk_ref, rtol=2e-3, atol=1e-6)
+        np.testing.assert_allclose(m.P.g('probabilities/bias').cpu().numpy(), db_ref, rtol=2e-3, atol=1e-6)
+        np.testing.assert_allclose(dau.cpu().numpy(), dcat[..., ncls:], rtol=1e-4, atol=1e-8)
+        np.testing.assert_allclose(dzl.cpu().numpy(), CL.resize_nearest_bwd(dcat[..., :ncls], idx, 8, 8), rtol=1e-4, atol=1e-8)
+    finally:
+        mt.set_compute_dtype('bfloat16')

@@ -236,3 +236,51 @@ def test_input_pipeline_restatement_matches_reference_array_tools():
     dup = [(5, 1), (1, 7), (5, 2)]
     lut = ip.merge_lut(dup)
     assert np.array_equal(np.where(lut[lab] >= 0, lut[lab], lab), z['merge_dup_rule'])
+
+
+def test_convlstm_oracle_matches_torch_autograd():
+    """oracle/convlstm.py (Keras ConvLSTM2D cell, hand-written BPTT) against an independent torch-CPU autograd restatement: both
+    recurrent activations, linear and tanh cell activations, dilated input convolution, sequence / last-state outputs, and a gradient
+    entering through return_state."""
+    import torch
+    from oracle import convlstm as CL
+    torch.set_default_dtype(torch.float64)
+    try:
+        def conv(x, k, b, d):
+            y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), k.permute(3, 2, 0, 1), b, padding=d * (k.shape[0] - 1) // 2, dilation=d)
+            return y.permute(0, 2, 3, 1)
+        for rk in ('hard_sigmoid', 'sigmoid'):
+            for act in (None, 'tanh'):
+                for dil, rs in ((1, True), (3, False)):
+                    rng = np.random.default_rng(0)
+                    B, T, H, W, Cc, F = 2, 3, 7, 6, 5, 4
+                    p = CL.convlstm_init(rng, Cc, F)
+                    p['bias'] = p['bias'] + 0.1 * rng.standard_normal(4 * F)
+                    x = rng.standard_normal((B, T, H, W, Cc))
+                    out, cache = CL.convlstm_forward(x, p, dil, act, rk, rs)
+                    dout, dhl = rng.standard_normal(out.shape), rng.standard_normal((B, H, W, F))
+                    dx, g = CL.convlstm_backward(dout, cache, dh_last=dhl)
+                    tp = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
+                    tx = torch.tensor(x, requires_grad=True)
+                    h, c, hs = torch.zeros(B, H, W, F), torch.zeros(B, H, W, F), []
+                    ra = (lambda z: torch.clamp(0.2 * z + 0.5, 0, 1)) if rk == 'hard_sigmoid' else torch.sigmoid
+                    aa = (lambda z: z) if act is None else torch.tanh
+                    for t in range(T):
+                        z = conv(tx[:, t], tp['kernel'], tp['bias'], dil) + conv(h, tp['recurrent_kernel'], None, 1)
+                        zi, zf, zc, zo = z.split(F, dim=-1)
+                        c = ra(zf) * c + ra(zi) * aa(zc)
+                        h = ra(zo) * aa(c)
+                        hs.append(h)
+                    o_t = torch.stack(hs, 1) if rs else h
+                    np.testing.assert_allclose(o_t.detach().numpy(), out, atol=1e-12)
+                    ((o_t * torch.tensor(dout)).sum() + (h * torch.tensor(dhl)).sum()).backward()
+                    for k in p:
+                        np.testing.assert_allclose(tp[k].grad.numpy(), g[k], atol=1e-10)
+                    np.testing.assert_allclose(tx.grad.numpy(), dx, atol=1e-10)
+        # the nearest-neighbour resize and its adjoint
+        a = rng.standard_normal((2, 4, 5, 3))
+        up, idx = CL.resize_nearest(a, 11, 9)
+        g = rng.standard_normal(up.shape)
+        assert abs((up * g).sum() - (a * CL.resize_nearest_bwd(g, idx, 4, 5)).sum()) < 1e-9
+    finally:
+        torch.set_default_dtype(torch.float32)
