@@ -205,3 +205,65 @@ class LSTMLayersOracle:
         g = self.features_bwd(da2)
         g['dense.kernel'], g['dense.bias'] = dk, db
         return g
+
+
+class LSTMAutoencoderOracle:
+    """get_lstm_autoencoder (utils/model_tools.py:810-872) with build_lstm_layers2 (:719-771) as its encoder: forward of both outputs
+    and the gradients of  sum(mse_4d-style upstream gradients)  through both branches."""
+
+    def __init__(self, n_channels, n_time, n_classes, rec_act='hard_sigmoid', seed=0, head_max=2.0, dtype=np.float64):
+        rng = np.random.default_rng(seed)
+        F = 16
+        self.F, self.T, self.rec_act, self.head_max = F, n_time, rec_act, head_max
+        self.p = {'l1': convlstm_init(rng, n_channels, F, dtype=dtype), 'l2': convlstm_init(rng, F, F, dtype=dtype),
+                  'dec': convlstm_init(rng, F, 32, dtype=dtype)}
+        for b in ('bn1', 'bn2'):
+            self.p[b] = {'gamma': np.ones(F, dtype), 'beta': np.zeros(F, dtype)}
+        for name, cin in (('temporal', 32), ('single', F + 2)):
+            lim = np.sqrt(6.0 / (cin + n_classes))
+            self.p[name] = {'kernel': rng.uniform(-lim, lim, (1, 1, cin, n_classes)).astype(dtype), 'bias': np.zeros(n_classes, dtype)}
+
+    def _head(self, a, name):
+        z = K.conv2d_same(a, self.p[name]['kernel'], self.p[name]['bias'])
+        return z, (np.clip(z, 0.0, self.head_max) if self.head_max is not None else np.maximum(z, 0))
+
+    def forward(self, x, sincos):
+        p = self.p
+        B, T = x.shape[:2]
+        s1, c1 = convlstm_forward(x, p['l1'], 1, None, self.rec_act, True)
+        z1, m1, v1 = bn5_train(s1, p['bn1']['gamma'], p['bn1']['beta'])
+        a1 = np.maximum(z1, 0)
+        h2, c2 = convlstm_forward(a1, p['l2'], 3, None, self.rec_act, False)
+        z2, m2, v2 = bn5_train(h2, p['bn2']['gamma'], p['bn2']['beta'])
+        enc = np.maximum(c1['h_last'] + z2, 0)
+        rep = np.repeat(enc[:, None], T, axis=1)
+        dseq, cd = convlstm_forward(rep, p['dec'], 1, None, self.rec_act, True)
+        zt, tout = self._head(dseq.reshape((B * T,) + dseq.shape[2:]), 'temporal')
+        cat = np.concatenate([enc, sincos], -1)
+        zs, sout = self._head(cat, 'single')
+        self.c = dict(c1=c1, s1=s1, st1=(m1, v1), a1=a1, c2=c2, h2=h2, st2=(m2, v2), enc=enc, cd=cd, dseq=dseq, zt=zt, zs=zs, cat=cat, B=B, T=T)
+        return tout.reshape((B, T) + tout.shape[1:]), sout
+
+    def backward(self, dtout, dsout):
+        p, c, g = self.p, self.c, {}
+        B, T = c['B'], c['T']
+
+        def head_bwd(z, dout, a, name):
+            mask = (z > 0) & ((z < self.head_max) if self.head_max is not None else True)
+            da, g[name + '.kernel'], g[name + '.bias'] = K.conv2d_same_bwd(a, p[name]['kernel'], dout * mask)
+            return da
+        ddseq = head_bwd(c['zt'], dtout.reshape(c['zt'].shape), c['dseq'].reshape((B * T,) + c['dseq'].shape[2:]), 'temporal')
+        drep, gd = convlstm_backward(ddseq.reshape(c['dseq'].shape), c['cd'])
+        denc = drep.sum(axis=1)
+        dcat = head_bwd(c['zs'], dsout, c['cat'], 'single')
+        denc = denc + dcat[..., :self.F]
+        gm = denc * (c['enc'] > 0)
+        dh2, g['bn2.gamma'], g['bn2.beta'] = bn5_train_bwd(c['h2'], p['bn2']['gamma'], *c['st2'], gm)
+        da1, g2 = convlstm_backward(dh2, c['c2'])
+        dz1 = da1 * (c['a1'] > 0)
+        ds1, g['bn1.gamma'], g['bn1.beta'] = bn5_train_bwd(c['s1'], p['bn1']['gamma'], *c['st1'], dz1)
+        _, g1 = convlstm_backward(ds1, c['c1'], dh_last=gm)
+        for pre, gg in (('l1', g1), ('l2', g2), ('dec', gd)):
+            for k, v in gg.items():
+                g[f'{pre}.{k}'] = v
+        return g

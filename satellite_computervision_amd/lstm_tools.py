@@ -130,13 +130,15 @@ class ConvLSTM2D:
         self.wk, self.wk_d = ops.pack_weights(P.p(f'{self.name}/kernel'), cpad, dtype)
         self.wr, self.wr_d = ops.pack_weights(P.p(f'{self.name}/recurrent_kernel'), ops.rup(self.F, 16), dtype)
 
-    def forward(self, x, T, B, training, dtype, want_stats=True):
+    def forward(self, x, T, B, training, dtype, want_stats=True, repeat=False):
         """x: Act, time-major (T * B, H, W, Cpad).  Returns the raw output Act ((T * B, ..) or (B, ..), F channels) and its BatchNorm
-        statistics rows (sum, sum of squares of the stored h) for the BatchNormalization every reference call site applies next."""
+        statistics rows (sum, sum of squares of the stored h) for the BatchNormalization every reference call site applies next.
+        repeat: x is ONE image set (B, H, W, C) presented at every step (tf.repeat(tf.expand_dims(encoded, 1), n_time, 1),
+        utils/model_tools.py:831-832): its input convolution is computed once."""
         self._pack(dtype)
         F, P = self.F, self.P
         n, H, W, _ = x.t.shape
-        assert n == T * B
+        assert n == (B if repeat else T * B)
         td = x.t.dtype
         dev = x.t.device
         Fp = ops.rup(F, 16)
@@ -150,7 +152,7 @@ class ConvLSTM2D:
         for t in range(T):
             hg = ops.conv2d(hseq[(t - 1) * B:t * B], self.wr, 4 * F) if t > 0 else None
             d = LstmGatesDesc()
-            d.xg, d.ldx = xg[t * B:(t + 1) * B].data_ptr(), xg.shape[-1]
+            d.xg, d.ldx = (xg if repeat else xg[t * B:(t + 1) * B]).data_ptr(), xg.shape[-1]
             d.hg, d.ldh_g = (hg.data_ptr(), hg.shape[-1]) if hg is not None else (None, 0)
             d.c_prev = cseq[t - 1].data_ptr() if t > 0 else None
             d.c_out, d.h_out, d.ldh = cseq[t].data_ptr(), hseq[t * B:(t + 1) * B].data_ptr(), Fp
@@ -159,7 +161,7 @@ class ConvLSTM2D:
                 d.stats, d.stats_ld = stats.data_ptr(), Fp
             d.npix, d.filters, d.rec_act, d.act, d.dtype = npix, F, rk, self.act, ops.DTYPE_CODE[td]
             check(lib.satcv_convlstm_gates_fwd(C.byref(d), ops.stream_ptr()))
-        self.ctx = dict(x=x, T=T, B=B, H=H, W=W, hseq=hseq, cseq=cseq, gates=gates, rk=rk, td=td)
+        self.ctx = dict(x=x, T=T, B=B, H=H, W=W, hseq=hseq, cseq=cseq, gates=gates, rk=rk, td=td, repeat=repeat)
         out = hseq if self.rs else hseq[(T - 1) * B:]
         self.h_last = hseq[(T - 1) * B:]
         return Act(out, F), stats, (T * B * H * W if self.rs else B * H * W)
@@ -205,7 +207,13 @@ class ConvLSTM2D:
             dh_rec = ops.conv2d_dgrad(dz[t * B:(t + 1) * B], self.wr_d, F) if t > 0 else None
         x = c['x']
         # weight gradients: the input kernel over all T * B images at once, the recurrent kernel over steps 1 .. T-1 (h_{t-1} = hseq[t-1])
-        ops.conv2d_wgrad(x.t, dz, self.cin, 4 * F, dil=self.dil, in_scale=x.scale, in_shift=x.shift, in_relu=x.relu, dw=P.g(f'{self.name}/kernel'))
+        dz_in = dz
+        if c['repeat']:          # the same input at every step: its gradients are those of the SUM of dz over the steps (linearity)
+            dz_in = dz[:B].clone()
+            for t in range(1, T):
+                check(lib.satcv_add_act(dz_in.data_ptr(), None, None, dz[t * B:(t + 1) * B].data_ptr(), None, None, 0, dz_in.data_ptr(), npix, 4 * F,
+                                        ops.DTYPE_CODE[td], ops.stream_ptr()))
+        ops.conv2d_wgrad(x.t, dz_in, self.cin, 4 * F, dil=self.dil, in_scale=x.scale, in_shift=x.shift, in_relu=x.relu, dw=P.g(f'{self.name}/kernel'))
         if T > 1:
             ops.conv2d_wgrad(c['hseq'][:(T - 1) * B], dz[B:], F, 4 * F, dw=P.g(f'{self.name}/recurrent_kernel'))
         nb = lib.satcv_bias_grad_workspace(T * B * H * W, 4 * F)
@@ -213,7 +221,7 @@ class ConvLSTM2D:
         check(lib.satcv_bias_grad(dz.data_ptr(), 4 * F, T * B * H * W, 4 * F, ops.DTYPE_CODE[td], P.g(f'{self.name}/bias').data_ptr(), ws.data_ptr(), ops.stream_ptr()))
         if not need_dx:
             return None
-        return ops.conv2d_dgrad(dz, self.wk_d, self.cin, dil=self.dil)
+        return ops.conv2d_dgrad(dz_in, self.wk_d, self.cin, dil=self.dil)
 
 
 class BatchNorm:
@@ -369,6 +377,40 @@ class LSTMLayers:
         da1 = self.l2.backward(dh2)
         ds1 = self.bn1.backward(da1)
         return self.l1.backward(ds1, need_dx=need_dx)
+
+
+class LSTMLayers2:
+    """build_lstm_layers2 (utils/model_tools.py:719-771): ConvLSTM2D(16, return_sequences, return_state) 'conv_lstm' -> BatchNormalization
+    'batch_norm' -> ReLU -> ConvLSTM2D(16, dilation (3, 3), last state) 'dilated_conv_lstm' -> BatchNormalization 'batch_norm2';
+    output = ReLU(state_h + normalized2) with state_h the FIRST layer's final hidden state."""
+
+    def __init__(self, params, rng, n_channels, filters=16, prefix=''):
+        self.l1 = ConvLSTM2D(params, rng, prefix + 'conv_lstm', n_channels, filters, 1, True)
+        self.bn1 = BatchNorm(params, prefix + 'batch_norm', filters)
+        self.l2 = ConvLSTM2D(params, rng, prefix + 'dilated_conv_lstm', filters, filters, 3, False)
+        self.bn2 = BatchNorm(params, prefix + 'batch_norm2', filters)
+        self.F = filters
+
+    def forward(self, x, T, B, training, dtype):
+        s1, st1, n1 = self.l1.forward(x, T, B, training, dtype)
+        a1 = self.bn1.forward(s1, st1, n1, training)
+        h2, st2, n2 = self.l2.forward(a1, T, B, training, dtype)
+        z2 = self.bn2.forward(h2, st2, n2, training, relu=False)
+        state_h = self.l1.h_last
+        out = torch.empty_like(state_h)
+        nb, H, W, cp = state_h.shape
+        check(lib.satcv_add_act(z2.t.data_ptr(), z2.scale.data_ptr(), z2.shift.data_ptr(), state_h.data_ptr(), None, None, 1, out.data_ptr(),
+                                nb * H * W, cp, ops.DTYPE_CODE[out.dtype], ops.stream_ptr()))
+        self.out = out
+        return Act(out, self.F)
+
+    def backward(self, dout, need_dx=False):
+        g = dout.clone()
+        check(lib.satcv_relu_bwd(self.out.data_ptr(), g.data_ptr(), g.numel(), ops.DTYPE_CODE[g.dtype], ops.stream_ptr()))
+        dh2 = self.bn2.backward(g)                    # the masked gradient serves both addends
+        da1 = self.l2.backward(dh2)
+        ds1 = self.bn1.backward(da1)
+        return self.l1.backward(ds1, dstate_h=g, need_dx=need_dx)
 
 
 def _ingest_seq(x, cpad, dtype):
@@ -578,3 +620,81 @@ def get_hybrid_model(unet_dim, lstm_dim, n_classes, filters=[32, 64, 128, 256], 
     if compile_model:
         m.compile(optimizer=optim, loss=loss, metrics=metrics)
     return m
+
+
+class LSTMAutoencoder(_SeqModelBase):
+    """get_lstm_autoencoder (utils/model_tools.py:810-872): inputs [timeseries (B, T, H, W, C), sincos (B, H, W, 2)];
+    encoded = build_lstm_layers2(timeseries); branch 1: encoded repeated n_time times -> ConvLSTM2D(32, return_sequences) 'lstm_decoder'
+    -> TimeDistributed(Conv2D(n_classes, 1x1)) 'temporal_dense' -> activation; branch 2: concat([encoded, sincos]) -> Conv2D(n_classes,
+    1x1) 'single_dense' -> activation.  Outputs [temporal (B, T, H, W, n_classes), single (B, H, W, n_classes)].  The reference leaves
+    the model uncompiled; train_on_batch applies the compiled loss to BOTH outputs and adds the two (Keras' default for a list of outputs)."""
+
+    def __init__(self, n_channels, n_time, n_classes, activation='relu', max_value=2.0, seed=None):
+        rng = np.random.default_rng(seed if seed is not None else mt._RNG.integers(1 << 31))
+        self.P = _Params()
+        self.n_channels, self.n_time, self.n_classes = n_channels, n_time, n_classes
+        self.enc = LSTMLayers2(self.P, rng, n_channels)
+        self.dec = ConvLSTM2D(self.P, rng, 'lstm_decoder', self.enc.F, 32, 1, True)
+        self.temporal = Dense1x1(self.P, rng, 'temporal_dense', [32], n_classes, activation, max_value)
+        self.single = Dense1x1(self.P, rng, 'single_dense', [self.enc.F, 2], n_classes, activation, max_value)
+        self._finish()
+
+    def _forward(self, xs, training):
+        x, sincos = xs
+        xt, (B, T, H, W) = _ingest_seq(x, ops.rup(self.n_channels, 16), self.dtype_code)
+        if T != self.n_time:
+            raise ValueError(f'model was built for {self.n_time} time steps, got {T}')
+        enc = self.enc.forward(Act(xt, self.n_channels), T, B, training, self.dtype_code)
+        dseq, _, _ = self.dec.forward(enc, T, B, training, self.dtype_code, want_stats=False, repeat=True)
+        tout = self.temporal.forward([(dseq, False)])                         # (T * B, H, W, k), time-major
+        sc = sincos if isinstance(sincos, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(sincos, dtype=np.float32))
+        sc = sc.to(_dev(), torch.float32).contiguous()
+        sout = self.single.forward([(enc, False), (Act(sc, 2), False)])
+        self._shape = (B, T, H, W)
+        return tout, sout
+
+    def predict(self, x, batch_size=None, verbose=0, **kw):
+        tout, sout = self._forward(x, False)
+        B, T, H, W = self._shape
+        return [tout.view(T, B, H, W, -1).permute(1, 0, 2, 3, 4).contiguous().cpu().numpy(), sout.cpu().numpy()]
+
+    def train_on_batch(self, x, y):
+        if self._loss is None:
+            raise RuntimeError('compile() the model before fit/train')
+        self.P.grad.zero_()
+        tout, sout = self._forward(x, True)
+        B, T, H, W = self._shape
+        ty, sy = y
+        ty = torch.as_tensor(np.ascontiguousarray(ty, dtype=np.float32)).to(_dev()).permute(1, 0, 2, 3, 4).contiguous().view(T * B, H, W, -1)
+        l1, d1 = self._loss_grad(tout, ty, 'linear')
+        l2, d2 = self._loss_grad(sout, sy, 'linear')
+        (ddec,) = self.temporal.backward(d1, need_dx=(True,))
+        denc1 = self.dec.backward(ddec, need_dx=True)                          # gradient of `encoded` through the repeated sequence
+        denc2, _ = self.single.backward(d2, need_dx=(True, False))
+        check(lib.satcv_add_act(denc1.data_ptr(), None, None, denc2.data_ptr(), None, None, 0, denc1.data_ptr(), B * H * W, denc1.shape[-1],
+                                ops.DTYPE_CODE[denc1.dtype], ops.stream_ptr()))
+        self.enc.backward(denc1)
+        self._adam()
+        return float(l1.item()) + float(l2.item())
+
+
+def get_lstm_autoencoder(n_channels, n_time, n_classes, activation='relu', compile=False, optim=None, metrics=None, loss=None, max_value=2.0):
+    """utils/model_tools.py:810-872"""
+    m = LSTMAutoencoder(n_channels, n_time, n_classes, activation, max_value)
+    if compile and optim is not None and loss is not None:
+        m.compile(optimizer=optim, loss=loss, metrics=metrics)
+    return m
+
+
+def build_lstm_layers(params, rng, n_channels, return_sequences=False, dropout=None):
+    """utils/model_tools.py:666-717 (layer stack object; the model builders above call it)"""
+    if dropout is not None:
+        raise NotImplementedError('dropout inside the LSTM stack')
+    return LSTMLayers(params, rng, n_channels, return_sequences=return_sequences)
+
+
+def build_lstm_layers2(params, rng, n_channels, return_sequences=False, return_state=False, dropout=None):
+    """utils/model_tools.py:719-771"""
+    if dropout is not None or return_sequences:
+        raise NotImplementedError('build_lstm_layers2 is lowered as the reference calls it (return_sequences=False, no dropout)')
+    return LSTMLayers2(params, rng, n_channels)

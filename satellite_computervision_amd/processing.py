@@ -245,3 +245,146 @@ class SiameseDataGenerator(UNETDataGenerator):
             labels = labels * torch.minimum(tb[..., c:c + 1], ta[..., c:c + 1])
         torch.cuda.current_stream().synchronize()
         return [tb[..., :self.n_channels].contiguous(), ta[..., :self.n_channels].contiguous()], labels.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ time-series generators
+# LSTMDataGenerator / LSTMAutoencoderGenerator / HybridDataGenerator (utils/processing.py:895-1187) feed the ConvLSTM2D models of
+# lstm_tools.py.  The sequences are small (6 x 32 x 32 x 6 per tile), so their host-side preparation stays NumPy -- the helpers below
+# are pinned by the reference's own function bodies (tests/golden/timeseries_reference.npz) -- and the device work starts at
+# satcv_ingest_seq; the U-Net half of the hybrid generator goes through the device pipeline above.
+def normalize_timeseries(arr, maxval=10000, axis=-1, e=0.00001):
+    """utils/processing.py:185-193: arr / maxval with NaN -> 0"""
+    normalized = np.asarray(arr) / maxval
+    return np.where(np.isnan(normalized), 0.0, normalized)
+
+
+def rearrange_timeseries(arr, nbands, time_dim=1):
+    """utils/processing.py:195-218: rotate the sequence to a random start (random.randint, the reference's generator), split off the
+    last image's first `nbands` bands as the label; re-draw while a label image sums to zero.  Returns (feats, labels, starttime)."""
+    timesteps = arr.shape[time_dim]
+    starttime = random.randint(0, timesteps - 1)
+    rearranged = np.concatenate([arr[:, starttime:timesteps], arr[:, 0:starttime]], axis=1)
+    feats = rearranged[:, 0:-1]
+    labels = rearranged[:, -1, :, :, 0:nbands]
+    if 0.0 in np.sum(labels, axis=(1, 2, 3)):
+        feats, labels, starttime = rearrange_timeseries(arr, nbands)
+    return feats, labels, starttime
+
+
+def sin_cos(t, freq=6):
+    """utils/processing.py:220-223"""
+    import math
+    theta = 2 * math.pi * (t / freq)
+    return (math.sin(theta), math.cos(theta))
+
+
+def make_harmonics(times, timesteps, dims):
+    """utils/array_tools.py:12-24: (B, H, W, 2) planes of sin / cos of each start time"""
+    xys = [sin_cos(time, timesteps) for time in times]
+    return np.stack([np.stack([np.full(dims, x), np.full(dims, y)], axis=-1) for x, y in xys], axis=0)
+
+
+class LSTMDataGenerator:
+    """utils/processing.py:895-972.  Files hold (T, C, H, W) arrays (.npy paths or in-memory arrays); a batch is centre-trimmed to `dim`,
+    cut to `n_timesteps`, moved to (B, T, H, W, C) and divided by 10000 (NaN -> 0).  to_fit: (features, label) = a random rotation of the
+    sequence with its last image's first n_channels bands as the target (the reference's rearrange_timeseries; its trailing
+    `array_tools.split_timeseries(rearranged)` call receives a tuple and cannot run -- the split it describes is what rearrange_timeseries
+    already returns)."""
+
+    def __init__(self, files=None, to_fit=True, batch_size=32, dim=(256, 256), n_channels=4, n_timesteps=6, shuffle=True):
+        self.files, self.to_fit, self.batch_size, self.dim = files, to_fit, batch_size, tuple(dim)
+        self.n_channels, self.n_timesteps, self.shuffle = n_channels, n_timesteps, shuffle
+        self.on_epoch_end()
+
+    def __len__(self):
+        return int(np.floor(len(self.files) / self.batch_size))
+
+    def on_epoch_end(self):
+        self.indexes = np.arange(len(self.files))
+        if self.shuffle:
+            np.random.shuffle(self.indexes)
+
+    def _load_numpy_data(self, files_temp):
+        return [_load(f) for f in files_temp]
+
+    def _batch(self, index, steps):
+        idx = self.indexes[index * self.batch_size:(index + 1) * self.batch_size]
+        files_temp = [self.files[k] for k in idx]
+        batch = np.stack(self._load_numpy_data(files_temp), axis=0)                      # (B, T, C, H, W)
+        t0, t1 = (batch.shape[3] - self.dim[0]) // 2, (batch.shape[4] - self.dim[1]) // 2
+        cut = batch[:, 0:steps, :, t0:t0 + self.dim[0], t1:t1 + self.dim[1]]
+        return normalize_timeseries(np.moveaxis(cut, 2, 4), axis=1), files_temp
+
+    def __getitem__(self, index):
+        normalized, _ = self._batch(index, self.n_timesteps)
+        if self.to_fit:
+            feats, labels, _ = rearrange_timeseries(normalized, self.n_channels)
+            return feats.astype(np.float32), labels.astype(np.float32)
+        return normalized.astype(np.float32)
+
+
+class LSTMAutoencoderGenerator(LSTMDataGenerator):
+    """utils/processing.py:974-1049: n_timesteps + 1 images per tile; to_fit: ([features, harmonics], [reversed features, next image],
+    sample weights or None); the file stem's third `_` field is the start date of the series."""
+
+    def __init__(self, harmonics=True, sample_weights=False, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.add_harmonics, self.sample_weights = harmonics, sample_weights
+
+    def __getitem__(self, index):
+        normalized, files_temp = self._batch(index, self.n_timesteps + 1)
+        starts = [int(Path(str(f)).stem.split('_')[2]) for f in files_temp] if self.add_harmonics else None
+        harmonics = None
+        if self.to_fit:
+            feats, y, start = rearrange_timeseries(normalized, self.n_channels)
+            temporal_y = np.flip(feats, axis=1)
+            weights = [None, abs(feats[:, -1] - y) / (feats[:, -1] + y)] if self.sample_weights else None
+            if self.add_harmonics:
+                harmonics = make_harmonics([s_ + start - self.n_timesteps for s_ in starts], self.n_timesteps, self.dim)
+            return ([feats.astype(np.float32), None if harmonics is None else harmonics.astype(np.float32)],
+                    [np.ascontiguousarray(temporal_y, dtype=np.float32), y.astype(np.float32)], weights)
+        if self.add_harmonics:
+            harmonics = make_harmonics(starts, self.n_timesteps, self.dim)
+        return [normalized.astype(np.float32), None if harmonics is None else harmonics.astype(np.float32)]
+
+
+class HybridDataGenerator(UNETDataGenerator):
+    """utils/processing.py:1051-1187: the U-Net sources (NAIP, DEM, HAG, lidar, SSURGO) through the device pipeline of UNETDataGenerator,
+    the Sentinel-2 / Sentinel-1 SEQUENCES ((T, C, h, w) files, divided by 10000 / -50, the Sentinel-2 one colour-augmented when fitting)
+    concatenated along the band axis.  Returns [unet features (device), lstm features (B, T, h, w, c)] (+ one-hot labels)."""
+
+    def __init__(self, s1files=None, lstm_dim=(6, 32, 32, 6), lc_transitions=[(12, 3), (11, 3), (10, 3), (9, 8), (255, 0)],
+                 lu_transitions=[(82, 9), (84, 10)], unet_dim=(600, 600), *args, **kwargs):
+        self._s2seq = kwargs.pop('s2files', None)
+        super().__init__(*args, unet_dim=unet_dim, lc_transitions=lc_transitions, lu_transitions=lu_transitions, **kwargs)
+        self.s1files, self.lstm_dim, self.n_timesteps = s1files, tuple(lstm_dim), lstm_dim[0]
+
+    def _get_lstm_data(self, files_temp, rescale_val=1.0):
+        arrays = [_load(f) for f in files_temp]
+        want = (self.lstm_dim[0], self.lstm_dim[3], self.lstm_dim[1], self.lstm_dim[2])
+        assert len(arrays) > 0, 'No Array Found'
+        assert all(a.shape[0] >= want[0] and a.shape[2] >= want[2] and a.shape[3] >= want[3] for a in arrays), [a.shape for a in arrays]
+        batch = np.stack(arrays, axis=0)
+        t0, t1 = (batch.shape[3] - self.lstm_dim[1]) // 2, (batch.shape[4] - self.lstm_dim[2]) // 2
+        cut = batch[:, 0:self.n_timesteps, :, t0:t0 + self.lstm_dim[1], t1:t1 + self.lstm_dim[2]]
+        return normalize_timeseries(np.moveaxis(cut, 2, 4), maxval=rescale_val, axis=1)
+
+    def __getitem__(self, index):
+        idx = self.indexes[index * self.batch_size:(index + 1) * self.batch_size]
+        seqs = []
+        if self._s2seq:
+            s2 = self._get_lstm_data([self._s2seq[k] for k in idx], 10000.0)
+            if self.to_fit:                      # aug_array_color (utils/array_tools.py:159-190): per-batch contrast / brightness about the band means
+                contra, bright = random.uniform(1 - 0.05, 1 + 0.05), random.uniform(1 - 0.05, 1 + 0.05)
+                axes = tuple(range(1, s2.ndim - 1))
+                mean = s2.mean(axis=axes, keepdims=True)
+                s2 = (s2 - mean) * contra + mean * bright
+            seqs.append(s2)
+        if self.s1files:
+            seqs.append(self._get_lstm_data([self.s1files[k] for k in idx], -50.0))
+        lstm = np.concatenate(seqs, axis=-1).astype(np.float32)
+        rest = super().__getitem__(index)
+        if self.to_fit:
+            xu, y = rest
+            return [xu, lstm], y
+        return [rest, lstm]

@@ -38,7 +38,32 @@ class FakeModel:
         return 2.0 * x[..., :1]
 
 
+def timeseries_fixtures():
+    """utils/processing.py:185-223 (normalize_timeseries, rearrange_timeseries, sin_cos) and utils/array_tools.py:12-24 (make_harmonics):
+    the reference's own bodies executed with seeded `random` -> tests/golden/timeseries_reference.npz"""
+    import math
+    import random
+    pr = extract_functions(f'{REF}/utils/processing.py', {'normalize_timeseries', 'rearrange_timeseries', 'sin_cos'})
+    pr['randint'] = random.randint
+    pr['math'] = math
+    sys.path.insert(0, f'{REF}/utils')
+    import array_tools
+    rng = np.random.default_rng(21)
+    arr = rng.random((3, 6, 5, 4, 7)) * 9000
+    arr[0, 2, 1, 1, 3] = np.nan
+    out = {'arr': arr, 'normalized': pr['normalize_timeseries'](arr, axis=1), 'normalized_s1': pr['normalize_timeseries'](arr, maxval=-50.0, axis=1)}
+    for seed in (0, 1, 2, 3):
+        random.seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            f, l, st = pr['rearrange_timeseries'](out['normalized'], 4)
+        out[f'feats_{seed}'], out[f'labels_{seed}'], out[f'start_{seed}'] = f, l, np.int64(st)
+    out['harmonics'] = array_tools.make_harmonics(np.array([3, 10, 17]), 6, (4, 5))
+    out['sin_cos'] = np.array([pr['sin_cos'](t, 6) for t in range(8)])
+    np.savez_compressed(os.path.join(OUT, 'timeseries_reference.npz'), **out)
+
+
 def main():
+    timeseries_fixtures()
     pt = extract_functions(f'{REF}/utils/prediction_tools.py',
                            {'generate_chip_indices', 'extract_chips', 'predict_chips'})
     rt = extract_functions(f'{REF}/utils/raster_tools.py', {'generate_chip_indices'})

@@ -186,3 +186,74 @@ def test_hybrid_model_forward_and_training_step(lt):
         np.testing.assert_allclose(dzl.cpu().numpy(), CL.resize_nearest_bwd(dcat[..., :ncls], idx, 8, 8), rtol=1e-4, atol=1e-8)
     finally:
         mt.set_compute_dtype('bfloat16')
+
+
+def test_lstm_autoencoder_matches_oracle(lt):
+    """get_lstm_autoencoder (utils/model_tools.py:810-872) with its build_lstm_layers2 encoder (:719-771; ReLU(state_h + BN(h2))), fp32:
+    both outputs and every gradient of one training step (mse_4d on both outputs) against the float64 oracle."""
+    from satellite_computervision_amd import model_tools as mt
+    mt.set_compute_dtype('float32')
+    try:
+        B, T, H, W, Cc, ncls = 2, 3, 16, 16, 6, 6
+        o = CL.LSTMAutoencoderOracle(Cc, T, ncls, rec_act=lt.RECURRENT_ACTIVATION, seed=7)
+        m = lt.get_lstm_autoencoder(Cc, T, ncls)
+        names = {'l1': 'conv_lstm', 'l2': 'dilated_conv_lstm', 'dec': 'lstm_decoder', 'bn1': 'batch_norm', 'bn2': 'batch_norm2',
+                 'temporal': 'temporal_dense', 'single': 'single_dense'}
+        w = {}
+        for lk, lv in o.p.items():
+            for pk, pv in lv.items():
+                lv[pk] = pv.astype(np.float32).astype(np.float64)
+                w[f'{names[lk]}/{pk}'] = lv[pk]
+        m.set_weights_dict(w)
+        rng = np.random.default_rng(11)
+        x = rng.random((B, T, H, W, Cc)).astype(np.float32)
+        sc = rng.standard_normal((B, H, W, 2)).astype(np.float32)
+        t_ref, s_ref = o.forward(x.astype(np.float64), sc.astype(np.float64))
+        m.compile(optimizer=mt.Adam(0.0), loss=mt.mse_4d)
+        ty = np.flip(x, axis=1).copy()                       # LSTMAutoencoderGenerator: the reversed input sequence (utils/processing.py:1034)
+        sy = rng.random((B, H, W, ncls)).astype(np.float32)
+        l1, d1 = OL.mse_4d(ty.astype(np.float64), t_ref)
+        l2, d2 = OL.mse_4d(sy.astype(np.float64), s_ref)
+        g_ref = o.backward(d1, d2)
+        loss = m.train_on_batch([x, sc], [ty, sy])
+        np.testing.assert_allclose(loss, l1 + l2, rtol=1e-4)
+        for ok, gv in g_ref.items():
+            pre, pk = ok.split('.', 1)
+            g = m.P.g(f'{names[pre]}/{pk}').cpu().numpy().astype(np.float64).reshape(gv.shape)
+            assert cosine(g, gv) > 0.9999 and rel(g, gv) < 3e-3, (ok, cosine(g, gv), rel(g, gv))
+        tp, sp = m.predict([x, sc])
+        assert tp.shape == (B, T, H, W, ncls) and sp.shape == (B, H, W, ncls) and np.isfinite(tp).all()
+    finally:
+        mt.set_compute_dtype('bfloat16')
+
+
+def test_hybrid_generator_feeds_the_hybrid_model(lt):
+    """HybridDataGenerator (utils/processing.py:1051-1187) -> get_hybrid_model.fit: NAIP tiles through the device pipeline, the Sentinel-2
+    sequence through the NumPy helpers, one-hot labels; one epoch runs and the loss is finite."""
+    import random
+    from satellite_computervision_amd import model_tools as mt, processing as P
+    mt.set_compute_dtype('float32')
+    try:
+        rng = np.random.default_rng(3)
+        n = 4
+        naip = [rng.integers(0, 255, (4, 52, 52)).astype(np.uint8) for _ in range(n)]
+        s2 = [(rng.random((4, 6, 10, 10)) * 9000).astype(np.float32) for _ in range(n)]
+        lab = [rng.integers(0, 3, (1, 52, 52)).astype(np.uint8) for _ in range(n)]
+        random.seed(1)
+        gen = P.HybridDataGenerator(s2files=s2, lstm_dim=(3, 8, 8, 6), unet_dim=(48, 48), labelfiles=lab, naipfiles=naip, batch_size=2, n_channels=4,
+                                    n_classes=3, to_fit=True, shuffle=False, lc_transitions=[], lu_transitions=[])
+        (xu, xl), y = gen[0]
+        assert tuple(xu.shape) == (2, 48, 48, 4) and xl.shape == (2, 3, 8, 8, 6) and tuple(y.shape) == (2, 48, 48, 3)
+        assert float(y.sum()) == 2 * 48 * 48 and xl.max() <= 1.1
+        mt.reset_uids(); mt.set_seed(2)
+        m = lt.get_hybrid_model((48, 48, 4), (3, 8, 8, 6), 3, filters=[32, 64], factors=[3, 2], compile_model=True, optim=mt.Adam(1e-3),
+                                loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 1.0, 1.0]))
+        h = m.fit(gen, epochs=2)
+        assert len(h.history['loss']) == 2 and np.isfinite(h.history['loss']).all()
+        pred_gen = P.HybridDataGenerator(s2files=s2, lstm_dim=(3, 8, 8, 6), unet_dim=(48, 48), naipfiles=naip, batch_size=2, n_channels=4, n_classes=3,
+                                         to_fit=False, shuffle=False)
+        xu, xl = pred_gen[1]
+        pr = m.predict([xu, xl])
+        assert pr.shape == (2, 48, 48, 3)
+    finally:
+        mt.set_compute_dtype('bfloat16')
