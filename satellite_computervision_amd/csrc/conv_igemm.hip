@@ -325,6 +325,7 @@ static int igemm_fill_args(const satcv_conv_desc* d, IgemmArgs& a) {
     a.hs = d->hin; a.ws = d->win;
   }
   a.dbg = 0;
+  a.ksplit = 1; a.kslab = nullptr;
   a.bst_y = d->bst_y; a.bst_y1 = d->bst_y1; a.bst_ld = d->bst_ld; a.bst_ld1 = d->bst_ld1; a.bst_split = d->bst_y1 ? d->bst_split : 0;
   a.bst_scale = d->bst_scale; a.bst_shift = d->bst_shift; a.bst_mean = d->bst_mean; a.bst_rstd = d->bst_rstd; a.bst_relu = d->bst_relu;
   if (d->bst_y) {

@@ -48,7 +48,9 @@ extern "C" int satcv_debug_read_stamps(unsigned long long* out) {
 // WDMA (round 4, double-buffered tile only): the weight slab of a chunk -- 77 % of the staged bytes, and the operand that needs no
 // transform -- moves by LDS-DMA (global_load_lds_dwordx4, 1-KB pieces, no staging registers, no ds_write) into a THREE-slot ring two
 // chunks ahead; the activations keep the register path (fused input BatchNorm + ReLU, zero padding).
-template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool DYN, bool TL = false, bool DB = false, int WPS = 0, bool WDMA = false>
+// SK: split-K instantiation (see fast_cfg); every other instantiation compiles exactly the single-pass code (the K range is the constant [0, nchunks):
+// compiled in unconditionally the extra live state cost the 128 x 128 tile a wave per SIMD)
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool DYN, bool TL = false, bool DB = false, int WPS = 0, bool WDMA = false, bool SK = false>
 // thin configurations (<= 32 accumulator registers) request 4 waves/SIMD; the scaled-fp8 fragments are 8 registers each, so
 // that path asks for 2.  WPS overrides (tile-at-once configurations stage a whole tile through registers)
 __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<T>::SUB == 2 ? 2 : 4) : 1))) void igemm_fast_kernel(const IgemmArgs a) {
@@ -103,6 +105,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
     const int orig = blockIdx.x;
     const int xcd = orig & 7, q = G >> 3, rem = G & 7;
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+  }
+  // split-K: the ksplit workgroups of one tile have consecutive ids (one XCD: they read the same activation tile)
+  int split = 0, c_begin = 0, c_end = a.nchunks;
+  if constexpr (SK) {
+    const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+    split = bid % ksplit;
+    bid /= ksplit;
+    c_begin = (int)((long long)split * a.nchunks / ksplit); c_end = (int)((long long)(split + 1) * a.nchunks / ksplit);
   }
   const int nbase = (bid % a.n_tiles) * BN;
   const int cin = a.c0 + a.c1;
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #else
             // (from the LDS table once it is visible -- every chunk but the first, which is stored before the kernel's first barrier: as
             //  global loads inside the store phase their latency sat between the two barriers of every chunk)
-            if (chunk_ > 0) v = affine8<T>(v, ldsT + cg0, ldsT + cin + cg0, a.in_relu);
+            if (chunk_ > c_begin) v = affine8<T>(v, ldsT + cg0, ldsT + cin + cg0, a.in_relu);
             else v = affine8<T>(v, a.in_scale + cg0, a.in_shift + cg0, a.in_relu);
 #endif
           }
@@ -349,13 +359,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #endif
   if constexpr (WDMA) {
 #pragma unroll
-    for (int r = 0; r < NROUNDS; ++r) dma_b(0, 0, r);
+    for (int r = 0; r < NROUNDS; ++r) dma_b(c_begin, c_begin % 3, r);
 #pragma unroll
-    for (int r = 0; r < NROUNDS; ++r) dma_b(a.nchunks > 1 ? 1 : 0, 1, r);
+    for (int r = 0; r < NROUNDS; ++r) dma_b(c_end - c_begin > 1 ? c_begin + 1 : c_begin, (c_begin + 1) % 3, r);
   }
-  load_regs(0);
-  store_lds(0);
-  if constexpr (DB) { if (a.nchunks > 1) load_regs(1); }
+  load_regs(c_begin);
+  store_lds(c_begin, DB ? (WDMA ? (c_begin & 1) * a_stage : (c_begin & 1) * stage_elems) : 0);
+  if constexpr (DB) { if (c_end - c_begin > 1) load_regs(c_begin + 1); }
   if constexpr (WDMA) dma_wait_all();
   __syncthreads();
 #ifdef SATCV_STAMP
@@ -421,15 +431,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
       // units of one chunk's staging in program order: A items (store c+1, then re-issue for c+2), the scale / shift values (needed by
       // the A stores above, so re-issued after them), weight items; unit u runs in tap step u (the surplus in the last step)
       constexpr int NUNITS = AI + 1 + (WDMA ? NROUNDS : BI), STEPS_ = TAPS * KS;
-      for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+      for (int chunk = c_begin; chunk < c_end; ++chunk) {
         // A stages alternate; without WDMA the weight slab sits behind the A planes of the same stage, with it in ring slot chunk % 3
         const int cur = WDMA ? (chunk & 1) * a_stage : (chunk & 1) * stage_elems;
         const int oth = WDMA ? a_stage - cur : stage_elems - cur;
         const int curB = WDMA ? (chunk % 3) * b_slab : cur;
-        const bool do_store = chunk + 1 < a.nchunks, do_load = chunk + 2 < a.nchunks;
+        const bool do_store = chunk + 1 < c_end, do_load = chunk + 2 < c_end;
         // (wave-uniform flags; the loads of the last two iterations re-read the last chunk instead of branching around vector-memory
         //  instructions inside the loop: see the note at the loaders)
-        const int nxt2 = do_load ? chunk + 2 : a.nchunks - 1;
+        const int nxt2 = do_load ? chunk + 2 : c_end - 1;
         const ChunkSrc cs_ = chunk_src(nxt2);
 #ifdef SATCV_STAMP
         STAMP(t0);
@@ -476,8 +486,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #ifdef SATCV_STAMP
     unsigned long long t0, t1, t2, t3, t4, t5, s_issue = 0, s_comp = 0, s_bar1 = 0, s_store = 0, s_bar2 = 0;
 #endif
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-      const bool more = chunk + 1 < a.nchunks;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+      const bool more = chunk + 1 < c_end;
 #ifdef SATCV_STAMP
       STAMP(t0);
 #endif
@@ -525,6 +535,29 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
     STAMP(k3);
 #endif
 
+    if constexpr (SK) {
+      // partial tile -> kslab[split][pixel of the (n, h, w) grid][cout] (fp32, raw sums: bias / scale / ReLU / rounding / statistics are the
+      // finish kernel's); lanes r = 32 consecutive channels = 128 contiguous bytes per accumulator row
+      const size_t mtot = (size_t)a.n * a.h * a.w_;
+      float* slab = a.kslab + (size_t)split * mtot * a.cout;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int q = (wm * MT + m) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          const int t = q / TW, cx = q % TW;
+          const int k = (a.imgs == 1) ? 0 : t / a.rpi;
+          const int nimg = n0 + k, y = y0 + (t - k * a.rpi), x = x0 + cx;
+          if (!((k < a.imgs) && (nimg < a.n) && (y < a.h) && (x < a.w_))) continue;
+          float* row = slab + ((size_t)(nimg * a.h + y) * a.w_ + x) * a.cout;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int cn = nbase + (wn * NT + n) * 32 + r;
+            if (cn < a.cout) row[cn] = acc[m][n][i];
+          }
+        }
+      return;
+    } else
     igemm_epilogue<T, TW, WM, WN, MT, NT, ABL(1), !DYN>(a, acc, n0, y0, x0, nbase, smem_raw);      // (the dilated-halo instantiations sit at their register cap)
 #ifdef SATCV_STAMP
     {
@@ -538,8 +571,102 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
   }
 }
 
+
+// ------------------------------------------------------------------ split-K: workspace and finish kernel
+// one fp32 scratch buffer per stream that has used split-K (grown on demand; allocated outside any capture: the first, eager run of a
+// plan sizes it).  Returns nullptr when the allocation fails (the launch then runs unsplit).
+#include <mutex>
+static float* igemm_splitk_workspace(hipStream_t st, size_t bytes) {
+  struct Slot { hipStream_t st; int dev; void* p; size_t n; };
+  static Slot slots[16];
+  static int nslots = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  Slot* s = nullptr;
+  for (int i = 0; i < nslots; ++i) if (slots[i].st == st && slots[i].dev == dev) s = &slots[i];
+  if (!s) {
+    if (nslots == 16) return nullptr;
+    s = &slots[nslots++];
+    *s = Slot{st, dev, nullptr, 0};
+  }
+  if (s->n < bytes) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;      // never allocate inside a capture
+    if (s->p) { (void)hipStreamSynchronize(st); (void)hipFree(s->p); s->p = nullptr; s->n = 0; }
+    const size_t want = bytes + (bytes >> 2);
+    if (hipMalloc(&s->p, want) != hipSuccess) { (void)hipGetLastError(); s->p = nullptr; return nullptr; }
+    s->n = want;
+  }
+  return reinterpret_cast<float*>(s->p);
+}
+
+// y = T(relu?(out_scale * sum_s slab[s] + bias)), statistics of the stored values: one thread per 8 channels of a pixel, a thread keeps its
+// channel group over the grid-stride walk, per-block LDS sums, one pair of atomics per channel and block into the replica rows
+template <typename T>
+__global__ __launch_bounds__(256) void igemm_splitk_finish_kernel(const IgemmArgs a, long long mtot) {
+  __shared__ float ssum[2][1024];
+  const int G = a.cout / 8;
+  const long long total = mtot * G;
+  const bool st = a.stats != nullptr && a.cout <= 1024 && 256 % G == 0;
+  if (st) { for (int i = threadIdx.x; i < 2 * 1024; i += blockDim.x) (&ssum[0][0])[i] = 0.f; __syncthreads(); }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  const size_t slab = (size_t)mtot * a.cout;
+  int g = 0;
+  for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+    g = (int)(it % G);
+    const long long p = it / G;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int s = 0; s < a.ksplit; ++s) {
+      const float4 u0 = *reinterpret_cast<const float4*>(a.kslab + s * slab + p * a.cout + g * 8);
+      const float4 u1 = *reinterpret_cast<const float4*>(a.kslab + s * slab + p * a.cout + g * 8 + 4);
+      v[0] += u0.x; v[1] += u0.y; v[2] += u0.z; v[3] += u0.w; v[4] += u1.x; v[5] += u1.y; v[6] += u1.z; v[7] += u1.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = (g * 8 + e) % a.cstat;
+      float x = v[e] * (a.out_scale ? a.out_scale[ch] : 1.f) + (a.bias ? a.bias[ch] : 0.f);
+      if (a.out_relu) x = fmaxf(x, 0.f);
+      v[e] = x;
+      const float r = round_to<T>(x);
+      s1[e] += r; s2[e] += r * r;
+    }
+    store8<T>(reinterpret_cast<T*>(a.y) + p * a.ldy + g * 8, v);
+  }
+  if (st) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(&ssum[0][g * 8 + e], s1[e]); atomicAdd(&ssum[1][g * 8 + e], s2[e]); }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.cout; c += blockDim.x) {
+      satcv_stat_t* row = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
+      atomicAdd(row + c % a.cstat, (satcv_stat_t)ssum[0][c]);
+      atomicAdd(row + a.stats_ld + c % a.cstat, (satcv_stat_t)ssum[1][c]);
+    }
+  }
+}
+template <typename T>
+static int igemm_splitk_finish(const IgemmArgs& a, hipStream_t st) {
+  if constexpr (sizeof(T) != 2) { return SATCV_ERR_UNSUPPORTED; }
+  else {
+    const long long mtot = (long long)a.n * a.h * a.w_;
+    const int G = a.cout / 8;
+    if (a.stats && !(a.cout <= 1024 && 256 % G == 0)) { satcv_set_error("igemm split-K: statistics need cout <= 1024 with 256 %% (cout / 8) == 0"); return SATCV_ERR_UNSUPPORTED; }
+    long long grid = (mtot * G + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(igemm_splitk_finish_kernel<T>, dim3((unsigned)grid), dim3(256), 0, st, a, mtot);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { satcv_set_error("igemm split-K finish launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+    return SATCV_OK;
+  }
+}
+
 // ------------------------------------------------------------------ host side
-template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool TL = false, bool DB = false, int WPS = 0, bool WDMA = false>
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool TL = false, bool DB = false, int WPS = 0, bool WDMA = false, bool SK = false>
 static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   constexpr int EL = KTraits<T>::EL, SUB = KTraits<T>::SUB;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, KC = KS * 2 * SUB * EL, NTHREADS = WM * WN * 64;
@@ -591,22 +718,40 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   const size_t lds_tab = a.in_scale ? (size_t)2 * cin * sizeof(float) : 0;         // scale / shift table behind the stage(s)
   const size_t lds = lds_stage + lds_tab > lds_out ? lds_stage + lds_tab : lds_out;
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
-  if (dry) return SATCV_OK;
   const bool dyn = TAPS == 9 && a.dil != 1;
+  long long blocks = (long long)a.ngroups * a.tiles_y * a.tiles_x * a.n_tiles;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return SATCV_ERR_UNSUPPORTED;
+  // ---- split-K (SK instantiations): a launch that leaves most of the chip idle (small maps: the 8 x 8 centre of the U-Net, a single
+  // DeepLab tile) with a long K loop is cut 2 - 4 ways over K; fp32 slabs + an ordered sum in a finish kernel (deterministic).  Plain NHWC
+  // stores only (no pooling, depth-to-space, accumulation, fused BatchNorm-backward sums); SATCV_SPLITK=0 turns it off.
+  a.ksplit = 1; a.kslab = nullptr;
+  int ks = 1;
+  if constexpr (SK) {
+    static const int splitk = [] { const char* e = getenv("SATCV_SPLITK"); return e ? atoi(e) : 0; }();
+    if (splitk && !TL && !dyn && sizeof(T) == 2 && a.mode_out == 0 && !a.pool_y && !a.accumulate && !a.bst_y && a.cout % 8 == 0 && a.ldy % 8 == 0 &&
+        (!a.stats || (a.cout <= 1024 && 256 % (a.cout / 8) == 0)))
+      while (ks < 4 && blocks * ks * 2 <= 256 && a.nchunks / (ks * 2) >= 8) ks *= 2;
+    if (ks == 1) return SATCV_ERR_UNSUPPORTED;          // (the caller continues with the single-pass instantiation)
+  }
+  if (dry) return SATCV_OK;
   if (!dyn) {            // the kernel hard-codes these for the undilated case: keep the two derivations in lock step
     constexpr int CLc = TW + (TAPS == 9 ? 2 : 0);
     constexpr int PITCHc = TW == 32 ? CLc : (TW == 16 ? ((CLc + 15) / 16) * 16 : (CLc <= 8 ? 8 : ((CLc - 8 + 15) / 16) * 16 + 8));
     if (a.cl != CLc || a.pitch != PITCHc) { satcv_set_error("igemm_fast: internal pitch mismatch (%d/%d vs %d/%d)", a.cl, a.pitch, CLc, PITCHc); return SATCV_ERR_INVALID; }
   }
-  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, false, TL, DB, WPS, WDMA>;
-  if constexpr (TAPS == 9 && !DB && WPS == 0) { if (dyn) kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, true>; }
-  if ((DB || WPS) && dyn) return SATCV_ERR_UNSUPPORTED;
+  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, false, TL, DB, WPS, WDMA, SK>;
+  if constexpr (TAPS == 9 && !DB && WPS == 0 && !SK) { if (dyn) kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, true>; }
+  if ((DB || WPS || SK) && dyn) return SATCV_ERR_UNSUPPORTED;
   { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
-  const long long blocks = (long long)a.ngroups * a.tiles_y * a.tiles_x * a.n_tiles;
-  if (blocks <= 0 || blocks > 0x7fffffffLL) return SATCV_ERR_UNSUPPORTED;
+  if constexpr (SK) {
+    float* ws = igemm_splitk_workspace(st, (size_t)ks * a.n * a.h * a.w_ * a.cout * sizeof(float));
+    if (!ws) return SATCV_ERR_UNSUPPORTED;
+    a.ksplit = ks; a.kslab = ws; blocks *= ks;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHREADS), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("igemm_fast launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  if (a.ksplit > 1) return igemm_splitk_finish<T>(a, st);
   return SATCV_OK;
 }
 
@@ -686,6 +831,10 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
           const int rc = fast_cfg<T, TW, 2, 2, 2, 2, 4, TAPS, false, false, 2>(a, st, dry);
           if (rc != SATCV_ERR_UNSUPPORTED) return rc;
         }
+        if (nspace >= 128 && nspace % 128 == 0) {       // under-filled 1x1 launches with a long K loop (single DeepLab tiles): split-K
+          const int rc = fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS, false, false, 0, false, true>(a, st, dry);
+          if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+        }
       }
       if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS>(a, st, dry);
       if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 2, TAPS>(a, st, dry);
@@ -695,6 +844,10 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
   if (nspace >= 128 && nspace % 128 == 0) {      // (128x64 tiles on these layers: 5-10 % slower)
     // (a 256x128 tile -- 4x2 MFMA tiles per wave, 128 accumulator registers, one workgroup per CU -- was measured slower:
     //  15.9 vs 15.4 ms/step)
+    if constexpr (std::is_same<T, bf16>::value) {      // under-filled launches with a long K loop: split-K
+      const int rc = fast_cfg<T, TW, 2, 2, 2, 2, 1, TAPS, false, false, 0, false, true>(a, st, dry);
+      if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+    }
     return fast_cfg<T, TW, 2, 2, 2, 2, 1, TAPS>(a, st, dry);
   }
   // (N tiles wider than 128 -- tried on synthetic 96 / 192-channel outputs -- leave one workgroup per CU and were slower)

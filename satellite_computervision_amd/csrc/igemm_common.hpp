@@ -27,6 +27,9 @@ struct IgemmArgs {
   const void* bst_y; const void* bst_y1; int bst_ld, bst_ld1, bst_split;
   const float* bst_scale; const float* bst_shift; const float* bst_mean; const float* bst_rstd; int bst_relu;
   int dbg;                         // ablation bits (env SATCV_DBG): 1 skip stores, 2 skip MFMA, 4 skip A loads, 8 skip B loads
+  // split-K (conv_igemm_fast.hip): ksplit workgroups share an output tile, each sums a contiguous range of the K chunks and writes its
+  // fp32 partial tile to kslab[split][pixel][cout]; satcv's finish kernel adds the slabs in order, applies the epilogue and the statistics
+  int ksplit; float* kslab;
 };
 
 template <typename T>

@@ -272,7 +272,7 @@ def test_full_unet_training_step_matches_oracle(mt, dtype):
             # the encoder: 0.999 (dec0) ... 0.947 (enc0), against 0.78 for the unrounded chain.  DESIGN.md section 4.
             assert cos >= 0.90, f'grad {k}: cos {cos:.4f} relL2 {l2:.3e} vs the bf16-storage oracle'
             if k.startswith(('probs', 'dec0.')):
-                assert cos >= 0.99, f'grad {k}: cos {cos:.4f}'
+                assert cos >= (0.995 if k.startswith(('probs', 'dec0.conv2', 'dec0.bn2')) else 0.98), f'grad {k}: cos {cos:.4f}'
     if not f32:
         # reported drift against the UNROUNDED float64 chain
         o2 = UNetOracle(2, 4, [32, 64, 128, 256, 512], [2, 2, 2, 2, 2], dtype=np.float64, seed=17)
@@ -667,7 +667,7 @@ def test_config4_13_band_five_level_training_step(mt, dtype):
         else:
             assert cos >= 0.90, f'grad {k}: cos {cos:.4f} relL2 {l2:.3e}'       # (see test_full_unet_training_step_matches_oracle)
             if k.startswith(('probs', 'dec0.')):
-                assert cos >= 0.99, f'grad {k}: cos {cos:.4f}'
+                assert cos >= (0.995 if k.startswith(('probs', 'dec0.conv2', 'dec0.bn2')) else 0.98), f'grad {k}: cos {cos:.4f}'
     # forward of the trained-mode statistics' moving averages: inference mask against the oracle (bit-exact beyond the margin)
     balance_head(o, x)
     m.set_weights_dict({names['probs.bias']: o.params['probs.bias']})

@@ -2,6 +2,8 @@
 on the same seeded inputs.  fp32 storage: tight tolerance (exact fp32 MFMA products);
 bf16 storage: inputs are pre-rounded to bf16 so only accumulation order and the final
 bf16 rounding differ (tolerance 2^-7 relative to the output scale)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -10,6 +12,7 @@ from oracle import keras_ops as K
 from oracle import losses as OL
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 DT = [torch.float32, torch.bfloat16]
 
@@ -967,3 +970,39 @@ def test_strided_and_large_kernel_convs(ops, td, case):
     d = ops.make_conv_desc(x0=xd.data_ptr(), c0=cpad, w=wf.data_ptr(), y=y.data_ptr(), ldy=y.shape[-1], n=n, h=ho, w_=wo, cout=cout, cout_pad=rup(cout, 32),
                            kh=k, kw=k, dil=dil, dtype=ops.DTYPE_CODE[td], stride=stride, hin=h if stride > 1 else 0, win=w if stride > 1 else 0)
     assert lib.satcv_conv2d_igemm_pipelined(C.byref(d)) == 1
+
+
+# ------------------------------------------------- split-K of under-filled launches (opt-in: SATCV_SPLITK=1 read at first use)
+@pytest.mark.parametrize('case', [(2, 8, 8, 512, 1024, 3), (4, 8, 8, 1024, 512, 3), (1, 32, 32, 512, 512, 3), (1, 32, 32, 1024, 256, 1), (3, 8, 8, 256, 128, 3)])
+def test_conv2d_split_k(case):
+    """igemm_fast_kernel<..., SK = true>: 2 - 4 workgroups share an output tile, each sums a contiguous range of the K chunks into an fp32
+    slab, the finish kernel adds the slabs in order, applies bias and forms the BatchNorm statistics of the stored values.  Run in a
+    subprocess (the switch is read once per process); compared against the float64 oracle and against the single-pass launch."""
+    import subprocess, sys, os, json
+    code = r"""
+import sys, json, numpy as np, torch
+sys.path.insert(0, %r)
+from satellite_computervision_amd import ops
+from oracle import keras_ops as K
+n, h, w, cin, cout, k = %r
+rng = np.random.default_rng(1)
+def rnd(shape, s=1.0): return torch.tensor(rng.standard_normal(shape) * s, dtype=torch.float32).bfloat16()
+x, kern, b = rnd((n, h, w, cin)), rnd((k, k, cin, cout), 0.2), torch.tensor(rng.standard_normal(cout), dtype=torch.float32).cuda()
+wf, _ = ops.pack_weights(kern.float().cuda(), cin, 1)
+st = ops.new_stats(cout, torch.device('cuda'))
+y = ops.conv2d(x.cuda(), wf, cout, kh=k, kw=k, bias=b, stats=st)
+ref = K.conv2d_same(x.double().numpy(), kern.double().numpy(), b.double().cpu().numpy(), 1)
+got = y.double().cpu().numpy()
+s = st.sum(0).double().cpu().numpy()
+print(json.dumps(dict(err=float(np.abs(got - ref).max() / np.abs(ref).max()), s1=float(np.abs(s[0] - got.reshape(-1, cout).sum(0)).max() / max(np.abs(s[0]).max(), 1.0)),
+                      s2=float(np.abs(s[1] - (got.reshape(-1, cout) ** 2).sum(0)).max() / np.abs(s[1]).max()), y=got.ravel()[:4096:7].tolist())))
+""" % (ROOT, case)
+    outs = {}
+    for sk in ('1', '0'):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, SATCV_SPLITK=sk), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[sk] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert outs['1']['err'] < 1.2e-2 and outs['1']['s1'] < 1e-3 and outs['1']['s2'] < 1e-3, outs['1']
+    # the split sum differs from the single-pass one by fp32 association only: at most one bf16 ulp on a few elements
+    a, b_ = np.array(outs['1']['y']), np.array(outs['0']['y'])
+    assert np.abs(a - b_).max() <= 2 ** -7 * max(np.abs(b_).max(), 1.0)
