@@ -215,6 +215,12 @@ int satcv_bn_finalize_train(satcv_stat_t* stats, int32_t stats_ld, int32_t c, fl
 int satcv_bn_affine_infer(const float* gamma, const float* beta, const float* moving_mean,
                           const float* moving_var, float eps, int32_t c, float* scale, float* shift,
                           void* stream);
+/* The same for every BatchNormalization of an inference plan in one launch: `jobs_device` is a DEVICE array of njobs entries. */
+typedef struct satcv_bn_affine_job {
+  const float* gamma; const float* beta; const float* moving_mean; const float* moving_var;
+  float* scale; float* shift; int64_t c;
+} satcv_bn_affine_job;
+int satcv_bn_affine_infer_batched(const satcv_bn_affine_job* jobs_device, int32_t njobs, float eps, void* stream);
 
 /* act = relu(scale*yraw+shift) (written if act != NULL), pooled = maxpool_f(act) ('valid'),
  * optional sum/sumsq rows of `act` (feeds the decoder's concat BatchNormalization).

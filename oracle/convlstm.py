@@ -267,3 +267,73 @@ class LSTMAutoencoderOracle:
             for k, v in gg.items():
                 g[f'{pre}.{k}'] = v
         return g
+
+
+class HierarchicalOracle:
+    """get_hierarchical_model (utils/model_tools.py:1016-1060): build_acnn_layers2 trunk (:941-979) + build_lstm_layers (:666-717) + the
+    three softmax heads; forward of the three outputs and the gradients given dL/dlogits of each head."""
+
+    def __init__(self, nclasses, acnn_nclasses, acnn_sub_nclasses, nchannels, lstm_channels, nfilters, depth, rec_act='hard_sigmoid', seed=0):
+        rng = np.random.default_rng(seed)
+        self.depth, self.mid, self.F = depth, (depth - 1) // 2, nfilters
+        self.p = {}
+        for l in range(depth):
+            cin = nchannels if l == 0 else nfilters
+            for nm, ci in ((f'Conv{l}_1', cin), (f'DilateConv{l}_2', nfilters)):
+                lim = np.sqrt(6.0 / (9 * ci + 9 * nfilters))
+                self.p[nm] = {'kernel': rng.uniform(-lim, lim, (3, 3, ci, nfilters)), 'bias': np.zeros(nfilters)}
+            for nm in (f'bn{l}_1', f'bn{l}_2'):
+                self.p[nm] = {'gamma': np.ones(nfilters), 'beta': np.zeros(nfilters)}
+        self.lstm = LSTMLayersOracle(lstm_channels, 1, filters=64, rec_act=rec_act, seed=seed + 1)
+        for nm, ci, co in (('sub_probs', nfilters, acnn_sub_nclasses), ('acnn_probs', nfilters, acnn_nclasses), ('lstm_probs', 64 + nfilters, nclasses)):
+            lim = np.sqrt(6.0 / (ci + co))
+            self.p[nm] = {'kernel': rng.uniform(-lim, lim, (1, 1, ci, co)), 'bias': np.zeros(co)}
+
+    def forward(self, xa, xl):
+        p, c = self.p, {}
+        f, s = xa, None
+        feats = []
+        for l in range(self.depth):
+            y1 = K.conv2d_same(f, p[f'Conv{l}_1']['kernel'], p[f'Conv{l}_1']['bias'])
+            z1, m1, v1 = bn5_train(y1, p[f'bn{l}_1']['gamma'], p[f'bn{l}_1']['beta'])
+            s_new = np.maximum(z1 if l == 0 else z1 + s, 0)
+            y2 = K.conv2d_same(s_new, p[f'DilateConv{l}_2']['kernel'], p[f'DilateConv{l}_2']['bias'], 3)
+            z2, m2, v2 = bn5_train(y2, p[f'bn{l}_2']['gamma'], p[f'bn{l}_2']['beta'])
+            f_new = np.maximum(z2, 0)
+            c[l] = dict(fin=f, y1=y1, st1=(m1, v1), s=s_new, y2=y2, st2=(m2, v2), f=f_new)
+            f, s = f_new, s_new
+            feats.append(f_new)
+        lf = self.lstm.features(xl)
+        up, idx = resize_nearest(lf, xa.shape[1], xa.shape[2])
+        cat = np.concatenate([up, feats[-1]], -1)
+        c.update(lf=lf, idx=idx, cat=cat)
+        self.c = c
+        head = lambda a, nm: K.softmax(K.conv2d_same(a, p[nm]['kernel'], p[nm]['bias']))
+        return [head(feats[self.mid], 'sub_probs'), head(feats[-1], 'acnn_probs'), head(cat, 'lstm_probs')]
+
+    def backward(self, dlogits):
+        """dlogits: [dL/dlogits of sub_probs, acnn_probs, lstm_probs]"""
+        p, c, g = self.p, self.c, {}
+        F = self.F
+        dmid, g['sub_probs.kernel'], g['sub_probs.bias'] = K.conv2d_same_bwd(c[self.mid]['f'], p['sub_probs']['kernel'], dlogits[0])
+        dlast, g['acnn_probs.kernel'], g['acnn_probs.bias'] = K.conv2d_same_bwd(c[self.depth - 1]['f'], p['acnn_probs']['kernel'], dlogits[1])
+        dcat, g['lstm_probs.kernel'], g['lstm_probs.bias'] = K.conv2d_same_bwd(c['cat'], p['lstm_probs']['kernel'], dlogits[2])
+        dlf = resize_nearest_bwd(dcat[..., :64], c['idx'], c['lf'].shape[1], c['lf'].shape[2])
+        for k, v in self.lstm.features_bwd(dlf).items():
+            g['lstm.' + k] = v
+        df = {self.depth - 1: dlast + dcat[..., 64:]}
+        df[self.mid] = df.get(self.mid, 0) + dmid
+        dfeat, ds_next = None, None
+        for l in range(self.depth - 1, -1, -1):
+            cl = c[l]
+            d = df.get(l, 0) + (dfeat if dfeat is not None else 0)
+            dz2 = d * (cl['f'] > 0)
+            dy2, g[f'bn{l}_2.gamma'], g[f'bn{l}_2.beta'] = bn5_train_bwd(cl['y2'], p[f'bn{l}_2']['gamma'], *cl['st2'], dz2)
+            ds, g[f'DilateConv{l}_2.kernel'], _ = K.conv2d_same_bwd(cl['s'], p[f'DilateConv{l}_2']['kernel'], dy2, 3)
+            if ds_next is not None:
+                ds = ds + ds_next
+            gm = ds * (cl['s'] > 0)
+            dy1, g[f'bn{l}_1.gamma'], g[f'bn{l}_1.beta'] = bn5_train_bwd(cl['y1'], p[f'bn{l}_1']['gamma'], *cl['st1'], gm)
+            dfeat, g[f'Conv{l}_1.kernel'], _ = K.conv2d_same_bwd(cl['fin'], p[f'Conv{l}_1']['kernel'], dy1)
+            ds_next = gm if l > 0 else None
+        return g

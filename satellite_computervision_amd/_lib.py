@@ -136,6 +136,7 @@ _SIGS = {
     'satcv_bn_finalize_train': (C.c_int, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32,
                                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'satcv_bn_affine_infer': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp]),
+    'satcv_bn_affine_infer_batched': (C.c_int, [c_vp, c_i32, c_f32, c_vp]),
     'satcv_bn_relu_pool': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'satcv_bn_relu_pool_amax': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     'satcv_bn_bwd_reduce': (C.c_int, [C.POINTER(BnBwdDesc), c_vp]),

@@ -363,6 +363,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #pragma unroll
     for (int r = 0; r < NROUNDS; ++r) dma_b(c_end - c_begin > 1 ? c_begin + 1 : c_begin, (c_begin + 1) % 3, r);
   }
+  if constexpr (TL && SK) {
+    if (c_begin > 0) {                            // split-K of a tap-loop launch: this workgroup's first chunk may belong to a later tap
+      const int tap0 = c_begin / a.cpt;
+      gather_pixels(n0, y0, x0, (tap0 / a.kw) * a.dil - a.halh_tl, (tap0 % a.kw) * a.dil - a.halw_tl);
+    }
+  }
   load_regs(c_begin);
   store_lds(c_begin, DB ? (WDMA ? (c_begin & 1) * a_stage : (c_begin & 1) * stage_elems) : 0);
   if constexpr (DB) { if (c_end - c_begin > 1) load_regs(c_begin + 1); }
@@ -727,10 +733,16 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   a.ksplit = 1; a.kslab = nullptr;
   int ks = 1;
   if constexpr (SK) {
+    // Plain (halo-tile / 1x1) launches: OPT-IN (SATCV_SPLITK=1).  Measured on the U-Net's 8 x 8 data gradient (1024 -> 512, 128 workgroups):
+    // 87.8 -> 72 us alone, nothing in the step (the weight-gradient stream fills the idle CUs anyway), and a K order that depends on the
+    // launch's workgroup count would break the bit-identity of inference across batch splits.  Tap-loop launches (dilated / strided
+    // convolutions: ASPP, the ResNet backbone of the build-defined DeepLab): ON (SATCV_SPLITK_TL=0 turns it off) -- a single 512 x 512
+    // tile puts 16 workgroups on the chip for 576 chunks of its stage-4 convolutions, 318 us per launch whatever the batch.
     static const int splitk = [] { const char* e = getenv("SATCV_SPLITK"); return e ? atoi(e) : 0; }();
-    if (splitk && !TL && !dyn && sizeof(T) == 2 && a.mode_out == 0 && !a.pool_y && !a.accumulate && !a.bst_y && a.cout % 8 == 0 && a.ldy % 8 == 0 &&
-        (!a.stats || (a.cout <= 1024 && 256 % (a.cout / 8) == 0)))
-      while (ks < 4 && blocks * ks * 2 <= 256 && a.nchunks / (ks * 2) >= 8) ks *= 2;
+    static const int splitk_tl = [] { const char* e = getenv("SATCV_SPLITK_TL"); return e ? atoi(e) : 1; }();
+    if ((TL ? splitk_tl : splitk) && !dyn && sizeof(T) == 2 && a.mode_out == 0 && !a.pool_y && !a.accumulate && !a.bst_y && a.cout % 8 == 0 && a.ldy % 8 == 0 &&
+        a.stride == 1 && (!a.stats || (a.cout <= 1024 && 256 % (a.cout / 8) == 0)))
+      while (ks < (TL ? 16 : 4) && blocks * ks * 2 <= 256 && a.nchunks / (ks * 2) >= 8) ks *= 2;
     if (ks == 1) return SATCV_ERR_UNSUPPORTED;          // (the caller continues with the single-pass instantiation)
   }
   if (dry) return SATCV_OK;
@@ -810,7 +822,13 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
         if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 1, TAPS, true>(a, st, dry);
         return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS, true>(a, st, dry);
       }
-      if (nspace >= 128 && nspace % 128 == 0) return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS, true>(a, st, dry);
+      if (nspace >= 128 && nspace % 128 == 0) {
+        if constexpr (std::is_same<T, bf16>::value) {      // few workgroups, hundreds of chunks (a single DeepLab tile): split-K
+          const int rc = fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS, true, false, 0, false, true>(a, st, dry);
+          if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+        }
+        return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS, true>(a, st, dry);
+      }
       if (nspace >= 64 && nspace % 64 == 0) return fast_cfg<T, TW, 2, 2, 2, 1, 2, TAPS, true>(a, st, dry);
       // (the 256x32 tile with 32-channel chunks needs 64-92 bytes of scratch in its tap-loop form: the 16-channel form does not)
       return fast_cfg<T, TW, 4, 1, 2, 1, 1, TAPS, true>(a, st, dry);

@@ -264,7 +264,13 @@ class Plan:
         self.outputs = {}
         self.sync_bn = bool(training and getattr(rt.model, 'sync_bn', False) and parallel.active())
         self.amax_of = {}                     # encoder output tensor id -> arg-max bytes of its 2 x 2 pooling windows (training)
+        self._bn_jobs = []
         self._build()
+        if self._bn_jobs:
+            tab = torch.tensor([[int(v or 0) for v in j] for j in self._bn_jobs], dtype=torch.int64).to(rt.dev)      # satcv_bn_affine_job rows: 6 pointers + c
+            self.keep.append(tab)
+            nj = len(self._bn_jobs)
+            self.fwd.insert(0, lambda st: check(lib.satcv_bn_affine_infer_batched(tab.data_ptr(), nj, BN_EPS, st)))
 
     # -- helpers
     def _z(self, *shape, dtype=None):
@@ -323,7 +329,9 @@ class Plan:
                 _fp(stats, off), ld, c, float(count), g, b, BN_EPS, BN_MOMENTUM, updates, bessel, mm, mv,
                 _fp(a['scale'], aoff), _fp(a['shift'], aoff), _fp(a['mean'], aoff), _fp(a['rstd'], aoff), st)))
         else:
-            self.fwd.append(lambda st: check(lib.satcv_bn_affine_infer(g, b, mm, mv, BN_EPS, c, _fp(a['scale'], aoff), _fp(a['shift'], aoff), st)))
+            # inference: scale / shift depend on the parameters only -- every layer's pair is computed by ONE launch at the head of the
+            # list (satcv_bn_affine_infer_batched, table built at the end of _build)
+            self._bn_jobs.append((g, b, mm, mv, _fp(a['scale'], aoff), _fp(a['shift'], aoff), c))
         return a
 
     def _materialize(self, t, r, f=1, pooled=None, sink=None, actslot=None):

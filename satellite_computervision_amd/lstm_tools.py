@@ -698,3 +698,158 @@ def build_lstm_layers2(params, rng, n_channels, return_sequences=False, return_s
     if dropout is not None or return_sequences:
         raise NotImplementedError('build_lstm_layers2 is lowered as the reference calls it (return_sequences=False, no dropout)')
     return LSTMLayers2(params, rng, n_channels)
+
+
+# ------------------------------------------------------------------------------------------------ hierarchical model (ACNN + LSTM)
+class ConvBN:
+    """layers.Conv2D(filters, 3, padding='same', dilation_rate=d) -> layers.BatchNormalization(): one implicit-GEMM launch with the
+    BatchNorm statistics in its epilogue; the normalisation (+ ReLU) stays pending for the consumers, as in the U-Net engine"""
+
+    def __init__(self, params, rng, conv_name, bn_name, cin, cout, dilation=1, k=3):
+        self.P, self.name, self.cin, self.cout, self.dil, self.k = params, conv_name, cin, cout, dilation, k
+        params.add(f'{conv_name}/kernel', (k, k, cin, cout), _glorot(rng, (k, k, cin, cout), k * k * cin, k * k * cout))
+        params.add(f'{conv_name}/bias', (cout,), lambda: np.zeros(cout, np.float32))
+        self.bn = BatchNorm(params, bn_name, cout)
+
+    def forward(self, x, training, dtype, relu):
+        P = self.P
+        self.wf, self.wd = ops.pack_weights(P.p(f'{self.name}/kernel'), ops.rup(self.cin, 16), dtype)
+        cp = ops.rup(self.cout, 16)
+        stats = ops.new_stats(cp, x.t.device) if training else None
+        y = ops.conv2d(x.t, self.wf, self.cout, kh=self.k, kw=self.k, dil=self.dil, bias=P.p(f'{self.name}/bias'), in_scale=x.scale, in_shift=x.shift,
+                       in_relu=x.relu, stats=stats)
+        self.x = x
+        n, h, w, _ = y.shape
+        return self.bn.forward(Act(y, self.cout), stats, n * h * w, training, relu=relu)
+
+    def backward(self, da, need_dx=True):
+        """da: gradient of the normalised (+ ReLU) output.  (The bias in front of a training-mode BatchNormalization has an exactly zero
+        gradient: it is left at 0, as in the engine.)"""
+        dy = self.bn.backward(da)
+        x = self.x
+        ops.conv2d_wgrad(x.t, dy, self.cin, self.cout, kh=self.k, kw=self.k, dil=self.dil, in_scale=x.scale, in_shift=x.shift, in_relu=x.relu,
+                         dw=self.P.g(f'{self.name}/kernel'))
+        return ops.conv2d_dgrad(dy, self.wd, self.cin, kh=self.k, kw=self.k, dil=self.dil) if need_dx else None
+
+
+def _add_grads(a, b):
+    """a += b (two gradient tensors of one activation with several consumers)"""
+    n = a.numel() // a.shape[-1]
+    check(lib.satcv_add_act(a.data_ptr(), None, None, b.data_ptr(), None, None, 0, a.data_ptr(), n, a.shape[-1], ops.DTYPE_CODE[a.dtype], ops.stream_ptr()))
+    return a
+
+
+class ACNN2Trunk:
+    """build_acnn_layers2 (utils/model_tools.py:941-979): n_blocks x [Conv{l}_1 -> bn{l}_1 -> (+ previous sum, from block 1 on) -> ReLU{l}_1 ;
+    DilateConv{l}_2 (rate 3) -> bn{l}_2 -> ReLU{l}_2].  forward returns the ReLU{l}_2 activations of every block (pending BatchNorm + ReLU);
+    backward takes a gradient per tapped block."""
+
+    def __init__(self, params, rng, nchannels, n_blocks=16, feature_num=16):
+        self.n, self.F = n_blocks, feature_num
+        self.c1, self.c2 = [], []
+        for l in range(n_blocks):
+            self.c1.append(ConvBN(params, rng, f'Conv{l}_1', f'bn{l}_1', nchannels if l == 0 else feature_num, feature_num))
+            self.c2.append(ConvBN(params, rng, f'DilateConv{l}_2', f'bn{l}_2', feature_num, feature_num, dilation=3))
+
+    def forward(self, x, training, dtype):
+        feats, self.sums, fa = [], [], None
+        f = x
+        for l in range(self.n):
+            normed = self.c1[l].forward(f, training, dtype, relu=(l == 0))
+            y = normed.t
+            n, h, w, cp = y.shape
+            out = torch.empty_like(y)
+            if l == 0:          # ReLU0_1(bn0_1(conv)): materialised, the next block adds it
+                check(lib.satcv_bn_relu_pool(y.data_ptr(), normed.scale.data_ptr(), normed.shift.data_ptr(), out.data_ptr(), cp, None, None, 0, n, h, w, cp, 1,
+                                             ops.DTYPE_CODE[y.dtype], ops.stream_ptr()))
+            else:               # ReLU{l}_1(bn{l}_1(conv) + previous sum)
+                check(lib.satcv_add_act(y.data_ptr(), normed.scale.data_ptr(), normed.shift.data_ptr(), fa.data_ptr(), None, None, 1, out.data_ptr(),
+                                        n * h * w, cp, ops.DTYPE_CODE[y.dtype], ops.stream_ptr()))
+            fa = out
+            self.sums.append(out)
+            f = self.c2[l].forward(Act(fa, self.F), training, dtype, relu=True)
+            feats.append(f)
+        return feats
+
+    def backward(self, dfeats):
+        """dfeats: {block index: gradient of its ReLU{l}_2 activation} (storage type); gradients of deeper consumers are added here"""
+        dfa_next, dfeat = None, None            # gradient of the sum of block l + 1 w.r.t. the sum of block l; gradient of feature l from Conv{l+1}_1
+        for l in range(self.n - 1, -1, -1):
+            df = dfeats.get(l)
+            if dfeat is not None:
+                df = dfeat if df is None else _add_grads(df, dfeat)
+            dsum = self.c2[l].backward(df) if df is not None else None           # gradient of the sum fa_l through DilateConv{l}_2
+            if dfa_next is not None:
+                dsum = dfa_next if dsum is None else _add_grads(dsum, dfa_next)
+            if dsum is None:
+                dfeat = dfa_next = None
+                continue
+            g = dsum                                  # through ReLU{l}_1: mask by the materialised sum; serves both addends
+            check(lib.satcv_relu_bwd(self.sums[l].data_ptr(), g.data_ptr(), g.numel(), ops.DTYPE_CODE[g.dtype], ops.stream_ptr()))
+            if l == 0:
+                # block 0's ReLU belongs to its BatchNorm: the gradient was masked above, the BatchNorm backward runs in linear mode
+                self.c1[0].bn.ctx['relu'] = False
+                self.c1[0].backward(g, need_dx=False)
+                dfeat = dfa_next = None
+            else:
+                dfeat = self.c1[l].backward(g, need_dx=True)               # gradient of feature l - 1 (the ReLU{l-1}_2 activation)
+                dfa_next = g
+
+
+class HierarchicalModel(_SeqModelBase):
+    """get_hierarchical_model (utils/model_tools.py:1016-1060): get_acnn_model2's trunk with three softmax heads -- 'sub_probs' on the
+    middle block's ReLU{(depth-1)//2}_2, 'acnn_probs' on the last block's, 'lstm_probs' on concat([nearest-resized build_lstm_layers output,
+    last block's activation]).  Inputs [acnn_input (B, H, W, C), lstm_input (B, T, h, w, c)], outputs [sub_probs, acnn_probs, lstm_probs]."""
+
+    def __init__(self, nclasses, acnn_nclasses, acnn_sub_nclasses, acnn_dim, lstm_dim, nfilters, depth, seed=None):
+        rng = np.random.default_rng(seed if seed is not None else mt._RNG.integers(1 << 31))
+        self.P = _Params()
+        self.acnn_dim, self.lstm_dim, self.depth, self.mid = tuple(acnn_dim), tuple(lstm_dim), depth, (depth - 1) // 2
+        self.trunk = ACNN2Trunk(self.P, rng, acnn_dim[-1], depth, nfilters)
+        self.lstm = LSTMLayers(self.P, rng, lstm_dim[-1])
+        self.sub = Dense1x1(self.P, rng, 'sub_probs', [nfilters], acnn_sub_nclasses, 'softmax')
+        self.acnn = Dense1x1(self.P, rng, 'acnn_probs', [nfilters], acnn_nclasses, 'softmax')
+        self.fuse = Dense1x1(self.P, rng, 'lstm_probs', [self.lstm.F, nfilters], nclasses, 'softmax')
+        self._finish()
+
+    def _forward(self, xs, training):
+        xa, xl = xs
+        xa = xa if isinstance(xa, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(xa, dtype=np.float32))
+        x = ops.ingest_nhwc(xa.to(_dev(), torch.float32), ops.rup(self.acnn_dim[-1], 16), self.dtype_code)
+        feats = self.trunk.forward(Act(x, self.acnn_dim[-1]), training, self.dtype_code)
+        xt, (B, T, hh, ww) = _ingest_seq(xl, ops.rup(self.lstm_dim[-1], 16), self.dtype_code)
+        lf = self.lstm.forward(Act(xt, self.lstm_dim[-1]), T, B, training, self.dtype_code)
+        H, W = x.shape[1], x.shape[2]
+        return [self.sub.forward([(feats[self.mid], False)]), self.acnn.forward([(feats[-1], False)]),
+                self.fuse.forward([(lf, True), (feats[-1], False)], out_hw=(H, W))]
+
+    def predict(self, x, batch_size=None, verbose=0, **kw):
+        return [o.cpu().numpy() for o in self._forward(x, False)]
+
+    def train_on_batch(self, x, y):
+        if self._loss is None:
+            raise RuntimeError('compile() the model before fit/train')
+        self.P.grad.zero_()
+        outs = self._forward(x, True)
+        total, dl = 0.0, []
+        for o, yy in zip(outs, y):
+            loss, d = self._loss_grad(o, yy, 'softmax')
+            total += float(loss.item())
+            dl.append(d)
+        (dmid,) = self.sub.backward(dl[0], need_dx=(True,))
+        (dlast,) = self.acnn.backward(dl[1], need_dx=(True,))
+        dlf, dlast2 = self.fuse.backward(dl[2], need_dx=(True, True))
+        self.lstm.backward(dlf)
+        dfe = {self.depth - 1: _add_grads(dlast, dlast2)}
+        if self.mid == self.depth - 1:
+            _add_grads(dfe[self.mid], dmid)
+        else:
+            dfe[self.mid] = dmid
+        self.trunk.backward(dfe)
+        self._adam()
+        return total
+
+
+def get_hierarchical_model(nclasses, acnn_nclasses, acnn_sub_nclasses, acnn_dim, lstm_dim, nfilters, depth):
+    """utils/model_tools.py:1016-1060"""
+    return HierarchicalModel(nclasses, acnn_nclasses, acnn_sub_nclasses, acnn_dim, lstm_dim, nfilters, depth)

@@ -1044,7 +1044,7 @@ class Model:
 
     # ---- hipGraph replay of launch-bound inference plans (satcv_graph_begin / _end / _launch, include/satcv.h)
     # A plan of many short kernels -- DeepLab-v3 / ResNet-50 at batch 1: ~170 dependent launches of a few microseconds each -- is bound by
-    # the HOST: a ctypes launch costs 10-20 us, the kernels 2-6 us.  Such a plan (at least SATCV_INFER_GRAPH_MIN launches, default 96) is
+    # the HOST: a ctypes launch costs 10-20 us, the kernels 2-6 us.  Such a plan (at least SATCV_INFER_GRAPH_MIN launches, default 64) is
     # captured once per (plan, input address) after a warm-up run and replayed with ONE call; the U-Net plans (~50 launches, GPU-bound
     # even at batch 1) stay eager.  SATCV_INFER_GRAPH=0 turns it off, =2 forces it for every inference plan.
     def _replay_graph(self, plan):
@@ -1052,7 +1052,7 @@ class Model:
         fwd = getattr(plan, 'fwd', None)
         if mode == 0 or fwd is None or getattr(plan, 'training', False) or getattr(plan, 'dropouts', None):
             return False
-        if mode < 2 and len(fwd) < int(os.environ.get('SATCV_INFER_GRAPH_MIN', '96')):
+        if mode < 2 and len(fwd) < int(os.environ.get('SATCV_INFER_GRAPH_MIN', '64')):
             return False
         cache = plan.__dict__.setdefault('_graphs', {})
         key = tuple(sorted((getattr(plan, 'x_src', None) or {}).items()))      # (a resident batch is read in place: its address is part of the graph)

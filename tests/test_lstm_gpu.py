@@ -257,3 +257,71 @@ def test_hybrid_generator_feeds_the_hybrid_model(lt):
         assert pr.shape == (2, 48, 48, 3)
     finally:
         mt.set_compute_dtype('bfloat16')
+
+
+def test_hierarchical_model_matches_oracle(lt):
+    """get_hierarchical_model (utils/model_tools.py:1016-1060), fp32: the three softmax outputs and every gradient of one training step
+    (weighted categorical cross-entropy on each head, summed) against the float64 oracle -- the atrous trunk's residual sums, a middle
+    block feeding both its successor and a head, the last block feeding two heads, and the LSTM branch through the nearest resize."""
+    from satellite_computervision_amd import model_tools as mt
+    mt.set_compute_dtype('float32')
+    try:
+        ncls, nacnn, nsub, nf, depth = 3, 4, 5, 16, 3
+        B, H, W, Cc, T, hh, ww, lc = 2, 24, 24, 4, 2, 8, 8, 6
+        o = CL.HierarchicalOracle(ncls, nacnn, nsub, Cc, lc, nf, depth, rec_act=lt.RECURRENT_ACTIVATION, seed=3)
+        m = lt.get_hierarchical_model(ncls, nacnn, nsub, (H, W, Cc), (T, hh, ww, lc), nf, depth)
+        w = {}
+        for lk, lv in o.p.items():
+            for pk, pv in lv.items():
+                lv[pk] = pv.astype(np.float32).astype(np.float64)
+                w[f'{lk}/{pk}'] = lv[pk]
+        lnames = {'l1': 'conv_lstm', 'l2': 'dilated_conv_lstm', 'bn1': 'batch_norm', 'bn2': 'batch_norm2'}
+        for lk, lv in o.lstm.p.items():
+            if lk == 'dense':
+                continue
+            for pk, pv in lv.items():
+                lv[pk] = pv.astype(np.float32).astype(np.float64)
+                w[f'{lnames[lk]}/{pk}'] = lv[pk]
+        m.set_weights_dict(w)
+        rng = np.random.default_rng(6)
+        xa = rng.random((B, H, W, Cc)).astype(np.float32)
+        xl = rng.random((B, T, hh, ww, lc)).astype(np.float32)
+        refs = o.forward(xa.astype(np.float64), xl.astype(np.float64))
+        ys = [np.eye(k, dtype=np.float32)[rng.integers(0, k, (B, H, W))] for k in (nsub, nacnn, ncls)]
+        m.compile(optimizer=mt.Adam(0.0), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0] * 8))
+        # (one weight vector per head: the compiled loss carries max(n) weights, each head uses its first n)
+        losses, dls = [], []
+        for r, y, k in zip(refs, ys, (nsub, nacnn, ncls)):
+            l, dp, _ = OL.weighted_categorical_crossentropy(y.astype(np.float64), r, [1.0] * k)
+            losses.append(l)
+            dls.append(K.softmax_bwd(r, dp))
+        g_ref = o.backward(dls)
+        m._loss.weights = None
+        # per-head weights: run the step with unit weights of the right length per head
+        import satellite_computervision_amd.lstm_tools as LT
+        orig = LT._SeqModelBase._loss_grad
+
+        def per_head(self, out, y_true, activation):
+            self._loss.weights = np.ones(out.shape[-1], np.float32)
+            return orig(self, out, y_true, activation)
+        LT._SeqModelBase._loss_grad = per_head
+        try:
+            loss = m.train_on_batch([xa, xl], ys)
+        finally:
+            LT._SeqModelBase._loss_grad = orig
+        np.testing.assert_allclose(loss, sum(losses), rtol=1e-4)
+        outs = m.predict([xa, xl])          # inference-mode BatchNorm: shapes and normalisation only
+        assert [o_.shape for o_ in outs] == [r.shape for r in refs]
+        for ok, gv in g_ref.items():
+            if ok == 'lstm.input':
+                continue
+            if ok.startswith('lstm.'):
+                pre, pk = ok[5:].split('.', 1)
+                dk = f'{lnames[pre]}/{pk}'
+            else:
+                pre, pk = ok.split('.', 1)
+                dk = f'{pre}/{pk}'
+            g = m.P.g(dk).cpu().numpy().astype(np.float64).reshape(gv.shape)
+            assert cosine(g, gv) > 0.9999 and rel(g, gv) < 5e-3, (ok, cosine(g, gv), rel(g, gv))
+    finally:
+        mt.set_compute_dtype('bfloat16')
