@@ -583,7 +583,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 // plan sizes it).  Returns nullptr when the allocation fails (the launch then runs unsplit).
 #include <mutex>
 static float* igemm_splitk_workspace(hipStream_t st, size_t bytes) {
-  struct Slot { hipStream_t st; int dev; void* p; size_t n; };
+  struct Slot { hipStream_t st; int dev; void* p; size_t n; bool captured; };
   static Slot slots[16];
   static int nslots = 0;
   static std::mutex mu;
@@ -595,16 +595,21 @@ static float* igemm_splitk_workspace(hipStream_t st, size_t bytes) {
   if (!s) {
     if (nslots == 16) return nullptr;
     s = &slots[nslots++];
-    *s = Slot{st, dev, nullptr, 0};
+    *s = Slot{st, dev, nullptr, 0, false};
   }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
   if (s->n < bytes) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;      // never allocate inside a capture
-    if (s->p) { (void)hipStreamSynchronize(st); (void)hipFree(s->p); s->p = nullptr; s->n = 0; }
+    if (capturing) return nullptr;      // never allocate inside a capture (callers run the launch list once on the capture stream first)
+    // a buffer whose address sits in a captured graph stays alive when the stream later needs a larger one (a handful of growth events
+    // per process: one per larger plan shape)
+    if (s->p && !s->captured) { (void)hipStreamSynchronize(st); (void)hipFree(s->p); }
+    s->p = nullptr; s->n = 0; s->captured = false;
     const size_t want = bytes + (bytes >> 2);
     if (hipMalloc(&s->p, want) != hipSuccess) { (void)hipGetLastError(); s->p = nullptr; return nullptr; }
     s->n = want;
   }
+  if (capturing) s->captured = true;
   return reinterpret_cast<float*>(s->p);
 }
 

@@ -889,17 +889,27 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs a) {
     //  would be compiled into every slot behind a branch)  half 0: the X items, half 1: the DMA pieces
     auto half_tile = [&](auto HALF) {
       constexpr int H0 = decltype(HALF)::value * 4;
+      // the dY fragment and the first X fragment of k-step kq + 1 are requested during the last tap of k-step kq: a k-step otherwise
+      // opened with six reads and a wait in front of its first MFMA (8 exposed LDS latencies per tile instead of 2)
+      bf16x4 nb_lo[2], nb_hi[2], na_lo[2], na_hi[2];
+      int xoa_n[2], xob_n[2];
+      auto first_reads = [&](int ks, int slot_) {
+        nb_lo[slot_] = tr_read(ldsD + d_lane + ks * 16 * CO_T);
+        nb_hi[slot_] = tr_read(ldsD + d_lane + (ks * 16 + 4) * CO_T);
+        xoa_n[slot_] = tab[ks * 16 + q_lane] + wci * 32 + chb;
+        xob_n[slot_] = tab[ks * 16 + q_lane + 4] + wci * 32 + chb;
+        na_lo[slot_] = tr_read(ldsX + xoa_n[slot_]);
+        na_hi[slot_] = tr_read(ldsX + xob_n[slot_]);
+      };
+      first_reads(H0, 0);
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) {
-        const int ks = H0 + kq;
-        const bf16x4 blo = tr_read(ldsD + d_lane + ks * 16 * CO_T);
-        const bf16x4 bhi = tr_read(ldsD + d_lane + (ks * 16 + 4) * CO_T);
-        const bf16x8 bfr = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
-        const int xoa = tab[ks * 16 + q_lane] + wci * 32 + chb;
-        const int xob = tab[ks * 16 + q_lane + 4] + wci * 32 + chb;
+        const int cur_ = kq & 1;
+        const bf16x8 bfr = __builtin_shufflevector(nb_lo[cur_], nb_hi[cur_], 0, 1, 2, 3, 4, 5, 6, 7);
+        const int xoa = xoa_n[cur_], xob = xob_n[cur_];
         bf16x4 alo[2], ahi[2];
-        alo[0] = tr_read(ldsX + xoa);
-        ahi[0] = tr_read(ldsX + xob);
+        alo[0] = na_lo[cur_];
+        ahi[0] = na_hi[cur_];
 #pragma unroll
         for (int tap = 0; tap < NTAPS; ++tap) {
           if (tap + 1 < NTAPS) {
@@ -907,6 +917,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs a) {
             const int toff = (ky * (TW + 2) + kx) * XP;      // dilation 1: cl = TW + 2, an instruction immediate
             alo[(tap + 1) & 1] = tr_read(ldsX + xoa + toff);
             ahi[(tap + 1) & 1] = tr_read(ldsX + xob + toff);
+          } else if (kq + 1 < 4) {
+            first_reads(H0 + kq + 1, cur_ ^ 1);
           }
           const int slot = kq * NTAPS + tap;                 // 0 .. 35 inside the half
           if constexpr (decltype(HALF)::value == 0) {
@@ -1136,8 +1148,9 @@ static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
   // for the weight gradient to END (bn_bwd_finalize: 5 -> 12-280 us in the step).  The weight gradients have slack (their stream is
   // busy 4 of 10 ms): 160 workgroups make each of them ~12 % slower and the step 1.5 % faster (10.29 -> 10.13 ms, A/B/A/B; 128: the
   // same step, weight gradients 25 % slower; 224: -1.0 %; 96: the weight gradients become the critical path, +3 %).
-  // SATCV_WGRAD_WGS overrides.
-  static const int db_wgs = [] { const char* e = getenv("SATCV_WGRAD_WGS"); const int v = e ? atoi(e) : 160; return v >= 8 ? v : 160; }();
+  // With the round-4 LDS-DMA kernel (11 % faster by itself) the balance moved: 128 workgroups 8.53 ms, 160 8.64 ms (A/B on one box,
+  // medians of five 20-step regions, gpurun_out -> profiles/r04_ab_wgs.txt).  SATCV_WGRAD_WGS overrides.
+  static const int db_wgs = [] { const char* e = getenv("SATCV_WGRAD_WGS"); const int v = e ? atoi(e) : 128; return v >= 8 ? v : 128; }();
   const int wgs = d->whole_chip ? 256 : db_wgs;
   if (p.db) ns = nblk >= wgs ? 1 : wgs / nblk;
   if (ns > ptiles) ns = ptiles;

@@ -1072,6 +1072,8 @@ class Model:
             side = self.__dict__.setdefault('_capture_stream', torch.cuda.Stream())     # (the legacy default stream cannot be captured)
             side.wait_stream(cur)
             sp = C.c_void_p(side.cuda_stream)
+            plan.run_forward(sp)                 # per-stream set-up (the split-K slabs of this stream) outside the capture: the graph then
+            #                                      holds the same launches, bit for bit, as the eager list
             if lib.satcv_graph_begin(sp) != 0:
                 cache[key] = 'off'
                 return False
