@@ -108,7 +108,9 @@ typedef struct satcv_conv_desc {
   int32_t cstat;           /* modulus mapping N index -> bias/stats channel            */
   int32_t out_relu;        /* clamp outputs at 0 before storing                        */
   int32_t dtype;
-  int32_t accumulate;      /* y += result instead of y = result (fan-out of a tensor into several convs) */
+  int32_t accumulate;      /* 1: y += result instead of y = result (fan-out of a tensor into several convs);
+                            * 2: y = ReLU(y + result), the result rounded to the storage type first (residual join written in place
+                            *    over the shortcut; inference) */
   /* strided convolution (ResNet-style, symmetric zero padding dil*(k-1)/2): output grid (n,h,w_), input grid
    * (n,hin,win) with h = (hin-1)/stride+1.  stride 0/1 = dense.  Generic kernel only. */
   int32_t stride, hin, win;
@@ -219,6 +221,9 @@ int satcv_bn_affine_infer(const float* gamma, const float* beta, const float* mo
 typedef struct satcv_bn_affine_job {
   const float* gamma; const float* beta; const float* moving_mean; const float* moving_var;
   float* scale; float* shift; int64_t c;
+  /* optional (NULL: not written): bias_eff = scale * conv_bias + shift -- the additive term of a convolution whose epilogue applies
+   * its own inference BatchNormalization (out_scale = scale, bias = bias_eff), as the residual joins of the ResNet backbone do */
+  const float* conv_bias; float* bias_eff;
 } satcv_bn_affine_job;
 int satcv_bn_affine_infer_batched(const satcv_bn_affine_job* jobs_device, int32_t njobs, float eps, void* stream);
 

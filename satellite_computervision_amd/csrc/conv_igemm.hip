@@ -205,7 +205,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
           } else {
             off = ((size_t)(nimg * ho + y) * wo + x) * a.ldy + cn;
           }
-          const T tvv = a.accumulate ? (T)((float)yp[off] + v) : tv;
+          const T tvv = a.accumulate ? (T)(a.accumulate == 2 ? fmaxf((float)yp[off] + (float)tv, 0.f) : (float)yp[off] + v) : tv;
           yp[off] = tvv;
           const float fv = (float)tvv;
           s1 += fv; s2 += fv * fv;

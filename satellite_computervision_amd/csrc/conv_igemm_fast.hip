@@ -846,7 +846,13 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
         // ... and on the double-buffered 256-pixel x 128-channel tile, one barrier per chunk (SATCV_DB1X1=0: the single-buffered tile)
         static const bool db1 = !(getenv("SATCV_DB1X1") && atoi(getenv("SATCV_DB1X1")) == 0);
         // (forward transposed convs: 48.5 -> 40.2 and 50.3 -> 42.8 us at 8 x 8 and 16 x 16; their space-to-depth data gradients measured slower on it)
-        if (ks4 && db1 && a.mode_in == 0 && nspace >= 128 && nspace % 128 == 0 && (long long)cdiv(a.n * a.h * a.w_, 256) * (nspace / 128) >= 192) {
+        // ... or when even the 128-pixel tiles leave CUs idle (a single DeepLab tile: 16-128 workgroups): the launch then lasts one
+        // workgroup's K loop, whose chunk costs the single-buffered tile a full load latency between two barriers (~1.5 us for 0.3 us of
+        // MFMAs) -- SATCV_DB1X1_SMALL=0 turns this case off.  Same 64-channel chunks and k order: the two tiles give identical bits.
+        static const bool db1s = !(getenv("SATCV_DB1X1_SMALL") && atoi(getenv("SATCV_DB1X1_SMALL")) == 0);
+        const long long mt256 = cdiv(a.n * a.h * a.w_, 256), mt128 = cdiv(a.n * a.h * a.w_, 128);
+        if (ks4 && db1 && a.mode_in == 0 && nspace >= 128 && nspace % 128 == 0 &&
+            (mt256 * (nspace / 128) >= 192 || (db1s && mt128 * (nspace / 128) <= 256))) {
           const int rc = fast_cfg<T, TW, 4, 2, 2, 2, 4, TAPS, false, true>(a, st, dry);
           if (rc != SATCV_ERR_UNSUPPORTED) return rc;
         }

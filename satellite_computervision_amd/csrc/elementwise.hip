@@ -276,7 +276,9 @@ __global__ void bn_affine_infer_batched_kernel(const satcv_bn_affine_job* __rest
   const satcv_bn_affine_job j = jobs[blockIdx.x];
   for (int ch = threadIdx.x; ch < j.c; ch += blockDim.x) {
     const float sc = j.gamma[ch] / sqrtf(j.moving_var[ch] + eps);
-    j.scale[ch] = sc; j.shift[ch] = j.beta[ch] - j.moving_mean[ch] * sc;
+    const float sh = j.beta[ch] - j.moving_mean[ch] * sc;
+    j.scale[ch] = sc; j.shift[ch] = sh;
+    if (j.bias_eff) j.bias_eff[ch] = sh + (j.conv_bias ? j.conv_bias[ch] * sc : 0.f);      // BN(acc + b) = sc * acc + (sc * b + sh)
   }
 }
 extern "C" int satcv_bn_affine_infer_batched(const satcv_bn_affine_job* jobs_device, int32_t njobs, float eps, void* stream) {

@@ -382,8 +382,28 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     const T* sp = ldsO + q * OPITCH + vq * EPV;
     if (SKIP_STORES) continue;
     if (a.accumulate) {
+      // accumulate == 2: y = ReLU(y + result) -- the residual join of a ResNet bottleneck written in place over the shortcut
+      // (inference; engine.py fuses `add_relu` into the block's last convolution when nothing else reads the shortcut afterwards)
       const int ne = min(EPV, ncols - vq * EPV);
-      for (int e = 0; e < ne; ++e) yp[off + e] = (T)((float)yp[off + e] + (float)sp[e]);
+      if (ne == EPV && sizeof(T) == 2) {
+        uint4 ov = *reinterpret_cast<const uint4*>(yp + off);
+        const uint4 nv = *reinterpret_cast<const uint4*>(sp);
+        T* oe = reinterpret_cast<T*>(&ov);
+        const T* nn = reinterpret_cast<const T*>(&nv);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          float vv = (float)oe[e] + (float)nn[e];
+          if (a.accumulate == 2) vv = fmaxf(vv, 0.f);
+          oe[e] = (T)vv;
+        }
+        *reinterpret_cast<uint4*>(yp + off) = ov;
+      } else {
+        for (int e = 0; e < ne; ++e) {
+          float vv = (float)yp[off + e] + (float)sp[e];
+          if (a.accumulate == 2) vv = fmaxf(vv, 0.f);
+          yp[off + e] = (T)vv;
+        }
+      }
     } else if (ncols - vq * EPV >= EPV) {
       *reinterpret_cast<uint4*>(yp + off) = *reinterpret_cast<const uint4*>(sp);
     } else {

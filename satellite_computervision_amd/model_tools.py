@@ -1086,6 +1086,7 @@ class Model:
                 cache[key] = 'off'
                 return False
             cache[key] = ent = h.value
+            cur.wait_stream(side)                # (the eager pass on the capture stream writes the plan's buffers: finish it before the replay)
         if ent == 'off':
             return False
         check(lib.satcv_graph_launch(ent, C.c_void_p(cur.cuda_stream)))
