@@ -209,8 +209,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
     c.shp = a.in_scale ? a.in_shift + cg0 + slot_t * EL : reinterpret_cast<const float*>(a.w);
     return c;
   };
+  // double-buffered tap-loop form: the gather table changes with the tap while loads of an earlier tap are still held in registers, so an
+  // item's validity is captured when it is loaded
+  bool ra_ok[AI];
   auto load_a = [&](const ChunkSrc& c, int j) {
     const int p = a_p[j] < 0 ? 0 : a_p[j];
+    if constexpr (TL && DB) ra_ok[j] = a_p[j] >= 0;
     if (!ABL(4)) ra[j] = gload8<T>(c.src + (size_t)(p + c.sadd) * c.cs + (ABL(256) ? 0 : c.coff) + slot_t * EL);
     else ra[j] = zero8<T>();
   };
@@ -245,7 +249,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
         v = affine8<T>(v, a.in_scale + cg0, a.in_shift + cg0, a.in_relu);
       }
     }
-    v = select8<T>(a_p[j] >= 0, v);
+    if constexpr (TL && DB) v = select8<T>(ra_ok[j], v);
+    else v = select8<T>(a_p[j] >= 0, v);
     if (ABL(64)) { keep8<T>(v); return; }
     if (a_l[j] >= 0) lstore8<T>(ldsA + boff + a_l[j], v);
   };
@@ -369,9 +374,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
       gather_pixels(n0, y0, x0, (tap0 / a.kw) * a.dil - a.halh_tl, (tap0 % a.kw) * a.dil - a.halw_tl);
     }
   }
+  int tap_g = TL ? c_begin / a.cpt : 0;             // (double-buffered tap-loop form) the tap the gather table a_p currently describes
+  auto regather = [&](int chunk_) {
+    if constexpr (TL && DB) {
+      const int t = chunk_ / a.cpt;
+      if (t != tap_g) {                             // wave-uniform; no vector-memory instruction inside
+        tap_g = t;
+        gather_pixels(n0, y0, x0, (t / a.kw) * a.dil - a.halh_tl, (t % a.kw) * a.dil - a.halw_tl);
+      }
+    }
+  };
   load_regs(c_begin);
   store_lds(c_begin, DB ? (WDMA ? (c_begin & 1) * a_stage : (c_begin & 1) * stage_elems) : 0);
-  if constexpr (DB) { if (c_end - c_begin > 1) load_regs(c_begin + 1); }
+  if constexpr (DB) { if (c_end - c_begin > 1) { regather(c_begin + 1); load_regs(c_begin + 1); } }
   if constexpr (WDMA) dma_wait_all();
   __syncthreads();
 #ifdef SATCV_STAMP
@@ -447,6 +462,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
         //  instructions inside the loop: see the note at the loaders)
         const int nxt2 = do_load ? chunk + 2 : c_end - 1;
         const ChunkSrc cs_ = chunk_src(nxt2);
+        regather(nxt2);
 #ifdef SATCV_STAMP
         STAMP(t0);
         STAMP(t1);
@@ -714,7 +730,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   size_t lds_stage = (((size_t)KC * a.rl * a.pitch + (size_t)TAPS * KC * BN) * sizeof(T) + (size_t)(KC / EL) * 128) * (DB ? 2 : 1);      // + slot padding (< 128 B per plane)
   if (WDMA) lds_stage = 2 * ((size_t)KC * a.rl * a.pitch * sizeof(T) + (size_t)(KC / EL) * 128) + 3 * (size_t)TAPS * KC * BN * sizeof(T);      // two A stages + a three-slot weight ring
   if (WDMA && (((uintptr_t)a.w % 16) != 0 || a.cout_pad % 64 != 0)) return SATCV_ERR_UNSUPPORTED;
-  if (DB && (TL || a.mode_in != 0)) return SATCV_ERR_UNSUPPORTED;
+  if (DB && ((TL && TAPS != 1) || a.mode_in != 0)) return SATCV_ERR_UNSUPPORTED;
   size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
   if (a.bst_y) {
     // fused BatchNorm-backward reduce: only the epilogue's interior-tile path does it, so EVERY tile must be one; a second staging
@@ -831,6 +847,17 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
         if constexpr (std::is_same<T, bf16>::value) {      // few workgroups, hundreds of chunks (a single DeepLab tile): split-K
           const int rc = fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS, true, false, 0, false, true>(a, st, dry);
           if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+          // the double-buffered 256-pixel x 128-channel tile with 64-channel chunks (one barrier per chunk, the next chunk's loads in
+          // flight under the MFMAs; the gather table is re-derived when the chunk stream crosses into the next tap): the dilated 3 x 3
+          // convolutions of a DeepLab batch / the ASPP ran at 230-460 TFLOP/s on the single-buffered 128 x 128 tile with 32-channel
+          // chunks (8 MFMAs per wave between two barrier pairs).  SATCV_DB_TL=0: the single-buffered tile.  (Different chunk size: the
+          // two forms sum K in a different grouping -- the choice depends on the shape AND the tile count, like split-K above)
+          static const int db_tl = [] { const char* e = getenv("SATCV_DB_TL"); return e ? atoi(e) : 1; }();
+          if (db_tl && g_opt_igemm_db != 0 && cin % 64 == 0 && (!a.x1 || a.c0 % 64 == 0) &&
+              ((long long)cdiv(a.n * a.h * a.w_, 256) * (nspace / 128) >= (db_tl > 1 ? db_tl : 96))) {
+            const int rc2 = fast_cfg<T, TW, 4, 2, 2, 2, 4, TAPS, true, true>(a, st, dry);
+            if (rc2 != SATCV_ERR_UNSUPPORTED) return rc2;
+          }
         }
         return fast_cfg<T, TW, 2, 2, 2, 2, 2, TAPS, true>(a, st, dry);
       }

@@ -1514,3 +1514,16 @@ def structural_names(model):
             bn(f'dec{j}.bn{r}', node.attrs['owner'].bn_layer.name)
     conv('probs', head)
     return out
+
+
+# ---- ConvLSTM2D family (utils/model_tools.py:666-920, 1016-1109): the builders live in lstm_tools.py (tape executor, time-major tensors) and
+# are reachable under the reference's module name; resolved on first use because lstm_tools imports this module
+_LSTM_NAMES = ('build_lstm_layers', 'build_lstm_layers2', 'get_lstm_model', 'get_lstm_autoencoder', 'get_hybrid_model',
+               'get_hierarchical_model', 'ConvLSTM2D')
+
+
+def __getattr__(name):
+    if name in _LSTM_NAMES:
+        from . import lstm_tools
+        return getattr(lstm_tools, name)
+    raise AttributeError(f'module {__name__!r} has no attribute {name!r}')

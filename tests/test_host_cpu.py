@@ -201,3 +201,12 @@ def test_file_list_helpers_match_reference_fixture():
     assert got == z['match_subset']
     assert P.match_files(flat, {'naip': {'files': []}, 's2': {'files': []}, 'label': {'files': []}}, parts=slice(3, 5), flatdirectory=True) == z['match_flat']
     assert P.split_files(urls, labels=['label', 'naip', 's2']) == z['split']
+
+
+def test_lstm_builders_are_reachable_under_the_reference_module_name():
+    """a caller of utils/model_tools.py:666-920, 1016 finds the ConvLSTM2D builders under model_tools (they live in lstm_tools)"""
+    from satellite_computervision_amd import model_tools as mt, lstm_tools as lt
+    for name in ('build_lstm_layers', 'build_lstm_layers2', 'get_lstm_model', 'get_lstm_autoencoder', 'get_hybrid_model', 'get_hierarchical_model'):
+        assert getattr(mt, name) is getattr(lt, name)
+    with pytest.raises(AttributeError):
+        mt.no_such_builder
