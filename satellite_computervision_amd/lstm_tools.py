@@ -464,6 +464,47 @@ class _SeqModelBase:
         for k, v in d.items():
             self.P.p(k).copy_(torch.as_tensor(np.asarray(v, np.float32)).to(self.P.flat.device).view(self.P.specs[k][1]))
 
+    # Model.save_weights / load_weights / evaluate call sites of the reference (utils/model_tools.py:1162-1196 and the notebooks):
+    # the own .npz container; a model with a static-engine branch (the hybrid's U-Net) stores that branch under 'unet::<name>'
+    def _branch_models(self):
+        return {'unet': self.unet} if hasattr(self, 'unet') else {}
+
+    def save_weights(self, path):
+        d = {k: v for k, v in self.get_weights_dict().items()}
+        for tag, bm in self._branch_models().items():
+            d.update({f'{tag}::{k}': v for k, v in bm.get_weights_dict().items()})
+        np.savez(path if str(path).endswith('.npz') else str(path) + '.npz', **d)
+
+    def load_weights(self, path, **kw):
+        p = path if os.path.exists(path) else str(path) + '.npz'
+        with np.load(p, allow_pickle=False) as z:
+            own = {k: z[k] for k in z.files if '::' not in k}
+            missing = set(self.P.specs) - set(own)
+            if missing:
+                raise ValueError(f'{p}: no weights for {sorted(missing)[:4]}...')
+            self.set_weights_dict({k: own[k] for k in self.P.specs})
+            for tag, bm in self._branch_models().items():
+                bm.set_weights_dict({k.split('::', 1)[1]: z[k] for k in z.files if k.startswith(tag + '::')})
+
+    def _eval_forward(self, xb):
+        raise NotImplementedError(f'{type(self).__name__}.evaluate: multi-output model -- evaluate its outputs with predict()')
+
+    def evaluate(self, x=None, y=None, batch_size=None, verbose=0, **kw):
+        """mean loss of the compiled loss function over the batches (no parameter update)"""
+        if self._loss is None:
+            raise RuntimeError('compile() the model before evaluate')
+        multi = isinstance(x, (list, tuple))
+        n = (x[0] if multi else x).shape[0]
+        bs = batch_size or 32
+        tot, cnt = 0.0, 0
+        for i in range(0, n, bs):
+            xb = [a[i:i + bs] for a in x] if multi else x[i:i + bs]
+            out = self._eval_forward(xb)
+            loss, _ = self._loss_grad(out[0], y[i:i + bs], out[1])
+            k = (xb[0] if multi else xb).shape[0]
+            tot, cnt = tot + float(loss.item()) * k, cnt + k
+        return tot / max(cnt, 1)
+
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=0, steps_per_epoch=None, **kw):
         """x: array(s) or a Sequence / iterable of (x, y) batches (LSTMDataGenerator, HybridDataGenerator)"""
         hist = {'loss': []}
@@ -516,6 +557,9 @@ class LSTMModel(_SeqModelBase):
         bs = batch_size or 32
         outs = [self._forward(x[i:i + bs], False).cpu().numpy() for i in range(0, n, bs)]
         return np.concatenate(outs, 0)
+
+    def _eval_forward(self, xb):
+        return self._forward(xb, False), 'linear'
 
     def train_on_batch(self, x, y):
         if self._loss is None:
@@ -586,6 +630,9 @@ class HybridModel(_SeqModelBase):
         bs = batch_size or 8
         outs = [self._forward([a[i:i + bs] for a in x], False)[0].cpu().numpy() for i in range(0, n, bs)]
         return np.concatenate(outs, 0)
+
+    def _eval_forward(self, xb):
+        return self._forward(xb, False)[0], 'softmax'
 
     def train_on_batch(self, x, y):
         if self._loss is None:

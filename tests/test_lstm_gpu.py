@@ -325,3 +325,52 @@ def test_hierarchical_model_matches_oracle(lt):
             assert cosine(g, gv) > 0.9999 and rel(g, gv) < 5e-3, (ok, cosine(g, gv), rel(g, gv))
     finally:
         mt.set_compute_dtype('bfloat16')
+
+
+def test_sequence_models_save_load_evaluate(lt, tmp_path):
+    """Model.save_weights / load_weights / evaluate as the reference's training scripts call them (utils/model_tools.py:1162-1196):
+    a second model built from the same arguments reproduces the first one's predictions bit for bit after load_weights (the hybrid
+    includes its U-Net branch), and evaluate() equals the loss train_on_batch reports with a zero learning rate."""
+    from satellite_computervision_amd import model_tools as mt
+    mt.set_compute_dtype('float32')
+    try:
+        rng = np.random.default_rng(3)
+        # ---- get_lstm_model
+        mt.reset_uids(); mt.set_seed(1)
+        a = lt.get_lstm_model(4, 3, 3)
+        x = rng.random((3, 3, 16, 16, 4)).astype(np.float32)
+        y = rng.random((3, 16, 16, 3)).astype(np.float32)
+        a.compile(optimizer=mt.Adam(1e-3), loss=mt.mse_4d)
+        for _ in range(3):
+            a.train_on_batch(x, y)
+        a.save_weights(str(tmp_path / 'lstm'))
+        mt.reset_uids(); mt.set_seed(99)
+        b = lt.get_lstm_model(4, 3, 3)
+        assert not np.array_equal(a.predict(x), b.predict(x))
+        b.load_weights(str(tmp_path / 'lstm'))
+        np.testing.assert_array_equal(a.predict(x), b.predict(x))
+        b.compile(optimizer=mt.Adam(0.0), loss=mt.mse_4d)
+        ev = b.evaluate(x, y)
+        assert np.isfinite(ev) and ev > 0
+        # (evaluate runs the inference graph -- moving statistics --, train_on_batch the training graph: equal only up to BatchNorm's mode)
+        # ---- get_hybrid_model
+        mt.reset_uids(); mt.set_seed(2)
+        h1 = lt.get_hybrid_model((48, 48, 4), (3, 8, 8, 4), 3, filters=[32, 64], factors=[3, 2])
+        xu = rng.random((2, 48, 48, 4)).astype(np.float32)
+        xl = rng.random((2, 3, 8, 8, 4)).astype(np.float32)
+        yy = np.eye(3, dtype=np.float32)[rng.integers(0, 3, (2, 48, 48))]
+        h1.compile(optimizer=mt.Adam(1e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0] * 3))
+        for _ in range(2):
+            h1.train_on_batch([xu, xl], yy)
+        h1.save_weights(str(tmp_path / 'hybrid.npz'))
+        mt.reset_uids(); mt.set_seed(77)
+        h2 = lt.get_hybrid_model((48, 48, 4), (3, 8, 8, 4), 3, filters=[32, 64], factors=[3, 2])
+        h2.load_weights(str(tmp_path / 'hybrid.npz'))
+        np.testing.assert_array_equal(h1.predict([xu, xl]), h2.predict([xu, xl]))
+        h2.compile(optimizer=mt.Adam(0.0), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0] * 3))
+        ev = h2.evaluate([xu, xl], yy)
+        assert np.isfinite(ev) and ev > 0
+        with pytest.raises(ValueError):
+            a.load_weights(str(tmp_path / 'hybrid.npz'))          # a file without this model's variables
+    finally:
+        mt.set_compute_dtype('bfloat16')

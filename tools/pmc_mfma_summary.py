@@ -30,7 +30,7 @@ for k, c in agg.items():
               'lds_bank_conflict_rate': round(c.get('SQ_LDS_BANK_CONFLICT', 0.0) / max(c.get('SQ_LDS_IDX_ACTIVE', 0.0), 1.0), 4),
               'wave_wait_fraction': round(c.get('SQ_WAIT_ANY', 0.0) / max(c.get('SQ_WAVE_CYCLES', 0.0), 1.0), 4)}
 json.dump({'note': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES '
-                   '-- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline; mfma_util = MFMA pipe-busy cycles / (dispatch ns x 2.4 GHz x 1024 SIMDs); _vs_gui_active uses GRBM_GUI_ACTIVE/8 (the counter sums the 8 XCDs); '
+                   '-- python3 bench.py --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline; mfma_util = MFMA pipe-busy cycles / (dispatch ns x 2.4 GHz x 1024 SIMDs); _vs_gui_active uses GRBM_GUI_ACTIVE/8 (the counter sums the 8 XCDs); '
                    'kernels of both streams overlap, so GUI_ACTIVE of a dispatch includes time shared with the other stream',
            'classes': res}, open(out, 'w'), indent=1)
 for k, v in res.items():
