@@ -1006,3 +1006,64 @@ print(json.dumps(dict(err=float(np.abs(got - ref).max() / np.abs(ref).max()), s1
     # the split sum differs from the single-pass one by fp32 association only: at most one bf16 ulp on a few elements
     a, b_ = np.array(outs['1']['y']), np.array(outs['0']['y'])
     assert np.abs(a - b_).max() <= 2 ** -7 * max(np.abs(b_).max(), 1.0)
+
+
+@pytest.mark.parametrize('td', DT)
+@pytest.mark.parametrize('case', [(2, 32, 32, 128, 256, 1), (1, 17, 23, 64, 64, 1), (2, 32, 32, 64, 128, 3)])
+def test_conv2d_residual_join_in_place(ops, td, case):
+    """satcv_conv_desc.accumulate = 2 (round 4): y = ReLU(y + out_scale * conv(x) + bias) written in place over the shortcut, the
+    conv result rounded to the storage type before the addition -- the residual join of a ResNet bottleneck whose last convolution
+    applies its own inference BatchNormalization (bias = scale * b + shift from satcv_bn_affine_infer_batched, checked here too)."""
+    import ctypes as C
+    from satellite_computervision_amd._lib import lib, check
+    n, h, w, cin, cout, k = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (k, k, cin, cout), td, 0.1)
+    short = rnd(rng, (n, h, w, cout), td)
+    gamma, beta = rng.uniform(0.5, 1.5, cout), rng.normal(0, 0.3, cout)
+    mm, mv, b = rng.normal(0, 0.2, cout), rng.uniform(0.5, 2.0, cout), rng.normal(0, 0.2, cout)
+    g_, b_, mm_, mv_, cb_ = (f32dev(v) for v in (gamma, beta, mm, mv, b))
+    scale, shift, beff = (torch.zeros(cout, dtype=torch.float32, device=dev()) for _ in range(3))
+    tab = torch.tensor([[g_.data_ptr(), b_.data_ptr(), mm_.data_ptr(), mv_.data_ptr(), scale.data_ptr(), shift.data_ptr(), cout,
+                         cb_.data_ptr(), beff.data_ptr()]], dtype=torch.int64, device=dev())
+    check(lib.satcv_bn_affine_infer_batched(tab.data_ptr(), 1, 1e-3, ops.stream_ptr()))
+    sc_ref = gamma.astype(np.float32).astype(np.float64) / np.sqrt(mv.astype(np.float32).astype(np.float64) + 1e-3)
+    sh_ref = beta.astype(np.float32) - mm.astype(np.float32) * sc_ref
+    np.testing.assert_allclose(back(scale), sc_ref, rtol=2e-6)
+    np.testing.assert_allclose(back(shift), sh_ref, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(back(beff), sh_ref + b.astype(np.float32) * sc_ref, rtol=2e-5, atol=1e-6)
+    wf, _ = ops.pack_weights(f32dev(kern), cin, ops.DTYPE_CODE[td])
+    y = to_dev(short, td)
+    d = ops.make_conv_desc(x0=to_dev(x, td).data_ptr(), c0=cin, w=wf.data_ptr(), bias=beff.data_ptr(), out_scale=scale.data_ptr(), y=y.data_ptr(), ldy=cout,
+                           n=n, h=h, w_=w, cout=cout, cout_pad=rup(cout, 32), kh=k, kw=k, dil=1, dtype=ops.DTYPE_CODE[td], accumulate=2)
+    xd = to_dev(x, td); d.x0 = xd.data_ptr()
+    check(lib.satcv_conv2d_igemm(C.byref(d), ops.stream_ptr()))
+    conv = K.conv2d_same(x, kern, None, 1) * back(scale) + back(beff)
+    conv = torch.tensor(conv, dtype=torch.float32).to(td).to(torch.float64).numpy()          # rounded to the storage type first
+    ref = np.maximum(short + conv, 0.0)
+    close(back(y, cout), ref, td, f'residual join {case}')
+    assert (back(y, cout) >= 0).all()
+
+
+@pytest.mark.parametrize('case', [(8, 64, 64, 128, 128, 6, 0), (4, 64, 64, 192, 256, 2, 1), (16, 32, 32, 512, 256, 12, 0)])
+def test_dilated_conv_double_buffered_taploop(ops, case):
+    """the double-buffered tap-loop form (round 4: 256-pixel x 128-channel tile, 64-channel chunks, gather table re-derived at tap
+    boundaries, validity of an item captured when it is loaded): dilated 3x3 convolutions large enough to select it (>= 96 tiles),
+    with the fused input BatchNorm + ReLU and a dual-source input, against the float64 oracle."""
+    n, h, w, cin, cout, dil, dual = case
+    td = torch.bfloat16
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (3, 3, cin, cout), td, 0.05)
+    sc = rng.uniform(0.5, 1.5, cin).astype(np.float32).astype(np.float64)
+    sh = rng.normal(0, 0.5, cin).astype(np.float32).astype(np.float64)
+    wf, _ = ops.pack_weights(f32dev(kern), cin, ops.DTYPE_CODE[td])
+    act = torch.tensor(np.maximum(x * sc + sh, 0.0), dtype=torch.float32).to(td).to(torch.float64).numpy()     # the loader rounds the activated item
+    y_ref = K.conv2d_same(act, kern, None, dil)
+    if dual:
+        c0 = 128
+        y = ops.conv2d(to_dev(x[..., :c0], td), wf, cout, kh=3, kw=3, dil=dil, x1=to_dev(x[..., c0:], td), in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
+    else:
+        y = ops.conv2d(to_dev(x, td), wf, cout, kh=3, kw=3, dil=dil, in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
+    close(back(y, cout), y_ref, td, f'double-buffered tap loop {case}')
