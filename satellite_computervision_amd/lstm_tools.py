@@ -430,6 +430,7 @@ class _SeqModelBase:
         self.P.build()
         self.optimizer, self._loss = None, None
         self.compute_dtype = mt._DEFAULT_DTYPE
+        self._graphs = {}
 
     @property
     def dtype_code(self):
@@ -441,19 +442,66 @@ class _SeqModelBase:
         if not isinstance(spec, mt.LossSpec):
             raise ValueError('loss must be one of the model_tools loss functions (or a lambda wrapping one)')
         self._loss = spec
+        self.__dict__.pop('_loss_w_dev', None)
+        self._drop_graphs()
         self.P.state[0:1].fill_(self.optimizer._lr)
 
     def _loss_grad(self, out, y_true, activation):
         """fused device loss on the model output: returns (loss tensor, dL/dlogits for softmax / sigmoid heads, dL/dout for linear ones)"""
-        w = None if self._loss.weights is None else torch.as_tensor(self._loss.weights).to(out.device)
+        if self._loss.weights is None:
+            w = None
+        else:
+            w = self.__dict__.get('_loss_w_dev')
+            if w is None or w.device != out.device:
+                w = self._loss_w_dev = torch.as_tensor(np.asarray(self._loss.weights, dtype=np.float32)).to(out.device)
         y = y_true if isinstance(y_true, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y_true, dtype=np.float32))
         y = y.to(out.device, torch.float32).contiguous()
         loss, dlog = ops.loss_fwd_bwd(self._loss.kind, out, y, w, activation=activation, eps=self._loss.eps)
         return loss, dlog
 
-    def _adam(self):
+    # ---- hipGraph replay of a training step (SATCV_LSTM_GRAPH=0: always eager).  A ConvLSTM2D step is ~300 launches of a few
+    # microseconds on the tape (per time step: recurrent convolution, gate kernel, their backward twins): the host, not the GPU, sets
+    # the pace.  After two eager steps with the same shapes the third is captured (torch.cuda.graph: the tape's allocations come from
+    # the graph's private pool) and later steps copy the batch into the static input tensors and replay.  The learning rate is
+    # written outside the graph before every replay; everything else the step reads lives on the device.
+    def _drop_graphs(self):
+        self.__dict__['_graphs'] = {}
+
+    def _graphed_step(self, step_fn, tensors):
+        """step_fn(*device tensors) -> loss tensor (no host synchronisation inside); returns the loss tensor of this step"""
+        if os.environ.get('SATCV_LSTM_GRAPH', '1') == '0':
+            self.P.state[0:1].fill_(self.optimizer._lr)
+            return step_fn(*tensors)
+        graphs = self.__dict__.setdefault('_graphs', {})
+        key = (self.compute_dtype,) + tuple((tuple(t.shape), t.dtype) for t in tensors)
+        st = graphs.setdefault(key, {'n': 0})
+        self.P.state[0:1].fill_(self.optimizer._lr)
+        if 'g' not in st:
+            st['n'] += 1
+            if st['n'] <= 2 or st.get('off'):
+                return step_fn(*tensors)
+            try:
+                st['in'] = [t.clone() for t in tensors]
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    st['loss'] = step_fn(*st['in'])
+                st['g'] = g
+            except Exception as e:           # a step that cannot be captured stays eager (and says so once)
+                import warnings
+                warnings.warn(f'{type(self).__name__}: training step not captured ({e}); running eagerly')
+                st['off'] = True
+                st.pop('in', None)
+                return step_fn(*tensors)
+        for dst, src in zip(st['in'], tensors):
+            dst.copy_(src, non_blocking=True)
+        st['g'].replay()
+        return st['loss']
+
+    def _adam(self, set_lr=True):
         P, opt = self.P, self.optimizer
-        P.state[0:1].fill_(opt._lr)
+        if set_lr:
+            P.state[0:1].fill_(opt._lr)
         check(lib.satcv_adam_step(P.flat.data_ptr(), P.grad.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.flat.numel(), opt.beta_1, opt.beta_2,
                                   opt.epsilon, P.state.data_ptr(), P.lr_mul.data_ptr(), ops.stream_ptr()))
 
@@ -564,13 +612,18 @@ class LSTMModel(_SeqModelBase):
     def train_on_batch(self, x, y):
         if self._loss is None:
             raise RuntimeError('compile() the model before fit/train')
+        xd = (x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))).to(_dev(), torch.float32).contiguous()
+        yd = (y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))).to(_dev(), torch.float32).contiguous()
+        return float(self._graphed_step(self._train_device, (xd, yd)).item())
+
+    def _train_device(self, xd, yd):
         self.P.grad.zero_()
-        out = self._forward(x, True)
-        loss, dout = self._loss_grad(out, y, 'linear')
+        out = self._forward(xd, True)
+        loss, dout = self._loss_grad(out, yd, 'linear')
         (da,) = self.dense.backward(dout, need_dx=(True,))
         self.layers_.backward(da)
-        self._adam()
-        return float(loss.item())
+        self._adam(set_lr=False)
+        return loss
 
 
 def get_lstm_model(n_channels, n_classes, n_time, optim=None, metrics=None, loss=None, activation='relu', dropout=None, max_value=2.0):

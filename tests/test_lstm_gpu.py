@@ -1,6 +1,7 @@
 """ConvLSTM2D family on the GPU (satellite_computervision_amd/lstm_tools.py, csrc/convlstm.hip) against the NumPy float64 oracle
 (oracle/convlstm.py: Keras ConvLSTM2D cell as the reference calls it, utils/model_tools.py:666-920; parity unpinned, cross-checked
 against torch autograd in tests/test_oracle_cpu.py)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -372,5 +373,45 @@ def test_sequence_models_save_load_evaluate(lt, tmp_path):
         assert np.isfinite(ev) and ev > 0
         with pytest.raises(ValueError):
             a.load_weights(str(tmp_path / 'hybrid.npz'))          # a file without this model's variables
+    finally:
+        mt.set_compute_dtype('bfloat16')
+
+
+def test_lstm_training_step_graph_replay_matches_eager(lt):
+    """SATCV_LSTM_GRAPH: after two eager steps the third is captured and later ones replay.  Eight steps of get_lstm_model with and
+    without replay from the same seed and batches: equal loss curves and parameters (up to the summation order of the kernels a capture
+    selects: split-K slabs are never allocated inside a capture), learning-rate changes between replays take effect."""
+    from satellite_computervision_amd import model_tools as mt
+    mt.set_compute_dtype('float32')
+    try:
+        rng = np.random.default_rng(11)
+        xs = [rng.random((4, 3, 16, 16, 4)).astype(np.float32) for _ in range(8)]
+        ys = [rng.random((4, 16, 16, 3)).astype(np.float32) for _ in range(8)]
+
+        def run(flag):
+            os.environ['SATCV_LSTM_GRAPH'] = flag
+            mt.reset_uids(); mt.set_seed(5)
+            m = lt.get_lstm_model(4, 3, 3)
+            opt = mt.Adam(1e-3)
+            m.compile(optimizer=opt, loss=mt.mse_4d)
+            losses = []
+            for i, (x, y) in enumerate(zip(xs, ys)):
+                if i == 6:
+                    opt._lr = 1e-4                      # a ReduceLROnPlateau-style change between replays
+                losses.append(m.train_on_batch(x, y))
+            return m, losses
+
+        try:
+            me, le = run('0')
+            mg, lg = run('1')
+        finally:
+            os.environ.pop('SATCV_LSTM_GRAPH', None)
+        assert any('g' in st for st in mg._graphs.values()), 'no step was captured'
+        assert not any('g' in st for st in me._graphs.values())
+        np.testing.assert_allclose(lg, le, rtol=2e-4)
+        we, wg = me.get_weights_dict(), mg.get_weights_dict()
+        for k in we:
+            assert np.abs(we[k] - wg[k]).max() < 3e-4, (k, np.abs(we[k] - wg[k]).max())
+        assert le[-1] < le[0]
     finally:
         mt.set_compute_dtype('bfloat16')
