@@ -18,7 +18,7 @@
 //     halos run on the same XCD (private L2).
 #include "igemm_common.hpp"
 #include <cstdlib>
-extern int g_opt_igemm_db, g_opt_igemm_thin, g_opt_igemm_sched;      // api.hip: satcv_set_option
+extern int g_opt_igemm_db, g_opt_igemm_thin, g_opt_igemm_sched, g_opt_splitk;      // api.hip: satcv_set_option
 
 // compile-time ablation switches for profiling builds (-DSATCV_ABLATE=bits): 1 skip global stores, 2 skip MFMA,
 // 4 skip activation loads, 8 skip weight loads, 16 skip the LDS fragment reads, 32 skip the whole epilogue, 64 skip the LDS stores,
@@ -759,11 +759,17 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
     // launch's workgroup count would break the bit-identity of inference across batch splits.  Tap-loop launches (dilated / strided
     // convolutions: ASPP, the ResNet backbone of the build-defined DeepLab): ON (SATCV_SPLITK_TL=0 turns it off) -- a single 512 x 512
     // tile puts 16 workgroups on the chip for 576 chunks of its stage-4 convolutions, 318 us per launch whatever the batch.
-    static const int splitk = [] { const char* e = getenv("SATCV_SPLITK"); return e ? atoi(e) : 0; }();
+    const int splitk = g_opt_splitk;            // (satcv_set_option("splitk", 1): the build-defined DeepLab's inference plans set it around their launches)
     static const int splitk_tl = [] { const char* e = getenv("SATCV_SPLITK_TL"); return e ? atoi(e) : 1; }();
     if ((TL ? splitk_tl : splitk) && !dyn && sizeof(T) == 2 && a.mode_out == 0 && !a.pool_y && !a.accumulate && !a.bst_y && a.cout % 8 == 0 && a.ldy % 8 == 0 &&
         a.stride == 1 && (!a.stats || (a.cout <= 1024 && 256 % (a.cout / 8) == 0)))
-      while (ks < (TL ? 16 : 4) && blocks * ks * 2 <= 256 && a.nchunks / (ks * 2) >= 8) ks *= 2;
+      // (1 x 1 launches of a single tile: a 64-channel chunk costs a workgroup ~1.2 us of load latency whatever its MFMA count, so even
+      //  16 chunks are worth cutting four ways -- 4 chunks per split + a ~7 us finish launch against 16 chunks in a row)
+      //  (measured on DeepLab: +3.5 % at batch 1, -2.8 % at batch 4 when launches of 64+ workgroups were cut too: those stay whole)
+      constexpr bool DEEP1X1 = TAPS == 1 && !TL && KS == 4;
+      //  option value 2 (what the DeepLab plans set): plain launches of fewer than 64 workgroups only
+      const bool small_only = !TL && (DEEP1X1 || splitk == 2);
+      while (ks < (TL ? 16 : 4) && blocks * ks * 2 <= 256 && a.nchunks / (ks * 2) >= (DEEP1X1 ? 4 : 8) && !(small_only && blocks >= 64)) ks *= 2;
     if (ks == 1) return SATCV_ERR_UNSUPPORTED;          // (the caller continues with the single-pass instantiation)
   }
   if (dry) return SATCV_OK;
@@ -878,6 +884,10 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
         // MFMAs) -- SATCV_DB1X1_SMALL=0 turns this case off.  Same 64-channel chunks and k order: the two tiles give identical bits.
         static const bool db1s = !(getenv("SATCV_DB1X1_SMALL") && atoi(getenv("SATCV_DB1X1_SMALL")) == 0);
         const long long mt256 = cdiv(a.n * a.h * a.w_, 256), mt128 = cdiv(a.n * a.h * a.w_, 128);
+        if (ks4 && g_opt_splitk && nspace >= 128 && nspace % 128 == 0) {       // opt-in split-K of under-filled deep 1x1 launches
+          const int rc = fast_cfg<T, TW, 2, 2, 2, 2, 4, TAPS, false, false, 2, false, true>(a, st, dry);
+          if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+        }
         if (ks4 && db1 && a.mode_in == 0 && nspace >= 128 && nspace % 128 == 0 &&
             (mt256 * (nspace / 128) >= 192 || (db1s && mt128 * (nspace / 128) <= 256))) {
           const int rc = fast_cfg<T, TW, 4, 2, 2, 2, 4, TAPS, false, true>(a, st, dry);
