@@ -381,6 +381,7 @@ class Plan:
         sinks, cat_stats = {}, {}
         order = {id(nd): i for i, nd in enumerate(m.nodes)}
         fused_join = {}                            # add_relu node id -> the shortcut tensor its sum was written into
+        folded_plain = {}                          # tensor id -> a conv -> BatchNorm branch stored normalised, waiting for the join's other branch
         for node in m.nodes:
             if node.op == 'concat_bn_relu':
                 a, b = node.inputs
@@ -470,24 +471,40 @@ class Plan:
                 # BatchNormalization in the epilogue (out_scale / bias_eff from the batched affine launch) and writes
                 # ReLU(shortcut + result) IN PLACE over the shortcut (accumulate = 2): no add_relu launch, no third tensor
                 # (20 launches of ~10 us on a single 512 x 512 tile, 11 % of the kernel time at batch 16; SATCV_FUSE_RESIDUAL=0: separate)
-                join = consumers[tout.id][0] if (not training and sl is None and stride == 1 and not relu_out and FUSE_RESIDUAL
+                join = consumers[tout.id][0] if (not training and sl is None and not relu_out and FUSE_RESIDUAL
                                                  and len(consumers[tout.id]) == 1 and consumers[tout.id][0].op == 'add_relu'
-                                                 and consumers[tout.id][0].inputs[0] is tout) else None
+                                                 and tout in consumers[tout.id][0].inputs) else None
                 if join is not None:
-                    tsc = join.inputs[1]
+                    tsc = join.inputs[1] if join.inputs[0] is tout else join.inputs[0]      # the join's other addend
                     rs_ = vals.get(tsc.id)
-                    ok = (rs_ is not None and not rs_.affine and len(rs_.srcs) == 1 and rs_.srcs[0][1] == cout and rs_.srcs[0][0].shape[-1] == cout
-                          and (rs_.h, rs_.w) == (r.h, r.w) and tsc.node is not None and tsc.node.op == 'add_relu'
-                          and all(cn is join or order[id(cn)] < order[id(node)] for cn in consumers[tsc.id]))
-                    if ok:
-                        sb = rs_.srcs[0][0]
+                    fold_args = None
+                    if rs_ is None:
+                        # (B) the other addend is a conv -> BatchNorm branch that runs LATER in the list (the projection shortcut of a stage's
+                        # first block): store this branch normalised (its BatchNorm in the epilogue, nothing pending), the later branch
+                        # then adds itself in place (A)
+                        if (stride == 1 and tsc.node is not None and tsc.node.op == 'cba' and len(consumers[tsc.id]) == 1
+                                and tsc.node.attrs.get('bn', True) and not tsc.node.attrs.get('relu', True) and tsc.channels == cout):
+                            y = self._z(n, r.h, r.w, cout)
+                            fold_args = dict(y=y.data_ptr(), accumulate=0)
+                            folded_plain[tout.id] = y
+                            sb = y
+                    else:
+                        # (A) the other addend is final: a plain activated tensor written by an earlier join, or a branch stored normalised (B)
+                        src_ok = (tsc.id in folded_plain) or (tsc.node is not None and tsc.node.op == 'add_relu' and stride == 1)
+                        if (src_ok and not rs_.affine and len(rs_.srcs) == 1 and rs_.srcs[0][1] == cout and rs_.srcs[0][0].shape[-1] == cout
+                                and (rs_.h, rs_.w) == (r.h, r.w)
+                                and all(cn is join or order[id(cn)] < order[id(node)] for cn in consumers[tsc.id])):
+                            sb = rs_.srcs[0][0]
+                            fold_args = dict(y=sb.data_ptr(), accumulate=2)
+                            fused_join[id(join)] = sb
+                    if fold_args is not None:
                         be = self._z(cout, dtype=torch.float32)
                         aff = self._bn_forward(lay.bn_name, None, cout, 0, cout, n * r.h * r.w, node.attrs.get('bn_updates', 1),
                                                conv_bias=rt.pptr(lay.name + '/bias'), bias_eff=_fp(be))
-                        self.fwd.append(self._conv_step(w=pk['fwd'].data_ptr(), bias=_fp(be), out_scale=_fp(aff['scale']), y=sb.data_ptr(), ldy=cout,
+                        self.fwd.append(self._conv_step(w=pk['fwd'].data_ptr(), bias=_fp(be), out_scale=_fp(aff['scale']), ldy=cout,
                                                         n=n, h=r.h, w_=r.w, cout=cout, cout_pad=rup(cout, 32), kh=k, kw=k, dil=dil, dtype=dt,
-                                                        accumulate=2, **self._src_args(r)))
-                        fused_join[id(join)] = sb
+                                                        stride=stride, hin=hin if stride > 1 else 0, win=win if stride > 1 else 0,
+                                                        **fold_args, **self._src_args(r)))
                         vals[tout.id] = TRef([(sb, cout)], n, r.h, r.w)
                         ctx[id(node)] = dict(r=r, y=sb, yoff=0, ldy=cout, aff=None, aoff=0, cout=cout, k=k, dil=dil)
                         continue
