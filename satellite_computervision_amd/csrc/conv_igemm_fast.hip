@@ -762,7 +762,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
     const int splitk = g_opt_splitk;            // (satcv_set_option("splitk", 1): the build-defined DeepLab's inference plans set it around their launches)
     static const int splitk_tl = [] { const char* e = getenv("SATCV_SPLITK_TL"); return e ? atoi(e) : 1; }();
     if ((TL ? splitk_tl : splitk) && !dyn && sizeof(T) == 2 && a.mode_out == 0 && !a.pool_y && !a.accumulate && !a.bst_y && a.cout % 8 == 0 && a.ldy % 8 == 0 &&
-        a.stride == 1 && (!a.stats || (a.cout <= 1024 && 256 % (a.cout / 8) == 0)))
+        a.stride == 1 && (!a.stats || (a.cout <= 1024 && 256 % (a.cout / 8) == 0))) {
       // (1 x 1 launches of a single tile: a 64-channel chunk costs a workgroup ~1.2 us of load latency whatever its MFMA count, so even
       //  16 chunks are worth cutting four ways -- 4 chunks per split + a ~7 us finish launch against 16 chunks in a row)
       //  (measured on DeepLab: +3.5 % at batch 1, -2.8 % at batch 4 when launches of 64+ workgroups were cut too: those stay whole)
@@ -770,6 +770,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
       //  option value 2 (what the DeepLab plans set): plain launches of fewer than 64 workgroups only
       const bool small_only = !TL && (DEEP1X1 || splitk == 2);
       while (ks < (TL ? 16 : 4) && blocks * ks * 2 <= 256 && a.nchunks / (ks * 2) >= (DEEP1X1 ? 4 : 8) && !(small_only && blocks >= 64)) ks *= 2;
+    }
     if (ks == 1) return SATCV_ERR_UNSUPPORTED;          // (the caller continues with the single-pass instantiation)
   }
   if (dry) return SATCV_OK;
