@@ -210,3 +210,19 @@ def test_lstm_builders_are_reachable_under_the_reference_module_name():
         assert getattr(mt, name) is getattr(lt, name)
     with pytest.raises(AttributeError):
         mt.no_such_builder
+
+
+def test_library_was_built_from_the_sources_in_the_tree():
+    """the in-tree libsatcv.so is what every GPU run loads: its build stamp must equal the digest of the current sources and flags
+    (a source edit that does not compile, or a forgotten rebuild, would otherwise ship an old library to the GPU box unnoticed)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('_satcv_build_t', os.path.join(root, 'satellite_computervision_amd', 'build.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    deps = [os.path.join(b.CSRC, f) for f in os.listdir(b.CSRC) if f.endswith(('.hip', '.hpp'))]
+    deps.append(os.path.join(root, 'include', 'satcv.h'))
+    stamp = os.path.join(b.OBJDIR, 'stamp')
+    if not os.path.exists(stamp):
+        pytest.skip('no build stamp (library built elsewhere)')
+    assert open(stamp).read() == b._digest(deps), 'libsatcv.so is older than csrc/: run python -m satellite_computervision_amd.build'
