@@ -164,12 +164,19 @@ class LSTMLayersOracle:
         lim = np.sqrt(6.0 / (filters + n_classes))
         self.p['dense'] = {'kernel': rng.uniform(-lim, lim, (1, 1, filters, n_classes)).astype(dtype), 'bias': np.zeros(n_classes, dtype)}
 
-    def features(self, x):
+    def features(self, x, mask1=None):
+        """mask1: the layers.Dropout(dropout) between the two ConvLSTM2D layers (utils/model_tools.py:699-700) as a GIVEN mask
+        (B, T, H, W, F) of 0 or 1 / (1 - rate) -- the test hands over the mask the device drew"""
         p = self.p
         s1, c1 = convlstm_forward(x, p['l1'], 1, None, self.rec_act, True)
         z1, m1, v1 = bn5_train(s1, p['bn1']['gamma'], p['bn1']['beta'])
         a1 = np.maximum(z1, 0)
-        h2, c2 = convlstm_forward(a1, p['l2'], 3, None, self.rec_act, False)
+        self.mask1 = mask1
+        if mask1 is not None:
+            a1_in = a1 * mask1
+        else:
+            a1_in = a1
+        h2, c2 = convlstm_forward(a1_in, p['l2'], 3, None, self.rec_act, False)
         z2, m2, v2 = bn5_train(h2, p['bn2']['gamma'], p['bn2']['beta'])
         a2 = np.maximum(z2, 0)
         self.c = dict(c1=c1, s1=s1, st1=(m1, v1), a1=a1, c2=c2, h2=h2, st2=(m2, v2), a2=a2)
@@ -180,6 +187,8 @@ class LSTMLayersOracle:
         dz2 = da2 * (c['a2'] > 0)
         dh2, g['bn2.gamma'], g['bn2.beta'] = bn5_train_bwd(c['h2'], p['bn2']['gamma'], *c['st2'], dz2)
         da1, g2 = convlstm_backward(dh2, c['c2'])
+        if getattr(self, 'mask1', None) is not None:
+            da1 = da1 * self.mask1
         dz1 = da1 * (c['a1'] > 0)
         ds1, g['bn1.gamma'], g['bn1.beta'] = bn5_train_bwd(c['s1'], p['bn1']['gamma'], *c['st1'], dz1)
         dx, g1 = convlstm_backward(ds1, c['c1'])
@@ -190,8 +199,8 @@ class LSTMLayersOracle:
         g['input'] = dx
         return g
 
-    def forward(self, x):
-        a2 = self.features(x)
+    def forward(self, x, mask1=None):
+        a2 = self.features(x, mask1)
         z = K.conv2d_same(a2, self.p['dense']['kernel'], self.p['dense']['bias'])
         out = np.clip(z, 0.0, self.head_max) if self.head_max is not None else np.maximum(z, 0)
         self.c['z'] = z

@@ -282,6 +282,40 @@ class BatchNorm:
         return dy
 
 
+class Dropout:
+    """layers.Dropout(rate) (element-wise, utils/model_tools.py:699-700) / layers.SpatialDropout2D(rate) (whole feature maps,
+    :899-900, 904-905) on the tape: training draws a counter-based mask (satcv_dropout_mask: 0 or 1 / (1 - rate)) and materialises
+    act(x) * mask (satcv_dropout_apply applies the pending BatchNorm + ReLU on the way); inference passes the activation through."""
+
+    def __init__(self, rate, spatial, seed):
+        self.rate, self.spatial, self.seed, self.calls = float(rate), bool(spatial), int(seed), 0
+        self.mask = None
+
+    def forward(self, a, training):
+        if not training or self.rate <= 0.0:
+            self.mask = None
+            return a
+        n, h, w_, cp = a.t.shape
+        rows = n if self.spatial else n * h * w_
+        self.mask = torch.empty(rows, cp, dtype=torch.float32, device=a.t.device)
+        self.calls += 1
+        st = ops.stream_ptr()
+        check(lib.satcv_dropout_mask(self.seed, self.calls << 8, self.rate, rows * cp, self.mask.data_ptr(), st))
+        out = torch.empty_like(a.t)
+        check(lib.satcv_dropout_apply(a.t.data_ptr(), cp, a.scale.data_ptr() if a.bn else None, a.shift.data_ptr() if a.bn else None, 1 if a.relu else 0,
+                                      self.mask.data_ptr(), cp, 0 if self.spatial else 1, out.data_ptr(), cp, n, h * w_, cp, ops.DTYPE_CODE[out.dtype], st))
+        return Act(out, a.c)
+
+    def backward(self, g):
+        if self.mask is None:
+            return g
+        n, h, w_, cp = g.shape
+        out = torch.empty_like(g)
+        check(lib.satcv_dropout_apply(g.data_ptr(), cp, None, None, 0, self.mask.data_ptr(), cp, 0 if self.spatial else 1, out.data_ptr(), cp, n, h * w_, cp,
+                                      ops.DTYPE_CODE[g.dtype], ops.stream_ptr()))
+        return out
+
+
 class Dense1x1:
     """layers.Conv2D(cout, [1, 1]) over the concatenation of one or two sources, with softmax / sigmoid / linear / ReLU(max_value)
     (satcv_dense_small_fwd / _bwd); a source may sit on a coarser grid and be read through tf.image.resize(..., 'nearest')"""
@@ -359,9 +393,10 @@ class LSTMLayers:
     """build_lstm_layers (utils/model_tools.py:666-717): ConvLSTM2D(64) 'conv_lstm' -> BatchNormalization 'batch_norm' -> ReLU ->
     ConvLSTM2D(64, dilation (3, 3), return_sequences) 'dilated_conv_lstm' -> BatchNormalization 'batch_norm2' -> ReLU"""
 
-    def __init__(self, params, rng, n_channels, filters=64, return_sequences=False, prefix=''):
+    def __init__(self, params, rng, n_channels, filters=64, return_sequences=False, prefix='', dropout=None):
         self.l1 = ConvLSTM2D(params, rng, prefix + 'conv_lstm', n_channels, filters, 1, True)
         self.bn1 = BatchNorm(params, prefix + 'batch_norm', filters)
+        self.drop = Dropout(dropout, False, rng.integers(1 << 62)) if dropout else None       # layers.Dropout(dropout)(activated), :699-700
         self.l2 = ConvLSTM2D(params, rng, prefix + 'dilated_conv_lstm', filters, filters, 3, return_sequences)
         self.bn2 = BatchNorm(params, prefix + 'batch_norm2', filters)
         self.F = filters
@@ -369,12 +404,16 @@ class LSTMLayers:
     def forward(self, x, T, B, training, dtype):
         s1, st1, n1 = self.l1.forward(x, T, B, training, dtype)
         a1 = self.bn1.forward(s1, st1, n1, training)
+        if self.drop is not None:
+            a1 = self.drop.forward(a1, training)
         h2, st2, n2 = self.l2.forward(a1, T, B, training, dtype)
         return self.bn2.forward(h2, st2, n2, training)
 
     def backward(self, da2, need_dx=False):
         dh2 = self.bn2.backward(da2)
         da1 = self.l2.backward(dh2)
+        if self.drop is not None:
+            da1 = self.drop.backward(da1)
         ds1 = self.bn1.backward(da1)
         return self.l1.backward(ds1, need_dx=need_dx)
 
@@ -384,9 +423,10 @@ class LSTMLayers2:
     'batch_norm' -> ReLU -> ConvLSTM2D(16, dilation (3, 3), last state) 'dilated_conv_lstm' -> BatchNormalization 'batch_norm2';
     output = ReLU(state_h + normalized2) with state_h the FIRST layer's final hidden state."""
 
-    def __init__(self, params, rng, n_channels, filters=16, prefix=''):
+    def __init__(self, params, rng, n_channels, filters=16, prefix='', dropout=None):
         self.l1 = ConvLSTM2D(params, rng, prefix + 'conv_lstm', n_channels, filters, 1, True)
         self.bn1 = BatchNorm(params, prefix + 'batch_norm', filters)
+        self.drop = Dropout(dropout, False, rng.integers(1 << 62)) if dropout else None       # layers.Dropout(dropout)(activated), :752-753
         self.l2 = ConvLSTM2D(params, rng, prefix + 'dilated_conv_lstm', filters, filters, 3, False)
         self.bn2 = BatchNorm(params, prefix + 'batch_norm2', filters)
         self.F = filters
@@ -394,6 +434,8 @@ class LSTMLayers2:
     def forward(self, x, T, B, training, dtype):
         s1, st1, n1 = self.l1.forward(x, T, B, training, dtype)
         a1 = self.bn1.forward(s1, st1, n1, training)
+        if self.drop is not None:
+            a1 = self.drop.forward(a1, training)
         h2, st2, n2 = self.l2.forward(a1, T, B, training, dtype)
         z2 = self.bn2.forward(h2, st2, n2, training, relu=False)
         state_h = self.l1.h_last
@@ -409,6 +451,8 @@ class LSTMLayers2:
         check(lib.satcv_relu_bwd(self.out.data_ptr(), g.data_ptr(), g.numel(), ops.DTYPE_CODE[g.dtype], ops.stream_ptr()))
         dh2 = self.bn2.backward(g)                    # the masked gradient serves both addends
         da1 = self.l2.backward(dh2)
+        if self.drop is not None:
+            da1 = self.drop.backward(da1)
         ds1 = self.bn1.backward(da1)
         return self.l1.backward(ds1, dstate_h=g, need_dx=need_dx)
 
@@ -469,7 +513,7 @@ class _SeqModelBase:
 
     def _graphed_step(self, step_fn, tensors):
         """step_fn(*device tensors) -> loss tensor (no host synchronisation inside); returns the loss tensor of this step"""
-        if os.environ.get('SATCV_LSTM_GRAPH', '1') == '0':
+        if os.environ.get('SATCV_LSTM_GRAPH', '1') == '0' or getattr(self, '_no_graph', False):
             self.P.state[0:1].fill_(self.optimizer._lr)
             return step_fn(*tensors)
         graphs = self.__dict__.setdefault('_graphs', {})
@@ -584,12 +628,11 @@ class LSTMModel(_SeqModelBase):
     n_channels) -> build_lstm_layers -> Conv2D(n_classes, [1, 1]) -> activation (default layers.ReLU(max_value=2.0))."""
 
     def __init__(self, n_channels, n_classes, n_time, activation='relu', max_value=2.0, dropout=None, seed=None):
-        if dropout is not None:
-            raise NotImplementedError('dropout inside the LSTM stack')
         rng = np.random.default_rng(seed if seed is not None else mt._RNG.integers(1 << 31))
         self.P = _Params()
         self.n_channels, self.n_classes, self.n_time = n_channels, n_classes, n_time
-        self.layers_ = LSTMLayers(self.P, rng, n_channels)
+        self.layers_ = LSTMLayers(self.P, rng, n_channels, dropout=dropout)
+        self._no_graph = dropout is not None           # (a captured step would replay the mask drawn at capture time)
         self.dense = Dense1x1(self.P, rng, 'conv2d', [self.layers_.F], n_classes, activation, max_value)
         self._finish()
 
@@ -642,15 +685,16 @@ class HybridModel(_SeqModelBase):
     with a linear 1x1 head = the pre-activation of its `relu` dense layer), the rest on the tape."""
 
     def __init__(self, unet_dim, lstm_dim, n_classes, filters=(32, 64, 128, 256), factors=(3, 2, 2, 2), dropout=None, seed=None):
-        if dropout is not None:
-            raise NotImplementedError('dropout in the hybrid model')
         rng = np.random.default_rng(seed if seed is not None else mt._RNG.integers(1 << 31))
         self.unet_dim, self.lstm_dim, self.n_classes = tuple(unet_dim), tuple(lstm_dim), n_classes
         inp = mt.Input(shape=(None, None, unet_dim[-1]))
-        dec = mt.build_unet_layers(inp, list(filters), list(factors))
+        dec = mt.build_unet_layers(inp, list(filters), list(factors), dropout=dropout)
+        if dropout is not None:                       # layers.SpatialDropout2D(dropout)(unet_output), :899-900
+            dec = mt._dropout(dec, dropout, True)
         self.unet = mt.Model(inputs=inp, outputs=mt._Head(n_classes, 'linear', 'zeros', 'unet_dense')(dec))
         self.P = _Params()
-        self.lstm = LSTMLayers(self.P, rng, lstm_dim[-1])
+        self.lstm = LSTMLayers(self.P, rng, lstm_dim[-1], dropout=dropout)
+        self.lstm_drop = Dropout(dropout, True, rng.integers(1 << 62)) if dropout else None     # SpatialDropout2D on lstm_output, :904-905
         self.lstm_dense = Dense1x1(self.P, rng, 'lstm_dense', [self.lstm.F], n_classes, 'relu')
         self.fusion = Dense1x1(self.P, rng, 'probabilities', [n_classes, n_classes], n_classes, 'softmax')
         self._finish()
@@ -672,6 +716,8 @@ class HybridModel(_SeqModelBase):
         zu = plan.outputs[self.unet.outputs[0].id]                    # float32 (n, h, w, k): pre-activation of the U-Net's relu dense layer
         xt, (B, T, hh, ww) = _ingest_seq(xl, ops.rup(self.lstm_dim[-1], 16), self.dtype_code)
         feats = self.lstm.forward(Act(xt, self.lstm_dim[-1]), T, B, training, self.dtype_code)
+        if self.lstm_drop is not None:
+            feats = self.lstm_drop.forward(feats, training)
         zl = self.lstm_dense.forward([(feats, False)])                # float32 (B, hh, ww, k), already through its ReLU
         probs, classes = self.fusion.forward([(Act(zl, self.n_classes), True), (Act(zu, self.n_classes, relu=True), False)], out_hw=(h, w),
                                              want_classes=True)
@@ -697,6 +743,8 @@ class HybridModel(_SeqModelBase):
         loss, dlog = self._loss_grad(probs, y, 'softmax')
         dzl, dau = self.fusion.backward(dlog, need_dx=(True, True))
         (dfeat,) = self.lstm_dense.backward(dzl, need_dx=(True,))
+        if self.lstm_drop is not None:
+            dfeat = self.lstm_drop.backward(dfeat)
         self.lstm.backward(dfeat)
         # U-Net branch: d relu(z_u) -> dz_u (mask in place) -> the plan's logit gradient -> its backward pass + Adam + repack
         check(lib.satcv_relu_bwd(self._zu.data_ptr(), dau.data_ptr(), dau.numel(), F32, ops.stream_ptr()))
@@ -788,16 +836,14 @@ def get_lstm_autoencoder(n_channels, n_time, n_classes, activation='relu', compi
 
 def build_lstm_layers(params, rng, n_channels, return_sequences=False, dropout=None):
     """utils/model_tools.py:666-717 (layer stack object; the model builders above call it)"""
-    if dropout is not None:
-        raise NotImplementedError('dropout inside the LSTM stack')
-    return LSTMLayers(params, rng, n_channels, return_sequences=return_sequences)
+    return LSTMLayers(params, rng, n_channels, return_sequences=return_sequences, dropout=dropout)
 
 
 def build_lstm_layers2(params, rng, n_channels, return_sequences=False, return_state=False, dropout=None):
     """utils/model_tools.py:719-771"""
-    if dropout is not None or return_sequences:
-        raise NotImplementedError('build_lstm_layers2 is lowered as the reference calls it (return_sequences=False, no dropout)')
-    return LSTMLayers2(params, rng, n_channels)
+    if return_sequences:
+        raise NotImplementedError('build_lstm_layers2 is lowered as the reference calls it (return_sequences=False)')
+    return LSTMLayers2(params, rng, n_channels, dropout=dropout)
 
 
 # ------------------------------------------------------------------------------------------------ hierarchical model (ACNN + LSTM)

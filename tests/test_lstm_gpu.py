@@ -415,3 +415,83 @@ def test_lstm_training_step_graph_replay_matches_eager(lt):
         assert le[-1] < le[0]
     finally:
         mt.set_compute_dtype('bfloat16')
+
+
+def test_lstm_model_dropout_matches_oracle_given_the_mask(lt):
+    """build_lstm_layers(dropout=rate): layers.Dropout between the two ConvLSTM2D layers (utils/model_tools.py:699-700).  The device
+    draws the mask; the oracle receives that mask and must reproduce loss and every gradient (fp32); inference ignores dropout."""
+    from satellite_computervision_amd import model_tools as mt
+    mt.set_compute_dtype('float32')
+    try:
+        B, T, H, W, Cc, ncls, rate = 2, 3, 16, 16, 6, 4, 0.3
+        o = CL.LSTMLayersOracle(Cc, ncls, filters=64, rec_act=lt.RECURRENT_ACTIVATION, seed=5)
+        mt.reset_uids(); mt.set_seed(3)
+        m = lt.get_lstm_model(Cc, ncls, T, dropout=rate)
+        mt.reset_uids(); mt.set_seed(3)
+        m0 = lt.get_lstm_model(Cc, ncls, T)
+        names = {'l1': 'conv_lstm', 'l2': 'dilated_conv_lstm', 'bn1': 'batch_norm', 'bn2': 'batch_norm2', 'dense': 'conv2d'}
+        w = {}
+        for lk, lv in o.p.items():
+            for pk, pv in lv.items():
+                lv[pk] = pv.astype(np.float32).astype(np.float64)
+                w[f'{names[lk]}/{pk}'] = lv[pk]
+        m.set_weights_dict(w); m0.set_weights_dict(w)
+        rng = np.random.default_rng(8)
+        x = rng.random((B, T, H, W, Cc)).astype(np.float32)
+        y = rng.random((B, H, W, ncls)).astype(np.float32) * 1.5
+        np.testing.assert_array_equal(m.predict(x), m0.predict(x))              # inference: dropout is the identity
+        m.compile(optimizer=mt.Adam(0.0), loss=mt.mse_4d)
+        loss = m.train_on_batch(x, y)
+        mask = m.layers_.drop.mask.cpu().numpy().astype(np.float64).reshape(T, B, H, W, 64).transpose(1, 0, 2, 3, 4)
+        vals = np.unique(mask)
+        assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.0 / (1.0 - rate)) < 1e-6
+        assert abs((mask > 0).mean() - (1.0 - rate)) < 0.02
+        out_ref = o.forward(x.astype(np.float64), mask1=mask)
+        loss_ref, dout = OL.mse_4d(y.astype(np.float64), out_ref)
+        g_ref = o.backward(dout)
+        np.testing.assert_allclose(loss, loss_ref, rtol=1e-4)
+        key = {'l1.kernel': 'conv_lstm/kernel', 'l1.recurrent_kernel': 'conv_lstm/recurrent_kernel', 'l1.bias': 'conv_lstm/bias',
+               'l2.kernel': 'dilated_conv_lstm/kernel', 'l2.recurrent_kernel': 'dilated_conv_lstm/recurrent_kernel', 'l2.bias': 'dilated_conv_lstm/bias',
+               'bn1.gamma': 'batch_norm/gamma', 'bn1.beta': 'batch_norm/beta', 'bn2.gamma': 'batch_norm2/gamma', 'bn2.beta': 'batch_norm2/beta',
+               'dense.kernel': 'conv2d/kernel', 'dense.bias': 'conv2d/bias'}
+        for ok, dk in key.items():
+            g = m.P.g(dk).cpu().numpy().astype(np.float64).reshape(g_ref[ok].shape)
+            assert cosine(g, g_ref[ok]) > 0.9999 and rel(g, g_ref[ok]) < 2e-3, (ok, cosine(g, g_ref[ok]), rel(g, g_ref[ok]))
+        # a second step draws a different mask; steps with dropout are never replayed from a graph
+        m.train_on_batch(x, y); m.train_on_batch(x, y); m.train_on_batch(x, y)
+        mask2 = m.layers_.drop.mask.cpu().numpy().reshape(T, B, H, W, 64).transpose(1, 0, 2, 3, 4)
+        assert (mask2 != mask).mean() > 0.2
+        assert not any('g' in st for st in m._graphs.values())
+    finally:
+        mt.set_compute_dtype('bfloat16')
+
+
+def test_hybrid_model_with_dropout_trains(lt):
+    """get_hybrid_model(dropout=rate) (utils/model_tools.py:897-905): SpatialDropout2D inside the U-Net, on the U-Net output and on the
+    LSTM output, Dropout inside the LSTM stack.  Training moves every parameter group with a finite, falling loss; inference is
+    deterministic and normalised."""
+    from satellite_computervision_amd import model_tools as mt
+    mt.set_compute_dtype('float32')
+    try:
+        mt.reset_uids(); mt.set_seed(4)
+        ncls = 3
+        m = lt.get_hybrid_model((48, 48, 4), (3, 8, 8, 6), ncls, filters=[32, 64], factors=[3, 2], dropout=0.2)
+        rng = np.random.default_rng(2)
+        xu = rng.random((2, 48, 48, 4)).astype(np.float32)
+        xl = rng.random((2, 3, 8, 8, 6)).astype(np.float32)
+        y = np.eye(ncls, dtype=np.float32)[(xu[..., 0] > 0.5).astype(np.int64) + (xu[..., 1] > 0.7)]
+        p1, p2 = m.predict([xu, xl]), m.predict([xu, xl])
+        np.testing.assert_array_equal(p1, p2)
+        np.testing.assert_allclose(p1.sum(-1), 1.0, atol=1e-5)
+        m.compile(optimizer=mt.Adam(2e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0] * ncls))
+        w0, u0 = m.get_weights_dict(), m.unet.runtime.pflat.clone()
+        losses = [m.train_on_batch([xu, xl], y) for _ in range(25)]
+        assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5])
+        w1 = m.get_weights_dict()
+        for k in ('conv_lstm/kernel', 'dilated_conv_lstm/recurrent_kernel', 'lstm_dense/kernel', 'probabilities/kernel'):
+            assert np.abs(w1[k] - w0[k]).max() > 0, k
+        assert (m.unet.runtime.pflat != u0).any()
+        sm = m.lstm_drop.mask.cpu().numpy()
+        assert sm.shape == (2, 64) and set(np.unique(sm).round(4)) <= {0.0, 1.25}
+    finally:
+        mt.set_compute_dtype('bfloat16')
