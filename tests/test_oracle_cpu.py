@@ -284,3 +284,62 @@ def test_convlstm_oracle_matches_torch_autograd():
         assert abs((up * g).sum() - (a * CL.resize_nearest_bwd(g, idx, 4, 5)).sum()) < 1e-9
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+def test_round_bf16_matches_torch_and_store_dtype_oracle_stays_close():
+    """round 4: oracle/unet.py::round_bf16 is torch's round-to-nearest-even bfloat16 conversion; UNetOracle(store_dtype='bfloat16')
+    -- the oracle the bf16 chain tests compare against -- stores bf16-representable tensors and stays within the storage rounding of the
+    unrounded chain on a tiny net (forward 2e-2; gradients: cosine > 0.8 -- storage rounding through BatchNorm backward passes at 512 values
+    per channel is NOT small, which is why the device is compared with THIS oracle and not with the unrounded one: DESIGN.md section 4)."""
+    from oracle.unet import round_bf16
+    rng = np.random.default_rng(0)
+    v = np.concatenate([rng.standard_normal(4096) * 10.0 ** rng.integers(-6, 6, 4096), [0.0, -0.0, 1.0, 1.00390625, 1.0078125, 3.0e38]])
+    want = torch.tensor(v, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+    np.testing.assert_array_equal(round_bf16(v.astype(np.float64)), want)
+    filters, factors = [8, 16], [2, 2]
+    x = rng.random((2, 16, 16, 4))
+    t = np.eye(2)[(rng.random((2, 16, 16)) < 0.3).astype(np.int64)]
+    outs = {}
+    for sd in (None, 'bfloat16'):
+        o = UNetOracle(2, 4, filters, factors, dtype=np.float64, seed=5, store_dtype=sd)
+        probs, _ = o.forward(x, training=True)
+        _, dprobs, _ = OL.weighted_categorical_crossentropy(t, probs, [1.0, 20.0])
+        outs[sd] = (probs, o.backward(dprobs), o)
+    o_b = outs['bfloat16'][2]
+    y = o_b.cache['enc0.conv'][0] if isinstance(o_b.cache['enc0.conv'], (tuple, list)) else None
+    if y is not None and isinstance(y, np.ndarray):
+        np.testing.assert_array_equal(round_bf16(y), y)                   # a stored tensor is bf16-representable
+    np.testing.assert_allclose(outs['bfloat16'][0], outs[None][0], atol=2e-2)
+    for n in outs[None][2].trainable:
+        a, b = outs[None][1][n].ravel(), outs['bfloat16'][1][n].ravel()
+        if np.linalg.norm(a) > 1e-12:
+            assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.8, n
+
+
+def test_lstm_layers_oracle_dropout_mask_gradients_by_finite_differences():
+    """round 4: LSTMLayersOracle.forward(x, mask1) -- the layers.Dropout between the two ConvLSTM2D layers as a given mask
+    (utils/model_tools.py:699-700): analytic gradients of a scalar loss against central differences."""
+    from oracle import convlstm as CL
+    rng = np.random.default_rng(3)
+    B, T, H, W, Cc, ncls = 1, 2, 5, 5, 3, 2
+    o = CL.LSTMLayersOracle(Cc, ncls, filters=8, rec_act='sigmoid', seed=2)
+    x = rng.random((B, T, H, W, Cc))
+    mask = (rng.random((B, T, H, W, 8)) > 0.3) / 0.7
+    wgt = rng.standard_normal((B, H, W, ncls))
+
+    def loss():
+        return float((o.forward(x, mask1=mask) * wgt).sum())
+    base = loss()
+    g = o.backward(wgt)
+    assert np.isfinite(base)
+    for key, (lk, pk) in {'l1.kernel': ('l1', 'kernel'), 'l2.recurrent_kernel': ('l2', 'recurrent_kernel'), 'bn1.gamma': ('bn1', 'gamma'),
+                          'dense.kernel': ('dense', 'kernel')}.items():
+        arr = o.p[lk][pk]
+        for _ in range(3):
+            idx = tuple(rng.integers(0, s) for s in arr.shape)
+            old = arr[idx]
+            arr[idx] = old + 1e-5; lp = loss()
+            arr[idx] = old - 1e-5; lm = loss()
+            arr[idx] = old
+            fd = (lp - lm) / 2e-5
+            assert abs(fd - g[key][idx]) <= 2e-5 * max(1.0, abs(fd)), (key, idx, fd, g[key][idx])
