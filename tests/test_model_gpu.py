@@ -1482,3 +1482,50 @@ def test_frozen_layers_run_batchnorm_in_inference_mode(mt):
     l2 = TU.weighted_cce_mean(torch.tensor(t, dtype=torch.float64), pr2, [1.0, 2.0]).item()
     np.testing.assert_allclose(m.train_on_batch(x, t), l2, rtol=3e-5)
     assert any(not np.array_equal(w2[k], v) for k, v in m.get_weights_dict().items() if k.endswith('moving_mean'))
+
+
+def test_fit_uploads_host_batches_one_ahead_and_stays_bit_identical(mt):
+    """round 4: fit / evaluate upload host ndarray batches one batch ahead on a copy stream (model_tools._prefetch_to_device).  The
+    result must not depend on it: same seed, same data, with and without the prefetcher -> identical parameters, moving statistics,
+    loss history and evaluation; ragged last batches, steps_per_epoch on an endless generator and a two-input model included."""
+    rng = np.random.default_rng(5)
+    x = rng.random((22, 32, 32, 4)).astype(np.float32)             # 22 = 2 x 8 + 6: a ragged last batch
+    y = np.eye(2, dtype=np.float32)[(x[..., 0] + x[..., 3] > 1.0).astype(np.int64)]
+
+    def endless():
+        while True:
+            for i in range(0, 16, 8):
+                yield x[i:i + 8], y[i:i + 8]
+
+    def run(flag):
+        os.environ['SATCV_PREFETCH'] = flag
+        try:
+            mt.reset_uids(); mt.set_seed(0)
+            m = mt.get_unet_model(2, 4, filters=[32, 64], factors=[2, 2])
+            m.compile(optimizer=mt.Adam(2e-3), loss=lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0, 2.0]),
+                      metrics=['categorical_accuracy', mt.MeanIoU(2)])
+            h1 = m.fit(x, y, batch_size=8, epochs=3, validation_data=(x, y), verbose=0, shuffle=False)
+            h2 = m.fit(endless(), steps_per_epoch=5, epochs=2, verbose=0)
+            ev = m.evaluate(x, y, batch_size=8)
+            return m.get_weights_dict(), h1.history, h2.history, ev
+        finally:
+            os.environ.pop('SATCV_PREFETCH', None)
+
+    w1, ha1, hb1, ev1 = run('1')
+    w0, ha0, hb0, ev0 = run('0')
+    # (the reported loss scalar is a float atomic sum: last-bit differences between any two runs, DESIGN.md section 4)
+    for a_, b_ in ((ha1, ha0), (hb1, hb0)):
+        assert a_.keys() == b_.keys()
+        for k in a_:
+            np.testing.assert_allclose(a_[k], b_[k], rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(ev1, ev0, rtol=1e-5)
+    for k in w0:
+        assert np.array_equal(w0[k], w1[k]), k
+    # two inputs (Siamese): lists of arrays go through the same slots
+    mt.reset_uids(); mt.set_seed(1)
+    sm = mt.make_siamese_unet(4, filters=[32, 64], factors=[2, 2])
+    xa, xb_ = x[:8], x[8:16]
+    ys = (rng.random((8, 32, 32, 1)) < 0.3).astype(np.float32)
+    sm.compile(optimizer=mt.Adam(1e-3), loss=lambda yt, yp: mt.weighted_bce(yt, yp, 2.0))
+    h = sm.fit([xa, xb_], ys, batch_size=4, epochs=2, verbose=0, shuffle=False)
+    assert np.isfinite(h.history['loss']).all()

@@ -26,3 +26,11 @@ print(f'training   : HBM-resident {64/a:8.1f} tiles/s   host ndarray batches (in
 xp, yp = torch.from_numpy(x).pin_memory(), torch.from_numpy(y).pin_memory()
 b = t(lambda: m.train_step_device(xp, yp))
 print(f'training   : pinned host tensors {64/b:8.1f} tiles/s')
+xs, ys = np.concatenate([x] * 6), np.concatenate([y] * 6)
+for flag in ('1', '0'):
+    os.environ['SATCV_PREFETCH'] = flag
+    m.fit(xs, ys, batch_size=64, epochs=1, verbose=0, shuffle=False)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    m.fit(xs, ys, batch_size=64, epochs=2, verbose=0, shuffle=False)
+    torch.cuda.synchronize()
+    print(f'fit(host ndarrays, 12 steps of 64) SATCV_PREFETCH={flag}: {12 * 64 / (time.perf_counter() - t0):8.1f} tiles/s')
