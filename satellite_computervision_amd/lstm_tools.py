@@ -467,6 +467,11 @@ def _ingest_seq(x, cpad, dtype):
     return out, (B, T, H, W)
 
 
+def _dev_f32(a):
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return t.to(_dev(), torch.float32).contiguous()
+
+
 class _SeqModelBase:
     """compile / fit / predict / train_on_batch plumbing shared by the LSTM-family models (Adam through satcv_adam_step)"""
 
@@ -809,11 +814,14 @@ class LSTMAutoencoder(_SeqModelBase):
     def train_on_batch(self, x, y):
         if self._loss is None:
             raise RuntimeError('compile() the model before fit/train')
+        tensors = tuple(_dev_f32(a) for a in x) + tuple(_dev_f32(a) for a in y)
+        return float(self._graphed_step(self._train_device, tensors).item())
+
+    def _train_device(self, xs, sincos, ty, sy):
         self.P.grad.zero_()
-        tout, sout = self._forward(x, True)
+        tout, sout = self._forward([xs, sincos], True)
         B, T, H, W = self._shape
-        ty, sy = y
-        ty = torch.as_tensor(np.ascontiguousarray(ty, dtype=np.float32)).to(_dev()).permute(1, 0, 2, 3, 4).contiguous().view(T * B, H, W, -1)
+        ty = ty.permute(1, 0, 2, 3, 4).contiguous().view(T * B, H, W, -1)
         l1, d1 = self._loss_grad(tout, ty, 'linear')
         l2, d2 = self._loss_grad(sout, sy, 'linear')
         (ddec,) = self.temporal.backward(d1, need_dx=(True,))
@@ -822,8 +830,8 @@ class LSTMAutoencoder(_SeqModelBase):
         check(lib.satcv_add_act(denc1.data_ptr(), None, None, denc2.data_ptr(), None, None, 0, denc1.data_ptr(), B * H * W, denc1.shape[-1],
                                 ops.DTYPE_CODE[denc1.dtype], ops.stream_ptr()))
         self.enc.backward(denc1)
-        self._adam()
-        return float(l1.item()) + float(l2.item())
+        self._adam(set_lr=False)
+        return l1 + l2
 
 
 def get_lstm_autoencoder(n_channels, n_time, n_classes, activation='relu', compile=False, optim=None, metrics=None, loss=None, max_value=2.0):
@@ -975,12 +983,16 @@ class HierarchicalModel(_SeqModelBase):
     def train_on_batch(self, x, y):
         if self._loss is None:
             raise RuntimeError('compile() the model before fit/train')
+        tensors = tuple(_dev_f32(a) for a in x) + tuple(_dev_f32(a) for a in y)
+        return float(self._graphed_step(self._train_device, tensors).item())
+
+    def _train_device(self, xa, xl, y0, y1, y2):
         self.P.grad.zero_()
-        outs = self._forward(x, True)
-        total, dl = 0.0, []
-        for o, yy in zip(outs, y):
+        outs = self._forward([xa, xl], True)
+        total, dl = None, []
+        for o, yy in zip(outs, (y0, y1, y2)):
             loss, d = self._loss_grad(o, yy, 'softmax')
-            total += float(loss.item())
+            total = loss if total is None else total + loss
             dl.append(d)
         (dmid,) = self.sub.backward(dl[0], need_dx=(True,))
         (dlast,) = self.acnn.backward(dl[1], need_dx=(True,))
@@ -992,7 +1004,7 @@ class HierarchicalModel(_SeqModelBase):
         else:
             dfe[self.mid] = dmid
         self.trunk.backward(dfe)
-        self._adam()
+        self._adam(set_lr=False)
         return total
 
 

@@ -495,3 +495,45 @@ def test_hybrid_model_with_dropout_trains(lt):
         assert sm.shape == (2, 64) and set(np.unique(sm).round(4)) <= {0.0, 1.25}
     finally:
         mt.set_compute_dtype('bfloat16')
+
+
+@pytest.mark.parametrize('which', ['autoencoder', 'hierarchical'])
+def test_multi_output_sequence_models_graph_replay_matches_eager(lt, which):
+    """get_lstm_autoencoder / get_hierarchical_model: training steps replayed from a captured graph (third step on) against the eager
+    tape -- same seed and batches, six steps: equal losses and parameters up to the kernels' summation order."""
+    from satellite_computervision_amd import model_tools as mt
+    mt.set_compute_dtype('float32')
+    try:
+        rng = np.random.default_rng(21)
+        if which == 'autoencoder':
+            B, T, H, W, Cc, ncls = 2, 3, 16, 16, 6, 6
+            xs = [[rng.random((B, T, H, W, Cc)).astype(np.float32), rng.standard_normal((B, H, W, 2)).astype(np.float32)] for _ in range(6)]
+            ys = [[np.flip(x[0], axis=1).copy(), rng.random((B, H, W, ncls)).astype(np.float32)] for x in xs]
+            build = lambda: lt.get_lstm_autoencoder(Cc, T, ncls)
+            loss = mt.mse_4d
+        else:
+            ncls, nacnn, nsub, nf, depth = 3, 4, 5, 16, 3
+            B, H, W, Cc, T, hh, ww, lc = 2, 24, 24, 4, 2, 8, 8, 6
+            xs = [[rng.random((B, H, W, Cc)).astype(np.float32), rng.random((B, T, hh, ww, lc)).astype(np.float32)] for _ in range(6)]
+            ys = [[np.eye(k, dtype=np.float32)[rng.integers(0, k, (B, H, W))] for k in (nsub, nacnn, ncls)] for _ in range(6)]
+            build = lambda: lt.get_hierarchical_model(ncls, nacnn, nsub, (H, W, Cc), (T, hh, ww, lc), nf, depth)
+            loss = lambda yt, yp: mt.weighted_categorical_crossentropy(yt, yp, [1.0] * 8)
+
+        def run(flag):
+            os.environ['SATCV_LSTM_GRAPH'] = flag
+            mt.reset_uids(); mt.set_seed(9)
+            m = build()
+            m.compile(optimizer=mt.Adam(1e-3), loss=loss)
+            return m, [m.train_on_batch(x, y) for x, y in zip(xs, ys)]
+        try:
+            me, le = run('0')
+            mg, lg = run('1')
+        finally:
+            os.environ.pop('SATCV_LSTM_GRAPH', None)
+        assert any('g' in st for st in mg._graphs.values()), 'no step was captured'
+        np.testing.assert_allclose(lg, le, rtol=5e-4)
+        we, wg = me.get_weights_dict(), mg.get_weights_dict()
+        for k in we:
+            assert np.abs(we[k] - wg[k]).max() < 5e-4, (k, np.abs(we[k] - wg[k]).max())
+    finally:
+        mt.set_compute_dtype('bfloat16')
