@@ -18,7 +18,7 @@
 //     halos run on the same XCD (private L2).
 #include "igemm_common.hpp"
 #include <cstdlib>
-extern int g_opt_igemm_db, g_opt_igemm_thin, g_opt_igemm_sched, g_opt_splitk;      // api.hip: satcv_set_option
+extern int g_opt_igemm_db, g_opt_igemm_thin, g_opt_igemm_sched, g_opt_splitk, g_opt_igemm_m16;      // api.hip: satcv_set_option
 
 // compile-time ablation switches for profiling builds (-DSATCV_ABLATE=bits): 1 skip global stores, 2 skip MFMA,
 // 4 skip activation loads, 8 skip weight loads, 16 skip the LDS fragment reads, 32 skip the whole epilogue, 64 skip the LDS stores,
@@ -50,7 +50,13 @@ extern "C" int satcv_debug_read_stamps(unsigned long long* out) {
 // chunks ahead; the activations keep the register path (fused input BatchNorm + ReLU, zero padding).
 // SK: split-K instantiation (see fast_cfg); every other instantiation compiles exactly the single-pass code (the K range is the constant [0, nchunks):
 // compiled in unconditionally the extra live state cost the 128 x 128 tile a wave per SIMD)
-template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool DYN, bool TL = false, bool DB = false, int WPS = 0, bool WDMA = false, bool SK = false>
+// M16 (round 5, double-buffered tiles with chunks of a multiple of 32 channels): the contraction runs on v_mfma_f32_16x16x32_bf16 -- K = 32 per
+// instruction, a lane quarter (l >> 4) feeds 8 channels, so a K step reads FOUR slot planes of one tap; a wave's 64 x 64 output is 4 x 4
+// blocks of 16 x 16 kept in the same 64 accumulator registers (igemm_common.hpp: AccMap).  Same matrix cycles and LDS bytes per FLOP as
+// the 32x32x16 form; the chip holds a higher clock under this shape (profiles/r04_exp_mfma_16x16x32_timing.txt: -5...-8 % on every
+// MFMA-bound launch), and a 32-channel chunk halves the barriers per MFMA.  The slot planes are padded to a multiple of 256 bytes: the four
+// 16-lane groups of a ds_read_b128 then take 16 distinct 16-byte bank slots each (MI355X_MICROARCH.md, LDS table).
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool DYN, bool TL = false, bool DB = false, int WPS = 0, bool WDMA = false, bool SK = false, bool M16 = false>
 // thin configurations (<= 32 accumulator registers) request 4 waves/SIMD; the scaled-fp8 fragments are 8 registers each, so
 // that path asks for 2.  WPS overrides (tile-at-once configurations stage a whole tile through registers)
 __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<T>::SUB == 2 ? 2 : 4) : 1))) void igemm_fast_kernel(const IgemmArgs a) {
@@ -62,7 +68,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
   // DYN = dilated 3x3 taps: halo width and LDS pitch come from the arguments.  Otherwise they are compile-time functions of the
   // tile width, which turns every tap / sub-slot offset of the fragment reads into an instruction immediate (no address VGPRs).
   constexpr int CLc = TW + (TAPS == 9 ? 2 : 0);
-  constexpr int PITCHc = TW == 32 ? CLc : (TW == 16 ? ((CLc + 15) / 16) * 16 : (CLc <= 8 ? 8 : ((CLc - 8 + 15) / 16) * 16 + 8));
+  // (M16: the 16 lanes of a fragment quarter read 16 consecutive pixels of ONE row when TW >= 16, so the row pitch is free: no padding)
+  constexpr int PITCHc = igemm_pitch(TW, CLc, M16);
+  static_assert(!M16 || (std::is_same<T, bf16>::value && DB && !SK && !DYN && KS % 2 == 0 && TW >= 16), "16x16x32 form: double-buffered bf16 tiles, chunks of 32 k channels, tiles at least 16 pixels wide");
   const int pitch = DYN ? a.pitch : PITCHc;
   const int cl = DYN ? a.cl : CLc;
   const int dil = DYN ? a.dil : 1;
@@ -79,7 +87,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
   // 8 lanes of a group store 2 pixels x 4 slots, so the plane stride must be 32 B modulo 128 B for the eight 16-byte stores to
   // fall on distinct banks (unpadded 1x1 / 32-channel-chunk planes are multiples of 512 B: measured 43 % bank-conflict cycles)
   const int plane = a.rl * pitch * EL;
-  const int spad = SLOTS > 2 ? ((32 - (plane * (int)sizeof(T)) % 128 + 128) % 128) / (int)sizeof(T) : 0;
+  const int spad = M16 ? ((256 - (plane * (int)sizeof(T)) % 256) % 256) / (int)sizeof(T)
+                       : (SLOTS > 2 ? ((32 - (plane * (int)sizeof(T)) % 128 + 128) % 128) / (int)sizeof(T) : 0);
   const int slot_stride = plane + spad;
   const int a_stage = SLOTS * slot_stride;                                    // A planes of one stage
   constexpr int b_slab = TAPS * SLOTS * BN * EL;                              // weight slab of one chunk
@@ -143,15 +152,19 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
     b_g[j] = ((run / SLOTS) * (cin / EL) + (run % SLOTS)) * a.cout_pad + nbase + co;
   }
 
-  int a_off[MT];
+  // fragment addresses of this lane: one per 32-row tile (32x32x16: row l & 31, slot offset from the lane half added per step) or one per
+  // 16-row block (16x16x32: row l & 15, the slot plane of the lane quarter folded in)
+  constexpr int NAF = M16 ? 2 * MT : MT;
+  int a_off[NAF];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int q = (wm * MT + m) * 32 + r;
+  for (int m = 0; m < NAF; ++m) {
+    const int q = M16 ? (wm * MT * 32 + m * 16 + (lane & 15)) : ((wm * MT + m) * 32 + r);
     const int t = q / TW, cx = q % TW;
     const int k = (a.imgs == 1) ? 0 : t / a.rpi;
     const int l0 = (k < a.imgs) ? k * a.seg + (t - k * a.rpi) : 0;
-    a_off[m] = (l0 * pitch + cx) * EL;
+    a_off[m] = (l0 * pitch + cx) * EL + (M16 ? (lane >> 4) * slot_stride : 0);
   }
+  const int b_lane16 = ((lane >> 4) * BN + wn * NT * 32 + (lane & 15)) * EL;      // (M16) weight fragment: slot of the lane quarter, column l & 15
 
   const T* wp = reinterpret_cast<const T*>(a.w);
   Raw8<T> ra[AI], rb[BI];
@@ -408,6 +421,32 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
     // (rot is a wave-uniform run-time value: the tap offsets of a staggered wave are scalar additions instead of instruction immediates;
     //  two compile-time copies of the loop cost 200 bytes of scratch per lane)
     auto compute_chunk = [&](int boff, int boffB, auto&& side) {
+      if constexpr (M16) {
+        constexpr int K32 = KS / 2, STEPS = TAPS * K32;      // K = 32 per step: four slot planes of one tap
+        FragT<T> af[2][2 * MT], bf[2][2 * NT];
+        auto read_step = [&](int st, int buf) {
+          const int tap = st / K32, k32 = st % K32;
+          const int ky = TAPS == 1 ? 0 : tap / 3, kx = TAPS == 1 ? 0 : tap % 3;
+          const int tap_off = (ky * pitch + kx) * EL;          // (dilation 1; compile-time)
+#pragma unroll
+          for (int m = 0; m < 2 * MT; ++m) af[buf][m] = lds_frag<T>(ldsA + boff + k32 * 4 * slot_stride + a_off[m] + tap_off);
+#pragma unroll
+          for (int n = 0; n < 2 * NT; ++n) bf[buf][n] = lds_frag<T>(ldsB + boffB + b_lane16 + ((tap * SLOTS + k32 * 4) * BN + n * 16) * EL);
+        };
+        read_step(0, 0);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+          asm volatile("" ::: "memory");
+          if (st + 1 < STEPS) read_step(st + 1, (st + 1) & 1);
+          side(st);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!ABL(2)) mma16_step<MT, NT>(acc, af[st & 1], bf[st & 1]);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(acc[m][n]));
+      } else {
       constexpr int STEPS = TAPS * KS;
       FragT<T> af[2][MT], bf[2][NT];
       auto read_step = [&](int st_, int buf) {
@@ -444,6 +483,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #pragma unroll
           for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(acc[m][n]));
       }
+      }
     };
     if constexpr (DB) {
 #ifdef SATCV_STAMP
@@ -451,7 +491,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
 #endif
       // units of one chunk's staging in program order: A items (store c+1, then re-issue for c+2), the scale / shift values (needed by
       // the A stores above, so re-issued after them), weight items; unit u runs in tap step u (the surplus in the last step)
-      constexpr int NUNITS = AI + 1 + (WDMA ? NROUNDS : BI), STEPS_ = TAPS * KS;
+      constexpr int NUNITS = AI + 1 + (WDMA ? NROUNDS : BI), STEPS_ = M16 ? TAPS * KS / 2 : TAPS * KS;
       for (int chunk = c_begin; chunk < c_end; ++chunk) {
         // A stages alternate; without WDMA the weight slab sits behind the A planes of the same stage, with it in ring slot chunk % 3
         const int cur = WDMA ? (chunk & 1) * a_stage : (chunk & 1) * stage_elems;
@@ -471,7 +511,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
         auto side = [&](int st) {
 #pragma unroll
           for (int u = 0; u < NUNITS; ++u) {
-            if ((u < STEPS_ ? u : STEPS_ - 1) != st) continue;
+            // (M16: a step is 16 MFMAs of 16 cycles -- the units are spread evenly over the steps, in program order)
+            if ((M16 ? (u * STEPS_) / NUNITS : (u < STEPS_ ? u : STEPS_ - 1)) != st) continue;
             if (u < AI) { if (do_store) store_a(chunk + 1, oth, u); load_a(cs_, u); }
 #ifdef SATCV_RS_GLOBAL                                  // (A/B build: the scale / shift values by global loads, as before)
             else if (u == AI) load_p(cs_, false);
@@ -580,7 +621,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WPS ? WPS : (MT * NT <= 2 ? (KTraits<
         }
       return;
     } else
-    igemm_epilogue<T, TW, WM, WN, MT, NT, ABL(1), !DYN>(a, acc, n0, y0, x0, nbase, smem_raw);      // (the dilated-halo instantiations sit at their register cap)
+    igemm_epilogue<T, TW, WM, WN, MT, NT, ABL(1), !DYN, true, M16>(a, acc, n0, y0, x0, nbase, smem_raw);      // (the dilated-halo instantiations sit at their register cap)
 #ifdef SATCV_STAMP
     {
       unsigned long long k4;
@@ -693,7 +734,7 @@ static int igemm_splitk_finish(const IgemmArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ host side
-template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool TL = false, bool DB = false, int WPS = 0, bool WDMA = false, bool SK = false>
+template <typename T, int TW, int WM, int WN, int MT, int NT, int KS, int TAPS, bool TL = false, bool DB = false, int WPS = 0, bool WDMA = false, bool SK = false, bool M16 = false>
 static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   constexpr int EL = KTraits<T>::EL, SUB = KTraits<T>::SUB;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32, TH = BM / TW, KC = KS * 2 * SUB * EL, NTHREADS = WM * WN * 64;
@@ -705,9 +746,7 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   a.seg = a.rpi + 2 * a.halh;
   a.rl = a.imgs * a.seg;
   a.cl = TW + 2 * a.halw;
-  if (TW == 32) a.pitch = a.cl;
-  else if (TW == 16) a.pitch = cdiv(a.cl, 16) * 16;
-  else a.pitch = (a.cl <= 8) ? 8 : (cdiv(a.cl - 8, 16) * 16 + 8);
+  a.pitch = igemm_pitch(TW, a.cl, M16);
   a.n_tiles = cdiv(a.cout, BN);
   const int cin = a.c0 + a.c1;
   a.cpt = cin / KC;
@@ -729,6 +768,11 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   if (a.mode_out == 0 && a.cout % (16 / (int)sizeof(T)) != 0 && a.cout < a.ldy) { /* tail handled by scalar stores */ }
   size_t lds_stage = (((size_t)KC * a.rl * a.pitch + (size_t)TAPS * KC * BN) * sizeof(T) + (size_t)(KC / EL) * 128) * (DB ? 2 : 1);      // + slot padding (< 128 B per plane)
   if (WDMA) lds_stage = 2 * ((size_t)KC * a.rl * a.pitch * sizeof(T) + (size_t)(KC / EL) * 128) + 3 * (size_t)TAPS * KC * BN * sizeof(T);      // two A stages + a three-slot weight ring
+  if (M16) {      // slot planes padded to multiples of 256 bytes (exact: the TW = 32 form with a 1024-channel table fills the 160 KB to the byte)
+    const size_t plane_b = (((size_t)a.rl * a.pitch * EL * sizeof(T) + 255) / 256) * 256;
+    const size_t a_st = (size_t)(KC / EL) * plane_b, b_sl = (size_t)TAPS * KC * BN * sizeof(T);
+    lds_stage = WDMA ? 2 * a_st + 3 * b_sl : 2 * (a_st + b_sl);
+  }
   if (WDMA && (((uintptr_t)a.w % 16) != 0 || a.cout_pad % 64 != 0)) return SATCV_ERR_UNSUPPORTED;
   if (DB && ((TL && TAPS != 1) || a.mode_in != 0)) return SATCV_ERR_UNSUPPORTED;
   size_t lds_out = (size_t)BM * (BN + 16 / sizeof(T)) * sizeof(T) + (size_t)(WM + 1) * 2 * BN * sizeof(float);
@@ -776,10 +820,10 @@ static int fast_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   if (dry) return SATCV_OK;
   if (!dyn) {            // the kernel hard-codes these for the undilated case: keep the two derivations in lock step
     constexpr int CLc = TW + (TAPS == 9 ? 2 : 0);
-    constexpr int PITCHc = TW == 32 ? CLc : (TW == 16 ? ((CLc + 15) / 16) * 16 : (CLc <= 8 ? 8 : ((CLc - 8 + 15) / 16) * 16 + 8));
+    constexpr int PITCHc = igemm_pitch(TW, CLc, M16);
     if (a.cl != CLc || a.pitch != PITCHc) { satcv_set_error("igemm_fast: internal pitch mismatch (%d/%d vs %d/%d)", a.cl, a.pitch, CLc, PITCHc); return SATCV_ERR_INVALID; }
   }
-  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, false, TL, DB, WPS, WDMA, SK>;
+  auto kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, false, TL, DB, WPS, WDMA, SK, M16>;
   if constexpr (TAPS == 9 && !DB && WPS == 0 && !SK) { if (dyn) kern = igemm_fast_kernel<T, TW, WM, WN, MT, NT, KS, TAPS, true>; }
   if ((DB || WPS || SK) && dyn) return SATCV_ERR_UNSUPPORTED;
   { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
@@ -816,6 +860,17 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
         // weights by LDS-DMA into a three-slot ring (SATCV_WDMA=0: register-staged weights; the ring does not fit beside the halo tiles
         // of the 8-pixel-wide maps, which stay on the register path)
         static const int wdma = [] { const char* e = getenv("SATCV_WDMA"); return e ? atoi(e) : 1; }();
+        // round 5: the 16x16x32 tile of conv_igemm_m16.hip -- 32-channel chunks, weights in tap-row units.  Maps at least 16 pixels wide,
+        // Cin % 64 == 0 (the 8-pixel-wide maps keep the 32x32x16 register path).  It sums K in another grouping than the 32x32x16 tiles, and
+        // which tile serves a shape depends on the launch's tile count: option igemm_m16 = 1 (default) therefore limits it to launches that
+        // write statistics -- training-mode forward convolutions and data gradients with fused BatchNorm-backward sums --, so that inference
+        // stays bit-identical across batch splits; a training plan raises the option to 2 (every eligible launch)
+        // around its steps (engine.Plan.run_forward / run_backward); SATCV_M16=0 turns the tile off
+        const int m16 = g_opt_igemm_m16;
+        if (m16 >= 2 || (m16 == 1 && (a.stats || a.bst_y))) {
+          const int rc = igemm_m16_launch(a, st, dry);
+          if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+        }
         if (wdma) {
           const int rc = fast_cfg<T, TW, 4, 2, 2, 2, 1, TAPS, false, true, 0, true>(a, st, dry);
           if (rc != SATCV_ERR_UNSUPPORTED) return rc;

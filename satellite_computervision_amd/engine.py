@@ -24,6 +24,8 @@ import torch
 from . import ops, parallel
 from ._lib import lib, check, F32, BF16, STAT_ROWS
 
+_M16_DEFAULT = int(os.environ.get('SATCV_M16', '1'))      # library default of option igemm_m16 (csrc/api.hip)
+
 BN_EPS = 1e-3
 BN_MOMENTUM = 0.99
 
@@ -1326,11 +1328,22 @@ class Plan:
             self.bwd.append(join)
 
     # -- execution
+    # (a training plan lets EVERY eligible deep 3x3 launch -- also the data gradients that carry no statistics -- run on the 16x16x32 tile;
+    #  inference keeps the library default, which preserves bit-identical results across batch splits: csrc/conv_igemm_fast.hip)
+    def _run(self, steps, st):
+        raise_m16 = self.training and _M16_DEFAULT == 1
+        if raise_m16:
+            lib.satcv_set_option(b'igemm_m16', 2)
+        try:
+            for s in steps:
+                s(st)
+        finally:
+            if raise_m16:
+                lib.satcv_set_option(b'igemm_m16', _M16_DEFAULT)
+
     def run_forward(self, st):
-        for s in self.fwd:
-            s(st)
+        self._run(self.fwd, st)
 
     def run_backward(self, st):
-        for s in self.bwd:
-            s(st)
+        self._run(self.bwd, st)
 

@@ -225,6 +225,9 @@ DB_CASES = [
     (1, 16, 16, 64, 128), (2, 16, 16, 1024, 512), (2, 16, 16, 512, 512), (3, 8, 8, 512, 1024), (2, 32, 32, 512, 256),
     (2, 32, 32, 128, 256), (1, 64, 64, 256, 128), (3, 20, 24, 64, 128), (5, 8, 8, 80, 128), (1, 40, 72, 96, 128), (7, 4, 4, 64, 128),
     (2, 12, 12, 64, 256),
+    # round 5, the 16x16x32 tile (csrc/conv_igemm_m16.hip: Cin % 64 == 0, maps at least 16 pixels wide and a tile high): ragged tile rows for
+    # both tile widths, an odd image count, two and many 32-channel chunks
+    (1, 40, 48, 128, 128), (3, 20, 64, 64, 128), (1, 24, 32, 192, 256),
 ]
 
 
@@ -253,6 +256,39 @@ def test_conv2d_double_buffered_tile(ops, td, case, force_db):
     _, wd = ops.pack_weights(f32dev(kern2), cout, ops.DTYPE_CODE[td])
     dx = ops.conv2d_dgrad(to_dev(dy, td), wd, cout)
     close(back(dx, cout), dx_ref, td, f'db dgrad {case}')
+
+
+@pytest.mark.parametrize('case', [(4, 16, 16, 512, 512, 0), (2, 32, 32, 256, 128, 0), (2, 16, 16, 128, 256, 128), (1, 64, 64, 128, 128, 64)])
+def test_16x16x32_tile_fused_bn_backward_sums(ops, case, force_db):
+    """the fused BatchNorm-backward sums (bst_*) in the epilogue of the 16x16x32 tile, whose accumulator layout differs from the 32x32x16
+    one (a lane owns two columns): against float64 sums of the stored gradient; the stored gradient itself against the oracle."""
+    n, h, w, cin, cout, split = case
+    td = torch.bfloat16
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (3, 3, cin, cout), td, 0.1)
+    ref = K.conv2d_same(x, kern, np.zeros(cout), 1)
+    v = torch.tensor(rnd(rng, (n, h, w, cout), td) * 1.5 + 0.25, dtype=torch.float32).to(td).double().numpy()
+    sc, sh = rng.standard_normal(cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32) * 0.5
+    mu, rs = rng.standard_normal(cout).astype(np.float32) * 0.3, (0.5 + rng.random(cout)).astype(np.float32)
+    wf, _ = ops.pack_weights(f32dev(kern), cin, ops.DTYPE_CODE[td])
+    v0 = to_dev(v[..., :split] if split else v, td)
+    v1 = to_dev(v[..., split:], td) if split else None
+    for relu in (1, 0):
+        stats = ops.new_stats(cout, dev())
+        bst = dict(y=v0, ld=v0.shape[-1], scale=f32dev(sc), shift=f32dev(sh), mean=f32dev(mu), rstd=f32dev(rs), relu=relu)
+        if split:
+            bst.update(y1=v1, ld1=v1.shape[-1], split=split)
+        y = ops.conv2d(to_dev(x, td), wf, cout, stats=stats, bst=bst)
+        g = back(y, cout)
+        close(g, ref, td, f'16x16x32 conv {case}')
+        mask = (v * sc.astype(np.float64) + sh.astype(np.float64) > 0) if relu else np.ones_like(v, bool)
+        gg = np.where(mask, g, 0.0)
+        xh = (v - mu.astype(np.float64)) * rs.astype(np.float64)
+        got = stats.sum(0).double().cpu().numpy()
+        tol = 2e-4 * np.sqrt(n * h * w) * max(1.0, float(np.abs(g).max()))
+        np.testing.assert_allclose(got[0], gg.sum((0, 1, 2)), rtol=1e-4, atol=tol, err_msg=f'sum g {case} relu={relu}')
+        np.testing.assert_allclose(got[1], (gg * xh).sum((0, 1, 2)), rtol=1e-4, atol=tol * float(np.abs(xh).max()), err_msg=f'sum g xhat {case} relu={relu}')
 
 
 def test_conv2d_double_buffered_dual_source_affine(ops, force_db):
