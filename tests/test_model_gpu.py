@@ -918,6 +918,51 @@ def test_full_size_training_step_permutation_property(mt):
     assert torch.isfinite(g1).all() and g1.abs().max() > 0
 
 
+@pytest.mark.parametrize('channels', [4, 13])
+def test_timed_configuration_bf16_batch64_training_step_properties(mt, channels):
+    """The configuration bench.py times (BASELINE configs[1]; configs[3] with 13 bands): ONE bf16 training step of get_unet_model(2, C) at
+    batch 64 of 256 x 256 tiles -- the only size at which the 16x16x32 deep tile (csrc/conv_igemm_m16.hip, wave roles), the LDS-DMA weight
+    gradient on 128 workgroups, the multi-image deep tiles and the fused thin-layer backward all run as benchmarked.  Size-independent
+    properties: (1) two identical steps give BIT-identical gradients and loss sums (fixed summation orders everywhere), (2) the batch is a
+    set: a permutation of the tiles leaves the loss and every gradient unchanged up to the re-ordered sums (measured relL2 3.5e-2 with the
+    32x32x16 tiles, 3.7e-2 with the 16x16x32 tile: re-ordered BatchNorm sums move statistics in the last bit, which flips bf16 storage
+    roundings of every tensor below, and BatchNorm's mean removal amplifies those -- DESIGN.md section 4; the fp32 step of the test above
+    holds 1e-2.  Bound 8e-2 on the flat gradient, 0.3 per kernel: a wrong tile mapping or a dropped slab would be O(1) in its layer),
+    (3) every gradient is finite and non-zero, the loss equals the mean over the tiles of the per-tile losses of the same step's
+    probabilities within bf16 tolerance."""
+    mt.reset_uids(); mt.set_seed(31)
+    m = mt.get_unet_model(2, channels)
+    m.compute_dtype = 'bfloat16'
+    m.compile(optimizer=mt.Adam(0.0), loss=lambda t, p: mt.weighted_categorical_crossentropy(t, p, [1.0, 20.0]))
+    rng = np.random.default_rng(77 + channels)
+    x = rng.beta(2, 5, (64, 256, 256, channels)).astype(np.float32)
+    lab = (rng.random((64, 256, 256)) < 0.05).astype(np.int64)
+    y = np.eye(2, dtype=np.float32)[lab]
+    l1 = m.train_on_batch(x, y)
+    g1 = m.runtime.gflat.clone()
+    l1b = m.train_on_batch(x, y)
+    g1b = m.runtime.gflat.clone()
+    assert torch.equal(g1, g1b), 'two identical bf16 steps at batch 64 must give bit-identical gradients'
+    assert abs(l1 - l1b) <= 1e-6 * abs(l1)
+    assert torch.isfinite(g1).all() and np.isfinite(l1)
+    perm = rng.permutation(64)
+    l2 = m.train_on_batch(x[perm], y[perm])
+    g2 = m.runtime.gflat.clone()
+    assert abs(l1 - l2) < 2e-4 * abs(l1), (l1, l2)
+    rel = ((g1 - g2).norm() / g1.norm()).item()
+    print(f'bf16 batch-64 gradient repeatability ({channels} bands): permuted batch relL2 {rel:.2e}')
+    assert rel < 8e-2, rel
+    # per-layer: every kernel gradient non-zero and permutation-stable (a layer served by a wrong tile map would stand out here even if
+    # the flat norm hid it)
+    for name, off in m.runtime.offsets.items():
+        if not name.endswith('/kernel'):
+            continue
+        sz = m.runtime.get_grad(name).numel()
+        a, b = g1[off:off + sz], g2[off:off + sz]
+        assert a.abs().max() > 0, name
+        assert ((a - b).norm() / a.norm()).item() < 0.3, name
+
+
 @pytest.mark.parametrize('n,h,w', [(1, 4, 4), (5, 12, 20), (3, 40, 72), (2, 100, 36), (7, 8, 264)])
 def test_ragged_shapes_forward_and_gradients(mt, n, h, w):
     """tile sizes that are not multiples of any kernel tile (partial tiles in x and y, several images per workgroup, a 1x1
