@@ -155,9 +155,25 @@ typedef struct satcv_wgrad_desc {
   int32_t accumulate;                /* dw += result (a layer applied to several inputs: shared weights) */
   int32_t whole_chip;                /* 1: nothing runs beside this launch (the last weight gradient of a backward pass): one workgroup
                                         per CU instead of the 160 that leave room for the other stream's kernels */
+  int32_t defer_reduce;              /* 1: the launch only writes its fp32 partial slabs to `workspace` (which then belongs to this layer
+                                        until the sum has run); the caller sums them later, many layers per launch:
+                                        satcv_conv2d_wgrad_reduce_job + satcv_reduce_slabs_batched.  Plain 1x1 / 3x3 path only. */
 } satcv_wgrad_desc;
 int64_t satcv_conv2d_wgrad_workspace(const satcv_wgrad_desc* d);
 int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream);
+
+/* Deferred, batched slab sum (round 5).  Every weight-gradient launch ends in an ordered sum of its workgroups' fp32 partial slabs into the
+ * Keras-layout gradient -- a launch of 5-30 us per layer, 21 per training step.  With defer_reduce the producers skip it; the caller
+ * collects one job per layer (the slab geometry the library chose), keeps the layers' workspaces apart, and runs ONE launch over a DEVICE
+ * array of jobs + the exclusive prefix sum of satcv_reduce_job_items().  The summation order is fixed (a job's `lanes` partial sums over
+ * slabs l, l + lanes, ..., combined in increasing lane order): results are bit-reproducible. */
+typedef struct satcv_reduce_job {
+  const float* ws; float* dw;
+  int32_t nslab, taps, kpad, npad, cin, nvalid, transposed, accumulate, lanes, pad_;
+} satcv_reduce_job;
+int satcv_conv2d_wgrad_reduce_job(const satcv_wgrad_desc* d, satcv_reduce_job* job);      /* the sum satcv_conv2d_wgrad(d) deferred */
+int64_t satcv_reduce_job_items(const satcv_reduce_job* job);
+int satcv_reduce_slabs_batched(const satcv_reduce_job* jobs_dev, const int64_t* prefix_dev, int32_t njobs, int64_t total_items, void* stream);
 
 /* Fused backward of a thin conv -> BatchNormalization -> ReLU block (conv_batch_act, utils/model_tools.py:174-186; Keras autodiff of
  * Conv2D :178 + BatchNormalization :179 + Activation :180 inside Model.fit): ONE launch replaces satcv_bn_bwd_apply + the data-gradient
@@ -200,9 +216,12 @@ typedef struct satcv_bwdf_desc {
    * g[p][c] = bf16(dlogits[p][0] w[c][0] + dlogits[p][1] w[c][1]), what satcv_head_bwd would have stored as dx (pass dx = NULL there).
    * hg_dlogits (npix, 2) fp32, hg_w the head's Keras kernel (cout, 2) fp32, hg_ncls == 2; 32 -> 32 channels only. */
   const float* hg_dlogits; const float* hg_w; int32_t hg_ncls;
+  int32_t defer_reduce;                /* 1: leave the weight-gradient slabs in `workspace` (satcv_conv2d_bwd_fused_reduce_job describes the
+                                          deferred sum for satcv_reduce_slabs_batched) */
 } satcv_bwdf_desc;
 int64_t satcv_conv2d_bwd_fused_workspace(const satcv_bwdf_desc* d);
 int satcv_conv2d_bwd_fused(const satcv_bwdf_desc* d, void* stream);
+int satcv_conv2d_bwd_fused_reduce_job(const satcv_bwdf_desc* d, satcv_reduce_job* job);
 
 /* --------------------------------------------------------------- batch norm
  * layers.BatchNormalization (utils/model_tools.py:179,308,313,316): eps, momentum as given.

@@ -53,7 +53,7 @@ class WgradDesc(C.Structure):
                 ('n', c_i32), ('h', c_i32), ('w_', c_i32),
                 ('kh', c_i32), ('kw', c_i32), ('dil', c_i32),
                 ('mode_dy', c_i32), ('f', c_i32), ('transposed', c_i32),
-                ('workspace', c_vp), ('workspace_bytes', c_i64), ('dtype', c_i32), ('accumulate', c_i32), ('whole_chip', c_i32)]
+                ('workspace', c_vp), ('workspace_bytes', c_i64), ('dtype', c_i32), ('accumulate', c_i32), ('whole_chip', c_i32), ('defer_reduce', c_i32)]
 
 
 class BwdfDesc(C.Structure):
@@ -67,7 +67,12 @@ class BwdfDesc(C.Structure):
                 ('workspace', c_vp), ('workspace_bytes', c_i64), ('dtype', c_i32), ('accumulate', c_i32),
                 ('bst_sums', c_vp), ('bst_sums_ld', c_i32), ('bst_mean', c_vp), ('bst_rstd', c_vp), ('bst_act_form', c_i32),
                 ('dpool', c_vp), ('lddp', c_i32), ('amax', c_vp),
-                ('hg_dlogits', c_vp), ('hg_w', c_vp), ('hg_ncls', c_i32)]
+                ('hg_dlogits', c_vp), ('hg_w', c_vp), ('hg_ncls', c_i32), ('defer_reduce', c_i32)]
+
+
+class ReduceJob(C.Structure):
+    _fields_ = [('ws', c_vp), ('dw', c_vp), ('nslab', c_i32), ('taps', c_i32), ('kpad', c_i32), ('npad', c_i32), ('cin', c_i32), ('nvalid', c_i32),
+                ('transposed', c_i32), ('accumulate', c_i32), ('lanes', c_i32), ('pad_', c_i32)]
 
 
 class BnBwdDesc(C.Structure):
@@ -131,8 +136,12 @@ _SIGS = {
     'satcv_conv2d_igemm_pipelined': (C.c_int, [C.POINTER(ConvDesc)]),
     'satcv_conv2d_wgrad_workspace': (c_i64, [C.POINTER(WgradDesc)]),
     'satcv_conv2d_wgrad': (C.c_int, [C.POINTER(WgradDesc), c_vp]),
+    'satcv_conv2d_wgrad_reduce_job': (C.c_int, [C.POINTER(WgradDesc), C.POINTER(ReduceJob)]),
+    'satcv_reduce_job_items': (c_i64, [C.POINTER(ReduceJob)]),
+    'satcv_reduce_slabs_batched': (C.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp]),
     'satcv_conv2d_bwd_fused_workspace': (c_i64, [C.POINTER(BwdfDesc)]),
     'satcv_conv2d_bwd_fused': (C.c_int, [C.POINTER(BwdfDesc), c_vp]),
+    'satcv_conv2d_bwd_fused_reduce_job': (C.c_int, [C.POINTER(BwdfDesc), C.POINTER(ReduceJob)]),
     'satcv_bn_finalize_train': (C.c_int, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32,
                                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'satcv_bn_affine_infer': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp]),

@@ -27,6 +27,7 @@
 #define FABL(bit) ((BWDF_ABL & (bit)) != 0)
 
 int wgrad_reduce_slabs(const float* ws, float* dw, int nslab, int taps, int kpad, int npad, int cin, int nvalid, int accumulate, hipStream_t st);   // conv_wgrad.hip
+void reduce_job_fill(satcv_reduce_job* job, const float* ws, float* dw, int nslab, int taps, int kpad, int npad, int cin, int nvalid, int transposed, int accumulate);
 void satcv_prof_begin(int kind, double flops, hipStream_t st);
 void satcv_prof_end(int kind, hipStream_t st);
 
@@ -600,13 +601,14 @@ static bool bwdf_shape_ok(const satcv_bwdf_desc* d, int& cin_s) {
 }
 
 template <int CIN, int COUT, int NW, int WPS, bool POOL = false, bool NODG = false, int CINS = CIN, bool HG = false>
-static int bwdf_launch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int64_t* ws_bytes) {
+static int bwdf_launch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int64_t* ws_bytes, satcv_reduce_job* job = nullptr) {
   using G = BwdfGeom<CIN, COUT, NW, NODG>;
   static_assert(G::LDS <= 160 * 1024, "tile + weights exceed the LDS");
   const long long total = (long long)d->n * (d->h / 8) * (d->w_ / 32);
   const int grid = bwdf_grid(G::LDS, NW, WPS, total);
   if (grid <= 0) { satcv_set_error("bwd_fused: device query failed"); return SATCV_ERR_HIP; }
   const size_t need = (size_t)grid * 9 * CIN * COUT * sizeof(float);
+  if (job) { reduce_job_fill(job, d->workspace, d->dw, grid, 9, CIN, COUT, d->cin, COUT, 0, d->accumulate); return SATCV_OK; }
   if (query) { *ws_bytes = (int64_t)need; return SATCV_OK; }
   SATCV_CHECK((size_t)d->workspace_bytes >= need, "bwd_fused: workspace %lld < %zu", (long long)d->workspace_bytes, need);
   BwdfArgs a;
@@ -628,24 +630,30 @@ static int bwdf_launch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int
   satcv_prof_end(3, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("bwd_fused launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  if (d->defer_reduce) return SATCV_OK;              // the caller sums the slabs later (satcv_reduce_slabs_batched)
   return wgrad_reduce_slabs(d->workspace, d->dw, grid, 9, CIN, COUT, d->cin, COUT, d->accumulate, st);
 }
 
-static int bwdf_dispatch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int64_t* ws_bytes) {
+static int bwdf_dispatch(const satcv_bwdf_desc* d, hipStream_t st, bool query, int64_t* ws_bytes, satcv_reduce_job* job = nullptr) {
   int cin_s;
   if (!bwdf_shape_ok(d, cin_s)) return SATCV_ERR_UNSUPPORTED;
   if (d->dpool) {
     // (32 -> 64 with the pooled gradient: 92 registers of prefetched items -- the 8-wave form needs 172 bytes of scratch; one wave per SIMD fits)
-    if (d->dx) return bwdf_launch<32, 64, 4, 1, true, false>(d, st, query, ws_bytes);
-    return bwdf_launch<32, 32, 8, 2, true, true, 16>(d, st, query, ws_bytes);
+    if (d->dx) return bwdf_launch<32, 64, 4, 1, true, false>(d, st, query, ws_bytes, job);
+    return bwdf_launch<32, 32, 8, 2, true, true, 16>(d, st, query, ws_bytes, job);
   }
   // (32 -> 32: 8 waves x 1 workgroup per CU measured equal to 4 waves x 2 workgroups and leaves registers for the fused sums; with the
   //  weight-gradient products balanced over the waves the 4-wave form -- 256 registers, 32 bytes of scratch -- measured 365 vs 346 us)
-  if (cin_s == 32 && d->hg_dlogits) return bwdf_launch<32, 32, 8, 2, false, false, 32, true>(d, st, query, ws_bytes);
+  if (cin_s == 32 && d->hg_dlogits) return bwdf_launch<32, 32, 8, 2, false, false, 32, true>(d, st, query, ws_bytes, job);
   if (d->hg_dlogits) return SATCV_ERR_UNSUPPORTED;
-  if (cin_s == 32) return bwdf_launch<32, 32, 8, 2>(d, st, query, ws_bytes);
-  if (d->cout == 32) return bwdf_launch<64, 32, 8, 2>(d, st, query, ws_bytes);
-  return bwdf_launch<64, 64, 4, 1>(d, st, query, ws_bytes);
+  if (cin_s == 32) return bwdf_launch<32, 32, 8, 2>(d, st, query, ws_bytes, job);
+  if (d->cout == 32) return bwdf_launch<64, 32, 8, 2>(d, st, query, ws_bytes, job);
+  return bwdf_launch<64, 64, 4, 1>(d, st, query, ws_bytes, job);
+}
+
+extern "C" int satcv_conv2d_bwd_fused_reduce_job(const satcv_bwdf_desc* d, satcv_reduce_job* job) {
+  SATCV_CHECK(d && job && d->dw && d->workspace, "bwd_fused_reduce_job: null pointer");
+  return bwdf_dispatch(d, nullptr, false, nullptr, job);
 }
 
 extern "C" int64_t satcv_conv2d_bwd_fused_workspace(const satcv_bwdf_desc* d) {

@@ -1391,6 +1391,7 @@ extern "C" int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream) {
   satcv_prof_begin(2, flops, st);
   rc = wgrad_any(d, p, st);
   if (rc == SATCV_ERR_UNSUPPORTED && p.ntaps == 9) {
+    if (d->defer_reduce) { satcv_prof_end(2, st); satcv_set_error("wgrad: defer_reduce is not available on the per-tap path of strongly dilated convolutions"); return SATCV_ERR_UNSUPPORTED; }
     // halo tile of a strongly dilated conv does not fit the LDS: treat every tap as a shifted 1x1 product
     satcv_wgrad_desc d1 = *d;
     d1.kh = d1.kw = 1;
@@ -1406,5 +1407,84 @@ extern "C" int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream) {
   }
   satcv_prof_end(2, st);
   if (rc) return rc;
+  if (d->defer_reduce) return SATCV_OK;            // the caller sums the slabs later (satcv_reduce_slabs_batched)
   return wgrad_reduce_launch(d, p, d->dw, nvalid, st);
+}
+
+// ------------------------------------------------------------------ deferred, batched slab sum (include/satcv.h)
+// item = (float4 of 4 consecutive output channels, lane of its group): lane l sums slabs l, l + lanes, ... (four interleaved chains, added
+// in a fixed order), the group's lanes are combined in increasing lane order.  One thread block walks items of possibly several jobs.
+static int reduce_job_lanes(int nslab) { int l = 1; while (l < 16 && 2 * l <= nslab / 2) l *= 2; return l; }      // >= 2 slabs per lane
+extern "C" int64_t satcv_reduce_job_items(const satcv_reduce_job* j) {
+  if (!j || j->nvalid % 4 != 0 || j->lanes < 1) return -1;
+  return (int64_t)j->taps * j->cin * (j->nvalid / 4) * j->lanes;
+}
+__global__ __launch_bounds__(256) void reduce_slabs_batched_kernel(const satcv_reduce_job* __restrict__ jobs, const long long* __restrict__ prefix, int njobs,
+                                                                   long long total) {
+  for (long long it0 = (long long)blockIdx.x * 256; it0 < total; it0 += (long long)gridDim.x * 256) {
+    const long long it = it0 + threadIdx.x;
+    const bool act = it < total;
+    const long long itc = act ? it : total - 1;
+    int ji = 0;
+    for (int q = 1; q < njobs; ++q) ji += (prefix[q] <= itc) ? 1 : 0;      // (a few dozen jobs: a linear scan of an L1-resident table)
+    const satcv_reduce_job j = jobs[ji];
+    const long long loc = itc - prefix[ji];
+    const int P = j.lanes, l = (int)(loc % P);
+    const long long o4 = loc / P;
+    const int nv4 = j.nvalid / 4;
+    const int co = (int)(o4 % nv4) * 4, ci = (int)((o4 / nv4) % j.cin), tap = (int)(o4 / ((long long)nv4 * j.cin));
+    const size_t slab = (size_t)j.taps * j.kpad * j.npad;
+    const float* p = j.ws + ((size_t)tap * j.kpad + ci) * j.npad + co;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    int sp = l;
+    for (; sp + 3 * P < j.nslab; sp += 4 * P) {
+      const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)sp * slab), v1 = *reinterpret_cast<const float4*>(p + (size_t)(sp + P) * slab);
+      const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(sp + 2 * P) * slab), v3 = *reinterpret_cast<const float4*>(p + (size_t)(sp + 3 * P) * slab);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; sp < j.nslab; sp += P) { const float4 v = *reinterpret_cast<const float4*>(p + (size_t)sp * slab); a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w; }
+    float4 r = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+    // lanes of a group are consecutive threads of one wave (256 and 64 are multiples of every lanes value): ordered tree, lane 0 keeps it
+    for (int o = 1; o < P; o <<= 1) {
+      const float x = __shfl_down(r.x, o, 64), y = __shfl_down(r.y, o, 64), z = __shfl_down(r.z, o, 64), w = __shfl_down(r.w, o, 64);
+      if ((l & (2 * o - 1)) == 0) { r.x += x; r.y += y; r.z += z; r.w += w; }
+    }
+    if (act && l == 0) {
+      if (j.transposed) {
+        float* dst = j.dw + (size_t)co * j.cin + ci;
+        const float rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(size_t)e * j.cin] = j.accumulate ? dst[(size_t)e * j.cin] + rr[e] : rr[e];
+      } else {
+        float4* dst = reinterpret_cast<float4*>(j.dw + ((size_t)tap * j.cin + ci) * j.nvalid + co);
+        if (j.accumulate) { const float4 o = *dst; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+        *dst = r;
+      }
+    }
+  }
+}
+extern "C" int satcv_reduce_slabs_batched(const satcv_reduce_job* jobs_dev, const int64_t* prefix_dev, int32_t njobs, int64_t total_items, void* stream) {
+  SATCV_CHECK(jobs_dev && prefix_dev && njobs > 0 && njobs <= 4096 && total_items > 0, "reduce_slabs_batched: bad arguments");
+  long long grid = (total_items + 255) / 256; if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(reduce_slabs_batched_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev,
+                     reinterpret_cast<const long long*>(prefix_dev), njobs, (long long)total_items);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { satcv_set_error("reduce_slabs_batched launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
+  return SATCV_OK;
+}
+void reduce_job_fill(satcv_reduce_job* job, const float* ws, float* dw, int nslab, int taps, int kpad, int npad, int cin, int nvalid, int transposed, int accumulate) {
+  job->ws = ws; job->dw = dw; job->nslab = nslab; job->taps = taps; job->kpad = kpad; job->npad = npad; job->cin = cin; job->nvalid = nvalid;
+  job->transposed = transposed; job->accumulate = accumulate; job->lanes = reduce_job_lanes(nslab); job->pad_ = 0;
+}
+extern "C" int satcv_conv2d_wgrad_reduce_job(const satcv_wgrad_desc* d, satcv_reduce_job* job) {
+  SATCV_CHECK(d && job && d->dw && d->workspace, "wgrad_reduce_job: null pointer");
+  WgradPlan p;
+  int rc = wgrad_plan(d, p); if (rc) return rc;
+  const int nvalid = d->mode_dy ? d->f * d->f * d->cout : d->cout;
+  if (nvalid % 4 != 0) { satcv_set_error("wgrad_reduce_job: %d output channels are not a multiple of 4", nvalid); return SATCV_ERR_UNSUPPORTED; }
+  reduce_job_fill(job, d->workspace, d->dw, p.nsplit, p.ntaps, p.kpad, p.npad, d->cin, nvalid, d->transposed, d->accumulate);
+  return SATCV_OK;
 }

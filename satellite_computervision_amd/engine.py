@@ -726,6 +726,15 @@ class Plan:
         shared_layers = {k for k, v in _cnt.items() if v > 1}      # layers applied to several inputs (Siamese encoders)
         ws_need = 0
         wdescs = []
+        # deferred, batched slab sums (satcv_reduce_slabs_batched; SATCV_DEFER_REDUCE=0: one sum launch behind every weight-gradient launch):
+        # a deferring launch keeps a workspace of its own; the sums run in groups, one launch per ~16 MiB of finished gradients (the bucket size
+        # of the gradient exchange, whose checkpoints move to the group boundaries)
+        # MEASURED (profiles/r05_ab_defer_reduce.txt, A/B/A/B on one box): 8.59 ms per step with one sum launch per layer, 8.625 with 4 batched
+        # launches -- the per-layer sum reads slabs that were written microseconds earlier (37 MB: L2 / Infinity-Cache resident), the deferred one
+        # finds 150-220 MB of slabs of several layers pushed out to HBM.  Opt-in (SATCV_DEFER_REDUCE=1).
+        DEFER = int(os.environ.get('SATCV_DEFER_REDUCE', '0')) != 0
+        rpending = []                       # (descriptor, 'w' | 'f', gradient bytes) of launches whose sum has not been scheduled yet
+        rgroups = []                        # {'items': [(desc, kind)], 'tab': device job table, filled once the workspaces are assigned}
         fused_ws_need = 0                   # the fused thin-layer backward launches run on the MAIN stream: a workspace of their own
         fdescs = []
         # loss -> dlogits is written by Model.train step into this buffer
@@ -895,7 +904,13 @@ class Plan:
             nb = lib.satcv_conv2d_wgrad_workspace(C.byref(d))
             if nb < 0:
                 raise RuntimeError(lib.satcv_last_error().decode())
-            ws_need = max(ws_need, nb)
+            nvalid = (f * f if f else 1) * cout
+            if DEFER and not accum and lay.name not in shared_layers and nvalid % 4 == 0 and not (k == 3 and dil > 1):
+                d.defer_reduce = 1
+                d._own_ws = nb
+                rpending.append((d, 'w', 4 * k * k * cin_real * nvalid))
+            else:
+                ws_need = max(ws_need, nb)
             wdescs.append(d)
             self.keep.append(d)
             label = f"wgrad k{k} d{dil} n{n} {hh}x{ww} {sa['c0']}+{sa['c1']}->{cout}{' convT f%d' % f if f else ''}"
@@ -934,6 +949,29 @@ class Plan:
                 if his:
                     layer_hi[node.layer.name] = max(layer_hi[node.layer.name], max(his))
 
+        def flush_reduces(force=False):
+            """schedule the batched slab sum of the launches recorded so far (on the weight-gradient stream, behind an event of the main
+            stream: the fused thin-layer launches write their slabs there).  Returns False while a group is still being collected."""
+            if not rpending:
+                return True
+            if not force and sum(b for _, _, b in rpending) < (16 << 20):
+                return False
+            grp = {'items': [(d, kind) for d, kind, _ in rpending], 'tab': None}
+            rpending.clear()
+            rgroups.append(grp)
+            ev = torch.cuda.Event() if self.side is not None else None
+
+            def flush(st, grp=grp, ev=ev):
+                t = grp['tab']
+                if self.side is not None:
+                    ev.record(torch.cuda.current_stream())
+                    self.side.wait_event(ev)
+                    st = C.c_void_p(self.side.cuda_stream)
+                check(lib.satcv_reduce_slabs_batched(t['jobs'].data_ptr(), t['prefix'].data_ptr(), t['n'], t['total'], st))
+            flush.label = f"wgrad_reduce_batched {len(grp['items'])} layers"
+            self.bwd.append(flush)
+            return True
+
         def grads_ready(node):
             lay = node.layer
             if lay is None or lay.name not in pending:
@@ -941,6 +979,8 @@ class Plan:
             pending[lay.name] -= 1
             if pending[lay.name] == 0:
                 del pending[lay.name]
+            if not flush_reduces(force=not pending):
+                return                                  # (the gradients above `lo` are not final before their slabs are summed)
             lo = max((layer_hi[k] for k in pending), default=0)
 
             def ckpt(st, lo=lo):
@@ -1091,7 +1131,12 @@ class Plan:
                     elif sums_below is not None:
                         fused[tin.id] = sums_below
                 if fz is not None:
-                    fused_ws_need = max(fused_ws_need, nbf)
+                    if DEFER and not accum and lay.name not in shared_layers:
+                        fz.defer_reduce = 1
+                        fz._own_ws = nbf
+                        rpending.append((fz, 'f', 4 * 9 * pk['cin'] * cout))
+                    else:
+                        fused_ws_need = max(fused_ws_need, nbf)
                     fdescs.append(fz)
                     self.keep.append(fz)
                     cnt = float(n * hh * ww)
@@ -1167,7 +1212,12 @@ class Plan:
                     elif ent is not None:
                         ent['parts'].add('pool')
                 if fzp is not None:
-                    fused_ws_need = max(fused_ws_need, nbp)
+                    if DEFER and not accum and lay.name not in shared_layers:
+                        fzp.defer_reduce = 1
+                        fzp._own_ws = nbp
+                        rpending.append((fzp, 'f', 4 * 9 * pkp['cin'] * cout))
+                    else:
+                        fused_ws_need = max(fused_ws_need, nbp)
                     fdescs.append(fzp)
                     self.keep.append(fzp)
                     self.bwd += [fin] if (pre is not None or red is None) else [red, fin]
@@ -1314,11 +1364,33 @@ class Plan:
         if ws_need:
             ws = self._z(max(ws_need // 4, 1), dtype=torch.float32)
             for d in wdescs:
-                d.workspace, d.workspace_bytes = ws.data_ptr(), ws_need
+                if not d.defer_reduce:
+                    d.workspace, d.workspace_bytes = ws.data_ptr(), ws_need
         if fused_ws_need:
             wsf = self._z(max(fused_ws_need // 4, 1), dtype=torch.float32)
             for d in fdescs:
-                d.workspace, d.workspace_bytes = wsf.data_ptr(), fused_ws_need
+                if not d.defer_reduce:
+                    d.workspace, d.workspace_bytes = wsf.data_ptr(), fused_ws_need
+        flush_reduces(force=True)
+        if rgroups:
+            from ._lib import ReduceJob
+            own = [d for g in rgroups for d, _ in g['items']]
+            arena = self._z(max(sum((d._own_ws + 255) // 256 * 256 for d in own) // 4, 1), dtype=torch.float32)
+            off = 0
+            for d in own:
+                d.workspace, d.workspace_bytes = arena.data_ptr() + off, d._own_ws
+                off += (d._own_ws + 255) // 256 * 256
+            for g in rgroups:
+                jobs, prefix, tot = [], [], 0
+                for d, kind in g['items']:
+                    j = ReduceJob()
+                    check((lib.satcv_conv2d_wgrad_reduce_job if kind == 'w' else lib.satcv_conv2d_bwd_fused_reduce_job)(C.byref(d), C.byref(j)))
+                    prefix.append(tot)
+                    tot += int(lib.satcv_reduce_job_items(C.byref(j)))
+                    jobs.append(j)
+                arr = (ReduceJob * len(jobs))(*jobs)
+                g['tab'] = dict(jobs=torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(rt.dev),
+                                prefix=torch.tensor(prefix, dtype=torch.int64, device=rt.dev), n=len(jobs), total=tot)
         if self.side is not None:
             evj = torch.cuda.Event()
 

@@ -168,7 +168,7 @@ def conv2d_transpose_dgrad(dy, w_dgrad, cin, cout, f, *, out=None, stats=None, b
 
 
 def make_wgrad_desc(*, x0, c0, dy, lddy, dw, cin, cout, n, h, w_, dtype, x1=None, c1=0, in_scale=None, in_shift=None,
-                    in_relu=0, kh=3, kw=3, dil=1, mode_dy=0, f=1, transposed=0, workspace=None, workspace_bytes=0, accumulate=0, whole_chip=0):
+                    in_relu=0, kh=3, kw=3, dil=1, mode_dy=0, f=1, transposed=0, workspace=None, workspace_bytes=0, accumulate=0, whole_chip=0, defer_reduce=0):
     d = WgradDesc()
     d.x0, d.x1, d.c0, d.c1 = x0, x1, c0, c1
     d.in_scale, d.in_shift, d.in_relu = in_scale, in_shift, int(in_relu)
@@ -177,6 +177,7 @@ def make_wgrad_desc(*, x0, c0, dy, lddy, dw, cin, cout, n, h, w_, dtype, x1=None
     d.mode_dy, d.f, d.transposed = mode_dy, f, transposed
     d.workspace, d.workspace_bytes, d.dtype, d.accumulate = workspace, workspace_bytes, dtype, int(accumulate)
     d.whole_chip = int(whole_chip)
+    d.defer_reduce = int(defer_reduce)
     return d
 
 

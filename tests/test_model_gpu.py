@@ -918,6 +918,32 @@ def test_full_size_training_step_permutation_property(mt):
     assert torch.isfinite(g1).all() and g1.abs().max() > 0
 
 
+def test_deferred_batched_slab_sums_agree_with_the_per_layer_sums(mt, monkeypatch):
+    """round 5: the slab sums of the weight-gradient launches run deferred, several layers per launch (satcv_reduce_slabs_batched, engine.Plan);
+    SATCV_DEFER_REDUCE=0 keeps one sum launch per layer.  Same slabs, another (fixed) summation order: every gradient of a four-level bf16
+    step agrees to fp32 rounding, and the deferred form is bit-reproducible."""
+    def grads(defer):
+        monkeypatch.setenv('SATCV_DEFER_REDUCE', defer)
+        mt.reset_uids(); mt.set_seed(9)
+        m = mt.get_unet_model(2, 4, [32, 64, 128, 256], [2, 2, 2, 2])
+        m.compute_dtype = 'bfloat16'
+        m.compile(optimizer=mt.Adam(0.0), loss=lambda t, p: mt.weighted_categorical_crossentropy(t, p, [1.0, 5.0]))
+        rng = np.random.default_rng(4)
+        x = rng.random((4, 64, 96, 4)).astype(np.float32)
+        y = np.eye(2, dtype=np.float32)[(rng.random((4, 64, 96)) < 0.3).astype(np.int64)]
+        m.train_on_batch(x, y)
+        g = m.runtime.gflat.clone()
+        m.train_on_batch(x, y)
+        assert torch.equal(g, m.runtime.gflat)
+        labels = [getattr(s, 'label', '') for s in m.runtime.plan(4, 64, 96, True).bwd]
+        return g, sum('wgrad_reduce_batched' in l for l in labels)
+    g1, n1 = grads('1')
+    g0, n0 = grads('0')
+    assert n1 >= 1 and n0 == 0
+    assert ((g1 - g0).norm() / g0.norm()).item() < 1e-5
+    assert (g1 - g0).abs().max().item() <= 1e-4 * g0.abs().max().item()
+
+
 @pytest.mark.parametrize('channels', [4, 13])
 def test_timed_configuration_bf16_batch64_training_step_properties(mt, channels):
     """The configuration bench.py times (BASELINE configs[1]; configs[3] with 13 bands): ONE bf16 training step of get_unet_model(2, C) at

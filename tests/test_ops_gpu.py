@@ -291,6 +291,49 @@ def test_16x16x32_tile_fused_bn_backward_sums(ops, case, force_db):
         np.testing.assert_allclose(got[1], (gg * xh).sum((0, 1, 2)), rtol=1e-4, atol=tol * float(np.abs(xh).max()), err_msg=f'sum g xhat {case} relu={relu}')
 
 
+def test_reduce_slabs_batched(ops):
+    """satcv_reduce_slabs_batched: several layers' fp32 partial slabs summed in ONE launch (few / many slabs -> 1 ... 16 lanes per output, plain HWIO
+    and transposed-conv layouts, accumulate, padded slab rows) against float64 sums; two runs are bit-identical (fixed summation order)."""
+    import ctypes
+    from satellite_computervision_amd._lib import lib, check, ReduceJob
+    rng = np.random.default_rng(3)
+    specs = [  # nslab, taps, cin, nvalid, kpad, npad, transposed, accumulate
+        (2, 9, 64, 128, 64, 128, 0, 0), (8, 9, 32, 32, 32, 32, 0, 0), (128, 9, 16, 32, 32, 32, 0, 1), (37, 1, 24, 64, 32, 64, 0, 0),
+        (16, 1, 128, 4 * 64, 128, 256, 1, 0), (5, 1, 32, 4 * 32, 32, 128, 1, 1)]
+    jobs, keep, prefix, tot = [], [], [], 0
+    for nslab, taps, cin, nvalid, kpad, npad, tr, acc in specs:
+        ws = torch.tensor(rng.standard_normal((nslab, taps, kpad, npad)).astype(np.float32), device=dev())
+        dw0 = rng.standard_normal((taps, cin, nvalid) if not tr else (nvalid, cin)).astype(np.float32)
+        dw = torch.tensor(dw0, device=dev())
+        j = ReduceJob()
+        j.ws, j.dw, j.nslab, j.taps, j.kpad, j.npad, j.cin, j.nvalid, j.transposed, j.accumulate = ws.data_ptr(), dw.data_ptr(), nslab, taps, kpad, npad, cin, nvalid, tr, acc
+        lanes = 1
+        while lanes < 16 and 2 * lanes <= nslab // 2:
+            lanes *= 2
+        j.lanes = lanes
+        prefix.append(tot)
+        tot += int(lib.satcv_reduce_job_items(ctypes.byref(j)))
+        jobs.append(j); keep.append((ws, dw, dw0))
+    arr = (ReduceJob * len(jobs))(*jobs)
+    jd = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev())
+    pd = torch.tensor(prefix, dtype=torch.int64, device=dev())
+    outs = []
+    for rep in range(2):
+        for (ws, dw, dw0) in keep:
+            dw.copy_(torch.tensor(dw0))
+        check(lib.satcv_reduce_slabs_batched(jd.data_ptr(), pd.data_ptr(), len(jobs), tot, ops.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append([dw.clone() for (_, dw, _) in keep])
+    for (nslab, taps, cin, nvalid, kpad, npad, tr, acc), (ws, dw, dw0), o0, o1 in zip(specs, keep, outs[0], outs[1]):
+        assert torch.equal(o0, o1)
+        ref = ws.double().sum(0)[:, :cin, :nvalid].cpu().numpy()
+        if tr:
+            ref = ref[0].T                                       # (f, f, cout, cin) flattened = [nvalid][cin]
+        if acc:
+            ref = ref + dw0
+        np.testing.assert_allclose(o0.cpu().numpy(), ref, rtol=2e-6, atol=2e-5 * np.sqrt(nslab))
+
+
 def test_conv2d_double_buffered_dual_source_affine(ops, force_db):
     """decoder conv1 through the double-buffered tile: concat([skip, up]) -> BN -> ReLU in the loader, 512 + 512 -> 128 channels."""
     td = torch.bfloat16
