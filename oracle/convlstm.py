@@ -206,6 +206,17 @@ class LSTMLayersOracle:
         self.c['z'] = z
         return out
 
+    def forward_infer(self, x, moving, eps=1e-3):
+        """inference mode (Model.predict): each BatchNormalization uses its MOVING statistics, moving = {'bn1': (mean, var), 'bn2': (mean, var)}
+        (Keras: gamma (x - moving_mean) / sqrt(moving_var + eps) + beta); no dropout"""
+        p = self.p
+        s1, _ = convlstm_forward(x, p['l1'], 1, None, self.rec_act, True)
+        a1 = np.maximum(p['bn1']['gamma'] * (s1 - moving['bn1'][0]) / np.sqrt(moving['bn1'][1] + eps) + p['bn1']['beta'], 0)
+        h2, _ = convlstm_forward(a1, p['l2'], 3, None, self.rec_act, False)
+        a2 = np.maximum(p['bn2']['gamma'] * (h2 - moving['bn2'][0]) / np.sqrt(moving['bn2'][1] + eps) + p['bn2']['beta'], 0)
+        z = K.conv2d_same(a2, p['dense']['kernel'], p['dense']['bias'])
+        return np.clip(z, 0.0, self.head_max) if self.head_max is not None else np.maximum(z, 0)
+
     def backward(self, dout):
         z = self.c['z']
         mask = (z > 0) & ((z < self.head_max) if self.head_max is not None else True)

@@ -478,6 +478,7 @@ class _SeqModelBase:
     def _finish(self):
         self.P.build()
         self.optimizer, self._loss = None, None
+        self._metrics, self.metrics_names, self.stop_training = [], ['loss'], False
         self.compute_dtype = mt._DEFAULT_DTYPE
         self._graphs = {}
 
@@ -485,15 +486,47 @@ class _SeqModelBase:
     def dtype_code(self):
         return BF16 if self.compute_dtype == 'bfloat16' else F32
 
-    def compile(self, optimizer='adam', loss=None, metrics=None, **kw):
+    # ---- Keras surface of the reference's call sites (compile / fit / evaluate as in notebooks/UNET_G4G_2019_solar.ipynb:1206-1275 and
+    # utils/model_tools.py:1162-1176).  Arguments this implementation does not act on are REFUSED, never swallowed.
+    output_names = ('output',)
+
+    def compile(self, optimizer='adam', loss=None, metrics=None, loss_weights=None, **kw):
+        if kw:
+            raise TypeError(f'{type(self).__name__}.compile: unsupported arguments {sorted(kw)}')
+        if loss_weights is not None:
+            raise NotImplementedError(f'{type(self).__name__}.compile: loss_weights (the outputs\' losses are added with weight 1, the Keras default)')
         self.optimizer = mt.Adam() if isinstance(optimizer, str) else optimizer
         spec = loss(mt._LossArg('y_true'), mt._LossArg('y_pred')) if callable(loss) else loss
         if not isinstance(spec, mt.LossSpec):
             raise ValueError('loss must be one of the model_tools loss functions (or a lambda wrapping one)')
         self._loss = spec
+        ms = []
+        for m_ in (metrics or []):
+            if isinstance(m_, str) and m_ in ('accuracy', 'acc', 'categorical_accuracy'):
+                ms.append(('accuracy', None))
+            elif isinstance(m_, mt.MeanIoU):
+                ms.append((m_.name, m_.num_classes))
+            else:
+                raise ValueError(f'{type(self).__name__}.compile: metric {m_!r} is not supported (accuracy, model_tools.MeanIoU)')
+        self._metrics = ms
+        outs = list(self.output_names)
+        self.metrics_names = ['loss'] + ([f'{o}_loss' for o in outs] if len(outs) > 1 else [])
+        for o in outs:
+            self.metrics_names += [(f'{o}_{n}' if len(outs) > 1 else n) for n, _ in ms]
+        self.stop_training = False
         self.__dict__.pop('_loss_w_dev', None)
         self._drop_graphs()
         self.P.state[0:1].fill_(self.optimizer._lr)
+
+    @staticmethod
+    def _metric_value(kind, ncls, conf):
+        conf = conf.astype(np.float64)
+        if kind == 'accuracy':
+            return float(np.trace(conf) / max(conf.sum(), 1))
+        tp = np.diag(conf)
+        denom = conf.sum(0) + conf.sum(1) - tp
+        valid = denom > 0
+        return float((tp[valid] / denom[valid]).mean()) if valid.any() else 0.0
 
     def _loss_grad(self, out, y_true, activation):
         """fused device loss on the model output: returns (loss tensor, dL/dlogits for softmax / sigmoid heads, dL/dout for linear ones)"""
@@ -566,65 +599,158 @@ class _SeqModelBase:
     def _branch_models(self):
         return {'unet': self.unet} if hasattr(self, 'unet') else {}
 
+    @staticmethod
+    def _refuse_h5(path, what):
+        if str(path).endswith(('.h5', '.hdf5', '.keras')):
+            raise NotImplementedError(f'{what}({path!r}): the ConvLSTM2D family is stored in the .npz container (one array per variable, keyed by its '
+                                      f'Keras variable name); Keras HDF5 interchange covers the U-Net / ACNN models (model_tools.Model)')
+
     def save_weights(self, path):
+        self._refuse_h5(path, 'save_weights')
         d = {k: v for k, v in self.get_weights_dict().items()}
         for tag, bm in self._branch_models().items():
             d.update({f'{tag}::{k}': v for k, v in bm.get_weights_dict().items()})
         np.savez(path if str(path).endswith('.npz') else str(path) + '.npz', **d)
 
-    def load_weights(self, path, **kw):
+    save = save_weights                    # Model.save call sites (ModelCheckpoint(save_weights_only=False)): the same container
+
+    def load_weights(self, path, by_name=False, skip_mismatch=False):
+        """the container is keyed by variable names, so `by_name` changes nothing; skip_mismatch (utils/model_tools.py:1162) skips variables that
+        are absent from the file or have another shape instead of raising.  Returns the list of skipped names."""
+        self._refuse_h5(path, 'load_weights')
         p = path if os.path.exists(path) else str(path) + '.npz'
+        skipped = []
         with np.load(p, allow_pickle=False) as z:
             own = {k: z[k] for k in z.files if '::' not in k}
-            missing = set(self.P.specs) - set(own)
-            if missing:
-                raise ValueError(f'{p}: no weights for {sorted(missing)[:4]}...')
-            self.set_weights_dict({k: own[k] for k in self.P.specs})
+            take = {}
+            for k, (_, shape, *_rest) in self.P.specs.items():
+                if k in own and tuple(own[k].shape) == tuple(shape):
+                    take[k] = own[k]
+                elif skip_mismatch:
+                    skipped.append(k)
+                elif k not in own:
+                    raise ValueError(f'{p}: no weights for {k!r}')
+                else:
+                    raise ValueError(f'{p}: {k!r} has shape {tuple(own[k].shape)}, the model expects {tuple(shape)}')
+            self.set_weights_dict(take)
             for tag, bm in self._branch_models().items():
-                bm.set_weights_dict({k.split('::', 1)[1]: z[k] for k in z.files if k.startswith(tag + '::')})
+                bm.set_weights_dict({k.split('::', 1)[1]: z[k] for k in z.files if k.startswith(tag + '::')}, skip_mismatch=skip_mismatch)
+        if skipped:
+            import warnings
+            warnings.warn(f'load_weights({p!r}, skip_mismatch=True): skipped {skipped}')
+        return skipped
 
-    def _eval_forward(self, xb):
-        raise NotImplementedError(f'{type(self).__name__}.evaluate: multi-output model -- evaluate its outputs with predict()')
+    def _eval_outputs(self, xb):
+        """-> [(output tensor in the layout the loss kernel takes, activation tag, labels transform)] per model output"""
+        raise NotImplementedError
 
-    def evaluate(self, x=None, y=None, batch_size=None, verbose=0, **kw):
-        """mean loss of the compiled loss function over the batches (no parameter update)"""
+    @staticmethod
+    def _batches_of(x, y, batch_size, sample_weight=None):
+        """arrays -> slices; a Sequence / iterable of (x, y[, sample_weight]) batches -> itself"""
+        if y is not None:
+            if sample_weight is not None:
+                raise NotImplementedError('sample_weight: the fused device losses have no per-sample weights')
+            multi = isinstance(x, (list, tuple))
+            ymulti = isinstance(y, (list, tuple))
+            n = (x[0] if multi else x).shape[0]
+            bs = batch_size or 32
+            for i in range(0, n, bs):
+                yield ([a[i:i + bs] for a in x] if multi else x[i:i + bs]), ([a[i:i + bs] for a in y] if ymulti else y[i:i + bs])
+            return
+        it = (x[i] for i in range(len(x))) if hasattr(x, '__getitem__') and hasattr(x, '__len__') and not isinstance(x, (list, tuple, np.ndarray)) else iter(x)
+        for batch in it:
+            if len(batch) > 2 and batch[2] is not None and any(w is not None for w in (batch[2] if isinstance(batch[2], (list, tuple)) else [batch[2]])):
+                raise NotImplementedError('the batch carries sample weights (LSTMAutoencoderGenerator(sample_weights=True), utils/processing.py:974-1049): '
+                                          'the fused device losses have no per-sample weights -- build the generator with sample_weights=False')
+            xb = batch[0]
+            if isinstance(xb, (list, tuple)):
+                xb = [a for a in xb if a is not None]
+            yield xb, batch[1]
+
+    def evaluate(self, x=None, y=None, batch_size=None, verbose=0, sample_weight=None, steps=None, return_dict=False, **kw):
+        """Model.evaluate -> [loss, (per-output losses of a multi-output model,) metrics ...] aligned with metrics_names (the reference indexes
+        it: utils/model_tools.py:1164-1168); a bare float when the loss is the only entry.  Inference mode: moving statistics, no dropout."""
+        if kw:
+            raise TypeError(f'{type(self).__name__}.evaluate: unsupported arguments {sorted(kw)}')
         if self._loss is None:
             raise RuntimeError('compile() the model before evaluate')
-        multi = isinstance(x, (list, tuple))
-        n = (x[0] if multi else x).shape[0]
-        bs = batch_size or 32
-        tot, cnt = 0.0, 0
-        for i in range(0, n, bs):
-            xb = [a[i:i + bs] for a in x] if multi else x[i:i + bs]
-            out = self._eval_forward(xb)
-            loss, _ = self._loss_grad(out[0], y[i:i + bs], out[1])
-            k = (xb[0] if multi else xb).shape[0]
-            tot, cnt = tot + float(loss.item()) * k, cnt + k
-        return tot / max(cnt, 1)
-
-    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=0, steps_per_epoch=None, **kw):
-        """x: array(s) or a Sequence / iterable of (x, y) batches (LSTMDataGenerator, HybridDataGenerator)"""
-        hist = {'loss': []}
-        for _ in range(epochs):
+        nout = len(self.output_names)
+        tot = np.zeros(1 + (nout if nout > 1 else 0))
+        confs = [[np.zeros((nc or 1, nc or 1), np.int64) for _, nc in self._metrics] for _ in range(nout)]
+        cnt = 0
+        for i, (xb, yb) in enumerate(self._batches_of(x, y, batch_size, sample_weight)):
+            if steps is not None and i >= steps:
+                break
+            outs = self._eval_outputs(xb)
+            ys = list(yb) if isinstance(yb, (list, tuple)) else [yb]
+            k = (xb[0] if isinstance(xb, (list, tuple)) else xb).shape[0]
             losses = []
-            if y is None:
-                it = (x[i] for i in range(len(x))) if hasattr(x, '__getitem__') and hasattr(x, '__len__') and not isinstance(x, (list, tuple, np.ndarray)) else iter(x)
-                for i, batch in enumerate(it):
-                    if steps_per_epoch is not None and i >= steps_per_epoch:
-                        break
-                    losses.append(self.train_on_batch(batch[0], batch[1]))
-                if hasattr(x, 'on_epoch_end'):
-                    x.on_epoch_end()
-            else:
-                n = (x[0] if isinstance(x, (list, tuple)) else x).shape[0]
-                bs = batch_size or 32
-                for i in range(0, n, bs):
-                    xb = [a[i:i + bs] for a in x] if isinstance(x, (list, tuple)) else x[i:i + bs]
-                    losses.append(self.train_on_batch(xb, y[i:i + bs]))
-            hist['loss'].append(float(np.mean(losses)))
-        h = mt.History()
-        h.history = hist
-        return h
+            for oi, ((out, act, ytf), yy) in enumerate(zip(outs, ys)):
+                yd = ytf(_dev_f32(yy))
+                losses.append(float(self._loss_grad(out, yd, act)[0].item()))
+                if self._metrics:
+                    pred = out.float().argmax(-1).flatten().cpu().numpy()
+                    true = yd.argmax(-1).flatten().cpu().numpy()
+                    for mi, (kind, nc) in enumerate(self._metrics):
+                        ncl = nc or out.shape[-1]
+                        if confs[oi][mi].shape[0] != ncl:
+                            confs[oi][mi] = np.zeros((ncl, ncl), np.int64)
+                        np.add.at(confs[oi][mi], (true, pred), 1)
+            tot[0] += sum(losses) * k
+            if nout > 1:
+                tot[1:] += np.asarray(losses) * k
+            cnt += k
+        vals = list(tot / max(cnt, 1))
+        for oi in range(nout):
+            vals += [self._metric_value(kind, nc, confs[oi][mi]) for mi, (kind, nc) in enumerate(self._metrics)]
+        if return_dict:
+            return dict(zip(self.metrics_names, vals))
+        return vals if len(vals) > 1 else vals[0]
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=0, callbacks=None, validation_data=None, steps_per_epoch=None,
+            validation_steps=None, initial_epoch=0, sample_weight=None, shuffle=False, **kw):
+        """x: array(s) with y, or a Sequence / iterable of (x, y[, sample_weight]) batches (LSTMDataGenerator, LSTMAutoencoderGenerator,
+        HybridDataGenerator).  callbacks (model_tools.ModelCheckpoint / TensorBoard) see `loss` and the `val_` entries of evaluate() on
+        validation_data (arrays (x, y) or a batch iterable).  Arrays are taken in order (shuffle=True is refused: the reference fits from generators)."""
+        if kw:
+            raise TypeError(f'{type(self).__name__}.fit: unsupported arguments {sorted(kw)}')
+        if shuffle:
+            raise NotImplementedError(f'{type(self).__name__}.fit(shuffle=True): shuffle inside the generator (on_epoch_end), as the reference does')
+        if self._loss is None:
+            raise RuntimeError('compile() the model before fit')
+        hist = mt.History()
+        callbacks = list(callbacks or [])
+        for cb in callbacks:
+            cb.model = self
+        self.stop_training = False
+        for epoch in range(initial_epoch, epochs):
+            tot, cnt = 0.0, 0
+            for i, (xb, yb) in enumerate(self._batches_of(x, y, batch_size, sample_weight)):
+                if steps_per_epoch is not None and i >= steps_per_epoch:
+                    break
+                k = (xb[0] if isinstance(xb, (list, tuple)) else xb).shape[0]
+                tot, cnt = tot + self.train_on_batch(xb, yb) * k, cnt + k
+            logs = {'loss': tot / max(cnt, 1)}
+            if validation_data is not None:
+                if isinstance(validation_data, tuple) and len(validation_data) in (2, 3) and not hasattr(validation_data[0], '__next__'):
+                    v = self.evaluate(validation_data[0], validation_data[1], batch_size=batch_size, steps=validation_steps,
+                                      sample_weight=validation_data[2] if len(validation_data) == 3 else None, return_dict=True)
+                else:
+                    v = self.evaluate(validation_data, steps=validation_steps, return_dict=True)
+                logs.update({'val_' + k_: v_ for k_, v_ in v.items()})
+            for k_, v_ in logs.items():
+                hist.history[k_].append(v_)
+            hist.epoch.append(epoch)
+            if verbose:
+                print(f'Epoch {epoch + 1}/{epochs} - ' + ' - '.join(f'{k_}: {v_:.4f}' for k_, v_ in logs.items()))
+            for cb in callbacks:
+                if hasattr(cb, 'on_epoch_end'):
+                    cb.on_epoch_end(epoch, logs)
+            if hasattr(x, 'on_epoch_end'):
+                x.on_epoch_end()
+            if self.stop_training:
+                break
+        return hist
 
 
 class LSTMModel(_SeqModelBase):
@@ -654,10 +780,12 @@ class LSTMModel(_SeqModelBase):
         outs = [self._forward(x[i:i + bs], False).cpu().numpy() for i in range(0, n, bs)]
         return np.concatenate(outs, 0)
 
-    def _eval_forward(self, xb):
-        return self._forward(xb, False), 'linear'
+    def _eval_outputs(self, xb):
+        return [(self._forward(xb, False), 'linear', lambda t: t)]
 
-    def train_on_batch(self, x, y):
+    def train_on_batch(self, x, y, sample_weight=None):
+        if sample_weight is not None:
+            raise NotImplementedError('sample_weight: the fused device losses have no per-sample weights')
         if self._loss is None:
             raise RuntimeError('compile() the model before fit/train')
         xd = (x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))).to(_dev(), torch.float32).contiguous()
@@ -735,10 +863,14 @@ class HybridModel(_SeqModelBase):
         outs = [self._forward([a[i:i + bs] for a in x], False)[0].cpu().numpy() for i in range(0, n, bs)]
         return np.concatenate(outs, 0)
 
-    def _eval_forward(self, xb):
-        return self._forward(xb, False)[0], 'softmax'
+    output_names = ('probabilities',)
 
-    def train_on_batch(self, x, y):
+    def _eval_outputs(self, xb):
+        return [(self._forward(xb, False)[0], 'softmax', lambda t: t)]
+
+    def train_on_batch(self, x, y, sample_weight=None):
+        if sample_weight is not None:
+            raise NotImplementedError('sample_weight: the fused device losses have no per-sample weights')
         if self._loss is None:
             raise RuntimeError('compile() the model before fit/train')
         rt = self.unet.runtime
@@ -811,7 +943,16 @@ class LSTMAutoencoder(_SeqModelBase):
         B, T, H, W = self._shape
         return [tout.view(T, B, H, W, -1).permute(1, 0, 2, 3, 4).contiguous().cpu().numpy(), sout.cpu().numpy()]
 
-    def train_on_batch(self, x, y):
+    output_names = ('temporal', 'single')
+
+    def _eval_outputs(self, xb):
+        tout, sout = self._forward(xb, False)
+        B, T, H, W = self._shape
+        return [(tout, 'linear', lambda t: t.permute(1, 0, 2, 3, 4).contiguous().view(T * B, H, W, -1)), (sout, 'linear', lambda t: t)]
+
+    def train_on_batch(self, x, y, sample_weight=None):
+        if sample_weight is not None and any(w is not None for w in (sample_weight if isinstance(sample_weight, (list, tuple)) else [sample_weight])):
+            raise NotImplementedError('sample_weight: the fused device losses have no per-sample weights (LSTMAutoencoderGenerator(sample_weights=False))')
         if self._loss is None:
             raise RuntimeError('compile() the model before fit/train')
         tensors = tuple(_dev_f32(a) for a in x) + tuple(_dev_f32(a) for a in y)
@@ -980,7 +1121,14 @@ class HierarchicalModel(_SeqModelBase):
     def predict(self, x, batch_size=None, verbose=0, **kw):
         return [o.cpu().numpy() for o in self._forward(x, False)]
 
-    def train_on_batch(self, x, y):
+    output_names = ('sub_probs', 'acnn_probs', 'lstm_probs')
+
+    def _eval_outputs(self, xb):
+        return [(o, 'softmax', lambda t: t) for o in self._forward(xb, False)]
+
+    def train_on_batch(self, x, y, sample_weight=None):
+        if sample_weight is not None:
+            raise NotImplementedError('sample_weight: the fused device losses have no per-sample weights')
         if self._loss is None:
             raise RuntimeError('compile() the model before fit/train')
         tensors = tuple(_dev_f32(a) for a in x) + tuple(_dev_f32(a) for a in y)

@@ -125,10 +125,18 @@ def test_get_lstm_model_training_step_matches_oracle(lt, dtype):
             assert c > (0.9999 if f32 else 0.98), (ok, c, rel(g, g_ref[ok]))
             if f32:
                 assert rel(g, g_ref[ok]) < 2e-3, (ok, rel(g, g_ref[ok]))
-        # inference (moving statistics): after the step above both sides hold updated moving averages; compare through training-mode
-        # statistics instead -- predict() of a model whose moving statistics equal the batch statistics
+        # inference mode (Model.predict): each BatchNormalization uses its MOVING statistics.  Give both sides the same non-trivial moving
+        # mean / variance (the step above used learning rate 0: the weights are still the oracle's) and compare the predictions
+        mv = {'bn1': (rng.standard_normal(64) * 0.05, 0.5 + rng.random(64)), 'bn2': (rng.standard_normal(64) * 0.05, 0.5 + rng.random(64))}
+        m.set_weights_dict({'batch_norm/moving_mean': mv['bn1'][0], 'batch_norm/moving_var': mv['bn1'][1],
+                            'batch_norm2/moving_mean': mv['bn2'][0], 'batch_norm2/moving_var': mv['bn2'][1]})
+        mv64 = {k: (v[0].astype(np.float32).astype(np.float64), v[1].astype(np.float32).astype(np.float64)) for k, v in mv.items()}
+        pred_ref = o.forward_infer(x.astype(np.float64), mv64)
         pred = m.predict(x)
-        assert pred.shape == (B, H, W, ncls) and np.isfinite(pred).all() and pred.min() >= 0 and pred.max() <= 2.0
+        assert pred.shape == (B, H, W, ncls) and pred.min() >= 0 and pred.max() <= 2.0
+        err = np.abs(pred - pred_ref).max()
+        assert err < (2e-4 if f32 else 6e-2), err
+        assert rel(pred, pred_ref) < (1e-4 if f32 else 2e-2), rel(pred, pred_ref)
     finally:
         mt.set_compute_dtype('bfloat16')
 
@@ -535,5 +543,69 @@ def test_multi_output_sequence_models_graph_replay_matches_eager(lt, which):
         we, wg = me.get_weights_dict(), mg.get_weights_dict()
         for k in we:
             assert np.abs(we[k] - wg[k]).max() < 5e-4, (k, np.abs(we[k] - wg[k]).max())
+    finally:
+        mt.set_compute_dtype('bfloat16')
+
+
+def test_sequence_models_keras_surface(lt, tmp_path):
+    """compile(metrics=) / fit(validation_data=, callbacks=) / evaluate -> list aligned with metrics_names / load_weights(by_name, skip_mismatch)
+    of the ConvLSTM2D family as the reference's call sites use them (utils/model_tools.py:1162-1176, notebooks/UNET_G4G_2019_solar.ipynb:1206-1275),
+    and: arguments the implementation does not act on are refused, not swallowed."""
+    import json
+    from satellite_computervision_amd import model_tools as mt
+    mt.set_compute_dtype('float32')
+    try:
+        B, T, H, W, C, ncls = 4, 3, 16, 16, 5, 3
+        m = lt.get_lstm_model(C, ncls, T)
+        rng = np.random.default_rng(1)
+        x = rng.random((B, T, H, W, C)).astype(np.float32)
+        y = np.eye(ncls, dtype=np.float32)[rng.integers(0, ncls, (B, H, W))]
+        with pytest.raises(ValueError):
+            m.compile(optimizer=mt.Adam(1e-3), loss=mt.mse_4d, metrics=['no_such_metric'])
+        with pytest.raises(TypeError):
+            m.compile(optimizer=mt.Adam(1e-3), loss=mt.mse_4d, run_eagerly=True)
+        m.compile(optimizer=mt.Adam(1e-3), loss=mt.mse_4d, metrics=['accuracy', mt.MeanIoU(num_classes=ncls)])
+        assert m.metrics_names == ['loss', 'accuracy', 'mean_io_u']
+        ev = m.evaluate(x, y, batch_size=2)
+        assert isinstance(ev, list) and len(ev) == 3 and all(np.isfinite(ev)) and 0 <= ev[1] <= 1 and 0 <= ev[2] <= 1
+        # accuracy against the host argmax of predict()
+        acc = float((m.predict(x).argmax(-1) == y.argmax(-1)).mean())
+        assert abs(ev[1] - acc) < 1e-6
+        ck = mt.ModelCheckpoint(str(tmp_path / 'best.npz'), monitor='val_loss', save_best_only=True, save_weights_only=True)
+        tb = mt.TensorBoard(log_dir=str(tmp_path / 'tb'))
+        h = m.fit(x, y, batch_size=2, epochs=3, validation_data=(x, y), callbacks=[ck, tb])
+        assert len(h.history['loss']) == 3 and len(h.history['val_loss']) == 3 and len(h.history['val_mean_io_u']) == 3
+        assert h.history['loss'][-1] < h.history['loss'][0]
+        assert os.path.exists(tmp_path / 'best.npz') and ck.best == min(h.history['val_loss'])
+        lines = [json.loads(l) for l in open(tmp_path / 'tb' / 'scalars.jsonl')]
+        assert len(lines) == 3 and 'val_accuracy' in lines[0]
+        # generator batches with a third element: None weights pass, real weights are refused
+        assert np.isfinite(m.fit([(x[:2], y[:2], None), (x[2:], y[2:], None)], epochs=1).history['loss'][0])
+        with pytest.raises(NotImplementedError):
+            m.fit([(x[:2], y[:2], np.ones(2, np.float32))], epochs=1)
+        with pytest.raises(NotImplementedError):
+            m.train_on_batch(x, y, sample_weight=np.ones(B, np.float32))
+        with pytest.raises(TypeError):
+            m.fit(x, y, epochs=1, workers=4)
+        with pytest.raises(TypeError):
+            m.evaluate(x, y, callbacks=[])
+        # weights: by_name is implied by the container; skip_mismatch skips what does not fit instead of raising
+        m2 = lt.get_lstm_model(C, ncls + 1, T)
+        with pytest.raises(ValueError):
+            m2.load_weights(str(tmp_path / 'best.npz'))
+        skipped = m2.load_weights(str(tmp_path / 'best.npz'), by_name=True, skip_mismatch=True)
+        assert sorted(skipped) == ['conv2d/bias', 'conv2d/kernel']
+        m3 = lt.get_lstm_model(C, ncls, T)
+        m3.load_weights(str(tmp_path / 'best.npz'), by_name=True)
+        m3.compile(optimizer=mt.Adam(0.0), loss=mt.mse_4d)
+        assert isinstance(m3.evaluate(x, y), float)
+        with pytest.raises(NotImplementedError):
+            m.save_weights(str(tmp_path / 'w.h5'))
+        with pytest.raises(NotImplementedError):
+            m.load_weights(str(tmp_path / 'w.hdf5'))
+        # multi-output model: evaluate lists the total, the per-output losses and the per-output metrics
+        hm = lt.get_hierarchical_model(3, 4, 2, (16, 16, 4), (T, 8, 8, C), 16, 3)
+        hm.compile(optimizer=mt.Adam(1e-3), loss=mt.mse_4d, metrics=['accuracy'])
+        assert hm.metrics_names == ['loss', 'sub_probs_loss', 'acnn_probs_loss', 'lstm_probs_loss', 'sub_probs_accuracy', 'acnn_probs_accuracy', 'lstm_probs_accuracy']
     finally:
         mt.set_compute_dtype('bfloat16')
