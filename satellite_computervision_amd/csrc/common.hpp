@@ -45,6 +45,15 @@ void satcv_set_error(const char* fmt, ...);
 int satcv_ensure_dynamic_lds(const void* kern, size_t bytes);
 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// n * h * w * f * f pixels (f = depth-to-space / space-to-depth factor or 1) stay below 2^31 -- evaluated without overflowing anything itself
+static inline bool satcv_pixels_ok(long long n, long long h, long long w, long long f) {
+  if (n < 1 || h < 1 || w < 1 || f < 0 || f > 16 || n > (1LL << 31) || h > (1LL << 31) || w > (1LL << 31)) return false;
+  const long long hw = h * w;                            // < 2^62
+  if (hw >= (1LL << 31)) return false;
+  const long long t = n * hw;                            // < 2^62
+  if (t >= (1LL << 31)) return false;
+  return t * (f > 1 ? f * f : 1) < (1LL << 31);
+}
 
 // ---- 8-element vectors of the storage type (16 B for bf16, 32 B for f32) ----
 template <typename T>

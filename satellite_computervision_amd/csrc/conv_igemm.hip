@@ -300,6 +300,11 @@ static int igemm_fill_args(const satcv_conv_desc* d, IgemmArgs& a) {
   SATCV_CHECK((d->c1 == 0) == (d->x1 == nullptr), "igemm: x1/c1 mismatch");
   SATCV_CHECK(d->kh >= 1 && d->kw >= 1 && (d->kh & 1) && (d->kw & 1) && d->dil >= 1, "igemm: bad taps");
   SATCV_CHECK(d->n > 0 && d->h > 0 && d->w_ > 0 && d->cout > 0, "igemm: bad dims");
+  // (the kernels index pixels and elements of one tensor with 32-bit integers where it is safe to: refuse what would overflow them -- found by
+  //  the UBSan run of the host side, tests/asan/host_abi_driver.c)
+  SATCV_CHECK(satcv_pixels_ok(d->n, d->h, d->w_, d->f) && d->cout <= (1 << 20) && d->c0 <= (1 << 20) && d->c1 <= (1 << 20) &&
+              d->kh <= 15 && d->kw <= 15 && d->dil <= (1 << 15) && d->f <= 16 && d->stride <= 16,
+              "igemm: extents out of range (n*h*w must stay below 2^31 pixels, channels below 2^20)");
   SATCV_CHECK(d->cstat > 0, "igemm: cstat");
   SATCV_CHECK((!d->mode_in && !d->mode_out) || (d->f >= 2 && d->kh == 1 && d->kw == 1), "igemm: s2d/d2s need 1x1 taps and f>=2");
   SATCV_CHECK(!(d->accumulate && d->stats), "igemm: accumulate with statistics");

@@ -1091,6 +1091,11 @@ static int pick_tw_w(int w) {
 }
 
 static int wgrad_plan(const satcv_wgrad_desc* d, WgradPlan& p) {
+  if (!(d->n > 0 && d->h > 0 && d->w_ > 0 && d->c0 > 0 && d->c1 >= 0 && d->cout > 0 && d->dil >= 1 && d->f >= 0 && d->f <= 16 && d->dil <= (1 << 15) &&
+        satcv_pixels_ok(d->n, d->h, d->w_, d->f) && d->c0 <= (1 << 20) && d->c1 <= (1 << 20) && d->cout <= (1 << 20))) {
+    satcv_set_error("wgrad: extents out of range (n*h*w must stay below 2^31 pixels, channels below 2^20)");
+    return SATCV_ERR_INVALID;
+  }
   const int cinx = d->c0 + d->c1;
   const int nspace = d->mode_dy ? d->f * d->f * d->cout : d->cout;
   p.ntaps = d->kh * d->kw;

@@ -226,3 +226,27 @@ def test_library_was_built_from_the_sources_in_the_tree():
     if not os.path.exists(stamp):
         pytest.skip('no build stamp (library built elsewhere)')
     assert open(stamp).read() == b._digest(deps), 'libsatcv.so is older than csrc/: run python -m satellite_computervision_amd.build'
+
+
+def test_host_side_of_the_c_abi_under_asan_ubsan(tmp_path):
+    """SURVEY section 5, sanitizers (CPU build only: GPU AddressSanitizer is not available on this pool): every source of the library compiled
+    `--cuda-host-only -fsanitize=address,undefined` (satellite_computervision_amd/build.py::build_host_asan), driven by tests/asan/host_abi_driver.c --
+    descriptor validation with null / zeroed / absurd descriptors, ~430 000 tile / split / weight-gradient plans through the dry-run and workspace
+    queries, the reduce / pack job queries, the option table, CRC-32C against a bitwise restatement.  Any sanitizer report aborts the driver.
+    (Its first run found signed overflows of n * h * w in the planners for absurd extents: descriptors beyond 2^31 pixels are now refused.)"""
+    import subprocess
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_satcv_build', os.path.join(ROOT, 'satellite_computervision_amd', 'build.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    so = b.build_host_asan()
+    exe = tmp_path / 'host_abi_driver'
+    clang = '/opt/rocm/lib/llvm/bin/clang'
+    subprocess.run([clang, '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-g', '-O1', '-I', os.path.join(ROOT, 'include'),
+                    os.path.join(ROOT, 'tests', 'asan', 'host_abi_driver.c'), '-o', str(exe), '-L', os.path.dirname(so), '-lsatcv_hostasan',
+                    '-Wl,-rpath,' + os.path.dirname(so)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS='detect_leaks=0:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1'),
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'runtime error' not in r.stderr and 'AddressSanitizer' not in r.stderr, r.stderr[-4000:]
+    assert ' 0 failures' in r.stdout, r.stdout
