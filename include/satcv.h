@@ -223,6 +223,36 @@ int64_t satcv_conv2d_bwd_fused_workspace(const satcv_bwdf_desc* d);
 int satcv_conv2d_bwd_fused(const satcv_bwdf_desc* d, void* stream);
 int satcv_conv2d_bwd_fused_reduce_job(const satcv_bwdf_desc* d, satcv_reduce_job* job);
 
+/* Fused backward of decoder_block's up-sampling path (utils/model_tools.py:306-309: Conv2DTranspose(filters, up_size, strides = up_size) ->
+ * concatenate([skip, up]) -> BatchNormalization -> Activation('relu'), differentiated by Keras inside Model.fit), round 5.  For the `up`
+ * channels of the concatenation ONE launch replaces satcv_bn_bwd_apply (their half) + the space-to-depth data gradient + the weight gradient:
+ *     dup = scale * (g * [scale*yup+shift > 0] - c1 - xhat * c2)   in registers, never stored (g = gradient of the activated concatenation,
+ *           its `up` channels; yup = the transposed convolution's stored output; c1, c2 from satcv_bn_bwd_finalize of the concatenation)
+ *     dx (n, h, w, lddx)        = sum_{ij, co} dup[(2y+i, 2x+j)][co] K[i][j][co][ci]      w_dgrad: the data-gradient image of satcv_pack_weights(transposed)
+ *     dw (2, 2, cout, cin) fp32 = sum_pixels dup x^T                                       (Keras Conv2DTranspose kernel layout)
+ * and, with bst_sums, the sums of the BatchNorm backward of the layer whose output x is (as satcv_conv2d_bwd_fused does).  The bias gradient
+ * of the transposed convolution is identically zero under the BatchNormalization that follows it.  bf16, f = 2, cout 32 / 64, cin a
+ * multiple of 64, rows of w a multiple of 64 / 32 pixels: satcv_convt_bwd_fused_workspace() answers -1 otherwise and the caller keeps the
+ * three launches.  The `skip` channels keep satcv_bn_bwd_apply (c = their count). */
+typedef struct satcv_ctbf_desc {
+  const void* g; int32_t ldg;            /* (n, 2h, 2w, ldg), already offset to the first `up` channel */
+  const void* yup; int32_t ldy;          /* (n, 2h, 2w, ldy) */
+  const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_rstd;   /* [cout], of the `up` channels */
+  const float* bn_c1; const float* bn_c2; int32_t linear;
+  const void* x; int32_t ldx;            /* (n, h, w, ldx): the transposed convolution's input, with its pending BatchNorm + ReLU */
+  const float* in_scale; const float* in_shift; int32_t in_relu;
+  const void* w_dgrad; int32_t w_npad;   /* [4 cout / 8][w_npad][8] */
+  void* dx; int32_t lddx;
+  float* dw; int32_t cin, cout;
+  int32_t n, h, w_, f;                   /* INPUT grid; f = 2 */
+  float* workspace; int64_t workspace_bytes;
+  int32_t dtype, accumulate, defer_reduce;
+  satcv_stat_t* bst_sums; int32_t bst_sums_ld; const float* bst_mean; const float* bst_rstd;
+} satcv_ctbf_desc;
+int64_t satcv_convt_bwd_fused_workspace(const satcv_ctbf_desc* d);
+int satcv_convt_bwd_fused(const satcv_ctbf_desc* d, void* stream);
+int satcv_convt_bwd_fused_reduce_job(const satcv_ctbf_desc* d, satcv_reduce_job* job);
+
 /* --------------------------------------------------------------- batch norm
  * layers.BatchNormalization (utils/model_tools.py:179,308,313,316): eps, momentum as given.
  * Training: consume the [ROWS][2][ld] sum/sumsq rows (and zero them), produce per-channel
@@ -278,7 +308,8 @@ typedef struct satcv_bnbwd_desc {
   int32_t linear;                      /* 1: BatchNormalization without the ReLU (residual branch): g = da, no mask   */
   /* optional second source (c_split > 0): the BatchNormalization of concat([skip, up]) (utils/model_tools.py:307-308) in ONE pass
    * over the gradient `da` of the concatenation -- channels [0, c_split) are read from yraw / written to dy as above, channels
-   * [c_split, c) from yraw1 (stride ldy1) / to dy1 (stride lddy1).  Dense form only (no dpool, no dbias).                     */
+   * [c_split, c) from yraw1 (stride ldy1) / to dy1 (stride lddy1).  Dense form only (no dpool, no dbias).  satcv_bn_bwd_apply with
+   * dy1 == NULL applies the first c_split channels only (the others' gradient is formed by satcv_convt_bwd_fused in its loader).   */
   const void* yraw1; int32_t ldy1;
   void* dy1; int32_t lddy1;
   int32_t c_split;

@@ -70,6 +70,16 @@ class BwdfDesc(C.Structure):
                 ('hg_dlogits', c_vp), ('hg_w', c_vp), ('hg_ncls', c_i32), ('defer_reduce', c_i32)]
 
 
+class CtbfDesc(C.Structure):
+    _fields_ = [('g', c_vp), ('ldg', c_i32), ('yup', c_vp), ('ldy', c_i32),
+                ('bn_scale', c_vp), ('bn_shift', c_vp), ('bn_mean', c_vp), ('bn_rstd', c_vp), ('bn_c1', c_vp), ('bn_c2', c_vp), ('linear', c_i32),
+                ('x', c_vp), ('ldx', c_i32), ('in_scale', c_vp), ('in_shift', c_vp), ('in_relu', c_i32),
+                ('w_dgrad', c_vp), ('w_npad', c_i32), ('dx', c_vp), ('lddx', c_i32), ('dw', c_vp), ('cin', c_i32), ('cout', c_i32),
+                ('n', c_i32), ('h', c_i32), ('w_', c_i32), ('f', c_i32), ('workspace', c_vp), ('workspace_bytes', c_i64),
+                ('dtype', c_i32), ('accumulate', c_i32), ('defer_reduce', c_i32),
+                ('bst_sums', c_vp), ('bst_sums_ld', c_i32), ('bst_mean', c_vp), ('bst_rstd', c_vp)]
+
+
 class ReduceJob(C.Structure):
     _fields_ = [('ws', c_vp), ('dw', c_vp), ('nslab', c_i32), ('taps', c_i32), ('kpad', c_i32), ('npad', c_i32), ('cin', c_i32), ('nvalid', c_i32),
                 ('transposed', c_i32), ('accumulate', c_i32), ('lanes', c_i32), ('pad_', c_i32)]
@@ -142,6 +152,9 @@ _SIGS = {
     'satcv_conv2d_bwd_fused_workspace': (c_i64, [C.POINTER(BwdfDesc)]),
     'satcv_conv2d_bwd_fused': (C.c_int, [C.POINTER(BwdfDesc), c_vp]),
     'satcv_conv2d_bwd_fused_reduce_job': (C.c_int, [C.POINTER(BwdfDesc), C.POINTER(ReduceJob)]),
+    'satcv_convt_bwd_fused_workspace': (c_i64, [C.POINTER(CtbfDesc)]),
+    'satcv_convt_bwd_fused': (C.c_int, [C.POINTER(CtbfDesc), c_vp]),
+    'satcv_convt_bwd_fused_reduce_job': (C.c_int, [C.POINTER(CtbfDesc), C.POINTER(ReduceJob)]),
     'satcv_bn_finalize_train': (C.c_int, [c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32,
                                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'satcv_bn_affine_infer': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp]),

@@ -1380,6 +1380,17 @@ int wgrad_reduce_slabs(const float* ws, float* dw, int nslab, int taps, int kpad
   return wgrad_reduce_launch(&d, p, dw, nvalid, st);
 }
 
+// ... and for the transposed-convolution layout (f, f, cout, cin) of convt_bwd_fused.hip: slabs [nslab][kpad = cin][npad = f f cout]
+int wgrad_reduce_slabs_t(const float* ws, float* dw, int nslab, int kpad, int npad, int cin, int nvalid, int accumulate, hipStream_t st) {
+  satcv_wgrad_desc d;
+  memset(&d, 0, sizeof(d));
+  d.workspace = const_cast<float*>(ws); d.cin = cin; d.accumulate = accumulate; d.transposed = 1;
+  WgradPlan p;
+  memset(&p, 0, sizeof(p));
+  p.nsplit = nslab; p.ntaps = 1; p.kpad = kpad; p.npad = npad;
+  return wgrad_reduce_launch(&d, p, dw, nvalid, st);
+}
+
 extern "C" int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream) {
   SATCV_CHECK(d && d->x0 && d->dy && d->dw && d->workspace, "wgrad: null pointer");
   SATCV_CHECK(d->c0 > 0 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && (d->c1 == 0) == (d->x1 == nullptr), "wgrad: bad source channels");

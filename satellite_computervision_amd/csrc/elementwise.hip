@@ -568,7 +568,8 @@ __global__ void bn_bwd_kernel(const satcv_bnbwd_desc d) {
 }
 // Dense variant (no pooled gradient): pure linear sweep, 32-bit incremental indexing.
 template <typename T, bool APPLY>
-__global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbwd_desc d, const int rev) {
+__global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbwd_desc d, const int rev, const int cld) {
+  // cld: channel count the coefficient vector [c1 | c2] was built for (= d.c, or the whole concatenation when only its first part is applied)
   extern __shared__ float lds[];
   const int c = d.c, G = c / 8;
   const unsigned npix = (unsigned)d.n * d.h * d.w_;
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbw
   for (int e = 0; e < 8; ++e) {
     const int ch = g * 8 + e;
     sc[e] = d.scale[ch]; sh[e] = d.shift[ch]; mu[e] = d.mean[ch]; rs[e] = d.rstd[ch];
-    c1[e] = APPLY ? d.coef[ch] : 0.f; c2[e] = APPLY ? d.coef[c + ch] : 0.f;
+    c1[e] = APPLY ? d.coef[ch] : 0.f; c2[e] = APPLY ? d.coef[cld + ch] : 0.f;
     s1[e] = 0.f; s2[e] = 0.f;
   }
   if (active) {
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbw
     }
   }
   if (!APPLY) block_channel_reduce(lds, s1, s2, g, active, c, d.sums, d.sums_ld);
-  else if (d.sk_sums) block_channel_reduce(lds, s1, s2, g, active && !second, c, d.sk_sums, d.sk_sums_ld, d.c_split);
+  else if (d.sk_sums) block_channel_reduce(lds, s1, s2, g, active && !second, c, d.sk_sums, d.sk_sums_ld, d.c_split > 0 ? d.c_split : -1);
   else if (d.dbias) {
     for (int i = threadIdx.x; i < c; i += blockDim.x) lds[i] = 0.f;
     __syncthreads();
@@ -650,7 +651,7 @@ static int bnbwd_check(const satcv_bnbwd_desc* d, bool apply) {
   if (d->c_split > 0) {
     SATCV_CHECK(d->c_split % 8 == 0 && d->c_split < d->c && d->yraw1 && d->ldy1 >= d->c - d->c_split && !d->dpool && d->da && !d->dbias &&
                 (long long)d->n * d->h * d->w_ < 0x7fffffffLL, "bn_bwd: second source needs the dense form (da, no dpool / dbias), c_split %% 8 == 0");
-    if (apply) SATCV_CHECK(d->dy1 && d->lddy1 >= d->c - d->c_split, "bn_bwd_apply: dy1 missing");
+    if (apply) SATCV_CHECK(!d->dy1 || d->lddy1 >= d->c - d->c_split, "bn_bwd_apply: dy1 channel stride");      // (dy1 NULL: only the first source's channels are applied)
   }
   return SATCV_OK;
 }
@@ -659,7 +660,7 @@ extern "C" int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream) {
   const int f = d->dpool ? d->f : 1;
   const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
   if (!d->dpool && d->da && (long long)d->n * d->h * d->w_ < 0x7fffffffLL) {
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), (EW_BLOCK + 1) * 16 * sizeof(float), (hipStream_t)stream, *d, 0));
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), (EW_BLOCK + 1) * 16 * sizeof(float), (hipStream_t)stream, *d, 0, d->c));
   } else {
     DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), (EW_BLOCK + 1) * 16 * sizeof(float), (hipStream_t)stream, *d));
   }
@@ -670,10 +671,21 @@ extern "C" int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream) {
   static const int rev = getenv("SATCV_BN_REV") ? atoi(getenv("SATCV_BN_REV")) : 1;
   int rc = bnbwd_check(d, true); if (rc) return rc;
   const int f = d->dpool ? d->f : 1;
+  if (d->c_split > 0 && !d->dy1) {
+    // two-source descriptor without a destination for the second source: the gradient of the `up` channels of a decoder concatenation is
+    // formed by satcv_convt_bwd_fused in its loader -- apply the first c_split channels only (coefficients still indexed for all d->c)
+    satcv_bnbwd_desc e = *d;
+    e.c = d->c_split; e.c_split = 0; e.yraw1 = nullptr;
+    const long long it1 = (long long)d->n * d->h * d->w_ * (e.c / 8);
+    const size_t lds_1 = d->sk_sums ? (EW_BLOCK + 1) * 16 * sizeof(float) : e.c * sizeof(float);
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, true>), dim3(ew_grid(it1)), dim3(EW_BLOCK), lds_1, (hipStream_t)stream, e, rev, d->c));
+    LAUNCH_OK("bn_bwd_apply");
+    return SATCV_OK;
+  }
   const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
   if (!d->dpool && d->da && (long long)d->n * d->h * d->w_ < 0x7fffffffLL) {
     const size_t lds_b = d->sk_sums ? (EW_BLOCK + 1) * 16 * sizeof(float) : d->c * sizeof(float);
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), lds_b, (hipStream_t)stream, *d, rev));
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), lds_b, (hipStream_t)stream, *d, rev, d->c));
   } else {
     DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), d->c * sizeof(float), (hipStream_t)stream, *d));
   }

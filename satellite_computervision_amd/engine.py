@@ -76,6 +76,10 @@ BIAS_NOISE = os.environ.get('SATCV_BN_BIAS_NOISE', '0') == '1'
 # step time is the same either way (9.54 ms, three A/B pairs) and the 3x3 data gradients run without their own layer's weight
 # gradient beside them (roofline.frac 0.251 -> 0.262); SATCV_WGRAD_LATE=0 restores the earlier order
 WGRAD_LATE = os.environ.get('SATCV_WGRAD_LATE', '1') == '1'
+# round 5: decoder_block's up-sampling path backward as one launch (csrc/convt_bwd_fused.hip) for these Conv2DTranspose filter counts (SATCV_CTBF=0: off;
+# SATCV_CTBF_COUTS restricts the set)
+CTBF = os.environ.get('SATCV_CTBF', '1') != '0'
+CTBF_COUTS = tuple(int(v) for v in os.environ.get('SATCV_CTBF_COUTS', '32,64').split(',') if v)
 FUSE_RESIDUAL = os.environ.get('SATCV_FUSE_RESIDUAL', '1') == '1'      # inference: residual joins written by the block's last convolution
 FUSE_DGRAD_ALL = os.environ.get('SATCV_FUSE_DGRAD_BN_BWD', '1') == '2'      # 2: every eligible data gradient carries the BN-backward sums
 
@@ -1312,6 +1316,21 @@ class Plan:
                     # the skip is the activated output of an encoder block that is also max-pooled: this apply pass has dskip and that
                     # activation in registers -- it also forms the skip part of the encoder BatchNorm's backward sums (sk_sums)
                     sec = dict(yraw1=rb.srcs[0][0].data_ptr(), ldy1=cb, dy1=du.data_ptr(), lddy1=cb, c_split=ca)
+                    # round 5: the `up` channels' part of this apply pass, the transposed convolution's data gradient and its weight gradient as ONE
+                    # launch (satcv_convt_bwd_fused, built at the convT node below): the apply pass then covers the skip channels only
+                    ctbf = None
+                    cxt = ctx.get(id(tb.node)) if tb.node.op == 'convT' else None
+                    if (CTBF and dt == ops.BF16 and cxt is not None and bn not in self.frozen and upl.name not in shared_layers and cxt['f'] == 2
+                            and cb in CTBF_COUTS and len(consumers.get(tb.id, [])) == 1):
+                        rT = cxt['r']
+                        saT = self._src_args(rT)
+                        probe = ops.make_ctbf_desc(g=gptr_ + ca * es, ldg=ctot, yup=rb.srcs[0][0].data_ptr(), ldy=cb, bn_scale=None, bn_shift=None, bn_mean=None,
+                                                   bn_rstd=None, bn_c1=None, bn_c2=None, x=saT['x0'], ldx=saT['c0'], w_dgrad=rt.packed[upl.name]['dgrad'].data_ptr(),
+                                                   w_npad=rup(rT.c, 32), dx=saT['x0'], lddx=rT.c, dw=rt.gptr(upl.name + '/kernel'), cin=rT.c, cout=cb, n=n,
+                                                   h=rT.h, w_=rT.w, dtype=dt)
+                        if saT['x1'] is None and saT['c0'] == rT.c == rt.packed[upl.name]['cin'] and lib.satcv_convt_bwd_fused_workspace(C.byref(probe)) > 0:
+                            ctbf = dict(g=gptr_ + ca * es, ldg=ctot, yup=rb.srcs[0][0].data_ptr(), ldy=cb, aff=aff, aoff=ca, ctot=ctot)
+                            sec['dy1'] = None
                     ent = None
                     if (bn not in self.frozen and ta.id not in gact and any(cn.op == 'pool' for cn in consumers[ta.id])
                             and len([cn for cn in consumers[ta.id] if cn.op != 'pool']) == 1 and ta.channels == ca):
@@ -1324,11 +1343,15 @@ class Plan:
                                               second=sec)
                     if ent is not None:
                         a_.label += ' +skipsums'
+                    if ctbf is not None:
+                        a_.label += ' (skip half)'
+                        a_.work = dict(kind='bn_bwd_apply', px=n * hh * ww, c=ca, esize=es)
+                        ctbf['coef'] = a_.coef
                     self.bwd += [f_, a_] if (pre is not None or r_ is None) else [r_, f_, a_]
                     gact[ta.id] = (dskip, 0, ca)
                     self.dbg['dskip:' + bn] = dskip
                     self.dbg['du:' + bn] = du
-                    graw[tb.id] = du
+                    graw[tb.id] = ctbf if ctbf is not None else du
                     continue
                 ra_, fa_, aa_ = bn_bwd_steps(gptr_, ctot, None, 0, 1, ra.srcs[0][0].data_ptr(), ca, aff, 0, sums, 0, ctot, ca, hh, ww,
                                              dskip.data_ptr(), ca, None, rt.gptr(bn + '/gamma'), rt.gptr(bn + '/beta'), frozen=bn in self.frozen)
@@ -1348,6 +1371,35 @@ class Plan:
                     continue
                 lay, r, cout, f = node.layer, cx['r'], cx['cout'], cx['f']
                 pk = rt.packed[lay.name]
+                if isinstance(du, dict):
+                    # fused: BatchNorm-backward apply of the `up` channels + data gradient + weight gradient (csrc/convt_bwd_fused.hip)
+                    cb_, sa = du, self._src_args(r)
+                    cinp = r.c
+                    gin = self._z(n, r.h, r.w, cinp)
+                    af_, ao_, ct_ = cb_['aff'], cb_['aoff'], cb_['ctot']
+                    fz = ops.make_ctbf_desc(g=cb_['g'], ldg=cb_['ldg'], yup=cb_['yup'], ldy=cb_['ldy'], bn_scale=_fp(af_['scale'], ao_), bn_shift=_fp(af_['shift'], ao_),
+                                            bn_mean=_fp(af_['mean'], ao_), bn_rstd=_fp(af_['rstd'], ao_), bn_c1=_fp(cb_['coef'], ao_), bn_c2=_fp(cb_['coef'], ct_ + ao_),
+                                            x=sa['x0'], ldx=sa['c0'], in_scale=sa['in_scale'], in_shift=sa['in_shift'], in_relu=sa['in_relu'],
+                                            w_dgrad=pk['dgrad'].data_ptr(), w_npad=rup(cinp, 32), dx=gin.data_ptr(), lddx=cinp, dw=rt.gptr(lay.name + '/kernel'),
+                                            cin=cinp, cout=cout, n=n, h=r.h, w_=r.w, dtype=dt)
+                    bt = bst_target(tin) if (sa['in_relu'] and sa['in_scale'] is not None) else None
+                    if bt is not None and bt[1] == cinp and bt[0].get('relu', 0) == 1:
+                        sums_below = self._z(STAT_ROWS, 2, cinp, dtype=torch.float64)
+                        fz.bst_sums, fz.bst_sums_ld, fz.bst_mean, fz.bst_rstd = _fp(sums_below), cinp, bt[0]['mean'], bt[0]['rstd']
+                        fused[tin.id] = sums_below
+                    nbc = lib.satcv_convt_bwd_fused_workspace(C.byref(fz))
+                    if nbc <= 0:
+                        raise RuntimeError('convt_bwd_fused: the probe accepted this shape, the final descriptor did not')
+                    wsc = self._z(max(nbc // 4, 1), dtype=torch.float32)
+                    fz.workspace, fz.workspace_bytes = wsc.data_ptr(), nbc
+                    self.keep.append(fz)
+                    cstep = lambda st, fz=fz: check(lib.satcv_convt_bwd_fused(C.byref(fz), st))
+                    cstep.label = f"convt_bwd_fused n{n} {r.h}x{r.w} {cinp}<-4x{cout}{' +bnred' if fz.bst_sums else ''}"
+                    cstep.work = dict(kind='convt_bwd_fused', px=n * r.h * r.w, cin=cinp, cout=cout, esize=es)
+                    self.bwd.append(cstep)
+                    gact[tin.id] = (gin, 0, cinp)
+                    self.dbg['dx:' + lay.name] = gin
+                    continue
                 wstep = wgrad_step(r, du.data_ptr(), cout, lay, pk['cin'], cout, r.h, r.w, 1, 1, f=f)
                 if not WGRAD_LATE:
                     self.bwd.append(wstep)

@@ -425,3 +425,44 @@ def confusion(classes, y_true, ncls):
 
 def adam_step(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-7, lr_mul=None):
     check(lib.satcv_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), beta1, beta2, eps, ptr(state), ptr(lr_mul), stream_ptr()))
+
+
+def make_ctbf_desc(*, g, ldg, yup, ldy, bn_scale, bn_shift, bn_mean, bn_rstd, bn_c1, bn_c2, x, ldx, w_dgrad, w_npad, dx, lddx, dw, cin, cout, n, h, w_,
+                   dtype, linear=0, in_scale=None, in_shift=None, in_relu=0, workspace=None, workspace_bytes=0, accumulate=0, defer_reduce=0,
+                   bst_sums=None, bst_sums_ld=0, bst_mean=None, bst_rstd=None):
+    from ._lib import CtbfDesc
+    d = CtbfDesc()
+    d.g, d.ldg, d.yup, d.ldy = g, ldg, yup, ldy
+    d.bn_scale, d.bn_shift, d.bn_mean, d.bn_rstd, d.bn_c1, d.bn_c2, d.linear = bn_scale, bn_shift, bn_mean, bn_rstd, bn_c1, bn_c2, int(linear)
+    d.x, d.ldx, d.in_scale, d.in_shift, d.in_relu = x, ldx, in_scale, in_shift, int(in_relu)
+    d.w_dgrad, d.w_npad, d.dx, d.lddx, d.dw, d.cin, d.cout = w_dgrad, w_npad, dx, lddx, dw, cin, cout
+    d.n, d.h, d.w_, d.f = n, h, w_, 2
+    d.workspace, d.workspace_bytes, d.dtype, d.accumulate, d.defer_reduce = workspace, workspace_bytes, dtype, int(accumulate), int(defer_reduce)
+    d.bst_sums, d.bst_sums_ld, d.bst_mean, d.bst_rstd = bst_sums, bst_sums_ld, bst_mean, bst_rstd
+    return d
+
+
+def convt_bwd_fused(g_cat, c_skip, yup, scale, shift, mean, rstd, coef, x, w_dgrad, cin, cout, *, in_scale=None, in_shift=None, in_relu=False,
+                    linear=False, bst=None):
+    """backward of Conv2DTranspose(k = s = 2) under concat -> BatchNorm -> ReLU for the `up` channels (satcv_convt_bwd_fused).  g_cat (n, 2h, 2w, c_skip +
+    cout): gradient of the activated concatenation; the six vectors cover ALL its channels (coef = [c1 | c2]); returns (dx, dw (2, 2, cout, cin))."""
+    n, h, w_ = x.shape[0], x.shape[1], x.shape[2]
+    ctot = g_cat.shape[-1]
+    dx = torch.empty(n, h, w_, cin, dtype=x.dtype, device=x.device)
+    dw = torch.empty(2, 2, cout, cin, dtype=torch.float32, device=x.device)
+    es = g_cat.element_size()
+
+    def off(v):
+        return v.data_ptr() + 4 * c_skip
+    d = make_ctbf_desc(g=g_cat.data_ptr() + es * c_skip, ldg=ctot, yup=_p(yup), ldy=yup.shape[-1], bn_scale=off(scale), bn_shift=off(shift), bn_mean=off(mean),
+                       bn_rstd=off(rstd), bn_c1=coef.data_ptr() + 4 * c_skip, bn_c2=coef.data_ptr() + 4 * (ctot + c_skip), x=_p(x), ldx=x.shape[-1],
+                       w_dgrad=_p(w_dgrad), w_npad=rup(cin, 32), dx=_p(dx), lddx=cin, dw=_p(dw), cin=cin, cout=cout, n=n, h=h, w_=w_, dtype=DTYPE_CODE[x.dtype],
+                       linear=linear, in_scale=_p(in_scale), in_shift=_p(in_shift), in_relu=in_relu,
+                       **({} if bst is None else dict(bst_sums=_p(bst['sums']), bst_sums_ld=cin, bst_mean=_p(bst.get('mean')), bst_rstd=_p(bst.get('rstd')))))
+    nb = lib.satcv_convt_bwd_fused_workspace(C.byref(d))
+    if nb < 0:
+        raise RuntimeError('convt_bwd_fused: shape outside the kernel limits')
+    ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=x.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nb
+    check(lib.satcv_convt_bwd_fused(C.byref(d), stream_ptr()))
+    return dx, dw

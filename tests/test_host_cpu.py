@@ -164,7 +164,7 @@ def test_descriptor_layouts_match_the_header(tmp_path):
     import subprocess
     from satellite_computervision_amd import _lib
     pairs = {'satcv_conv_desc': _lib.ConvDesc, 'satcv_pack_job': _lib.PackJob, 'satcv_tile_desc': _lib.TileDesc, 'satcv_wgrad_desc': _lib.WgradDesc,
-             'satcv_bnbwd_desc': _lib.BnBwdDesc, 'satcv_head_desc': _lib.HeadDesc, 'satcv_bwdf_desc': _lib.BwdfDesc, 'satcv_reduce_job': _lib.ReduceJob}
+             'satcv_bnbwd_desc': _lib.BnBwdDesc, 'satcv_head_desc': _lib.HeadDesc, 'satcv_bwdf_desc': _lib.BwdfDesc, 'satcv_reduce_job': _lib.ReduceJob, 'satcv_ctbf_desc': _lib.CtbfDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "satcv.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

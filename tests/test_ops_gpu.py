@@ -560,6 +560,82 @@ def test_conv2d_transpose_streaming_data_gradient_with_fused_bn_sums(ops, case):
         np.testing.assert_allclose(s[1], (gg * xh).sum((0, 1, 2)), rtol=1e-4, atol=tol * float(np.abs(xh).max()), err_msg=f'sum g xhat {case} relu={relu}')
 
 
+@pytest.mark.parametrize('case', [
+    # n, h, w, cin, cout, input BatchNorm + ReLU, fused sums of the layer below, linear BatchNorm
+    (2, 8, 64, 64, 32, True, True, False),        # dec0's shape class: one channel block, 64-pixel tiles
+    (1, 4, 128, 64, 32, False, False, False),     # activated input (no affine)
+    (3, 6, 64, 128, 64, True, True, False),       # dec1: one 128-channel block, 32-pixel tiles; odd image count
+    (2, 16, 32, 192, 64, True, True, False),      # Cin not a multiple of 128: three 64-channel blocks share the g / y tiles
+    (1, 5, 64, 128, 64, True, False, True),       # BatchNormalization without ReLU; more workgroups than tiles per slab
+])
+def test_convt_bwd_fused(ops, case):
+    """satcv_convt_bwd_fused: the `up` half of decoder_block's backward (utils/model_tools.py:306-309 differentiated) in one launch -- BatchNorm-backward
+    apply of the concatenation's `up` channels, space-to-depth data gradient and weight gradient of the transposed convolution, sums of the
+    BatchNorm backward of the layer below -- against the float64 oracle on the bf16-rounded dup (the value both products consume on the device)."""
+    n, h, w, cin, cout, aff, sums, linear = case
+    td = torch.bfloat16
+    rng = np.random.default_rng(sum(case[:5]) + 7)
+    cs = cout                                      # skip channels in front of the `up` channels
+    xr = rnd(rng, (n, h, w, cin), td) * 1.2 + 0.1
+    kt = rnd(rng, (2, 2, cout, cin), td, 0.15)
+    gcat = rnd(rng, (n, 2 * h, 2 * w, cs + cout), td)
+    yup = torch.tensor(rnd(rng, (n, 2 * h, 2 * w, cout), td) * 1.3 + 0.2, dtype=torch.float32).to(td).double().numpy()
+    ctot = cs + cout
+    sc, sh = rng.standard_normal(ctot).astype(np.float32), rng.standard_normal(ctot).astype(np.float32) * 0.5
+    mu, rs = rng.standard_normal(ctot).astype(np.float32) * 0.3, (0.5 + rng.random(ctot)).astype(np.float32)
+    c1, c2 = rng.standard_normal(ctot).astype(np.float32) * 0.05, rng.standard_normal(ctot).astype(np.float32) * 0.05
+    xsc, xsh = (rng.random(cin) + 0.5).astype(np.float32), (rng.standard_normal(cin) * 0.3).astype(np.float32)
+    xmu, xrs = rng.standard_normal(cin).astype(np.float32) * 0.3, (0.5 + rng.random(cin)).astype(np.float32)
+    if aff:
+        # keep the input's pre-activations away from 0: the device forms them in fp32, the oracle in float64, and a ReLU mask that flips on a
+        # pre-activation of ~1e-7 moves a fused sum by a whole gradient value
+        for _ in range(3):
+            pre = xr * xsc.astype(np.float64) + xsh.astype(np.float64)
+            xr = np.where(np.abs(pre) < 0.03, xr + 0.25 / xsc.astype(np.float64), xr)
+            xr = torch.tensor(xr, dtype=torch.float32).to(td).double().numpy()
+    # oracle
+    u = slice(cs, ctot)
+    g_up = gcat[..., u]
+    act = yup * sc[u].astype(np.float64) + sh[u].astype(np.float64)
+    gm = g_up if linear else np.where(act > 0, g_up, 0.0)
+    xhat = (yup - mu[u].astype(np.float64)) * rs[u].astype(np.float64)
+    dup = sc[u].astype(np.float64) * (gm - c1[u].astype(np.float64) - xhat * c2[u].astype(np.float64))
+    dup = torch.tensor(dup, dtype=torch.float32).to(td).double().numpy()          # the device rounds dup to bf16 before both products
+    if aff:
+        xa = np.maximum(xr * xsc.astype(np.float64) + xsh.astype(np.float64), 0)
+        xa = torch.tensor(xa, dtype=torch.float32).to(td).double().numpy()
+    else:
+        xa = xr
+    dx_ref, dk_ref, _ = K.conv2d_transpose_ks_bwd(xa, kt, dup)
+    # device
+    _, wd = ops.pack_weights(f32dev(kt), cin, ops.DTYPE_CODE[td], transposed=True)
+    coef = torch.tensor(np.concatenate([c1, c2]), device=dev())
+    stats = ops.new_stats(cin, dev()) if sums else None
+    bst = dict(sums=stats, mean=f32dev(xmu), rstd=f32dev(xrs)) if sums else None
+    dx, dk = ops.convt_bwd_fused(to_dev(gcat, td), cs, to_dev(yup, td), f32dev(sc), f32dev(sh), f32dev(mu), f32dev(rs), coef, to_dev(xr, td), wd, cin, cout,
+                                 in_scale=f32dev(xsc) if aff else None, in_shift=f32dev(xsh) if aff else None, in_relu=aff, linear=linear, bst=bst)
+    torch.cuda.synchronize()
+    close(back(dx, cin), dx_ref, td, f'convT fused dx {case}')
+    close(back(dk), dk_ref, td, f'convT fused dK {case}', k=0.5)
+    if sums:
+        g = back(dx, cin)
+        v_mask = xa > 0
+        gg = np.where(v_mask, g, 0.0)
+        # xhat of the layer below from its raw output: (x - mean) * rstd
+        xh = (xr - xmu.astype(np.float64)) * xrs.astype(np.float64)
+        sgot = stats.sum(0).double().cpu().numpy()
+        tol = 3e-3 * np.sqrt(n * h * w) * max(1.0, float(np.abs(g).max()))
+        np.testing.assert_allclose(sgot[0], gg.sum((0, 1, 2)), rtol=2e-3, atol=tol, err_msg=f'sum g {case}')
+        # the device rebuilds xhat from the bf16 activation: one more storage rounding per element (DESIGN section 4)
+        np.testing.assert_allclose(sgot[1], (gg * xh).sum((0, 1, 2)), rtol=2e-2, atol=8 * tol * float(np.abs(xh).max()), err_msg=f'sum g xhat {case}')
+    # unsupported shapes are refused by the workspace query (the engine then keeps the three launches)
+    from satellite_computervision_amd._lib import lib
+    import ctypes
+    bad = ops.make_ctbf_desc(g=1 << 20, ldg=64, yup=1 << 20, ldy=48, bn_scale=None, bn_shift=None, bn_mean=None, bn_rstd=None, bn_c1=None, bn_c2=None, x=1 << 20, ldx=64,
+                             w_dgrad=1 << 20, w_npad=64, dx=1 << 20, lddx=64, dw=1 << 20, cin=64, cout=48, n=1, h=8, w_=64, dtype=1)
+    assert lib.satcv_convt_bwd_fused_workspace(ctypes.byref(bad)) < 0
+
+
 # ------------------------------------------------------------------------ batch norm
 @pytest.mark.parametrize('td', DT)
 @pytest.mark.parametrize('f', [2, 3])
