@@ -376,7 +376,8 @@ extern "C" int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream) {
   if (!igemm_force_generic()) {
     rc = convt_thin_launch(a, d->dtype, st);                 // thin transposed convolutions: streaming kernel
     if (rc == SATCV_ERR_UNSUPPORTED) rc = convt_thin_dgrad_launch(a, d->dtype, st);      // ... and their data gradients
-    if (rc == SATCV_ERR_UNSUPPORTED) rc = igemm_ws_launch(a, d->dtype, st, false);            // thin 3x3 layers: persistent weights-stationary kernel
+    if (rc == SATCV_ERR_UNSUPPORTED) rc = igemm_tr_launch(a, d->dtype, st, false);            // thin 3x3 layers: staging / matrix wave roles (round 5)
+    if (rc == SATCV_ERR_UNSUPPORTED) rc = igemm_ws_launch(a, d->dtype, st, false);            // ... or the persistent weights-stationary kernel (64 -> 64, fp8)
     if (rc == SATCV_ERR_UNSUPPORTED) rc = igemm_fast_launch(a, d->dtype, st);
   }
   if (rc != SATCV_ERR_UNSUPPORTED) { /* launched (or failed hard) */ }

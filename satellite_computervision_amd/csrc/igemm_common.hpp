@@ -521,6 +521,8 @@ int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run = fa
 int igemm_m16_launch(IgemmArgs& a, hipStream_t st, bool dry);
 // persistent weights-stationary kernel of the thin 3x3 layers (conv_igemm_ws.hip); SATCV_ERR_UNSUPPORTED outside its limits
 int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run);
+// the thin 3x3 layers with wave roles (conv_thin_roles.hip); SATCV_ERR_UNSUPPORTED outside its limits
+int igemm_tr_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry);
 // streaming kernel of the thin transposed convolutions (conv_transpose_thin.hip); SATCV_ERR_UNSUPPORTED outside its limits
 int convt_thin_launch(const IgemmArgs& a, int dtype, hipStream_t st);
 int convt_thin_dgrad_launch(const IgemmArgs& a, int dtype, hipStream_t st);

@@ -105,7 +105,7 @@ def _p(t):
 
 
 def conv2d(x, w_packed, cout, *, kh=3, kw=3, dil=1, bias=None, x1=None, in_scale=None, in_shift=None, in_relu=False,
-           stats=None, out=None, out_relu=False, stride=1, bst=None):
+           stats=None, out=None, out_relu=False, stride=1, bst=None, out_scale=None, pool_y=None, pool_f=0):
     """layers.Conv2D(cout,(kh,kw),padding='same',dilation_rate=dil) (utils/model_tools.py:178) on
     NHWC storage tensors; optional fused input BatchNorm-affine+ReLU and output sum/sumsq.  stride > 1 (ResNet backbone of the
     build-defined DeepLab): symmetric padding dil*(k-1)/2, output (h-1)//stride+1."""
@@ -119,6 +119,7 @@ def conv2d(x, w_packed, cout, *, kh=3, kw=3, dil=1, bias=None, x1=None, in_scale
                        cout=cout, cout_pad=cpad, dtype=dtype, in_scale=_p(in_scale), in_shift=_p(in_shift),
                        in_relu=in_relu, bias=_p(bias), stats=_p(stats), stats_ld=stats.shape[-1] if stats is not None else 0,
                        kh=kh, kw=kw, dil=dil, out_relu=out_relu, stride=stride, hin=hin if stride > 1 else 0, win=win if stride > 1 else 0,
+                       out_scale=_p(out_scale), pool_y=_p(pool_y), pool_ld=pool_y.shape[-1] if pool_y is not None else 0, pool_f=pool_f,
                        bst={k: (_p(v) if torch.is_tensor(v) else v) for k, v in bst.items()} if bst else None)
     if bst and lib.satcv_conv2d_igemm_pipelined(C.byref(d)) != 1:
         raise ValueError('conv2d: this shape cannot carry the fused BatchNorm-backward reduce (bst); run satcv_bn_bwd_reduce separately')

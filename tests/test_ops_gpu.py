@@ -412,6 +412,70 @@ def test_conv2d_weights_stationary_thin_kernel(ops, case, force_thin):
         close(back(dx, cout2), dx_ref, td, f'ws dgrad {case}')
 
 
+def roles_launches():
+    from satellite_computervision_amd._lib import lib, check
+    import ctypes
+    v = ctypes.c_int32()
+    check(lib.satcv_get_option(b'thin_roles_launches', ctypes.byref(v)))
+    return v.value
+
+
+@pytest.fixture
+def force_roles(ops):
+    """every shape conv_thin_roles.hip serves runs on it (the default routes only the shapes it measured faster on)"""
+    from satellite_computervision_amd._lib import lib, check
+    import ctypes
+    old = ctypes.c_int32()
+    check(lib.satcv_get_option(b'thin_roles', ctypes.byref(old)))
+    check(lib.satcv_set_option(b'thin_roles', 2))
+    yield
+    check(lib.satcv_set_option(b'thin_roles', old.value))
+
+
+@pytest.mark.parametrize('case', [(2, 32, 32, 4, 32), (1, 64, 64, 32, 32), (2, 40, 96, 64, 32), (3, 24, 32, 32, 64), (2, 64, 96, 16, 64), (1, 8, 32, 32, 32),
+                                  (9, 136, 224, 16, 32), (5, 12, 64, 64, 32), (1, 256, 256, 32, 32)])
+def test_conv2d_thin_layers_with_wave_roles(ops, case, force_thin, force_roles):
+    """conv_thin_roles.hip (staging / matrix wave roles), all five instantiations: forward with bias + BatchNorm statistics of the stored values,
+    the input BatchNorm + ReLU in the loader with a two-source input, one and many tiles per workgroup, 4-row tiles (64 -> 32: also maps
+    whose height is a multiple of 4 only), the folded inference epilogue (multiplier, ReLU, fused 2 x 2 max-pool)."""
+    td = torch.bfloat16
+    n, h, w, cin, cout = case
+    rng = np.random.default_rng(hash(case) % 2**31 + 5)
+    cpad = rup(cin, 16)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (3, 3, cin, cout), td, 0.2)
+    b = rng.standard_normal(cout)
+    ref = K.conv2d_same(x, kern, b, 1)
+    wf, _ = ops.pack_weights(f32dev(kern), cpad, ops.DTYPE_CODE[td], want_dgrad=False)
+    stats = ops.new_stats(cout, dev())
+    before = roles_launches()
+    y = ops.conv2d(to_dev(x, td, cpad), wf, cout, bias=f32dev(b), stats=stats)
+    assert roles_launches() - before == 1, 'path taken'
+    got = back(y, cout)
+    close(got, ref, td, f'roles conv {case}')
+    s = stats.sum(0).double().cpu().numpy()
+    np.testing.assert_allclose(s[0, :cout], got.sum((0, 1, 2)), rtol=2e-4, atol=2e-3 * np.sqrt(n * h * w))
+    np.testing.assert_allclose(s[1, :cout], (got ** 2).sum((0, 1, 2)), rtol=2e-4)
+    if cin >= 32:
+        # two sources (concat([skip, up])) + the producing layer's BatchNorm + ReLU in the loader
+        c0 = cin // 2
+        sc, sh = (rng.random(cin) + 0.5).astype(np.float32), (rng.standard_normal(cin) * 0.3).astype(np.float32)
+        a_ref = np.maximum(x * sc.astype(np.float64) + sh.astype(np.float64), 0)
+        a_ref = torch.tensor(a_ref, dtype=torch.float32).to(td).double().numpy()
+        ref2 = K.conv2d_same(a_ref, kern, b, 1)
+        y2 = ops.conv2d(to_dev(x[..., :c0], td), wf, cout, x1=to_dev(x[..., c0:], td), bias=f32dev(b), in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
+        close(back(y2, cout), ref2, td, f'roles conv, two sources + affine {case}', k=2.0)
+    if h % 8 == 0:
+        # folded inference epilogue: per-channel multiplier, ReLU, 2 x 2 max-pool of the stored tile
+        osc = (rng.random(cout) + 0.5).astype(np.float32)
+        ref3 = np.maximum(K.conv2d_same(x, kern, np.zeros(cout), 1) * osc.astype(np.float64) + b, 0)
+        pooled = torch.zeros(n, h // 2, w // 2, cout, dtype=td, device=dev())
+        y3 = ops.conv2d(to_dev(x, td, cpad), wf, cout, bias=f32dev(b), out_scale=f32dev(osc), out_relu=True, pool_y=pooled, pool_f=2)
+        g3 = back(y3, cout)
+        close(g3, ref3, td, f'roles conv, folded epilogue {case}')
+        assert np.array_equal(back(pooled, cout), g3.reshape(n, h // 2, 2, w // 2, 2, cout).max((2, 4)))
+
+
 def test_conv2d_weights_stationary_dual_source_affine(ops, force_thin):
     """dec0.conv1 through the thin kernel: concat([skip 32, up 32]) -> BN -> ReLU in the loader, -> 32 channels"""
     td = torch.bfloat16
