@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libsatcv.so')
 OBJDIR = os.path.join(HERE, 'csrc', '_obj')
-SOURCES = ['api.hip', 'comm.hip', 'conv_igemm.hip', 'conv_igemm_fast.hip', 'conv_igemm_m16.hip', 'conv_igemm_ws.hip', 'conv_thin_roles.hip', 'conv_transpose_thin.hip', 'conv_bwd_fused.hip', 'convt_bwd_fused.hip', 'conv_wgrad.hip', 'convlstm.hip', 'elementwise.hip', 'input_pipeline.hip']
+SOURCES = ['api.hip', 'comm.hip', 'conv_igemm.hip', 'conv_igemm_fast.hip', 'conv_igemm_m16.hip', 'conv_igemm_m16p.hip', 'conv_igemm_ws.hip', 'conv_thin_roles.hip', 'conv_transpose_thin.hip', 'conv_bwd_fused.hip', 'convt_bwd_fused.hip', 'conv_wgrad.hip', 'convlstm.hip', 'elementwise.hip', 'input_pipeline.hip']
 EXTRA = []
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-Wno-unused-variable', '-Wno-pass-failed']

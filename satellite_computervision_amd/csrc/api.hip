@@ -136,6 +136,8 @@ int g_opt_wgrad_db = env_int("SATCV_WGRAD_DB", 1);
 int g_opt_igemm_sched = env_int("SATCV_IGEMM_SCHED", 0);
 int g_opt_igemm_thin = env_int("SATCV_THIN", 1);      // 0 off, 1 / 2 on wherever the shape limits allow (independent of the batch size)
 int g_opt_igemm_m16 = env_int("SATCV_M16", 1);       // the 16x16x32 deep 3x3 tile: 0 off, 1 launches that produce statistics (training), 2 every eligible launch
+int g_opt_m16p = env_int("SATCV_M16P", 1);               // conv_igemm_m16p.hip (persistent 16x16x32 tile): 0 off, 1 where a workgroup gets >= 2 tiles, 2 every eligible launch
+extern int g_m16p_launches;
 int g_tr_launches = 0;                                   // launches conv_thin_roles.hip took (tests: "path taken")
 int g_opt_thin_roles = env_int("SATCV_THIN_ROLES", 1);   // conv_thin_roles.hip: 0 off, 1 the shapes it measured faster on, 2 every shape it serves
 int g_opt_splitk = env_int("SATCV_SPLITK", 0);         // split-K of under-filled PLAIN (halo-tile / 1x1) launches: opt-in, see conv_igemm_fast.hip
@@ -149,6 +151,8 @@ static int* opt_slot(const char* key) {
   if (!strcmp(key, "igemm_m16")) return &g_opt_igemm_m16;
   if (!strcmp(key, "thin_roles")) return &g_opt_thin_roles;
   if (!strcmp(key, "thin_roles_launches")) return &g_tr_launches;
+  if (!strcmp(key, "m16p")) return &g_opt_m16p;
+  if (!strcmp(key, "m16p_launches")) return &g_m16p_launches;
   return nullptr;
 }
 extern "C" int satcv_set_option(const char* key, int32_t value) {

@@ -850,6 +850,13 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
     // deep 3x3 layers: 256-pixel x 128-channel tile, 8 waves, double-buffered stages (SATCV_DB=0 keeps the 128 x 128 tile)
     const int db_mode = g_opt_igemm_db;
     a.dbg = g_opt_igemm_sched;            // (experiment bits; none wired at present)
+    // round 5: the persistent 16x16x32 kernel (conv_igemm_m16p.hip) takes the mid layers -- 64 ... 256 input channels, Cout % 128 == 0, several
+    // tiles per workgroup -- under the same option as the one-tile 16x16x32 kernels below (launches that write statistics, or every launch of a
+    // training plan)
+    if (TW == 32 && a.dil == 1 && (g_opt_igemm_m16 >= 2 || (g_opt_igemm_m16 == 1 && (a.stats || a.bst_y)))) {
+      const int rc = igemm_m16p_launch(a, st, dry);
+      if (rc != SATCV_ERR_UNSUPPORTED) return rc;
+    }
     // (K = 9 x 64 is four chunks: the double-buffered tile's longer set-up and epilogue are not amortised -- 64 -> 128 channels at 128 x 128
     //  258 vs 235 us, at 64 x 64 67.6 vs 63.3 us on the 128 x 128 tile; from 128 input channels on it wins, profiles/r03_db_vs_single.txt)
     if (db_mode && a.dil == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && nspace % 128 == 0 && (cin >= 128 || db_mode >= 2)) {

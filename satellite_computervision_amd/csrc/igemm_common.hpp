@@ -519,6 +519,8 @@ static inline int igemm_pick_tw(int w) {
 int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run = false);
 // the deep 3x3 tile on v_mfma_f32_16x16x32_bf16 (conv_igemm_m16.hip); SATCV_ERR_UNSUPPORTED outside its limits
 int igemm_m16_launch(IgemmArgs& a, hipStream_t st, bool dry);
+// the same tile as a persistent, cross-tile pipelined kernel for the mid layers (conv_igemm_m16p.hip); SATCV_ERR_UNSUPPORTED outside its limits
+int igemm_m16p_launch(IgemmArgs& a, hipStream_t st, bool dry);
 // persistent weights-stationary kernel of the thin 3x3 layers (conv_igemm_ws.hip); SATCV_ERR_UNSUPPORTED outside its limits
 int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run);
 // the thin 3x3 layers with wave roles (conv_thin_roles.hip); SATCV_ERR_UNSUPPORTED outside its limits

@@ -291,6 +291,97 @@ def test_16x16x32_tile_fused_bn_backward_sums(ops, case, force_db):
         np.testing.assert_allclose(got[1], (gg * xh).sum((0, 1, 2)), rtol=1e-4, atol=tol * float(np.abs(xh).max()), err_msg=f'sum g xhat {case} relu={relu}')
 
 
+def m16p_launches():
+    from satellite_computervision_amd._lib import lib, check
+    import ctypes
+    v = ctypes.c_int32()
+    check(lib.satcv_get_option(b'm16p_launches', ctypes.byref(v)))
+    return v.value
+
+
+@pytest.fixture
+def force_m16p(ops):
+    """every launch conv_igemm_m16p.hip serves runs on it (the default leaves launches with one tile per workgroup to the one-tile kernels),
+    inference-style launches (no statistics) included"""
+    from satellite_computervision_amd._lib import lib, check
+    import ctypes
+    old = {}
+    for k, v in ((b'm16p', 2), (b'igemm_m16', 2)):
+        o = ctypes.c_int32()
+        check(lib.satcv_get_option(k, ctypes.byref(o)))
+        old[k] = o.value
+        check(lib.satcv_set_option(k, v))
+    yield
+    for k, v in old.items():
+        check(lib.satcv_set_option(k, v))
+
+
+# n, h, w, cin, cout, split of the input (two sources) / of the raw outputs of the fused sums
+M16P_CASES = [(2, 32, 32, 64, 128, 0), (1, 64, 64, 128, 256, 64), (9, 128, 96, 64, 128, 32), (3, 40, 64, 256, 128, 128), (40, 64, 64, 64, 128, 0), (2, 16, 64, 192, 384, 64)]
+
+
+@pytest.mark.parametrize('case', M16P_CASES)
+def test_conv2d_persistent_16x16x32_kernel(ops, case, force_m16p):
+    """conv_igemm_m16p.hip (persistent, cross-tile pipelined 16x16x32 tile; staging / matrix wave roles, weights by LDS-DMA, swapped MFMA
+    operands, swizzled staging image): one, two and many tiles per workgroup, ranges of unequal length, 1 - 3 output-channel blocks, 2 - 8
+    chunks per tile.  Forward with bias + statistics of the stored values; two sources + the producing layer's BatchNorm + ReLU in the loader;
+    the data gradient with the fused BatchNorm-backward sums over one or two raw-output tensors."""
+    n, h, w, cin, cout, split = case
+    td = torch.bfloat16
+    rng = np.random.default_rng(hash(case) % 2**31 + 11)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (3, 3, cin, cout), td, 0.1)
+    b = rng.standard_normal(cout)
+    ref = K.conv2d_same(x, kern, b, 1)
+    wf, _ = ops.pack_weights(f32dev(kern), cin, ops.DTYPE_CODE[td], want_dgrad=False)
+    stats = ops.new_stats(cout, dev())
+    before = m16p_launches()
+    y = ops.conv2d(to_dev(x, td), wf, cout, bias=f32dev(b), stats=stats)
+    assert m16p_launches() - before == 1, 'path taken'
+    got = back(y, cout)
+    close(got, ref, td, f'persistent conv {case}')
+    s = stats.sum(0).double().cpu().numpy()
+    np.testing.assert_allclose(s[0, :cout], got.sum((0, 1, 2)), rtol=2e-4, atol=2e-3 * np.sqrt(n * h * w))
+    np.testing.assert_allclose(s[1, :cout], (got ** 2).sum((0, 1, 2)), rtol=2e-4)
+    # no statistics (the launch of a training plan whose BatchNorm is frozen / an inference launch under option igemm_m16 = 2): same values
+    y_ns = ops.conv2d(to_dev(x, td), wf, cout, bias=f32dev(b))
+    assert torch.equal(y_ns, y)
+    if split:
+        sc, sh = (rng.random(cin) + 0.5).astype(np.float32), (rng.standard_normal(cin) * 0.3).astype(np.float32)
+        a_ref = np.maximum(x * sc.astype(np.float64) + sh.astype(np.float64), 0)
+        a_ref = torch.tensor(a_ref, dtype=torch.float32).to(td).double().numpy()
+        ref2 = K.conv2d_same(a_ref, kern, b, 1)
+        before = m16p_launches()
+        y2 = ops.conv2d(to_dev(x[..., :split], td), wf, cout, x1=to_dev(x[..., split:], td), bias=f32dev(b), in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
+        assert m16p_launches() - before == 1, 'path taken'
+        close(back(y2, cout), ref2, td, f'persistent conv, two sources + affine {case}', k=2.0)
+    # fused BatchNorm-backward sums (the launch writes dL/d act of a conv -> BN -> ReLU layer whose raw outputs are v)
+    ref0 = ref - b
+    v = torch.tensor(rnd(rng, (n, h, w, cout), td) * 1.5 + 0.25, dtype=torch.float32).to(td).double().numpy()
+    bsc, bsh = rng.standard_normal(cout).astype(np.float32), rng.standard_normal(cout).astype(np.float32) * 0.5
+    mu, rs = rng.standard_normal(cout).astype(np.float32) * 0.3, (0.5 + rng.random(cout)).astype(np.float32)
+    vs = cout // 2 if split else 0
+    v0 = to_dev(v[..., :vs] if vs else v, td)
+    v1 = to_dev(v[..., vs:], td) if vs else None
+    for relu in (1, 0):
+        st = ops.new_stats(cout, dev())
+        bst = dict(y=v0, ld=v0.shape[-1], scale=f32dev(bsc), shift=f32dev(bsh), mean=f32dev(mu), rstd=f32dev(rs), relu=relu)
+        if vs:
+            bst.update(y1=v1, ld1=v1.shape[-1], split=vs)
+        before = m16p_launches()
+        yb = ops.conv2d(to_dev(x, td), wf, cout, stats=st, bst=bst)
+        assert m16p_launches() - before == 1, 'path taken'
+        g = back(yb, cout)
+        close(g, ref0, td, f'persistent conv with fused sums {case}')
+        mask = (v * bsc.astype(np.float64) + bsh.astype(np.float64) > 0) if relu else np.ones_like(v, bool)
+        gg = np.where(mask, g, 0.0)
+        xh = (v - mu.astype(np.float64)) * rs.astype(np.float64)
+        gs = st.sum(0).double().cpu().numpy()
+        tol = 2e-4 * np.sqrt(n * h * w) * max(1.0, float(np.abs(g).max()))
+        np.testing.assert_allclose(gs[0], gg.sum((0, 1, 2)), rtol=1e-4, atol=tol, err_msg=f'sum g {case} relu={relu}')
+        np.testing.assert_allclose(gs[1], (gg * xh).sum((0, 1, 2)), rtol=1e-4, atol=tol * float(np.abs(xh).max()), err_msg=f'sum g xhat {case} relu={relu}')
+
+
 def test_reduce_slabs_batched(ops):
     """satcv_reduce_slabs_batched: several layers' fp32 partial slabs summed in ONE launch (few / many slabs -> 1 ... 16 lanes per output, plain HWIO
     and transposed-conv layouts, accumulate, padded slab rows) against float64 sums; two runs are bit-identical (fixed summation order)."""

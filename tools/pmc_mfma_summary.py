@@ -5,7 +5,7 @@ MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES (pipe-busy cycles summed over every 
 MI355X_MICROARCH.md) / (GRBM_GUI_ACTIVE cycles of the dispatch x 1024 SIMDs)."""
 import csv, glob, json, sys, collections
 d, out = sys.argv[1], sys.argv[2]
-CLASSES = (('bwd_fused', 'bwd_fused_3x3'), ('convt_thin', 'convT_streaming'), ('Li9ELb', 'igemm_3x3'), ('igemm_fast', 'igemm_1x1_convT'), ('igemm_kernel', 'igemm_generic'), ('wgrad_kernel', 'wgrad'), ('wgrad_db_kernel', 'wgrad'), ('wgrad_dma_kernel', 'wgrad'), ('wgrad_reduce', 'wgrad_reduce'), ('igemm_ws', 'igemm_3x3'),
+CLASSES = (('convt_bwd_fused', 'convT_bwd_fused'), ('bwd_fused', 'bwd_fused_3x3'), ('igemm_m16', 'igemm_3x3'), ('igemm_tr_kernel', 'igemm_3x3'), ('reduce_slabs_batched', 'wgrad_reduce'), ('convt_thin', 'convT_streaming'), ('Li9ELb', 'igemm_3x3'), ('igemm_fast', 'igemm_1x1_convT'), ('igemm_kernel', 'igemm_generic'), ('wgrad_kernel', 'wgrad'), ('wgrad_db_kernel', 'wgrad'), ('wgrad_dma_kernel', 'wgrad'), ('wgrad_reduce', 'wgrad_reduce'), ('igemm_ws', 'igemm_3x3'),
            ('bn_bwd', 'bn_bwd'), ('bn_relu_pool', 'bn_relu_pool'), ('head_', 'head'))
 f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
 CLOCK_GHZ = 2.4                                  # peak engine clock; the dispatch duration comes from the kernel trace of the same run

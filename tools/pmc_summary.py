@@ -6,7 +6,7 @@ Counter unit: KiB."""
 import csv, glob, json, sys, collections
 fdir, wdir, out = sys.argv[1], sys.argv[2], sys.argv[3]
 commit = sys.argv[4] if len(sys.argv) > 4 else 'unknown'
-CLASSES = (('bwd_fused', 'bwd_fused_3x3'), ('convt_thin', 'convT_streaming'), ('Li9ELb', 'igemm_3x3'), ('igemm_fast', 'igemm_1x1_convT'), ('igemm_kernel', 'igemm_generic'), ('wgrad_kernel', 'wgrad'), ('wgrad_db_kernel', 'wgrad'), ('wgrad_dma_kernel', 'wgrad'), ('wgrad_reduce', 'wgrad_reduce'), ('igemm_ws', 'igemm_3x3'),
+CLASSES = (('convt_bwd_fused', 'convT_bwd_fused'), ('bwd_fused', 'bwd_fused_3x3'), ('igemm_m16', 'igemm_3x3'), ('igemm_tr_kernel', 'igemm_3x3'), ('reduce_slabs_batched', 'wgrad_reduce'), ('convt_thin', 'convT_streaming'), ('Li9ELb', 'igemm_3x3'), ('igemm_fast', 'igemm_1x1_convT'), ('igemm_kernel', 'igemm_generic'), ('wgrad_kernel', 'wgrad'), ('wgrad_db_kernel', 'wgrad'), ('wgrad_dma_kernel', 'wgrad'), ('wgrad_reduce', 'wgrad_reduce'), ('igemm_ws', 'igemm_3x3'),
            ('bn_bwd', 'bn_bwd'), ('bn_relu_pool', 'bn_relu_pool'), ('head_', 'head'), ('adam', 'adam'), ('pack_kernel', 'pack'))
 
 def load(d):

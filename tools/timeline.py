@@ -28,7 +28,7 @@ print('per queue busy us:', {k: round(v / 1e3, 1) for k, v in q.items()})
 
 
 def cls(n):
-    for k in ('bwd_fused', 'convt_thin_dgrad', 'convt_thin', 'igemm_ws', 'igemm_fast', 'igemm_kernel', 'wgrad_dma', 'wgrad_db', 'bn_bwd_finalize2', 'wgrad_kernel', 'wgrad_reduce', 'bn_bwd_dense', 'bn_bwd_finalize', 'bn_bwd', 'bn_relu_pool', 'bn_finalize',
+    for k in ('convt_bwd_fused', 'bwd_fused', 'igemm_m16sym', 'igemm_m16', 'igemm_tr_kernel', 'reduce_slabs_batched', 'convt_thin_dgrad', 'convt_thin', 'igemm_ws', 'igemm_fast', 'igemm_kernel', 'wgrad_dma', 'wgrad_db', 'bn_bwd_finalize2', 'wgrad_kernel', 'wgrad_reduce', 'bn_bwd_dense', 'bn_bwd_finalize', 'bn_bwd', 'bn_relu_pool', 'bn_finalize',
               'pack_kernel', 'head_', 'loss', 'adam', 'Fill', 'ingest', 'dropout', 'maxpool'):
         if k in n:
             return k
