@@ -220,15 +220,23 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
       }
     };
     auto drain_rounds = [&](int cnt) __attribute__((always_inline)) {
+      // (the image reads of all rounds first: one LDS latency per interval, not one per round)
+      uint4 dv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r < cnt && d_round + r < G::ROUNDS) {
+          const int q = pq0 + (d_round + r) * 16;
+          dv[r] = *reinterpret_cast<const uint4*>(ldsO + q * BN + ((vq ^ (q & 15)) << 3));
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (r < cnt && d_round < G::ROUNDS) {
           const int q = pq0 + d_round * 16;
-          const uint4 dv = *reinterpret_cast<const uint4*>(ldsO + q * BN + ((vq ^ (q & 15)) << 3));
           unsigned off = ((unsigned)(q >> 5) * (unsigned)a.w_ + (unsigned)(q & 31)) * (unsigned)a.ldy + (unsigned)cg;
           asm volatile("" : "+v"(off));
-          *reinterpret_cast<uint4*>(d_o + off) = dv;
-          const bf16x8 d8 = __builtin_bit_cast(bf16x8, dv);
+          *reinterpret_cast<uint4*>(d_o + off) = dv[r];
+          const bf16x8 d8 = __builtin_bit_cast(bf16x8, dv[r]);
           if constexpr (BST) {
             const bf16x8 y8 = __builtin_bit_cast(bf16x8, yv[r]);
             int toff = vq * 8;
@@ -272,10 +280,16 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
     // one chunk = three intervals; PAR = parity of the chunk (= of the stage it is read from).  Chunk gc + 1 moves from its register set to
     // the other stage TWO ITEMS PER INTERVAL (the stage fell free at the barrier that started chunk gc), each pair reloaded at once with its
     // items of chunk gc + 3: the vector work of the stream is spread evenly over the intervals, like the drain's rounds
-    auto chunk_intervals = [&](auto PAR, int x, int t) __attribute__((always_inline)) {
+    // MAIN: the steady state -- every pair is stored and reloaded unconditionally.  hipcc sizes an `s_waitcnt vmcnt(N)` by the FEWEST
+    // vector-memory operations on any path between a load and its use; with the stream's end handled by conditions inside the loop, a path
+    // without reloads exists and every use waited for (nearly) everything in flight -- the drain's global stores of the interval before
+    // included (`vmcnt(1)` in front of each reload, ~1 us per interval).  The steady-state loop has no such path (>= 10 younger loads when
+    // a pair is used); the last chunks run in a second copy of the body with the conditions.
+    auto chunk_intervals = [&](auto PAR, auto MAINC, int x, int t) __attribute__((always_inline)) {
       constexpr int P = decltype(PAR)::value;
+      constexpr bool MAIN = decltype(MAINC)::value;
       const std::integral_constant<int, P ^ 1> SN{};
-      const bool st = gc + 1 < nc && !PABL(8), ld = gc + 3 < nc && !PABL(8) && !PABL(64);
+      const bool st = (MAIN || gc + 1 < nc) && !PABL(8), ld = (MAIN || gc + 3 < nc) && !PABL(8) && !PABL(64);
       auto pair = [&](auto J0C) __attribute__((always_inline)) {
         if (st) store_items(s_x, SN, J0C, I2);
         if (ld) load_items(SN, J0C, I2);
@@ -299,10 +313,18 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
       }
       ++gc;
     };
-    for (int t = 0; t < ntl; ++t) {
-      for (int x = 0; x < nch; x += 2) {
-        chunk_intervals(S0, x, t);
-        chunk_intervals(S1, x + 1, t);
+    {
+      int t = 0, x = 0;
+      auto advance = [&]() __attribute__((always_inline)) { x += 2; if (x == nch) { x = 0; ++t; } };
+      while (gc + 4 < nc) {                                                  // both chunks of the pair reload: gc + 1 + 3 < nc
+        chunk_intervals(S0, std::true_type{}, x, t);
+        chunk_intervals(S1, std::true_type{}, x + 1, t);
+        advance();
+      }
+      while (gc < nc) {
+        chunk_intervals(S0, std::false_type{}, x, t);
+        chunk_intervals(S1, std::false_type{}, x + 1, t);
+        advance();
       }
     }
     // the last tile's image
