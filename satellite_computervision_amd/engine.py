@@ -266,7 +266,9 @@ class Plan:
         self.x_inputs = []                    # fp32 staging tensor of every model input
         self.x_by_tid = {}
         self.x_src = {}                       # tensor id -> device pointer of a caller's batch read in place (Model._stage_x), else the staging tensor
-        self.side = torch.cuda.Stream() if (training and rt.model.wgrad_side_stream) else None
+        # (SATCV_SIDE_PRIORITY: HIP stream priority of the weight-gradient stream -- positive = lower than the main stream; measured)
+        _sp = os.environ.get('SATCV_SIDE_PRIORITY')
+        self.side = (torch.cuda.Stream(priority=int(_sp)) if _sp is not None else torch.cuda.Stream()) if (training and rt.model.wgrad_side_stream) else None
         self.step_count = 0
         self.outputs = {}
         self.sync_bn = bool(training and getattr(rt.model, 'sync_bn', False) and parallel.active())

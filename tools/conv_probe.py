@@ -56,3 +56,6 @@ def run(n, h, w, cin, cout, k=3):
 print('lib', os.environ.get('SATCV_LIB'), 'opts', args.opt, 'affine', args.affine)
 for shp in shapes:
     run(*shp)
+_v = C.c_int32()
+if lib.satcv_get_option(b'm16p_launches', C.byref(_v)) == 0:
+    print('launches on the persistent 16x16x32 kernel:', _v.value)

@@ -28,6 +28,9 @@ args = ap.parse_args()
 
 from satellite_computervision_amd import model_tools as mt, ops
 from satellite_computervision_amd._lib import lib, check
+# the launches are replayed one by one outside Plan._run, which raises option igemm_m16 to 2 around a training plan's steps (every eligible
+# launch on the 16x16x32 tiles, not only those that write statistics): do the same here, so that the probe times the kernels the step runs
+check(lib.satcv_set_option(b'igemm_m16', 2))
 for kv in args.opt:
     k, v = kv.split('=')
     check(lib.satcv_set_option(k.encode(), int(v)))
@@ -73,6 +76,9 @@ for phase, steps in (('fwd', plan.fwd), ('bwd', plan.bwd)):
         elif w['kind'] == 'bwd_fused':          # BatchNorm apply + data gradient + weight gradient in one launch: g, y, x in, dx out
             fl = 4.0 * w['px'] * w['cin'] * w['cout'] * w['taps']
             by = w['px'] * (2 * w['cout'] + 2 * w['cin']) * es
+        elif w['kind'] == 'convt_bwd_fused':    # concat-BN apply of the `up` half + transposed-conv data + weight gradient: g, y_up (4 px x cout each), x in, dx out
+            fl = 4.0 * w['px'] * w['cin'] * 4 * w['cout']
+            by = (2 * 4 * w['px'] * w['cout'] + 2 * w['px'] * w['cin']) * es
         elif w['kind'] == 'bn_bwd_reduce':
             fl, by = 0.0, 2 * w['px'] * w['c'] * es
         else:
@@ -89,11 +95,12 @@ def tot(pred):
 for name, pred in (('3x3 fwd+dgrad', lambda r: r['label'].startswith('conv_') and ' k3 ' in r['label']),
                    ('1x1/convT', lambda r: r['label'].startswith('conv_') and ' k1 ' in r['label']),
                    ('fused bwd', lambda r: r['label'].startswith('bwd_fused')),
+                   ('convT fused bwd', lambda r: r['label'].startswith('convt_bwd_fused')),
                    ('wgrad', lambda r: r['label'].startswith('wgrad')),
                    ('bn_bwd', lambda r: r['label'].startswith('bn_bwd'))):
     us, gf, roof, cnt = tot(pred)
     if cnt:
-        print(f"TOTAL {name:14s}: {cnt:3d} launches {us:9.1f} us  {gf / max(us, 1e-9) / 1e3:7.1f} TF/s  sum-of-rooflines {roof:8.1f} us  frac {roof / us:.3f}")
+        print(f"TOTAL {name:15s}: {cnt:3d} launches {us:9.1f} us  {gf / max(us, 1e-9) / 1e3:7.1f} TF/s  sum-of-rooflines {roof:8.1f} us  frac {roof / us:.3f}")
 for t in plan.keep:            # sums buffers are the float64 tensors of the plan: clear them, then one clean step
     if isinstance(t, torch.Tensor) and t.dtype == torch.float64:
         t.zero_()
