@@ -259,9 +259,63 @@ extern "C" int satcv_dense_small_fwd(const satcv_dense_desc* d, void* stream) {
 }
 
 // stage 1: dz = dout * act'(z) (ReLU(max) / linear; softmax and sigmoid heads receive dlogits from the loss kernel: pass activation 2),
-// dW and db by per-block LDS sums + float atomics (order-dependent in the last bits: these layers have a few hundred parameters);
-// dx of the sources at output resolution.  stage 2 (resized sources): every SOURCE pixel gathers over its pre-image (deterministic).
-__global__ __launch_bounds__(EW_BLOCK) void dense_small_bwd_kernel(const satcv_dense_desc d) {
+// dW and db, dx of the sources at output resolution.  stage 2 (resized sources): every SOURCE pixel gathers over its pre-image (deterministic).
+//
+// Round 5: ONE THREAD PER INPUT ROW.  Thread (pixel lane, row c) walks the lane's pixels, keeps dW[c][0 .. k) in registers and writes dx[p][c]; the
+// extra row `rows` of a lane carries db (and writes dz_out).  Lanes are summed through LDS once per block, blocks by float atomics (order-dependent
+// in the last bits, as before: these layers have a few hundred parameters).  The first form added every pixel's products to ONE LDS image with
+// atomics -- 256 threads on the same addresses: 0.31 ms per launch, half of a get_lstm_model training step (profiles/r05_lstm_kernel_stats.csv).
+__global__ __launch_bounds__(EW_BLOCK) void dense_small_bwd_kernel(const satcv_dense_desc d, const int rows, const int pl) {
+  extern __shared__ float red[];                  // [pl][rows + 1][k]
+  const int k = d.cout, rp = rows + 1;
+  const int lanep = threadIdx.x / rp, c = threadIdx.x - lanep * rp;
+  const bool live = lanep < pl;
+  const int si = (c < rows && c >= d.src[0].cin) ? 1 : 0;
+  const satcv_dense_src& s = d.src[si];
+  const int cc = c - (si ? d.src[0].cin : 0);
+  float acc[DENSE_KMAX], wr[DENSE_KMAX];
+#pragma unroll
+  for (int j = 0; j < DENSE_KMAX; ++j) { acc[j] = 0.f; wr[j] = (j < k && c < rows) ? d.w[c * k + j] : 0.f; }
+  if (live) {
+    for (long long p = (long long)blockIdx.x * pl + lanep; p < d.npix; p += (long long)gridDim.x * pl) {
+      float dz[DENSE_KMAX];
+#pragma unroll
+      for (int j = 0; j < DENSE_KMAX; ++j) {
+        float g = 0.f;
+        if (j < k) {
+          g = d.dout[p * k + j];
+          if (d.activation == 3) { const float o = d.out[p * k + j]; g = (o > 0.f && (d.max_value <= 0.f || o < d.max_value)) ? g : 0.f; }
+        }
+        dz[j] = g;
+      }
+      if (c == rows) {
+#pragma unroll
+        for (int j = 0; j < DENSE_KMAX; ++j) if (j < k) { acc[j] += dz[j]; if (d.dz_out) d.dz_out[p * k + j] = dz[j]; }
+      } else {
+        const long long q = dense_src_pix(s, p, d.h, d.w_);
+        const float a = dense_src_val(s, q, cc);
+        float dx = 0.f;
+#pragma unroll
+        for (int j = 0; j < DENSE_KMAX; ++j) { acc[j] += a * dz[j]; dx += dz[j] * wr[j]; }
+        if (s.dx && s.hs == 0) {
+          if (s.dx_dtype == SATCV_BF16) reinterpret_cast<bf16*>(s.dx)[q * s.lddx + cc] = (bf16)dx;
+          else reinterpret_cast<float*>(s.dx)[q * s.lddx + cc] = dx;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DENSE_KMAX; ++j) if (j < k) red[(lanep * rp + c) * k + j] = acc[j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < rp * k; i += blockDim.x) {
+    float t = 0.f;
+    for (int l = 0; l < pl; ++l) t += red[l * rp * k + i];
+    if (i < rows * k) atomicAdd(d.dw + i, t);
+    else atomicAdd(d.db + (i - rows * k), t);
+  }
+}
+// (more than 255 input rows: every pixel's products added to one LDS image with atomics)
+__global__ __launch_bounds__(EW_BLOCK) void dense_small_bwd_wide_kernel(const satcv_dense_desc d) {
   extern __shared__ float acc[];                  // [rows + 1][k]: dW rows then db
   const int k = d.cout;
   int rows = 0;
@@ -346,7 +400,15 @@ extern "C" int satcv_dense_small_bwd(const satcv_dense_desc* d, void* stream) {
   SATCV_CHECK(!resized || d->dz_out, "dense_small_bwd: a resized source with a data gradient needs dz_out");
   SATCV_CHECK((size_t)(rows + 1) * d->cout * sizeof(float) <= 48 * 1024, "dense_small_bwd: too many input channels");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(dense_small_bwd_kernel, dim3(lstm_grid(d->npix)), dim3(EW_BLOCK), (size_t)(rows + 1) * d->cout * sizeof(float), st, *d);
+  if (rows + 1 <= EW_BLOCK) {
+    const int pl = EW_BLOCK / (rows + 1);
+    long long grid = (d->npix + (long long)pl * 16 - 1) / ((long long)pl * 16);     // ~16 pixels per lane and block
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(dense_small_bwd_kernel, dim3((unsigned)grid), dim3(EW_BLOCK), (size_t)pl * (rows + 1) * d->cout * sizeof(float), st, *d, rows, pl);
+  } else {
+    hipLaunchKernelGGL(dense_small_bwd_wide_kernel, dim3(lstm_grid(d->npix)), dim3(EW_BLOCK), (size_t)(rows + 1) * d->cout * sizeof(float), st, *d);
+  }
   LSTM_OK("dense_small_bwd");
   int row0 = 0;
   for (int i = 0; i < d->nsrc; ++i) {
