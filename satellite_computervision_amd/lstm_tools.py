@@ -41,6 +41,54 @@ class _Params:
         self.flat = self.grad = self.m = self.v = None
         self.state = None
         self.init = {}
+        # MFMA operand images of the convolution kernels (kernel name -> forward / data-gradient image), valid for parameter version `ver`
+        self.version = 0
+        self._pk, self._pk_tab, self._pk_dtype = {}, None, None
+
+    def bump(self):
+        """the parameters changed (optimizer step, set_weights): every packed image is stale"""
+        self.version += 1
+
+    def get_packed(self, name, cin_pad, dtype):
+        """forward and data-gradient operand images of Conv2D kernel `name` (ops.pack_weights layouts).  The images live in persistent buffers;
+        when the parameters have changed since they were packed, ALL registered kernels are repacked by ONE launch (satcv_pack_weights_batched) --
+        a training step packed every layer's kernels with a launch each (40 launches of ~5 us in a get_lstm_model step: profiles/r05_lstm_kernel_stats.csv),
+        and inference repacked unchanged weights on every call."""
+        if self._pk_dtype != dtype:
+            self._pk, self._pk_tab, self._pk_dtype = {}, None, dtype
+        e = self._pk.get(name)
+        if e is None:
+            k = self.p(name)
+            fwd, dg = ops.pack_weights(k, cin_pad, dtype)
+            self._pk[name] = e = dict(fwd=fwd, dg=dg, cin_pad=cin_pad, shape=tuple(k.shape), ver=self.version)
+            self._pk_tab = None
+            return fwd, dg
+        if e['cin_pad'] != cin_pad:
+            raise ValueError(f'{name}: packed with cin_pad {e["cin_pad"]}, asked for {cin_pad}')
+        if e['ver'] != self.version:
+            self._repack_all(dtype)
+        return e['fwd'], e['dg']
+
+    def _repack_all(self, dtype):
+        from ._lib import PackJob
+        if self._pk_tab is None:
+            jobs = []
+            for name, e in self._pk.items():
+                kh, kw, cin, cout = e['shape']
+                src = self.p(name).data_ptr()
+                jobs.append(PackJob(src, e['fwd'].data_ptr(), 0, kh * kw, cin, cout, e['cin_pad'], ops.rup(cout, 32)))
+                jobs.append(PackJob(src, e['dg'].data_ptr(), 1, kh * kw, cin, cout, ops.rup(cout, 16), ops.rup(cin, 32)))
+            prefix, tot = [], 0
+            for j in jobs:
+                prefix.append(tot)
+                tot += int(lib.satcv_pack_job_items(C.byref(j)))
+            arr = (PackJob * len(jobs))(*jobs)
+            self._pk_tab = dict(jobs=torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(_dev()),
+                                prefix=torch.tensor(prefix, dtype=torch.int64, device=_dev()), n=len(jobs), total=tot)
+        t = self._pk_tab
+        check(lib.satcv_pack_weights_batched(t['jobs'].data_ptr(), t['prefix'].data_ptr(), t['n'], t['total'], dtype, ops.stream_ptr()))
+        for e in self._pk.values():
+            e['ver'] = self.version
 
     def add(self, name, shape, init, trainable=True):
         size = int(np.prod(shape))
@@ -127,8 +175,8 @@ class ConvLSTM2D:
     def _pack(self, dtype):
         P = self.P
         cpad = ops.rup(self.cin, 16)
-        self.wk, self.wk_d = ops.pack_weights(P.p(f'{self.name}/kernel'), cpad, dtype)
-        self.wr, self.wr_d = ops.pack_weights(P.p(f'{self.name}/recurrent_kernel'), ops.rup(self.F, 16), dtype)
+        self.wk, self.wk_d = P.get_packed(f'{self.name}/kernel', cpad, dtype)
+        self.wr, self.wr_d = P.get_packed(f'{self.name}/recurrent_kernel', ops.rup(self.F, 16), dtype)
 
     def forward(self, x, T, B, training, dtype, want_stats=True, repeat=False):
         """x: Act, time-major (T * B, H, W, Cpad).  Returns the raw output Act ((T * B, ..) or (B, ..), F channels) and its BatchNorm
@@ -578,6 +626,7 @@ class _SeqModelBase:
         for dst, src in zip(st['in'], tensors):
             dst.copy_(src, non_blocking=True)
         st['g'].replay()
+        self.P.bump()                           # (the replayed step updated the parameters: packed images are stale for eager callers)
         return st['loss']
 
     def _adam(self, set_lr=True):
@@ -586,6 +635,7 @@ class _SeqModelBase:
             P.state[0:1].fill_(opt._lr)
         check(lib.satcv_adam_step(P.flat.data_ptr(), P.grad.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.flat.numel(), opt.beta_1, opt.beta_2,
                                   opt.epsilon, P.state.data_ptr(), P.lr_mul.data_ptr(), ops.stream_ptr()))
+        P.bump()
 
     def get_weights_dict(self):
         return {k: self.P.p(k).detach().cpu().numpy().copy() for k in self.P.specs}
@@ -593,6 +643,7 @@ class _SeqModelBase:
     def set_weights_dict(self, d):
         for k, v in d.items():
             self.P.p(k).copy_(torch.as_tensor(np.asarray(v, np.float32)).to(self.P.flat.device).view(self.P.specs[k][1]))
+        self.P.bump()
 
     # Model.save_weights / load_weights / evaluate call sites of the reference (utils/model_tools.py:1162-1196 and the notebooks):
     # the own .npz container; a model with a static-engine branch (the hybrid's U-Net) stores that branch under 'unet::<name>'
@@ -1008,7 +1059,7 @@ class ConvBN:
 
     def forward(self, x, training, dtype, relu):
         P = self.P
-        self.wf, self.wd = ops.pack_weights(P.p(f'{self.name}/kernel'), ops.rup(self.cin, 16), dtype)
+        self.wf, self.wd = P.get_packed(f'{self.name}/kernel', ops.rup(self.cin, 16), dtype)
         cp = ops.rup(self.cout, 16)
         stats = ops.new_stats(cp, x.t.device) if training else None
         y = ops.conv2d(x.t, self.wf, self.cout, kh=self.k, kw=self.k, dil=self.dil, bias=P.p(f'{self.name}/bias'), in_scale=x.scale, in_shift=x.shift,
