@@ -356,6 +356,13 @@ extern "C" int satcv_conv2d_igemm_pipelined(const satcv_conv_desc* d) {
   IgemmArgs a;
   if (!d || igemm_fill_args(d, a) != SATCV_OK || igemm_force_generic()) return 0;
   if (a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dil >= a.h && a.dil >= a.w_) { a.kh = a.kw = 1; a.dil = 1; }
+  if (d->bst_y && a.dil == 3) {
+    // thin dilated layers (atrous CNNs): without the fused sums the launch runs on the persistent weights-stationary kernel at 3-4 x the rate of the
+    // tap-loop tile that could carry them -- the caller's separate reduce pass is the cheaper way (tools/family_time.py)
+    IgemmArgs b = a;
+    b.bst_y = nullptr; b.bst_y1 = nullptr;
+    if (igemm_ws_launch(b, d->dtype, nullptr, true) == SATCV_OK) return 0;
+  }
   return igemm_fast_launch(a, d->dtype, nullptr, true) == SATCV_OK ? 1 : 0;
 }
 

@@ -33,10 +33,12 @@ extern "C" int satcv_debug_read_stamps_ws(unsigned long long* out) { return hipM
 // tensor and the 44 KB tile leave ONE workgroup per CU, and 8 waves keep the two waves per SIMD of the other forms
 // T: bf16, or fp8 (e4m3 storage, 8-byte items, v_mfma_f32_32x32x16_fp8_fp8: the folded fp8 inference graph's thin layers -- same MFMA rate,
 // half the bytes of these HBM-bound layers)
-template <typename T, int CIN, int NT, int WPS, int WN = 1>
+// DIL: dilation rate (1, or 3: the dilated convolutions of the atrous CNNs, utils/model_tools.py:922-979 -- 16 / 32 channels at full resolution, which
+// the tap-loop tile of conv_igemm_fast.hip served at a tenth of their HBM roofline, tools/family_time.py); the halo is DIL pixels wide
+template <typename T, int CIN, int NT, int WPS, int WN = 1, int DIL = 1>
 __global__ __launch_bounds__(256 * WN, WPS) void igemm_ws_kernel(const IgemmArgs a, const int total_tiles) {
   constexpr int TW = 32, TH = 8, WM = 4, MT = 2, BM = 256, BN = WN * NT * 32, NTHREADS = 256 * WN, EL = 8;
-  constexpr int SLOTS = CIN / EL, CL = TW + 2, PITCH = CL, RL = TH + 2;
+  constexpr int SLOTS = CIN / EL, CL = TW + 2 * DIL, PITCH = CL, RL = TH + 2 * DIL;
   constexpr int PLANE = RL * PITCH * EL;                                   // elements of one slot plane
   // 8 consecutive lanes store 8 / SLOTS pixels x SLOTS slots with one ds_write_b128 (serviced in groups of 8 lanes over 32 banks):
   // the plane stride must be 128 / SLOTS bytes modulo 128 for the eight 16-byte stores to fall on distinct banks
@@ -84,8 +86,8 @@ __global__ __launch_bounds__(256 * WN, WPS) void igemm_ws_kernel(const IgemmArgs
     const int it = tid + j * NTHREADS;
     const int pix = it / SLOTS, c = pix % CL, L = pix / CL;
     a_l[j] = it < A_ITEMS ? slot_t * SLOT_STRIDE + (L * PITCH + c) * EL : -1;
-    a_yx[j] = ((L - 1) << 16) | ((c - 1) & 0xffff);
-    a_eoff[j] = ((L - 1) * a.w_ + (c - 1)) * cs;
+    a_yx[j] = ((L - DIL) << 16) | ((c - DIL) & 0xffff);
+    a_eoff[j] = ((L - DIL) * a.w_ + (c - DIL)) * cs;
   }
   int a_off[MT];
 #pragma unroll
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256 * WN, WPS) void igemm_ws_kernel(const IgemmArgs
       FragT<T> af[2][MT], bf[2][NT];
       auto read_step = [&](int st, int buf) {
         const int tap = st / KS, ks = st % KS;
-        const int tap_off = ((tap / 3) * PITCH + (tap % 3)) * EL;
+        const int tap_off = ((tap / 3) * DIL * PITCH + (tap % 3) * DIL) * EL;
         const int slot = ks * 2 + hh;
 #pragma unroll
         for (int m = 0; m < MT; ++m) af[buf][m] = lds_frag<T>(ldsA + slot * SLOT_STRIDE + a_off[m] + tap_off);
@@ -227,9 +229,9 @@ __global__ __launch_bounds__(256 * WN, WPS) void igemm_ws_kernel(const IgemmArgs
 }
 
 // ------------------------------------------------------------------ host side
-template <typename T, int CIN, int NT, int WPS, int WN = 1>
+template <typename T, int CIN, int NT, int WPS, int WN = 1, int DIL = 1>
 static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
-  constexpr int TW = 32, TH = 8, BN = WN * NT * 32, SLOTS = CIN / 8, RL = TH + 2, PITCH = TW + 2;
+  constexpr int TW = 32, TH = 8, BN = WN * NT * 32, SLOTS = CIN / 8, RL = TH + 2 * DIL, PITCH = TW + 2 * DIL;
   constexpr int ES = (int)sizeof(T);
   constexpr int PLANE = RL * PITCH * 8;
   constexpr int WANT = (SLOTS >= 8 ? 16 : 128 / SLOTS) / ES, BANKSPAN = 128 / ES;
@@ -240,13 +242,13 @@ static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
   constexpr size_t LDS = R0 + (size_t)9 * SLOTS * BN * 8 * ES;
   static_assert(LDS <= 160 * 1024, "weights + tile exceed the LDS");
   // tiling fields the shared epilogue reads
-  a.halh = a.halw = 1;
+  a.halh = a.halw = DIL;
   a.tiles_x = cdiv(a.w_, TW); a.tiles_y = cdiv(a.h, TH);
-  a.rpi = TH; a.imgs = 1; a.ngroups = a.n; a.seg = TH + 2; a.rl = RL; a.cl = TW + 2; a.pitch = PITCH; a.n_tiles = 1;
+  a.rpi = TH; a.imgs = 1; a.ngroups = a.n; a.seg = RL; a.rl = RL; a.cl = PITCH; a.pitch = PITCH; a.n_tiles = 1;
   const long long total = (long long)a.n * a.tiles_y * a.tiles_x;
   if (total <= 0 || total > 0x7fffffffLL) return SATCV_ERR_UNSUPPORTED;
   if (dry) return SATCV_OK;
-  auto kern = igemm_ws_kernel<T, CIN, NT, WPS, WN>;
+  auto kern = igemm_ws_kernel<T, CIN, NT, WPS, WN, DIL>;
   { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS); if (rc) return rc; }
   static int ncu = 0;
   if (!ncu) {
@@ -271,8 +273,23 @@ static int ws_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
 int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   if (!g_opt_igemm_thin || (dtype != SATCV_BF16 && dtype != SATCV_FP8)) return SATCV_ERR_UNSUPPORTED;
   const int cin = a.c0 + a.c1;
-  if (a.kh != 3 || a.kw != 3 || a.dil != 1 || a.stride != 1 || a.mode_in || a.mode_out || a.accumulate || a.bst_y) return SATCV_ERR_UNSUPPORTED;
+  // (accumulate == 1, y += result, on the bf16 forms without statistics / fused pool: residual data gradients)
+  if (a.kh != 3 || a.kw != 3 || (a.dil != 1 && a.dil != 3) || a.stride != 1 || a.mode_in || a.mode_out || a.bst_y) return SATCV_ERR_UNSUPPORTED;
+  if (a.accumulate && (a.accumulate != 1 || dtype != SATCV_BF16 || a.stats || a.pool_y || a.out_relu || a.out_scale)) return SATCV_ERR_UNSUPPORTED;
   if (a.pool_y && (8 % a.pool_f != 0 || 32 % a.pool_f != 0)) return SATCV_ERR_UNSUPPORTED;      // pooling windows inside one 8 x 32 tile
+  if (a.dil == 3) {
+    // dilation 3 (atrous CNNs): 16 / 32 stored input channels -> 16 / 32 output channels (16: a 32-column tile whose upper half is zero weights;
+    // the interior-tile epilogue skips the column groups beyond cout), bf16, no fused pool
+    if (dtype != SATCV_BF16 || a.pool_y || !(cin == 16 || cin == 32) || !(a.cout == 16 || a.cout == 32) || a.cout_pad != 32 || a.cstat != a.cout) return SATCV_ERR_UNSUPPORTED;
+    if (a.x1 && (a.c0 % 8 != 0)) return SATCV_ERR_UNSUPPORTED;
+    if (a.h % 8 != 0 || a.w_ % 32 != 0 || a.ldy % 8 != 0 || ((uintptr_t)a.y % 16) != 0) return SATCV_ERR_UNSUPPORTED;
+    return cin == 16 ? ws_cfg<bf16, 16, 1, 2, 1, 3>(a, st, dry) : ws_cfg<bf16, 32, 1, 2, 1, 3>(a, st, dry);
+  }
+  if (a.cout == 16 && dtype == SATCV_BF16 && !a.pool_y && (cin == 16 || cin == 32) && a.cout_pad == 32 && a.cstat == 16 && !(a.x1 && (a.c0 % 8 != 0)) &&
+      a.h % 8 == 0 && a.w_ % 32 == 0 && a.ldy % 8 == 0 && ((uintptr_t)a.y % 16) == 0) {
+    // 16 output channels (the 16-filter atrous CNN of utils/model_tools.py:992): a 32-column tile whose upper half is zero weights
+    return cin == 16 ? ws_cfg<bf16, 16, 1, 3>(a, st, dry) : ws_cfg<bf16, 32, 1, 3>(a, st, dry);
+  }
   if (!(cin == 16 || cin == 32 || cin == 64) || !(a.cout == 32 || a.cout == 64) || a.cout_pad != a.cout || a.cstat != a.cout) return SATCV_ERR_UNSUPPORTED;
   if (a.x1 && (a.c0 % 8 != 0)) return SATCV_ERR_UNSUPPORTED;
   const int epv = dtype == SATCV_FP8 ? 16 : 8;

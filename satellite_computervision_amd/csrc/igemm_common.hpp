@@ -295,11 +295,30 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
       yp = reinterpret_cast<T*>(a.y) + ((size_t)(n0 * a.h + y0) * a.w_ + x0) * a.ldy + nbase + vq * EPV;
       row_pitch = (size_t)a.w_ * a.ldy; col_pitch = (size_t)a.ldy;
     }
+    // (the interior-only instantiations also take tiles wider than the layer: a 32-column tile for 16 output channels -- thin dilated layers of
+    //  the atrous CNNs; its upper column groups hold zeros and are not stored)
+    const bool col_ok = GENERAL || nbase + vq * EPV < a.cout;
 #pragma unroll
     for (int it = tid; it < BM * VPR; it += NTHREADS) {
       const int q = it / VPR;                     // (compile-time divisors)
       const int t = q / TW, cx = q % TW;
-      *reinterpret_cast<uint4*>(yp + (size_t)t * row_pitch + (size_t)cx * col_pitch) = *reinterpret_cast<const uint4*>(ldsO + q * OPITCH + vq * EPV);
+      if (col_ok) {
+        T* dst = yp + (size_t)t * row_pitch + (size_t)cx * col_pitch;
+        uint4 nv = *reinterpret_cast<const uint4*>(ldsO + q * OPITCH + vq * EPV);
+        if constexpr (!GENERAL && sizeof(T) == 2) {
+          // accumulate == 1 on the interior-only instantiations: y += result (a data gradient joining the gradient another consumer of the same
+          // tensor wrote -- residual sums of the atrous CNNs); same arithmetic as the general path below
+          if (a.accumulate == 1) {
+            uint4 ov = *reinterpret_cast<const uint4*>(dst);
+            T* oe = reinterpret_cast<T*>(&ov);
+            const T* nn = reinterpret_cast<const T*>(&nv);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) oe[e] = (T)((float)oe[e] + (float)nn[e]);
+            nv = ov;
+          }
+        }
+        *reinterpret_cast<uint4*>(dst) = nv;
+      }
     }
     if constexpr (!GENERAL) {
       // fused max-pool of the tile just stored (folded inference encoder blocks; the interior-tile-only instantiations take these

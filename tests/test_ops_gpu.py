@@ -567,6 +567,59 @@ def test_conv2d_thin_layers_with_wave_roles(ops, case, force_thin, force_roles):
         assert np.array_equal(back(pooled, cout), g3.reshape(n, h // 2, 2, w // 2, 2, cout).max((2, 4)))
 
 
+@pytest.mark.parametrize('case', [(2, 32, 64, 16, 16), (1, 64, 64, 32, 32), (3, 16, 32, 4, 16), (2, 24, 96, 32, 16), (1, 8, 32, 16, 32)])
+def test_conv2d_weights_stationary_dilation_3(ops, case, force_thin):
+    """the thin persistent kernel with a 3-pixel halo: the dilated convolutions of the atrous CNNs (utils/model_tools.py:935, 968), 16 / 32 channels,
+    incl. 16 OUTPUT channels on a 32-column tile (upper column groups not stored) -- forward with bias + statistics, the fused input BatchNorm +
+    ReLU, and the data gradient (the transposed problem)."""
+    td = torch.bfloat16
+    n, h, w, cin, cout = case
+    rng = np.random.default_rng(hash(case) % 2**31 + 3)
+    cpad = rup(cin, 16)
+    x = rnd(rng, (n, h, w, cin), td)
+    kern = rnd(rng, (3, 3, cin, cout), td, 0.2)
+    b = rng.standard_normal(cout)
+    ref = K.conv2d_same(x, kern, b, 3)
+    wf, wd = ops.pack_weights(f32dev(kern), cpad, ops.DTYPE_CODE[td])
+    stats = ops.new_stats(rup(cout, 16), dev())
+    before = ws_launches()
+    y = ops.conv2d(to_dev(x, td, cpad), wf, cout, dil=3, bias=f32dev(b), stats=stats)
+    assert ws_launches() - before == 1, 'path taken'
+    got = back(y, cout)
+    close(got, ref, td, f'ws dilated conv {case}')
+    if cout == 16:
+        # the same 32-column tile for 16 output channels without dilation (the 16-filter atrous CNN's plain convolutions)
+        before = ws_launches()
+        y1 = ops.conv2d(to_dev(x, td, cpad), wf, cout, bias=f32dev(b))
+        assert ws_launches() - before == 1, 'path taken (dilation 1, 16 output channels)'
+        close(back(y1, cout), K.conv2d_same(x, kern, b, 1), td, f'ws conv, 16 output channels {case}')
+    s = stats.sum(0).double().cpu().numpy()
+    np.testing.assert_allclose(s[0, :cout], got.sum((0, 1, 2)), rtol=2e-4, atol=2e-3 * np.sqrt(n * h * w))
+    np.testing.assert_allclose(s[1, :cout], (got ** 2).sum((0, 1, 2)), rtol=2e-4)
+    if cin >= 16:
+        sc, sh = (rng.random(cin) + 0.5).astype(np.float32), (rng.standard_normal(cin) * 0.3).astype(np.float32)
+        a_ref = np.maximum(x * sc.astype(np.float64) + sh.astype(np.float64), 0)
+        a_ref = torch.tensor(a_ref, dtype=torch.float32).to(td).double().numpy()
+        ref2 = K.conv2d_same(a_ref, kern, b, 3)
+        y2 = ops.conv2d(to_dev(x, td), wf, cout, dil=3, bias=f32dev(b), in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
+        close(back(y2, cout), ref2, td, f'ws dilated conv + affine {case}', k=2.0)
+        # data gradient: dy has `cout` channels, dx `cin`
+        dy = rnd(rng, (n, h, w, cout), td)
+        dx_ref, _, _ = K.conv2d_same_bwd(np.zeros((n, h, w, cin)), kern, dy, 3)
+        before = ws_launches()
+        dx = ops.conv2d_dgrad(to_dev(dy, td), wd, cin, dil=3)
+        assert ws_launches() - before == 1, 'path taken (data gradient)'
+        close(back(dx, cin), dx_ref, td, f'ws dilated dgrad {case}')
+        # accumulate: dx += (the residual sum's second consumer)
+        g0 = rnd(rng, (n, h, w, cin), td)
+        acc = to_dev(g0, td)
+        before = ws_launches()
+        ops.conv2d_dgrad(to_dev(dy, td), wd, cin, dil=3, out=acc, accumulate=True)
+        assert ws_launches() - before == 1, 'path taken (accumulating data gradient)'
+        want = torch.tensor(torch.tensor(g0, dtype=torch.float32).to(td).double().numpy() + back(dx, cin), dtype=torch.float32).to(td).double().numpy()
+        np.testing.assert_allclose(back(acc, cin), want, rtol=0, atol=float(np.abs(want).max()) * 2 ** -7)
+
+
 def test_conv2d_weights_stationary_dual_source_affine(ops, force_thin):
     """dec0.conv1 through the thin kernel: concat([skip 32, up 32]) -> BN -> ReLU in the loader, -> 32 channels"""
     td = torch.bfloat16
