@@ -32,6 +32,16 @@
 #endif
 #define PABL(bit) ((SATCV_M16P_ABL & (bit)) != 0)
 
+// diagnostic build (-DSATCV_STAMP_M16P, tools/m16p_stamp_probe.py): s_memtime sums per wave of the first 8 workgroups -- matrix waves: [0] fragment reads +
+// MFMAs (+ dump), [1] the wait for their weight pieces, [2] the barrier; staging waves: [0] their interval's work, [2] the barrier; [3] intervals
+#ifdef SATCV_STAMP_M16P
+__device__ unsigned long long g_stamp_m16p[8][12][4];
+extern "C" int satcv_debug_read_stamps_m16p(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp_m16p), sizeof(g_stamp_m16p)) == hipSuccess ? 0 : -1; }
+#define PSTAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(t) do { } while (0)
+#endif
+
 extern int g_opt_m16p;                 // api.hip: 0 off, 1 on where a workgroup gets at least two tiles
 int g_m16p_launches = 0;               // launches taken here (satcv_get_option("m16p_launches"): tests assert the path)
 
@@ -277,6 +287,10 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
     if (2 < nc) { load_items(S0, I0, IALL); load_advance(); }
     __syncthreads();                                                         // (2) chunk 0 staged, weight unit 0 landed
     int gc = 0;                                                              // chunk being multiplied
+#ifdef SATCV_STAMP_M16P
+    unsigned long long z0, z1, z2, zs[4] = {0, 0, 0, 0};
+    PSTAMP(z0);
+#endif
     // one chunk = three intervals; PAR = parity of the chunk (= of the stage it is read from).  Chunk gc + 1 moves from its register set to
     // the other stage TWO ITEMS PER INTERVAL (the stage fell free at the barrier that started chunk gc), each pair reloaded at once with its
     // items of chunk gc + 3: the vector work of the stream is spread evenly over the intervals, like the drain's rounds
@@ -308,7 +322,12 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
           if (iv == 0) drain_prefetch(rpi);
           else if (iv < upt - 1) { drain_rounds(rpi); drain_prefetch(rpi); }
         }
+        PSTAMP(z1);
         __syncthreads();
+        PSTAMP(z2);
+#ifdef SATCV_STAMP_M16P
+        zs[0] += z1 - z0; zs[2] += z2 - z1; zs[3] += 1; z0 = z2;
+#endif
         if (iv == upt - 1) drain_begin(m_lo + t);                            // the barrier just passed published tile t's image
       }
       ++gc;
@@ -327,6 +346,9 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
         advance();
       }
     }
+#ifdef SATCV_STAMP_M16P
+    if (blockIdx.x < 8 && lane == 0) for (int i = 0; i < 4; ++i) g_stamp_m16p[blockIdx.x][wave][i] = zs[i];
+#endif
     // the last tile's image
     if (!PABL(16)) for (int r = 0; r < G::ROUNDS; ++r) { drain_prefetch(1); drain_rounds(1); }
     __syncthreads();                                                         // (3) staging waves only: the matrix waves have ended
@@ -394,6 +416,10 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
   __syncthreads();                                                           // (2)
   const int nu = ntl * upt;
   int gu = 0;
+#ifdef SATCV_STAMP_M16P
+  unsigned long long y0, y1, y2, y3, ys[4] = {0, 0, 0, 0};
+  PSTAMP(y0);
+#endif
   for (int t = 0; t < ntl; ++t) {
     for (int x = 0; x < nch; ++x) {
 #pragma unroll
@@ -445,12 +471,21 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
           }
           acc_init();
         }
+        PSTAMP(y1);
         if (!PABL(128)) dma_wait_all();
+        PSTAMP(y2);
         __syncthreads();
+        PSTAMP(y3);
+#ifdef SATCV_STAMP_M16P
+        ys[0] += y1 - y0; ys[1] += y2 - y1; ys[2] += y3 - y2; ys[3] += 1; y0 = y3;
+#endif
         ++gu;
       }
     }
   }
+#ifdef SATCV_STAMP_M16P
+  if (blockIdx.x < 8 && lane == 0) for (int i = 0; i < 4; ++i) g_stamp_m16p[blockIdx.x][wave][i] = ys[i];
+#endif
 }
 
 // ------------------------------------------------------------------ host side
