@@ -104,10 +104,69 @@ def pmc_traffic_per_launch():
             c = d['classes'].get('igemm_3x3') or d['classes'].get('igemm_3x3_1x1_convT')
             tot, nl = c['hbm_bytes_per_launch'] * c['launches'], c['launches']
             src = f"{os.path.basename(path)} @ {d.get('commit', 'round-1 tree 138affc')}"
-            return round(tot / nl / 1e6, 1), src
+            return round(tot / nl / 1e6, 1), src, str(d.get('csrc_digest', ''))
         except Exception:
             continue
-    return None, None
+    return None, None, ''
+
+
+def csrc_digest():
+    """sha256[:16] over the kernel sources (csrc/*.hip, *.hpp, include/satcv.h): what a PMC summary must have been measured at to describe the
+    library being run (tools/pmc_summary.py stores the same digest; documentation-only commits do not make a summary stale, kernel edits do)."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'satellite_computervision_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'satellite_computervision_amd', 'csrc', '*.hpp')))
+    for f in files + [os.path.join(ROOT, 'include', 'satcv.h')]:
+        h.update(os.path.basename(f).encode()); h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def box_probe():
+    """How fast is THIS box?  Boxes of the pool differ by +-4 %: two fixed launches through the C ABI, timed with HIP
+    events before the timed regions, so that the headline can be read against the box it ran on -- a streaming launch (BatchNorm-backward
+    apply over 64 x 256 x 256 x 32 bf16: two reads + one write, 805 MB) and a matrix-bound one (3x3 convolution 1024 -> 512 at 16 x 16,
+    batch 64: 154.6 GFLOP).  ~50 ms in total."""
+    from satellite_computervision_amd import ops
+    from satellite_computervision_amd._lib import lib, check
+    dev = torch.device('cuda')
+    out = {}
+
+    def timeit(f, reps):
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+    g = torch.Generator(device='cuda'); g.manual_seed(1)
+    n, h, w, c = 64, 256, 256, 32
+    x = torch.randn(n, h, w, c, device=dev, generator=g).to(torch.bfloat16)
+    gr = torch.randn(n, h, w, c, device=dev, generator=g).to(torch.bfloat16)
+    dy = torch.empty_like(x)
+    one, zero = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+    sums, coef = ops.new_stats(c, dev), torch.zeros(2, c, device=dev)
+    d = ops.make_bnbwd_desc(yraw=x.data_ptr(), ldy=c, scale=one.data_ptr(), shift=zero.data_ptr(), mean=zero.data_ptr(), rstd=one.data_ptr(), n=n, h=h, w_=w,
+                            c=c, dtype=1, da=gr.data_ptr(), ldda=c, sums=sums.data_ptr(), sums_ld=c, coef=coef.data_ptr(), dy=dy.data_ptr(), lddy_out=c)
+    st = ops.stream_ptr()
+    t = timeit(lambda: check(lib.satcv_bn_bwd_apply(C.byref(d), st)), 40)
+    out['stream_2r1w_TBps'] = round(3 * x.numel() * 2 / t / 1e12, 3)
+    n, h, w, cin, cout = 64, 16, 16, 1024, 512
+    x = torch.randn(n, h, w, cin, device=dev, generator=g).to(torch.bfloat16)
+    kern = torch.randn(3, 3, cin, cout, device=dev, generator=g) * 0.05
+    wf, _ = ops.pack_weights(kern, cin, 1, want_dgrad=False)
+    y = torch.empty(n, h, w, cout, device=dev, dtype=torch.bfloat16)
+    b = torch.zeros(cout, device=dev)
+    stt = ops.new_stats(cout, dev)
+    dc = ops.make_conv_desc(x0=x.data_ptr(), c0=cin, w=wf.data_ptr(), y=y.data_ptr(), ldy=cout, n=n, h=h, w_=w, cout=cout, cout_pad=ops.rup(cout, 32), dtype=1,
+                            bias=b.data_ptr(), stats=stt.data_ptr(), stats_ld=cout, kh=3, kw=3)
+    t = timeit(lambda: check(lib.satcv_conv2d_igemm(C.byref(dc), st)), 100)
+    out['conv3x3_1024_512_16x16_us'] = round(t * 1e6, 1)
+    out['conv3x3_1024_512_16x16_TFLOPs'] = round(2.0 * n * h * w * cin * cout * 9 / t / 1e12, 1)
+    return out
 
 
 def head_commit():
@@ -244,6 +303,9 @@ def main():
     ap.add_argument('--repeats', type=int, default=5,
                     help='the timed region of exactly --steps steps is run this many times (same work each); value = the MEDIAN region')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--prof-in-timed', action='store_true',
+                    help='(rounds 1-5 behaviour) record the per-class HIP events inside the timed regions; default: the timed regions run with '
+                         'satcv_prof_enable(0) and one EXTRA, untimed-for-the-headline region with the events on supplies the class times')
     ap.add_argument('--infer', action='store_true', help='(default) also time bf16 / fp8 inference and the config-5 chip rate, reported under "extra"')
     ap.add_argument('--no-infer', action='store_true', help='skip the inference timings')
     ap.add_argument('--full-infer', action='store_true', help='(kept for old command lines: the DeepLab-v3 config-3 timings are part of the default run)')
@@ -292,6 +354,7 @@ def main():
         torch.cuda.synchronize()
 
     model._head_plan(B, TILE, TILE, True)              # buffers and launch descriptors exist before any (warm-up or timed) step
+    probe = box_probe() if rank == 0 else None
     for i in range(args.warmup):
         xb, yb = pool[i % len(pool)]
         model.train_step_device(xb, yb, sync)
@@ -299,25 +362,38 @@ def main():
     # the timed region: EXACTLY --steps steps between barrier + synchronize pairs, max over ranks.  Boxes of the pool differ by several
     # percent and a 0.17-s region is short, so the region is repeated (identical work) and the MEDIAN region is the reported one; the
     # spread goes to extra.region_ms_per_step
-    check(lib.satcv_prof_enable(0b1111))
-    regions = []
-    for rep in range(max(args.repeats, 1)):
+    # Round 6: the HIP events that time the kernel classes (two per conv-class launch, ~55 launches per step on two streams) are OFF in the
+    # timed regions; one more region of the same --steps steps with them ON supplies the class times (roofline.achieved, extra.kernel_*) and
+    # its own ms_per_step goes to extra.ms_per_step_with_prof_events, so that the cost of the events is a number.
+    def region():
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             xb, yb = pool[i % len(pool)]
-            plan = model.train_step_device(xb, yb, sync)
+            pl = model.train_step_device(xb, yb, sync)
         barrier()
         dtr = time.perf_counter() - t0
         if dist is not None:
             tmax = torch.tensor([dtr], device='cuda')
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dtr = float(tmax.item())
+        return dtr, pl
+    if args.prof_in_timed:
+        check(lib.satcv_prof_enable(0b1111))
+    regions = []
+    for rep in range(max(args.repeats, 1)):
+        dtr, plan = region()
         regions.append(dtr)
+    if args.prof_in_timed:
+        nprof = args.steps * len(regions)           # steps the HIP-event sums cover
+        dt_prof = None
+    else:
+        check(lib.satcv_prof_enable(0b1111))
+        dt_prof, plan = region()
+        nprof = args.steps
     check(lib.satcv_prof_enable(0))
     loss = float(plan.loss_buf.item())
     dt = float(np.median(regions))
-    nprof = args.steps * len(regions)               # steps the HIP-event sums cover
 
     prof = {}
     for kind, name in ((0, 'conv3x3_igemm_fwd_dgrad'), (1, 'conv1x1_convT_gemm'), (2, 'conv_wgrad'), (3, 'conv3x3_fused_dgrad_wgrad')):
@@ -328,7 +404,10 @@ def main():
     extra = {'loss_last': loss, 'kernel_ms_per_step': {k: round(v['ms'] / nprof, 3) for k, v in prof.items()},
              'region_ms_per_step': {'median': round(1000 * dt / args.steps, 3), 'min': round(1000 * min(regions) / args.steps, 3),
                                     'max': round(1000 * max(regions) / args.steps, 3), 'repeats': len(regions)},
-             'kernel_tflops': {k: round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 1) for k, v in prof.items()}}
+             'kernel_tflops': {k: round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 1) for k, v in prof.items()},
+             'prof_events_in_timed_regions': bool(args.prof_in_timed),
+             'ms_per_step_with_prof_events': round(1000 * dt_prof / args.steps, 3) if dt_prof is not None else round(1000 * dt / args.steps, 3),
+             'box_probe': probe}
     if dist is not None:
         extra['grad_exchange'] = {'via': 'satcv_allreduce_grads (C ABI, RCCL)' if parallel.cabi_comm() is not None else f'torch.distributed {dist.get_backend()}',
                                   'payload': sync.payload, 'bucket_MiB': sync.per * 4 / 2 ** 20, 'calls': parallel._comm['calls']}
@@ -409,7 +488,16 @@ def main():
                                    'tflops': round(d3['flops'] / max(d3['ms'], 1e-9) / 1e9, 1),
                                    'data_gradient_gflop_per_step_inside': round(fused_dgrad_flops / 1e9, 1)}
         launches_per_step = max(d['launches'] / nprof, 1)
-        traffic, traffic_src = pmc_traffic_per_launch()
+        traffic, traffic_src, traffic_digest = pmc_traffic_per_launch()
+        hc = head_commit()
+        # the PMC summary is a committed file of an earlier run of this command (counters cannot be collected inside the timed run): it is
+        # STALE unless it was measured on these very kernel sources
+        built = ''
+        try:
+            built = open(os.path.join(ROOT, 'satellite_computervision_amd', '_build_commit.txt')).read().strip()
+        except Exception:
+            pass
+        traffic_stale = not (traffic_digest and traffic_digest == csrc_digest())
         out = {
             'metric': f'tiles/sec (train) 256x256x{CHN} U-Net', 'value': round(value, 2), 'unit': 'tiles/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -419,7 +507,7 @@ def main():
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'loss': 'weighted_categorical_crossentropy',
                        'optimizer': 'adam(9e-4)'},
             'roofline': {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                         'traffic': traffic, 'traffic_unit': 'MB per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src, 'head_commit': head_commit(),
+                         'traffic': traffic, 'traffic_unit': 'MB per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src, 'traffic_stale': traffic_stale, 'csrc_digest': csrc_digest(), 'head_commit': hc, 'build_commit': built,
                          'algorithmic_bytes_per_launch_MB': round((a3['bytes'] - fused_dgrad_bytes) / max(a3['launches'] - n_fused_dgrad, 1) / 1e6, 1),
                          'algorithmic_gflop_per_step': round(a3['flops'] / 1e9, 1),
                          'kernel': '3x3 implicit-GEMM conv (forward + data gradient launches; the thin layers\' data gradients run inside the fused backward launches: extra.fused_backward)',

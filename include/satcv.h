@@ -166,7 +166,9 @@ int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream);
  * Keras-layout gradient -- a launch of 5-30 us per layer, 21 per training step.  With defer_reduce the producers skip it; the caller
  * collects one job per layer (the slab geometry the library chose), keeps the layers' workspaces apart, and runs ONE launch over a DEVICE
  * array of jobs + the exclusive prefix sum of satcv_reduce_job_items().  The summation order is fixed (a job's `lanes` partial sums over
- * slabs l, l + lanes, ..., combined in increasing lane order): results are bit-reproducible. */
+ * slabs l, l + lanes, ..., combined in increasing lane order): results are bit-reproducible.  satcv_reduce_job_items() is the job's item
+ * count ROUNDED UP TO 16, so that every prefix is a multiple of 16 and a lane group never straddles a wavefront; total_items must be the sum
+ * of those values (SATCV_ERR_INVALID otherwise). */
 typedef struct satcv_reduce_job {
   const float* ws; float* dw;
   int32_t nslab, taps, kpad, npad, cin, nvalid, transposed, accumulate, lanes, pad_;
@@ -474,6 +476,11 @@ int satcv_confusion(const int32_t* classes, const float* y_true, int32_t ncls, i
  * step_count itself so that the launch is graph-replayable. */
 int satcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
                     float beta2, float eps, float* state, const float* lr_mul, void* stream);
+
+/* Clears the two buffers a training step accumulates into -- the flat gradient (bytes_a, a multiple of 16, 16-byte aligned) and a small
+ * second one (the loss scalar; bytes_b a multiple of 4) -- in ONE launch of the library's own (the optimizer loop of Model.fit,
+ * notebooks/UNET_G4G_2019_solar.ipynb:1267: Keras starts every step from zero gradients).  Either may be empty. */
+int satcv_zero2(void* a, int64_t bytes_a, void* b, int64_t bytes_b, void* stream);
 
 /* ---------------------------------------------------- data-parallel collectives
  * The reference has no multi-device code; this is the north-star's data-parallel `Model.fit`

@@ -197,6 +197,7 @@ _SIGS = {
     'satcv_convlstm_gates_bwd': (C.c_int, [C.POINTER(LstmGatesDesc), c_vp]),
     'satcv_dense_small_fwd': (C.c_int, [C.POINTER(DenseDesc), c_vp]),
     'satcv_dense_small_bwd': (C.c_int, [C.POINTER(DenseDesc), c_vp]),
+    'satcv_zero2': (C.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),
     'satcv_graph_begin': (C.c_int, [c_vp]),
     'satcv_graph_end': (C.c_int, [c_vp, C.POINTER(c_vp)]),
     'satcv_graph_launch': (C.c_int, [c_vp, c_vp]),

@@ -1433,18 +1433,24 @@ extern "C" int satcv_conv2d_wgrad(const satcv_wgrad_desc* d, void* stream) {
 static int reduce_job_lanes(int nslab) { int l = 1; while (l < 16 && 2 * l <= nslab / 2) l *= 2; return l; }      // >= 2 slabs per lane
 extern "C" int64_t satcv_reduce_job_items(const satcv_reduce_job* j) {
   if (!j || j->nvalid % 4 != 0 || j->lanes < 1) return -1;
-  return (int64_t)j->taps * j->cin * (j->nvalid / 4) * j->lanes;
+  // rounded up to a multiple of 16 (the largest `lanes`): with every job's prefix a multiple of 16 a lane group never straddles a wave, whatever
+  // the `lanes` of the jobs in front of it (the padded items are inactive in the kernel)
+  const int64_t real = (int64_t)j->taps * j->cin * (j->nvalid / 4) * j->lanes;
+  return (real + 15) / 16 * 16;
 }
 __global__ __launch_bounds__(256) void reduce_slabs_batched_kernel(const satcv_reduce_job* __restrict__ jobs, const long long* __restrict__ prefix, int njobs,
                                                                    long long total) {
   for (long long it0 = (long long)blockIdx.x * 256; it0 < total; it0 += (long long)gridDim.x * 256) {
     const long long it = it0 + threadIdx.x;
-    const bool act = it < total;
-    const long long itc = act ? it : total - 1;
+    const bool act0 = it < total;
+    const long long itc = act0 ? it : total - 1;
     int ji = 0;
     for (int q = 1; q < njobs; ++q) ji += (prefix[q] <= itc) ? 1 : 0;      // (a few dozen jobs: a linear scan of an L1-resident table)
     const satcv_reduce_job j = jobs[ji];
-    const long long loc = itc - prefix[ji];
+    const long long real = (long long)j.taps * j.cin * (j.nvalid / 4) * j.lanes;      // (the job's item count is `real` rounded up to 16)
+    const long long loc0 = itc - prefix[ji];
+    const bool act = act0 && loc0 < real;
+    const long long loc = loc0 < real ? loc0 : real - 1;
     const int P = j.lanes, l = (int)(loc % P);
     const long long o4 = loc / P;
     const int nv4 = j.nvalid / 4;
@@ -1484,6 +1490,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_batched_kernel(const satcv_r
 }
 extern "C" int satcv_reduce_slabs_batched(const satcv_reduce_job* jobs_dev, const int64_t* prefix_dev, int32_t njobs, int64_t total_items, void* stream) {
   SATCV_CHECK(jobs_dev && prefix_dev && njobs > 0 && njobs <= 4096 && total_items > 0, "reduce_slabs_batched: bad arguments");
+  SATCV_CHECK(total_items % 16 == 0, "reduce_slabs_batched: the prefix table must be built from satcv_reduce_job_items (multiples of 16)");
   long long grid = (total_items + 255) / 256; if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(reduce_slabs_batched_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev,
                      reinterpret_cast<const long long*>(prefix_dev), njobs, (long long)total_items);

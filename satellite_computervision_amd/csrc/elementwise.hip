@@ -1618,6 +1618,21 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 __global__ void adam_bump_kernel(float* state) { state[1] += 1.f; }
+// the buffers a training step accumulates into (flat gradient, loss scalar), cleared by ONE launch of the library's own
+__global__ __launch_bounds__(256) void zero2_kernel(uint4* __restrict__ a, long long na16, unsigned* __restrict__ b, long long nb4) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < na16; i += (long long)gridDim.x * blockDim.x) a[i] = z;
+  if (blockIdx.x == 0) for (long long i = threadIdx.x; i < nb4; i += blockDim.x) b[i] = 0u;
+}
+extern "C" int satcv_zero2(void* a, int64_t bytes_a, void* b, int64_t bytes_b, void* stream) {
+  SATCV_CHECK(bytes_a >= 0 && bytes_b >= 0 && (bytes_a == 0 || a) && (bytes_b == 0 || b), "zero2: bad args");
+  SATCV_CHECK(((uintptr_t)a % 16 == 0) && bytes_a % 16 == 0 && ((uintptr_t)b % 4 == 0) && bytes_b % 4 == 0, "zero2: a must be 16-byte, b 4-byte aligned and sized");
+  if (bytes_a == 0 && bytes_b == 0) return SATCV_OK;
+  hipLaunchKernelGGL(zero2_kernel, dim3(ew_grid(bytes_a / 16 + 1, 4096)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<uint4*>(a), (long long)(bytes_a / 16),
+                     reinterpret_cast<unsigned*>(b), (long long)(bytes_b / 4));
+  LAUNCH_OK("zero2");
+  return SATCV_OK;
+}
 extern "C" int satcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps, float* state,
                                const float* lr_mul, void* stream) {
   SATCV_CHECK(p && g && m && v && state && n > 0, "adam: bad args");

@@ -69,7 +69,16 @@ class _Params:
             self._repack_all(dtype)
         return e['fwd'], e['dg']
 
-    def _repack_all(self, dtype):
+    def prepare_capture(self):
+        """called right before a training step is captured into a graph: the captured step must CONTAIN the repack launch -- replays update
+        the parameters on the device and only bump `version` on the host, so a graph captured while the images happened to be fresh (an eager
+        predict / evaluate after the last optimizer step) would multiply with the images of capture time for ever.  The job table is built
+        here, outside the capture (a host-to-device copy)."""
+        if self._pk:
+            self._job_table()
+        self.bump()
+
+    def _job_table(self):
         from ._lib import PackJob
         if self._pk_tab is None:
             jobs = []
@@ -85,7 +94,10 @@ class _Params:
             arr = (PackJob * len(jobs))(*jobs)
             self._pk_tab = dict(jobs=torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(_dev()),
                                 prefix=torch.tensor(prefix, dtype=torch.int64, device=_dev()), n=len(jobs), total=tot)
-        t = self._pk_tab
+        return self._pk_tab
+
+    def _repack_all(self, dtype):
+        t = self._job_table()
         check(lib.satcv_pack_weights_batched(t['jobs'].data_ptr(), t['prefix'].data_ptr(), t['n'], t['total'], dtype, ops.stream_ptr()))
         for e in self._pk.values():
             e['ver'] = self.version
@@ -614,6 +626,7 @@ class _SeqModelBase:
                 st['in'] = [t.clone() for t in tensors]
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
+                self.P.prepare_capture()        # (the graph must hold the repack launch: see _Params.prepare_capture)
                 with torch.cuda.graph(g):
                     st['loss'] = step_fn(*st['in'])
                 st['g'] = g

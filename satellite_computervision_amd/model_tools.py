@@ -1269,8 +1269,9 @@ class Model:
         self._stage_x(plan, xb)
         self._stage_y(plan, yb)
         st = ops.stream_ptr()
-        rt.gflat.zero_()
-        plan.loss_buf.zero_()
+        check(lib.satcv_zero2(rt.gflat.data_ptr(), rt.gflat.numel() * 4 // 16 * 16, plan.loss_buf.data_ptr(), 4, st))
+        if rt.gflat.numel() % 4:
+            rt.gflat[rt.gflat.numel() // 4 * 4:].zero_()
         plan.step_count += 1                     # fresh dropout masks every step
         plan.run_forward(st)
         self._loss_launch(plan, st)

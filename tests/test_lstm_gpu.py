@@ -425,6 +425,43 @@ def test_lstm_training_step_graph_replay_matches_eager(lt):
         mt.set_compute_dtype('bfloat16')
 
 
+def test_lstm_graph_capture_after_an_interleaved_predict_repacks_weights(lt):
+    """train x2 -> predict -> train ...: the eager predict() repacks the operand images, so the step that gets CAPTURED finds them fresh.  The
+    captured graph must hold the repack launch all the same (_Params.prepare_capture) -- otherwise every replay multiplies with the images of
+    capture time.  Eight steps with a predict() before the third, with and without replay: same losses, same parameters."""
+    from satellite_computervision_amd import model_tools as mt
+    mt.set_compute_dtype('float32')
+    try:
+        rng = np.random.default_rng(23)
+        xs = [rng.random((4, 3, 16, 16, 4)).astype(np.float32) for _ in range(8)]
+        ys = [rng.random((4, 16, 16, 3)).astype(np.float32) for _ in range(8)]
+
+        def run(flag):
+            os.environ['SATCV_LSTM_GRAPH'] = flag
+            mt.reset_uids(); mt.set_seed(7)
+            m = lt.get_lstm_model(4, 3, 3)
+            m.compile(optimizer=mt.Adam(3e-3), loss=mt.mse_4d)
+            losses = []
+            for i, (x, y) in enumerate(zip(xs, ys)):
+                if i in (2, 5):
+                    m.predict(x)                        # fresh images when step 3 is captured; an eager repack between replays
+                losses.append(m.train_on_batch(x, y))
+            return m, losses
+
+        try:
+            me, le = run('0')
+            mg, lg = run('1')
+        finally:
+            os.environ.pop('SATCV_LSTM_GRAPH', None)
+        assert any('g' in st for st in mg._graphs.values()), 'no step was captured'
+        np.testing.assert_allclose(lg, le, rtol=2e-4)
+        we, wg = me.get_weights_dict(), mg.get_weights_dict()
+        for k in we:
+            assert np.abs(we[k] - wg[k]).max() < 3e-4, (k, np.abs(we[k] - wg[k]).max())
+    finally:
+        mt.set_compute_dtype('bfloat16')
+
+
 def test_lstm_model_dropout_matches_oracle_given_the_mask(lt):
     """build_lstm_layers(dropout=rate): layers.Dropout between the two ConvLSTM2D layers (utils/model_tools.py:699-700).  The device
     draws the mask; the oracle receives that mask and must reproduce loss and every gradient (fp32); inference ignores dropout."""

@@ -390,6 +390,8 @@ def test_reduce_slabs_batched(ops):
     rng = np.random.default_rng(3)
     specs = [  # nslab, taps, cin, nvalid, kpad, npad, transposed, accumulate
         (2, 9, 64, 128, 64, 128, 0, 0), (8, 9, 32, 32, 32, 32, 0, 0), (128, 9, 16, 32, 32, 32, 0, 1), (37, 1, 24, 64, 32, 64, 0, 0),
+        # 9 x 13 x 8 = 936 items of one lane (8 mod 16) in front of a 16-lane job: item counts are padded to 16 so that its groups stay inside a wave
+        (2, 9, 13, 32, 16, 32, 0, 0), (64, 9, 16, 64, 16, 64, 0, 0),
         (16, 1, 128, 4 * 64, 128, 256, 1, 0), (5, 1, 32, 4 * 32, 32, 128, 1, 1)]
     jobs, keep, prefix, tot = [], [], [], 0
     for nslab, taps, cin, nvalid, kpad, npad, tr, acc in specs:
