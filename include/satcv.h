@@ -131,6 +131,11 @@ typedef struct satcv_conv_desc {
    * kernel's tiles: satcv_conv2d_igemm_pipelined() answers 0 otherwise and the caller keeps the separate reduce launch. */
   const void* bst_y; const void* bst_y1; int32_t bst_ld, bst_ld1, bst_split;
   const float* bst_scale; const float* bst_shift; const float* bst_mean; const float* bst_rstd; int32_t bst_relu;
+  /* which tile family may serve this launch: 0 = the library option igemm_m16 decides (default 1: the 16x16x32 tiles only for launches that
+   * write statistics, so that inference results are bit-identical across batch splits); 2 = every eligible launch may run on the 16x16x32 /
+   * persistent tiles, whose choice depends on the launch's tile count -- what a TRAINING plan asks for, per launch (round 6: this used to be
+   * a process-global option toggled around the plan's steps).  Option igemm_m16 = 0 (SATCV_M16=0) still turns those tiles off. */
+  int32_t tile_policy;
 } satcv_conv_desc;
 int satcv_conv2d_igemm(const satcv_conv_desc* d, void* stream);
 /* 1 if this descriptor runs on the pipelined kernel (required by out_scale / pool_y / the fp8 dtypes), else 0; no launch. */

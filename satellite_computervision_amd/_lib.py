@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
                 ('cstat', c_i32), ('out_relu', c_i32), ('dtype', c_i32), ('accumulate', c_i32),
                 ('stride', c_i32), ('hin', c_i32), ('win', c_i32), ('out_scale', c_vp), ('pool_y', c_vp), ('pool_ld', c_i32), ('pool_f', c_i32),
                 ('bst_y', c_vp), ('bst_y1', c_vp), ('bst_ld', c_i32), ('bst_ld1', c_i32), ('bst_split', c_i32),
-                ('bst_scale', c_vp), ('bst_shift', c_vp), ('bst_mean', c_vp), ('bst_rstd', c_vp), ('bst_relu', c_i32)]
+                ('bst_scale', c_vp), ('bst_shift', c_vp), ('bst_mean', c_vp), ('bst_rstd', c_vp), ('bst_relu', c_i32), ('tile_policy', c_i32)]
 
 
 class PackJob(C.Structure):

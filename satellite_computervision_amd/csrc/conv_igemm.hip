@@ -333,6 +333,7 @@ static int igemm_fill_args(const satcv_conv_desc* d, IgemmArgs& a) {
   a.ksplit = 1; a.kslab = nullptr;
   a.bst_y = d->bst_y; a.bst_y1 = d->bst_y1; a.bst_ld = d->bst_ld; a.bst_ld1 = d->bst_ld1; a.bst_split = d->bst_y1 ? d->bst_split : 0;
   a.bst_scale = d->bst_scale; a.bst_shift = d->bst_shift; a.bst_mean = d->bst_mean; a.bst_rstd = d->bst_rstd; a.bst_relu = d->bst_relu;
+  a.tile_policy = d->tile_policy;
   if (d->bst_y) {
     SATCV_CHECK(d->stats && d->bst_scale && d->bst_shift && d->bst_mean && d->bst_rstd, "igemm: bst_y needs stats and the four BatchNorm vectors");
     SATCV_CHECK(!d->accumulate && !d->mode_out && !d->out_relu && !d->pool_y && d->cstat == d->cout, "igemm: bst_y needs a plain, non-accumulating store");

@@ -853,8 +853,10 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
     // round 5: the persistent 16x16x32 kernel (conv_igemm_m16p.hip) takes the mid layers -- 64 ... 256 input channels, Cout % 128 == 0, several
     // tiles per workgroup -- under the same option as the one-tile 16x16x32 kernels below (launches that write statistics, or every launch of a
     // training plan)
-    if (TW == 32 && a.dil == 1 && (g_opt_igemm_m16 >= 2 || (g_opt_igemm_m16 == 1 && (a.stats || a.bst_y)))) {
-      const int rc = igemm_m16p_launch(a, st, dry);
+    // (the per-launch tile_policy of a training plan raises the option's default 1 to 2; SATCV_M16=0 still wins)
+    const int m16 = (g_opt_igemm_m16 > 0 && a.tile_policy > g_opt_igemm_m16) ? a.tile_policy : g_opt_igemm_m16;
+    if (TW == 32 && a.dil == 1 && (m16 >= 2 || (m16 == 1 && (a.stats || a.bst_y)))) {
+      const int rc = igemm_m16p_launch(a, SATCV_BF16, st, dry);
       if (rc != SATCV_ERR_UNSUPPORTED) return rc;
     }
     // (K = 9 x 64 is four chunks: the double-buffered tile's longer set-up and epilogue are not amortised -- 64 -> 128 channels at 128 x 128
@@ -873,9 +875,8 @@ static int fast_tw(IgemmArgs& a, hipStream_t st, bool dry) {
         // write statistics -- training-mode forward convolutions and data gradients with fused BatchNorm-backward sums --, so that inference
         // stays bit-identical across batch splits; a training plan raises the option to 2 (every eligible launch)
         // around its steps (engine.Plan.run_forward / run_backward); SATCV_M16=0 turns the tile off
-        const int m16 = g_opt_igemm_m16;
         if (m16 >= 2 || (m16 == 1 && (a.stats || a.bst_y))) {
-          const int rc = igemm_m16_launch(a, st, dry);
+          const int rc = igemm_m16_launch(a, SATCV_BF16, st, dry);
           if (rc != SATCV_ERR_UNSUPPORTED) return rc;
         }
         if (wdma) {

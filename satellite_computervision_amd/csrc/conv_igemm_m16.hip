@@ -497,7 +497,8 @@ static int m16_cfg(IgemmArgs& a, hipStream_t st, bool dry) {
 
 // bf16 3x3, dilation 1, plain NHWC in and out, Cout % 128 == 0, Cin % 64 == 0, maps at least 16 pixels wide and a tile high;
 // SATCV_ERR_UNSUPPORTED otherwise (the caller continues with the 32x32x16 tiles)
-int igemm_m16_launch(IgemmArgs& a, hipStream_t st, bool dry) {
+int igemm_m16_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
+  if (dtype != SATCV_BF16) return SATCV_ERR_UNSUPPORTED;
   if (!(a.kh == 3 && a.kw == 3 && a.dil == 1 && a.stride == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && !a.out_scale)) return SATCV_ERR_UNSUPPORTED;
   switch (igemm_pick_tw(a.w_)) {
     case 32: return m16_cfg<32>(a, st, dry);

@@ -492,8 +492,9 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
 // bf16 3x3, dilation 1, plain NHWC in and out, whole 8 x 32 tiles, Cin % 64 == 0 (<= the LDS table), Cout % 128 == 0, bias + statistics or
 // fused BatchNorm-backward sums, no ReLU / multiplier / pool / accumulation in the epilogue.  SATCV_ERR_UNSUPPORTED otherwise (the caller
 // continues with the one-tile-per-workgroup kernels).
-int igemm_m16p_launch(IgemmArgs& a, hipStream_t st, bool dry) {
+int igemm_m16p_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   using G = M16PGeom;
+  if (dtype != SATCV_BF16) return SATCV_ERR_UNSUPPORTED;
   if (!g_opt_m16p) return SATCV_ERR_UNSUPPORTED;
   if (!(a.kh == 3 && a.kw == 3 && a.dil == 1 && a.stride == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && !a.out_scale && !a.out_relu && !a.accumulate))
     return SATCV_ERR_UNSUPPORTED;

@@ -30,6 +30,7 @@ struct IgemmArgs {
   // split-K (conv_igemm_fast.hip): ksplit workgroups share an output tile, each sums a contiguous range of the K chunks and writes its
   // fp32 partial tile to kslab[split][pixel][cout]; satcv's finish kernel adds the slabs in order, applies the epilogue and the statistics
   int ksplit; float* kslab;
+  int tile_policy;                 // satcv_conv_desc::tile_policy (0: option igemm_m16 decides, 2: every eligible launch on the 16x16x32 tiles)
 };
 
 template <typename T>
@@ -537,9 +538,9 @@ static inline int igemm_pick_tw(int w) {
 // shape is outside its static limits so that the caller falls back to the generic kernel.
 int igemm_fast_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run = false);
 // the deep 3x3 tile on v_mfma_f32_16x16x32_bf16 (conv_igemm_m16.hip); SATCV_ERR_UNSUPPORTED outside its limits
-int igemm_m16_launch(IgemmArgs& a, hipStream_t st, bool dry);
+int igemm_m16_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry);        // (dtype must be SATCV_BF16: the kernels reinterpret x / w / y as bf16)
 // the same tile as a persistent, cross-tile pipelined kernel for the mid layers (conv_igemm_m16p.hip); SATCV_ERR_UNSUPPORTED outside its limits
-int igemm_m16p_launch(IgemmArgs& a, hipStream_t st, bool dry);
+int igemm_m16p_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry);
 // persistent weights-stationary kernel of the thin 3x3 layers (conv_igemm_ws.hip); SATCV_ERR_UNSUPPORTED outside its limits
 int igemm_ws_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry_run);
 // the thin 3x3 layers with wave roles (conv_thin_roles.hip); SATCV_ERR_UNSUPPORTED outside its limits

@@ -260,6 +260,7 @@ class Plan:
     def __init__(self, rt, n, h, w, training, frozen=()):
         self.rt, self.n, self.h, self.w, self.training = rt, n, h, w, training
         self.frozen = set(frozen)
+        self.tile_policy = 2 if (training and _M16_DEFAULT == 1) else 0      # satcv_conv_desc.tile_policy of this plan's convolution launches
         self.fwd, self.bwd = [], []
         self.keep = []                        # ctypes descriptors / tensors kept alive
         self.dropouts = []                    # dropout masks (regenerated every training step)
@@ -294,6 +295,7 @@ class Plan:
         return int(hh), int(ww)
 
     def _conv_step(self, role='fwd', **kw):
+        kw.setdefault('tile_policy', self.tile_policy)
         d = ops.make_conv_desc(**kw)
         self.keep.append(d)
         fn = lambda st, d=d: check(lib.satcv_conv2d_igemm(C.byref(d), st))
@@ -866,6 +868,7 @@ class Plan:
             # the gradient of a max-pooled encoder output: this launch sees the pooled activation p = maxpool(relu(BN(y_enc))) (its own
             # input), so its epilogue can form the pooled part of that BatchNorm's backward sums in the activated form -- sum dp [p > 0],
             # sum dp p (bst_* with unit scale / rstd and zero shift / mean on the pooled tensor)
+            kw.setdefault('tile_policy', self.tile_policy)        # (the dry-run probes below must ask for the tile family the launch will get)
             if (POOL_SUMS and not kw.get('accumulate') and t.node.op == 'pool' and len(consumers[t.id]) == 1 and t.id not in gact
                     and len(vals[t.id].srcs) == 1 and vals[t.id].affine is None):
                 ent = act_sums_for(t.node.inputs[0])
@@ -1455,17 +1458,11 @@ class Plan:
 
     # -- execution
     # (a training plan lets EVERY eligible deep 3x3 launch -- also the data gradients that carry no statistics -- run on the 16x16x32 tile;
-    #  inference keeps the library default, which preserves bit-identical results across batch splits: csrc/conv_igemm_fast.hip)
+    #  inference keeps the library default, which preserves bit-identical results across batch splits: csrc/conv_igemm_fast.hip.  Round 6:
+    #  the choice travels in each launch's descriptor (satcv_conv_desc.tile_policy, set in _conv_step) -- no process-global option is touched)
     def _run(self, steps, st):
-        raise_m16 = self.training and _M16_DEFAULT == 1
-        if raise_m16:
-            lib.satcv_set_option(b'igemm_m16', 2)
-        try:
-            for s in steps:
-                s(st)
-        finally:
-            if raise_m16:
-                lib.satcv_set_option(b'igemm_m16', _M16_DEFAULT)
+        for s in steps:
+            s(st)
 
     def run_forward(self, st):
         self._run(self.fwd, st)

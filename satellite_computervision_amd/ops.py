@@ -80,8 +80,9 @@ def pack_weights(kernel_f32, cin_pad, dtype, transposed=False, want_dgrad=True, 
 # --------------------------------------------------------------------------- conv
 def make_conv_desc(*, x0, c0, w, y, ldy, n, h, w_, cout, cout_pad, dtype, x1=None, c1=0, in_scale=None, in_shift=None,
                    in_relu=0, bias=None, stats=None, stats_ld=0, kh=3, kw=3, dil=1, mode_in=0, mode_out=0, f=1,
-                   cstat=None, out_relu=0, accumulate=0, stride=1, hin=0, win=0, out_scale=None, pool_y=None, pool_ld=0, pool_f=0, bst=None):
+                   cstat=None, out_relu=0, accumulate=0, stride=1, hin=0, win=0, out_scale=None, pool_y=None, pool_ld=0, pool_f=0, bst=None, tile_policy=0):
     d = ConvDesc()
+    d.tile_policy = int(tile_policy)
     d.x0, d.x1, d.c0, d.c1 = x0, x1, c0, c1
     d.in_scale, d.in_shift, d.in_relu = in_scale, in_shift, int(in_relu)
     d.w, d.bias, d.y, d.ldy = w, bias, y, ldy
