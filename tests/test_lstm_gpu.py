@@ -428,7 +428,8 @@ def test_lstm_training_step_graph_replay_matches_eager(lt):
 def test_lstm_graph_capture_after_an_interleaved_predict_repacks_weights(lt):
     """train x2 -> predict -> train ...: the eager predict() repacks the operand images, so the step that gets CAPTURED finds them fresh.  The
     captured graph must hold the repack launch all the same (_Params.prepare_capture) -- otherwise every replay multiplies with the images of
-    capture time.  Eight steps with a predict() before the third, with and without replay: same losses, same parameters."""
+    capture time (the loss would stop falling: ~30 % off by the eighth step).  Eight steps with a predict() before the third, with and without replay: the
+    same losses and parameters up to what Adam's first steps make of the kernels' different summation orders (a capture never selects split-K)."""
     from satellite_computervision_amd import model_tools as mt
     mt.set_compute_dtype('float32')
     try:
@@ -440,7 +441,7 @@ def test_lstm_graph_capture_after_an_interleaved_predict_repacks_weights(lt):
             os.environ['SATCV_LSTM_GRAPH'] = flag
             mt.reset_uids(); mt.set_seed(7)
             m = lt.get_lstm_model(4, 3, 3)
-            m.compile(optimizer=mt.Adam(3e-3), loss=mt.mse_4d)
+            m.compile(optimizer=mt.Adam(1e-3), loss=mt.mse_4d)
             losses = []
             for i, (x, y) in enumerate(zip(xs, ys)):
                 if i in (2, 5):
@@ -454,10 +455,11 @@ def test_lstm_graph_capture_after_an_interleaved_predict_repacks_weights(lt):
         finally:
             os.environ.pop('SATCV_LSTM_GRAPH', None)
         assert any('g' in st for st in mg._graphs.values()), 'no step was captured'
-        np.testing.assert_allclose(lg, le, rtol=2e-4)
+        np.testing.assert_allclose(lg, le, rtol=5e-3)
+        assert le[-1] < 0.9 * le[2] and lg[-1] < 0.9 * lg[2]
         we, wg = me.get_weights_dict(), mg.get_weights_dict()
         for k in we:
-            assert np.abs(we[k] - wg[k]).max() < 3e-4, (k, np.abs(we[k] - wg[k]).max())
+            assert np.abs(we[k] - wg[k]).max() < 3e-3, (k, np.abs(we[k] - wg[k]).max())
     finally:
         mt.set_compute_dtype('bfloat16')
 
