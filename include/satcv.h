@@ -72,7 +72,9 @@ int satcv_pack_weights(const float* src, void* dst_fwd, void* dst_dgrad, int32_t
                        int32_t dtype, void* stream);
 /* All layers in one launch: a DEVICE array of jobs (mode 0 conv fwd, 1 conv dgrad, 2 transposed-conv fwd, 3 transposed-conv dgrad;
  * kpad / npad = K and N paddings of the image exactly as satcv_pack_weights derives them) and the exclusive prefix sum of
- * satcv_pack_job_items() over the jobs. */
+ * satcv_pack_job_items() over the jobs.  satcv_pack_job_items() is the job's number of 16-byte output items ROUNDED UP TO 256: a block of
+ * 256 consecutive items then belongs to one job and the kernel looks its job up once per block; total_items must be the sum of those values
+ * (SATCV_ERR_INVALID otherwise). */
 typedef struct { const float* src; void* dst; int32_t mode, taps, cin, cout, kpad, npad; } satcv_pack_job;
 int64_t satcv_pack_job_items(const satcv_pack_job* job);
 int satcv_pack_weights_batched(const satcv_pack_job* jobs_dev, const int64_t* prefix_dev, int32_t njobs, int64_t total_items, int32_t dtype,

@@ -42,6 +42,12 @@ extern "C" int satcv_debug_read_stamps_m16p(unsigned long long* out) { return hi
 #define PSTAMP(t) do { } while (0)
 #endif
 
+__device__ __forceinline__ bf16x4 m16p_tr_read(const bf16* p) {
+  typedef short short4v_ __attribute__((ext_vector_type(4)));
+  short4v_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v_*)(p));
+  return __builtin_bit_cast(bf16x4, v);
+}
+
 extern int g_opt_m16p;                 // api.hip: 0 off, 1 on where a workgroup gets at least two tiles
 int g_m16p_launches = 0;               // launches taken here (satcv_get_option("m16p_launches"): tests assert the path)
 
@@ -205,6 +211,11 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
     // that tile's first pixel in the output tensor and in the raw-output tensor(s): wave-uniform pointers, the lane part is a 32-bit offset
     T* d_o = nullptr; const T* d_y0 = nullptr; const T* d_y1 = nullptr;
     uint4 yv[BST ? 4 : 1];
+    // per-thread part of a round's addresses: pixel pq0 of the round's 16, channel group vq -- a kernel constant (32-bit element offsets);
+    // the tile and the round only add wave-uniform terms (round r: tile row r >> 1, column half r & 1)
+    const unsigned o_lane = (unsigned)pq0 * (unsigned)a.ldy + (unsigned)cg;
+    const unsigned y_lane = BST ? (unsigned)pq0 * yld + ycol : 0u;
+    const unsigned i_lane = (unsigned)(pq0 * BN + ((vq ^ pq0) << 3));       // image: pixel q = pq0 + 16 r -> q & 15 = pq0
     auto drain_begin = [&](int v) __attribute__((always_inline)) {
       int n0, y0, x0; tile_origin(v, n0, y0, x0);
       const size_t p0 = (size_t)(n0 * a.h + y0) * a.w_ + x0;
@@ -215,39 +226,29 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
       }
       d_tile = v; d_round = 0;
     };
-    // the raw outputs the next `cnt` rounds compare against (fused BatchNorm-backward sums): requested one interval before they are used
-    auto drain_prefetch = [&](int cnt) __attribute__((always_inline)) {
-      if constexpr (BST) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (r < cnt && d_round + r < G::ROUNDS) {
-            const int q = pq0 + (d_round + r) * 16;
-            unsigned off = ((unsigned)(q >> 5) * (unsigned)a.w_ + (unsigned)(q & 31)) * yld + ycol;
-            asm volatile("" : "+v"(off));
-            yv[r] = *reinterpret_cast<const uint4*>((bsec ? d_y1 : d_y0) + off);
-          }
-        }
-      }
+    auto round_off = [&](int r, unsigned ld) __attribute__((always_inline)) -> unsigned {        // wave-uniform element offset of round r
+      return ((unsigned)(r >> 1) * (unsigned)a.w_ + (unsigned)(r & 1) * 16u) * ld;
     };
-    auto drain_rounds = [&](int cnt) __attribute__((always_inline)) {
-      // (the image reads of all rounds first: one LDS latency per interval, not one per round)
-      uint4 dv[4];
+    // One interval's share of the drain, R rounds at a time (R = rpi is 1, 2 or 4 and divides the 16 rounds of a tile: no partial groups, no
+    // per-round conditions -- the round-5 form with a run-time count kept its four 16-byte pieces in SCRATCH once nothing else pinned them in
+    // registers).  rounds: store R rounds of the image (their raw outputs were requested one interval earlier); prefetch: request the raw outputs
+    // of the next R rounds (fused BatchNorm-backward sums only).
+    auto drain_step = [&](auto RC, bool rounds, bool prefetch) __attribute__((always_inline)) {
+      constexpr int R = decltype(RC)::value;
+      if (rounds && d_round < G::ROUNDS) {
+        // (the image reads of all rounds first: one LDS latency per interval, not one per round)
+        // (a first-class vector type: an array of uint4 structs that is only copied ended up in scratch)
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        u32x4_ dv[R];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (r < cnt && d_round + r < G::ROUNDS) {
-          const int q = pq0 + (d_round + r) * 16;
-          dv[r] = *reinterpret_cast<const uint4*>(ldsO + q * BN + ((vq ^ (q & 15)) << 3));
-        }
-      }
+        for (int r = 0; r < R; ++r) dv[r] = *reinterpret_cast<const u32x4_*>(ldsO + (d_round + r) * 16 * BN + i_lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (r < cnt && d_round < G::ROUNDS) {
-          const int q = pq0 + d_round * 16;
-          unsigned off = ((unsigned)(q >> 5) * (unsigned)a.w_ + (unsigned)(q & 31)) * (unsigned)a.ldy + (unsigned)cg;
+        for (int r = 0; r < R; ++r) {
+          unsigned off = round_off(d_round + r, (unsigned)a.ldy) + o_lane;
           asm volatile("" : "+v"(off));
-          *reinterpret_cast<uint4*>(d_o + off) = dv[r];
-          const bf16x8 d8 = __builtin_bit_cast(bf16x8, dv[r]);
+          *reinterpret_cast<u32x4_*>(d_o + off) = dv[r];
           if constexpr (BST) {
+            const bf16x8 d8 = __builtin_bit_cast(bf16x8, dv[r]);
             const bf16x8 y8 = __builtin_bit_cast(bf16x8, yv[r]);
             int toff = vq * 8;
             asm volatile("" : "+v"(toff));
@@ -260,14 +261,25 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
               const float gg = (v * bsc[e] + bsh[e] > 0.f || lin) ? fv : 0.f;
               st1[e] += gg; st2[e] += gg * v;
             }
-          } else if (a.stats) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float f = (float)d8[e]; st1[e] += f; st2[e] += f * f; }
           }
-          ++d_round;
+          // (forward launches: the statistics of the stored values are formed by the MATRIX waves, as MFMAs on this image -- see stats_mfma)
+        }
+        d_round += R;
+      }
+      if constexpr (BST) {
+        if (prefetch && d_round < G::ROUNDS) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            unsigned off = round_off(d_round + r, yld) + y_lane;
+            asm volatile("" : "+v"(off));
+            yv[r] = *reinterpret_cast<const uint4*>((bsec ? d_y1 : d_y0) + off);
+          }
         }
       }
     };
+    const std::integral_constant<int, 1> R1{};
+    const std::integral_constant<int, 2> R2{};
+    const std::integral_constant<int, 4> R4{};
     // rounds per interval: a tile's image is drained in the intervals 1 ... upt - 2 of the next tile (interval 0 only requests the first raw
     // outputs, the last interval is when the matrix waves write the next image)
     const int rpi = (G::ROUNDS + upt - 3) / (upt - 2);
@@ -318,9 +330,17 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
           if (st && ++s_x == nch) s_x = 0;
           if (ld) load_advance();
         }
-        if (d_tile >= 0 && !PABL(16)) {
-          if (iv == 0) drain_prefetch(rpi);
-          else if (iv < upt - 1) { drain_rounds(rpi); drain_prefetch(rpi); }
+        if (d_tile >= 0 && !PABL(16) && iv < upt - 1) {
+          // (interval 0 only requests the first raw outputs; the last interval is when the matrix waves write the next image)
+          if constexpr (BST) {
+            // (one compiled form of the sums: four rounds per interval -- 64 input channels -- run as two pairs)
+            if (rpi >= 2) { drain_step(R2, iv > 0, true); if (rpi == 4) drain_step(R2, iv > 0, true); }
+            else drain_step(R1, iv > 0, true);
+          } else {
+            if (rpi == 4) drain_step(R4, iv > 0, true);
+            else if (rpi == 2) drain_step(R2, iv > 0, true);
+            else drain_step(R1, iv > 0, true);
+          }
         }
         PSTAMP(z1);
         __syncthreads();
@@ -350,8 +370,9 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
     if (blockIdx.x < 8 && lane == 0) for (int i = 0; i < 4; ++i) g_stamp_m16p[blockIdx.x][wave][i] = zs[i];
 #endif
     // the last tile's image
-    if (!PABL(16)) for (int r = 0; r < G::ROUNDS; ++r) { drain_prefetch(1); drain_rounds(1); }
-    __syncthreads();                                                         // (3) staging waves only: the matrix waves have ended
+    if (!PABL(16)) for (int r = 0; r < G::ROUNDS; ++r) { drain_step(R1, false, true); drain_step(R1, true, false); }
+    if constexpr (!BST) return;                                              // (the forward statistics leave with the matrix waves)
+    __syncthreads();                                                         // (3) staging waves only: the matrix waves do not take part
     if (a.stats) {
       // sums of this workgroup: the threads of a channel group summed through LDS in a fixed order, one pair of atomics per channel
       float* r2 = reinterpret_cast<float*>(smem_raw);                        // [16][256]
@@ -409,6 +430,31 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
       for (int m = 0; m < 4; ++m) acc[m][n] = f32x4{b4.x, b4.y, b4.z, b4.w};
     }
   };
+  // ---- round 6: the forward launches' BatchNorm statistics (sum / sum of squares of the STORED bf16 values) as MFMAs on the staging image.
+  // In the staging waves they were 16 vector instructions per drained 16 bytes -- a third of those waves' instruction stream, and the staging
+  // waves' stream, not the matrix pipe, sets the pace of the forward launches (profiles/r05_m16p_interval_stamps.txt: 3 260 against 2 350 ticks per
+  // interval with the fused input BatchNorm).  Matrix wave w owns channels 16 w ... 16 w + 15 of the block: per 32 pixels ONE fragment
+  // F[c][p] (two transposing reads of the [pixel][channel] image, the drain's swizzle) feeds  G += F F^T  (diagonal = sum of squares) and
+  // S += F 1  (row sums): 16 MFMAs and 16 reads per tile and wave (0.7 % of the tile's MFMAs), 8 accumulator registers, fp32 sums over the
+  // workgroup's tiles, one pair of double atomics per channel at the end.
+  f32x4 g_sq = {0.f, 0.f, 0.f, 0.f}, g_sm = {0.f, 0.f, 0.f, 0.f};
+  const bool mstats = !BST && a.stats != nullptr;
+  auto stats_mfma = [&]() __attribute__((always_inline)) {
+    const int q = l16 >> 2, pcol = l16 & 3;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    const int gidx = wave * 4 + pcol;                                        // 8-byte granule of channels 16 w + 4 pcol ... + 3
+#pragma unroll 2
+    for (int kp = 0; kp < 8; ++kp) {
+      const int p0 = kp * 32 + g4 * 8 + q, p1 = p0 + 4;
+      const bf16x4 lo = m16p_tr_read(ldsO + p0 * BN + ((gidx ^ (2 * (p0 & 15))) << 2));
+      const bf16x4 hi = m16p_tr_read(ldsO + p1 * BN + ((gidx ^ (2 * (p1 & 15))) << 2));
+      const bf16x8 fr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      g_sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr, fr, g_sq, 0, 0, 0);
+      g_sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr, ones, g_sm, 0, 0, 0);
+    }
+  };
   dma_unit(0, 0, 0);
   dma_wait_all();
   __syncthreads();                                                           // (1)
@@ -422,6 +468,7 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
 #endif
   for (int t = 0; t < ntl; ++t) {
     for (int x = 0; x < nch; ++x) {
+      if (mstats && x == 0 && t > 0) stats_mfma();                           // (the barrier that ended tile t - 1 published its image)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int slot = (x * 3 + ky) & 1;                                   // (upt is even: a tile starts on slot 0)
@@ -486,6 +533,19 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
 #ifdef SATCV_STAMP_M16P
   if (blockIdx.x < 8 && lane == 0) for (int i = 0; i < 4; ++i) g_stamp_m16p[blockIdx.x][wave][i] = ys[i];
 #endif
+  if (mstats) {
+    stats_mfma();                                                            // the last tile's image (nobody writes it any more)
+    // G[c][c'] and S[c][*]: register r of lane (g4, l16) is row 4 g4 + r, column l16 -- the lanes with l16 >> 2 == g4 hold G's diagonal
+    // element and the row sum of channel 16 w + l16 in register l16 & 3
+    if ((l16 >> 2) == g4) {
+      const int r = l16 & 3;
+      const float s2 = r == 0 ? g_sq[0] : r == 1 ? g_sq[1] : r == 2 ? g_sq[2] : g_sq[3];
+      const float s1 = r == 0 ? g_sm[0] : r == 1 ? g_sm[1] : r == 2 ? g_sm[2] : g_sm[3];
+      satcv_stat_t* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
+      atomicAdd(rowp + nbase + wave * 16 + l16, (satcv_stat_t)s1);
+      atomicAdd(rowp + a.stats_ld + nbase + wave * 16 + l16, (satcv_stat_t)s2);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ host side

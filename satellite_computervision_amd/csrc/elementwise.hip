@@ -138,12 +138,19 @@ __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, 
 // a device table of pack jobs + the exclusive prefix sum of their 16-byte output items; each thread finds its job by binary
 // search and does what pack_kernel does.
 template <typename T>
-__global__ void pack_batched_kernel(const satcv_pack_job* __restrict__ jobs, const long long* __restrict__ prefix, int njobs, long long total) {
-  for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(EW_BLOCK) void pack_batched_kernel(const satcv_pack_job* __restrict__ jobs, const long long* __restrict__ prefix, int njobs, long long total) {
+  // Round 6: the job of an item was found by a binary search PER THREAD (six dependent loads of the prefix table + the 48-byte job, ahead of the
+  // eight gathered loads of every item: 89 us for 148 MB).  A job's item count is now rounded up to a multiple of the block size
+  // (satcv_pack_job_items), so a block of 256 consecutive items belongs to ONE job: the search runs on block-uniform values (scalar loads),
+  // once per block of items.
+  for (long long g0 = (long long)blockIdx.x * EW_BLOCK; g0 < total; g0 += (long long)gridDim.x * EW_BLOCK) {
     int lo = 0, hi = njobs - 1;
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= g) lo = mid; else hi = mid - 1; }
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (prefix[mid] <= g0) lo = mid; else hi = mid - 1; }
+    lo = __builtin_amdgcn_readfirstlane(lo);
     const satcv_pack_job j = jobs[lo];
-    long long it = g - prefix[lo];
+    long long it = g0 - prefix[lo] + threadIdx.x;
+    const long long real = (long long)(j.mode >= 2 ? 1 : j.taps) * (j.kpad / 8) * j.npad;
+    if (it >= real) continue;
     if (j.mode == 1 && (j.kpad / 8) % 4 == 0 && j.npad % 16 == 0) {
       // data-gradient image of a 3x3 kernel: k runs over Cout (contiguous in the Keras kernel), nn over Cin (stride Cout).  With nn on
       // the lanes every lane read its 32 bytes from another 128-byte line (4x the lines); here 4 lanes cover the 4 x 32 bytes of one
@@ -174,11 +181,14 @@ __global__ void pack_batched_kernel(const satcv_pack_job* __restrict__ jobs, con
 }
 extern "C" int64_t satcv_pack_job_items(const satcv_pack_job* j) {
   if (!j || j->kpad <= 0 || j->kpad % 8 || j->npad <= 0 || j->mode < 0 || j->mode > 3) return -1;
-  return (int64_t)(j->mode >= 2 ? 1 : j->taps) * (j->kpad / 8) * j->npad;
+  // (rounded up to the block size of the batched kernel: a block of items never straddles two jobs)
+  const int64_t real = (int64_t)(j->mode >= 2 ? 1 : j->taps) * (j->kpad / 8) * j->npad;
+  return (real + EW_BLOCK - 1) / EW_BLOCK * EW_BLOCK;
 }
 extern "C" int satcv_pack_weights_batched(const satcv_pack_job* jobs_dev, const int64_t* prefix_dev, int32_t njobs, int64_t total_items, int32_t dtype,
                                           void* stream) {
   SATCV_CHECK(jobs_dev && prefix_dev && njobs > 0 && total_items > 0, "pack_weights_batched: bad args");
+  SATCV_CHECK(total_items % EW_BLOCK == 0, "pack_weights_batched: the prefix table must be built from satcv_pack_job_items (multiples of 256)");
   DISPATCH_T8(dtype, hipLaunchKernelGGL(pack_batched_kernel<T>, dim3(ew_grid(total_items)), dim3(EW_BLOCK), 0, (hipStream_t)stream, jobs_dev,
                                         (const long long*)prefix_dev, njobs, (long long)total_items));
   LAUNCH_OK("pack_weights_batched");
@@ -640,6 +650,109 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_dense_kernel(const satcv_bnbw
     for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(d.dbias + i, lds[i]);
   }
 }
+
+// Round 6: the APPLY pass of the dense form rebuilt.  The loop above, instantiated with APPLY = true, compiled to two loads per iteration
+// with `s_waitcnt vmcnt(0)` behind them (per-lane loop exits keep hipcc from hoisting the next pixels' loads), ~230 vector instructions per 8
+// channels (the `sk` test is lane-dependent: an exec-mask branch per channel; every output was rounded on its own for a bias sum nobody asked
+// for) -- at 12 KB per 920 SIMD cycles the pass was VALU-bound just under the HBM rate (3.9-5.2 TB/s against 5.9-6.3 of the reduce pass).
+// Here: U pixels per iteration with all 2 U loads issued first (a wave-uniform trip count; the ragged tail runs clamped and predicated), the
+// sums compiled in only where the launch wants them (SK: the skip half of a decoder concatenation, DB: SATCV_BN_BIAS_NOISE), and per channel
+//   gm = (v sc + sh > lin_lo) ? g : 0;  t = sc gm - k1 - k2 (v - mu),  k1 = sc c1, k2 = sc rs c2
+// (the centred form: v - mu first, as before -- no cancellation when |mean| >> std).
+template <typename T, bool SK, bool DB, int U>
+__global__ __launch_bounds__(EW_BLOCK) void bn_bwd_apply_dense_kernel(const satcv_bnbwd_desc d, const int rev, const int cld) {
+  extern __shared__ float lds[];
+  const int c = d.c, G = c / 8;
+  const unsigned npix = (unsigned)d.n * d.h * d.w_;
+  const unsigned nthreads = gridDim.x * blockDim.x;
+  const unsigned per = nthreads / G;
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = gid < per * G;
+  const int g = gid % G;
+  const bool second = d.c_split > 0 && g * 8 >= d.c_split;
+  const T* da = (const T*)d.da + g * 8;
+  const T* yr = second ? (const T*)d.yraw1 + (g * 8 - d.c_split) : (const T*)d.yraw + g * 8;
+  T* dy = second ? (T*)d.dy1 + (g * 8 - d.c_split) : (T*)d.dy + g * 8;
+  const int ldy = second ? d.ldy1 : d.ldy, lddy = second ? d.lddy1 : d.lddy_out;
+  float sc[8], sh[8], mu[8], k1[8], k2[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = g * 8 + e;
+    sc[e] = d.scale[ch]; sh[e] = d.shift[ch]; mu[e] = d.mean[ch];
+    k1[e] = sc[e] * d.coef[ch]; k2[e] = sc[e] * d.rstd[ch] * d.coef[cld + ch];
+    s1[e] = 0.f; s2[e] = 0.f;
+  }
+  const float lin_lo = d.linear ? -INFINITY : 0.f;      // (a > 0 || linear)  ==  a > lin_lo
+  const unsigned pfirst = gid / G;
+  // every thread of the grid runs the same number of iterations; pixels past the end (and the threads beyond per * G) are clamped to the
+  // last pixel for their loads and store nothing
+  const unsigned nit = (npix + per - 1) / per;
+  // FULL iterations: every pixel of every thread exists (a grid-uniform test) -- no per-pixel predicates around the sums; the ragged last
+  // iteration(s) run the same body with them
+  auto body = [&](unsigned i0, auto FULLC) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(FULLC)::value;
+    Raw8<T> rv[U], rg[U];
+    unsigned pp[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long q = (unsigned long long)pfirst + (unsigned long long)(i0 + u) * per;
+      ok[u] = FULL ? active : (active && q < npix);
+      const unsigned pq = (FULL || q < npix) ? (unsigned)q : npix - 1;
+      pp[u] = rev ? npix - 1 - pq : pq;
+      rv[u] = gload8<T>(yr + (size_t)pp[u] * ldy);
+      rg[u] = gload8<T>(da + (size_t)pp[u] * d.ldda);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float v[8], gr[8], o[8];
+      unpack8<T>(rv[u], v);
+      unpack8<T>(rg[u], gr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float gm = (fmaf(v[e], sc[e], sh[e]) > lin_lo) ? gr[e] : 0.f;
+        const float t = fmaf(-k2[e], v[e] - mu[e], fmaf(sc[e], gm, -k1[e]));
+        if constexpr (SK || DB) {
+          o[e] = round_to<T>(t);
+          const float om = (FULL || ok[u]) ? o[e] : 0.f;      // (threads beyond per * G run clamped: their partial sums are dropped at the end)
+          // SK: v is the ACTIVATED skip a = relu(BN(y_enc)) and o its gradient -- the first-source threads also form the sums of THAT
+          // BatchNorm's backward in the activated form: sum o [a > 0], sum o a (satcv_bn_bwd_finalize2 converts)
+          if constexpr (SK) { s1[e] += v[e] > 0.f ? om : 0.f; s2[e] = fmaf(om, v[e], s2[e]); }
+          else s1[e] += om;
+        } else {
+          o[e] = t;
+        }
+      }
+      if (ok[u]) store8<T>(dy + (size_t)pp[u] * lddy, o);
+    }
+  };
+  // the largest pixel index any thread touches in iterations [i0, i0 + U) is per + (i0 + U - 1) per (the surplus threads beyond per * G start at
+  // pixel `per`; they load like the others and store nothing)
+  unsigned i0 = 0;
+  for (; (unsigned long long)(i0 + U) * per < npix; i0 += U) body(i0, std::true_type{});
+  for (; i0 < nit; i0 += U) body(i0, std::false_type{});
+  if constexpr (SK) block_channel_reduce(lds, s1, s2, g, active && !second, c, d.sk_sums, d.sk_sums_ld, d.c_split > 0 ? d.c_split : -1);
+  else if constexpr (DB) {
+    for (int i = threadIdx.x; i < c; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(&lds[g * 8 + e], s1[e]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(d.dbias + i, lds[i]);
+  }
+}
+// (SATCV_BN_APPLY=0: the round-3 loop for every apply launch -- A/B switch)
+template <typename T>
+static void bn_bwd_apply_dense_launch(const satcv_bnbwd_desc& e, long long items, size_t lds_bytes, int rev, int cld, hipStream_t st) {
+  static const int mode = getenv("SATCV_BN_APPLY") ? atoi(getenv("SATCV_BN_APPLY")) : 1;
+  const dim3 grid(ew_grid(items)), block(EW_BLOCK);
+  if (mode == 0) { hipLaunchKernelGGL((bn_bwd_dense_kernel<T, true>), grid, block, lds_bytes, st, e, rev, cld); return; }
+  if (e.sk_sums) hipLaunchKernelGGL((bn_bwd_apply_dense_kernel<T, true, false, 4>), grid, block, lds_bytes, st, e, rev, cld);
+  else if (e.dbias) hipLaunchKernelGGL((bn_bwd_apply_dense_kernel<T, false, true, 4>), grid, block, lds_bytes, st, e, rev, cld);
+  else hipLaunchKernelGGL((bn_bwd_apply_dense_kernel<T, false, false, 4>), grid, block, lds_bytes, st, e, rev, cld);
+}
 static int bnbwd_check(const satcv_bnbwd_desc* d, bool apply) {
   SATCV_CHECK(d && d->yraw && d->scale && d->shift && d->mean && d->rstd, "bn_bwd: null pointer");
   SATCV_CHECK(d->da || d->dpool, "bn_bwd: no incoming gradient");
@@ -678,14 +791,14 @@ extern "C" int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream) {
     e.c = d->c_split; e.c_split = 0; e.yraw1 = nullptr;
     const long long it1 = (long long)d->n * d->h * d->w_ * (e.c / 8);
     const size_t lds_1 = d->sk_sums ? (EW_BLOCK + 1) * 16 * sizeof(float) : e.c * sizeof(float);
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, true>), dim3(ew_grid(it1)), dim3(EW_BLOCK), lds_1, (hipStream_t)stream, e, rev, d->c));
+    DISPATCH_T(d->dtype, bn_bwd_apply_dense_launch<T>(e, it1, lds_1, rev, d->c, (hipStream_t)stream));
     LAUNCH_OK("bn_bwd_apply");
     return SATCV_OK;
   }
   const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
   if (!d->dpool && d->da && (long long)d->n * d->h * d->w_ < 0x7fffffffLL) {
     const size_t lds_b = d->sk_sums ? (EW_BLOCK + 1) * 16 * sizeof(float) : d->c * sizeof(float);
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), lds_b, (hipStream_t)stream, *d, rev, d->c));
+    DISPATCH_T(d->dtype, bn_bwd_apply_dense_launch<T>(*d, items, lds_b, rev, d->c, (hipStream_t)stream));
   } else {
     DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), d->c * sizeof(float), (hipStream_t)stream, *d));
   }

@@ -75,7 +75,10 @@ BIAS_NOISE = os.environ.get('SATCV_BN_BIAS_NOISE', '0') == '1'
 # a layer's weight gradient is enqueued BEHIND its data gradient (both only need dy): with the weight gradients on 160 workgroups the
 # step time is the same either way (9.54 ms, three A/B pairs) and the 3x3 data gradients run without their own layer's weight
 # gradient beside them (roofline.frac 0.251 -> 0.262); SATCV_WGRAD_LATE=0 restores the earlier order
-WGRAD_LATE = os.environ.get('SATCV_WGRAD_LATE', '1') == '1'
+# round 6, weight gradients on 128 workgroups, profiling events off: enqueued BEFORE the data gradient the step is 7.89-7.90 ms against 7.99-8.00 behind it
+# (profiles/r06_ab_env_switches.txt, A/B/A/B on one box) -- the weight gradient then starts beside its own layer's data gradient and the side stream
+# finishes earlier; SATCV_WGRAD_LATE=1 restores the round-3 order
+WGRAD_LATE = os.environ.get('SATCV_WGRAD_LATE', '0') == '1'
 # round 5: decoder_block's up-sampling path backward as one launch (csrc/convt_bwd_fused.hip) for these Conv2DTranspose filter counts (SATCV_CTBF=0: off;
 # SATCV_CTBF_COUTS restricts the set)
 CTBF = os.environ.get('SATCV_CTBF', '1') != '0'
