@@ -483,6 +483,12 @@ int satcv_confusion(const int32_t* classes, const float* y_true, int32_t ncls, i
  * step_count itself so that the launch is graph-replayable. */
 int satcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
                     float beta2, float eps, float* state, const float* lr_mul, void* stream);
+/* The same update on a SUB-RANGE of the flat buffers (pointers already offset, n elements), with the step counter incremented only when
+ * bump != 0: a step may be applied in several launches -- the part of the parameters whose gradients are final early in the backward pass
+ * on a second stream, beside the rest of the backward pass (engine.Plan, round 6) -- as long as exactly ONE of them, the last to run,
+ * bumps: every part then sees the same step number. */
+int satcv_adam_step_part(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
+                         float beta2, float eps, float* state, const float* lr_mul, int32_t bump, void* stream);
 
 /* Clears the two buffers a training step accumulates into -- the flat gradient (bytes_a, a multiple of 16, 16-byte aligned) and a small
  * second one (the loss scalar; bytes_b a multiple of 4) -- in ONE launch of the library's own (the optimizer loop of Model.fit,

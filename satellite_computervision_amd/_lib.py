@@ -186,6 +186,7 @@ _SIGS = {
     'satcv_loss_global_fwd_bwd': (C.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     'satcv_confusion': (C.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
     'satcv_adam_step': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp]),
+    'satcv_adam_step_part': (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp, c_i32, c_vp]),
     'satcv_comm_unique_id': (C.c_int, [c_vp]),
     'satcv_comm_init': (C.c_int, [C.POINTER(c_vp), c_i32, c_i32, c_vp]),
     'satcv_comm_destroy': (C.c_int, [c_vp]),

@@ -140,6 +140,9 @@ int g_opt_m16p = env_int("SATCV_M16P", 1);               // conv_igemm_m16p.hip 
 extern int g_m16p_launches;
 int g_tr_launches = 0;                                   // launches conv_thin_roles.hip took (tests: "path taken")
 int g_opt_thin_roles = env_int("SATCV_THIN_ROLES", 1);   // conv_thin_roles.hip: 0 off, 1 the shapes it measured faster on, 2 every shape it serves
+// conv_igemm_m16p.hip: s_setprio of the staging waves, decimal digits (plain launches)(launches with the fused input BatchNorm)(launches with the
+// fused BatchNorm-backward sums), each 0 ... 3 -- e.g. 30 = priority 3 for the forward launches that transform their input, 0 elsewhere
+int g_opt_m16p_prio = env_int("SATCV_M16P_PRIO", 30);      // (30: profiles/r06_ab_m16p_prio_step.txt)
 int g_opt_splitk = env_int("SATCV_SPLITK", 0);         // split-K of under-filled PLAIN (halo-tile / 1x1) launches: opt-in, see conv_igemm_fast.hip
 static int* opt_slot(const char* key) {
   if (!key) return nullptr;
@@ -152,6 +155,7 @@ static int* opt_slot(const char* key) {
   if (!strcmp(key, "thin_roles")) return &g_opt_thin_roles;
   if (!strcmp(key, "thin_roles_launches")) return &g_tr_launches;
   if (!strcmp(key, "m16p")) return &g_opt_m16p;
+  if (!strcmp(key, "m16p_prio")) return &g_opt_m16p_prio;
   if (!strcmp(key, "m16p_launches")) return &g_m16p_launches;
   return nullptr;
 }

@@ -48,6 +48,7 @@ __device__ __forceinline__ bf16x4 m16p_tr_read(const bf16* p) {
   return __builtin_bit_cast(bf16x4, v);
 }
 
+extern int g_opt_m16p_prio;            // api.hip
 extern int g_opt_m16p;                 // api.hip: 0 off, 1 on where a workgroup gets at least two tiles
 int g_m16p_launches = 0;               // launches taken here (satcv_get_option("m16p_launches"): tests assert the path)
 
@@ -115,10 +116,11 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
     // ================================================================ staging / draining waves (256 threads)
     constexpr int NS = G::NS, AI = G::AI;
     const int sid = tid - 512;
-#ifndef SATCV_M16P_PRIO
-#define SATCV_M16P_PRIO 0
-#endif
-    if (SATCV_M16P_PRIO) __builtin_amdgcn_s_setprio(SATCV_M16P_PRIO);
+    // priority of the staging waves (option m16p_prio, per launch kind: a.dbg).  They are the youngest waves of their SIMDs: at equal priority the
+    // matrix waves' MFMAs win the vector-issue arbitration (profiles/r06_m16p_stamp_variants.txt)
+    if (a.dbg == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.dbg == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.dbg == 3) __builtin_amdgcn_s_setprio(3);
     const int nc = ntl * nch;                                                // chunks of this workgroup's stream
     // activation items: item it = (pixel octet it >> 5, lane-in-octet it & 7, slot ((it >> 3) + it) & 3): the 8 lanes of a ds_write_b128 group
     // hold 8 consecutive pixels of one plane, a wave-instruction's global loads cover 16 pixels x 64 contiguous bytes
@@ -174,14 +176,19 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
       if (++l_x == nch) { l_x = 0; ++l_v; load_setup(); }                    // (one tile beyond the range at the very end: computed, never loaded)
     };
     // ---- store side: items J0 ... of the chunk in set SET (chunk-in-tile x: its scale / shift) -> stage SET
-    auto store_items = [&](int x, auto SET, auto J0C, auto NJC) __attribute__((always_inline)) {
-      constexpr int S = decltype(SET)::value, J0 = decltype(J0C)::value, NJ = decltype(NJC)::value;
-      float4 rs[4];
+    // (the scale / shift of a chunk's eight channels: read once per CHUNK -- at its first item pair -- and kept for its three intervals; read per
+    //  interval they were a second serial LDS round trip in front of the stores, behind the matrix waves' fragment bursts)
+    float4 rs[4];
+    auto load_table = [&](int x) __attribute__((always_inline)) {
       if (xaff) {
         const float4* tp = reinterpret_cast<const float4*>(ldsT + x * 32 + slot_t * 8);
         const float4* hp = reinterpret_cast<const float4*>(ldsT + cin + x * 32 + slot_t * 8);
         rs[0] = tp[0]; rs[1] = tp[1]; rs[2] = hp[0]; rs[3] = hp[1];
       }
+    };
+    auto store_items = [&](int x, auto SET, auto J0C, auto NJC) __attribute__((always_inline)) {
+      constexpr int S = decltype(SET)::value, J0 = decltype(J0C)::value, NJ = decltype(NJC)::value;
+      if (J0 == 0) load_table(x);
       T* d = ldsA + S * G::A_STAGE_E + slot_t * G::PLANE_E;
 #pragma unroll
       for (int j = J0; j < J0 + NJ; ++j) {
@@ -233,15 +240,19 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
     // per-round conditions -- the round-5 form with a run-time count kept its four 16-byte pieces in SCRATCH once nothing else pinned them in
     // registers).  rounds: store R rounds of the image (their raw outputs were requested one interval earlier); prefetch: request the raw outputs
     // of the next R rounds (fused BatchNorm-backward sums only).
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));      // (a first-class vector type: an array of uint4 structs that is only copied ended up in scratch)
+    u32x4_ dv[4];
+    // the interval's image pieces: requested FIRST in the interval (with the table reads of a chunk's first pair: one LDS round trip per interval)
+    auto drain_read = [&](auto RC, bool rounds) __attribute__((always_inline)) {
+      constexpr int R = decltype(RC)::value;
+      if (rounds && d_round < G::ROUNDS) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) dv[r] = *reinterpret_cast<const u32x4_*>(ldsO + (d_round + r) * 16 * BN + i_lane);
+      }
+    };
     auto drain_step = [&](auto RC, bool rounds, bool prefetch) __attribute__((always_inline)) {
       constexpr int R = decltype(RC)::value;
       if (rounds && d_round < G::ROUNDS) {
-        // (the image reads of all rounds first: one LDS latency per interval, not one per round)
-        // (a first-class vector type: an array of uint4 structs that is only copied ended up in scratch)
-        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-        u32x4_ dv[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) dv[r] = *reinterpret_cast<const u32x4_*>(ldsO + (d_round + r) * 16 * BN + i_lane);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           unsigned off = round_off(d_round + r, (unsigned)a.ldy) + o_lane;
@@ -323,6 +334,9 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int iv = x * 3 + ky;                                           // interval inside the tile
+        const bool dr = d_tile >= 0 && !PABL(16) && iv > 0 && iv < upt - 1;
+        if constexpr (BST) { if (rpi >= 2) drain_read(R2, dr); else drain_read(R1, dr); }
+        else { if (rpi == 4) drain_read(R4, dr); else if (rpi == 2) drain_read(R2, dr); else drain_read(R1, dr); }
         if (ky == 0) pair(I0);
         else if (ky == 1) pair(I2);
         else {
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
           // (interval 0 only requests the first raw outputs; the last interval is when the matrix waves write the next image)
           if constexpr (BST) {
             // (one compiled form of the sums: four rounds per interval -- 64 input channels -- run as two pairs)
-            if (rpi >= 2) { drain_step(R2, iv > 0, true); if (rpi == 4) drain_step(R2, iv > 0, true); }
+            if (rpi >= 2) { drain_step(R2, iv > 0, true); if (rpi == 4) { drain_read(R2, iv > 0); drain_step(R2, iv > 0, true); } }
             else drain_step(R1, iv > 0, true);
           } else {
             if (rpi == 4) drain_step(R4, iv > 0, true);
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
     if (blockIdx.x < 8 && lane == 0) for (int i = 0; i < 4; ++i) g_stamp_m16p[blockIdx.x][wave][i] = zs[i];
 #endif
     // the last tile's image
-    if (!PABL(16)) for (int r = 0; r < G::ROUNDS; ++r) { drain_step(R1, false, true); drain_step(R1, true, false); }
+    if (!PABL(16)) for (int r = 0; r < G::ROUNDS; ++r) { drain_step(R1, false, true); drain_read(R1, true); drain_step(R1, true, false); }
     if constexpr (!BST) return;                                              // (the forward statistics leave with the matrix waves)
     __syncthreads();                                                         // (3) staging waves only: the matrix waves do not take part
     if (a.stats) {
@@ -585,6 +599,7 @@ int igemm_m16p_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   a.n_tiles = a.cout / 128;
   a.cpt = cin / 32; a.nchunks = a.cpt; a.taploop = 0; a.halh_tl = a.halw_tl = 1;
   a.ksplit = 1; a.kslab = nullptr;
+  a.dbg = a.bst_y ? g_opt_m16p_prio % 10 : a.in_scale ? (g_opt_m16p_prio / 10) % 10 : (g_opt_m16p_prio / 100) % 10;
   const long long m_total = (long long)a.n * a.tiles_y * a.tiles_x;
   if (m_total <= 0 || m_total > 0x7fffffffLL || a.n_tiles > ncu) return SATCV_ERR_UNSUPPORTED;
   long long ranges = ncu / a.n_tiles;

@@ -1746,6 +1746,15 @@ extern "C" int satcv_zero2(void* a, int64_t bytes_a, void* b, int64_t bytes_b, v
   LAUNCH_OK("zero2");
   return SATCV_OK;
 }
+extern "C" int satcv_adam_step_part(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps, float* state,
+                                    const float* lr_mul, int32_t bump, void* stream) {
+  SATCV_CHECK(p && g && m && v && state && n > 0, "adam: bad args");
+  SATCV_CHECK(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0), "adam: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1, 4096)), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v, (long long)n, beta1, beta2, eps, state, lr_mul);
+  if (bump) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+  LAUNCH_OK("adam");
+  return SATCV_OK;
+}
 extern "C" int satcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps, float* state,
                                const float* lr_mul, void* stream) {
   SATCV_CHECK(p && g && m && v && state && n > 0, "adam: bad args");

@@ -84,6 +84,12 @@ WGRAD_LATE = os.environ.get('SATCV_WGRAD_LATE', '0') == '1'
 CTBF = os.environ.get('SATCV_CTBF', '1') != '0'
 CTBF_COUTS = tuple(int(v) for v in os.environ.get('SATCV_CTBF_COUTS', '32,64').split(',') if v)
 FUSE_RESIDUAL = os.environ.get('SATCV_FUSE_RESIDUAL', '1') == '1'      # inference: residual joins written by the block's last convolution
+# round 6 experiment, OFF by default: Adam + operand repack of the parameters whose gradients are final early in the backward pass (99.5 % of them
+# once the fourth encoder block is done) on the weight-gradient stream beside the rest of it.  Measured 7.87-7.89 ms against 7.82-7.87 without
+# (profiles/r06_ab_early_opt_and_reduce_stream.txt): the trace of a step shows why -- the weight-gradient stream is busy to the last
+# microsecond of the backward pass, so work moved onto it only lengthens it.  SATCV_EARLY_OPT=1 turns it on (tests run both).
+EARLY_OPT = os.environ.get('SATCV_EARLY_OPT', '0') == '1'
+EARLY_OPT_FRAC = 0.05
 FUSE_DGRAD_ALL = os.environ.get('SATCV_FUSE_DGRAD_BN_BWD', '1') == '2'      # 2: every eligible data gradient carries the BN-backward sums
 
 
@@ -184,7 +190,7 @@ class Runtime:
                     fwd=torch.zeros(ef, dtype=self.tdtype, device=self.dev),
                     dgrad=torch.zeros(ed, dtype=self.tdtype, device=self.dev),
                     k=(ks[0], ks[1]), cin=cin, cout=cout, cin_pad=cin_pad, transposed=tr)
-        self._ptab = None
+        self._ptabs = {}
         self.repack()
         self.plans = {}
 
@@ -211,11 +217,14 @@ class Runtime:
     def set_param(self, name, value):
         self.get_param(name).copy_(torch.as_tensor(np.asarray(value, np.float32)).to(self.dev).view(self.specs[name].shape))
 
-    def _pack_table(self):
-        """device table of every layer's pack jobs (forward + data-gradient image) for satcv_pack_weights_batched"""
+    def _pack_table(self, lo=0, hi=None):
+        """device table of the pack jobs (forward + data-gradient image) of every layer whose kernel starts in [lo, hi) of the flat parameter
+        buffer, for satcv_pack_weights_batched; None when no layer does"""
         from ._lib import PackJob
         jobs = []
         for lname, pk in self.packed.items():
+            if not (lo <= self.offsets[lname + '/kernel'] < (self.n_train if hi is None else hi)):
+                continue
             taps, cin, cout, cp = pk['k'][0] * pk['k'][1], pk['cin'], pk['cout'], pk['cin_pad']
             src = self.pptr(lname + '/kernel')
             if not pk['transposed']:
@@ -224,6 +233,8 @@ class Runtime:
             else:
                 jobs.append(PackJob(src, pk['fwd'].data_ptr(), 2, taps, cin, cout, cp, rup(taps * cout, 32)))
                 jobs.append(PackJob(src, pk['dgrad'].data_ptr(), 3, taps, cin, cout, rup(taps * cout, 16), rup(cin, 32)))
+        if not jobs:
+            return None
         prefix, tot = [], 0
         for j in jobs:
             prefix.append(tot)
@@ -233,14 +244,19 @@ class Runtime:
         pre = torch.tensor(prefix, dtype=torch.int64, device=self.dev)
         return dict(jobs=raw, prefix=pre, n=len(jobs), total=tot)
 
-    def repack(self):
-        """fp32 Keras-layout kernels -> MFMA operand images (after every weight update), one launch for all layers."""
+    def repack(self, lo=0, hi=None, stream=None):
+        """fp32 Keras-layout kernels -> MFMA operand images (after every weight update), one launch for all layers (or for the layers whose
+        kernels start in [lo, hi) of the flat buffer: the early part of a split optimizer step, engine.Plan)."""
         if not self.packed:
             return
-        if self._ptab is None:
-            self._ptab = self._pack_table()
-        t = self._ptab
-        check(lib.satcv_pack_weights_batched(t['jobs'].data_ptr(), t['prefix'].data_ptr(), t['n'], t['total'], self.dtype, ops.stream_ptr()))
+        key = (lo, hi)
+        if key not in self._ptabs:
+            self._ptabs[key] = self._pack_table(lo, hi)
+        t = self._ptabs[key]
+        if t is None:
+            return
+        check(lib.satcv_pack_weights_batched(t['jobs'].data_ptr(), t['prefix'].data_ptr(), t['n'], t['total'], self.dtype,
+                                             ops.stream_ptr() if stream is None else stream))
 
     def ensure_adam(self):
         if self.adam_m is None:
@@ -264,6 +280,7 @@ class Plan:
         self.rt, self.n, self.h, self.w, self.training = rt, n, h, w, training
         self.frozen = set(frozen)
         self.tile_policy = 2 if (training and _M16_DEFAULT == 1) else 0      # satcv_conv_desc.tile_policy of this plan's convolution launches
+        self.eo_lo, self.early_opt, self.eo_done = None, None, False          # split optimizer step (see _build_backward: `early`)
         self.fwd, self.bwd = [], []
         self.keep = []                        # ctypes descriptors / tensors kept alive
         self.dropouts = []                    # dropout masks (regenerated every training step)
@@ -744,6 +761,15 @@ class Plan:
         # launches -- the per-layer sum reads slabs that were written microseconds earlier (37 MB: L2 / Infinity-Cache resident), the deferred one
         # finds 150-220 MB of slabs of several layers pushed out to HBM.  Opt-in (SATCV_DEFER_REDUCE=1).
         DEFER = int(os.environ.get('SATCV_DEFER_REDUCE', '0')) != 0
+        # round 6: the slab sum of a side-stream weight gradient on a THIRD stream, behind an event of its launch.  The trace of a step
+        # (profiles/r06_step_timeline_before.txt) shows the weight-gradient stream running to the very end of the step, and a quarter of its
+        # time in the 21 slab sums (0.8 ms in the step for 0.17 ms of work: small HBM-bound launches between 128-workgroup MFMA launches).
+        # With a workspace of its own per layer the next weight gradient does not have to wait for the sum of the previous one.
+        # MEASURED, same box: 7.80-7.85 ms against 7.78-7.81 with the sums on the weight-gradient stream -- the step is bound by the chip's total work,
+        # not by the order of these launches (profiles/r06_ab_early_opt_and_reduce_stream.txt).  Off by default (SATCV_REDUCE_STREAM=1).
+        RED3 = (not DEFER) and self.side is not None and os.environ.get('SATCV_REDUCE_STREAM', '0') == '1'
+        self.rstream = torch.cuda.Stream() if RED3 else None
+        self._last_red_ev = None
         rpending = []                       # (descriptor, 'w' | 'f', gradient bytes) of launches whose sum has not been scheduled yet
         rgroups = []                        # {'items': [(desc, kind)], 'tab': device job table, filled once the workspaces are assigned}
         fused_ws_need = 0                   # the fused thin-layer backward launches run on the MAIN stream: a workspace of their own
@@ -917,10 +943,16 @@ class Plan:
             if nb < 0:
                 raise RuntimeError(lib.satcv_last_error().decode())
             nvalid = (f * f if f else 1) * cout
+            grp = None
             if DEFER and not accum and lay.name not in shared_layers and nvalid % 4 == 0 and not (k == 3 and dil > 1):
                 d.defer_reduce = 1
                 d._own_ws = nb
                 rpending.append((d, 'w', 4 * k * k * cin_real * nvalid))
+            elif RED3 and not accum and lay.name not in shared_layers and nvalid % 4 == 0 and not (k == 3 and dil > 1):
+                d.defer_reduce = 1
+                d._own_ws = nb
+                grp = {'items': [(d, 'w')], 'tab': None}       # (a one-job table, built with the others once the workspaces are assigned)
+                rgroups.append(grp)
             else:
                 ws_need = max(ws_need, nb)
             wdescs.append(d)
@@ -936,10 +968,19 @@ class Plan:
             ev = torch.cuda.Event()
             side, sptr = self.side, C.c_void_p(self.side.cuda_stream)
 
-            def run(st, d=d, ev=ev):
+            evw, evr = (torch.cuda.Event(), torch.cuda.Event()) if grp is not None else (None, None)
+
+            def run(st, d=d, ev=ev, grp=grp, evw=evw, evr=evr):
                 ev.record(torch.cuda.current_stream())
                 side.wait_event(ev)
                 check(lib.satcv_conv2d_wgrad(C.byref(d), sptr))
+                if grp is not None:
+                    t = grp['tab']
+                    evw.record(side)
+                    self.rstream.wait_event(evw)
+                    check(lib.satcv_reduce_slabs_batched(t['jobs'].data_ptr(), t['prefix'].data_ptr(), t['n'], t['total'], C.c_void_p(self.rstream.cuda_stream)))
+                    evr.record(self.rstream)
+                    self._last_red_ev = evr
             run.label, run.work = label, work
             return run
 
@@ -994,10 +1035,38 @@ class Plan:
             if not flush_reduces(force=not pending):
                 return                                  # (the gradients above `lo` are not final before their slabs are summed)
             lo = max((layer_hi[k] for k in pending), default=0)
+            # ---- round 6: the optimizer step of the parameters in [lo, n) beside the REST of the backward pass.  When what is still pending is a
+            # few per cent of the parameters (the three thin encoder blocks of get_unet_model hold 0.5 %), everything above `lo` is final: Adam
+            # and the operand repack of that range run on the weight-gradient stream -- idle from here on: the thin layers' weight gradients
+            # are part of the fused launches of the main stream -- while the main stream finishes the encoder's backward pass; the step's tail
+            # then only updates [0, lo).  Single replica only (a gradient exchange must see every gradient first): Model.train_step_device
+            # sets plan.early_opt per step.
+            if EARLY_OPT and self.side is not None and self.eo_lo is None and pending and 0 < lo <= EARLY_OPT_FRAC * rt.n_train and lo % 4 == 0:
+                self.eo_lo = lo
+                evo = torch.cuda.Event()
+
+                def early(st, lo=lo, evo=evo):
+                    eo = self.early_opt
+                    if eo is None:
+                        return
+                    evo.record(torch.cuda.current_stream())
+                    self.side.wait_event(evo)
+                    if self._last_red_ev is not None:
+                        self.side.wait_event(self._last_red_ev)
+                    sp = C.c_void_p(self.side.cuda_stream)
+                    n = rt.n_train - lo
+                    check(lib.satcv_adam_step_part(_fp(rt.pflat, lo), _fp(rt.gflat, lo), _fp(rt.adam_m, lo), _fp(rt.adam_v, lo), n, eo['beta_1'], eo['beta_2'],
+                                                   eo['epsilon'], rt.adam_state.data_ptr(), _fp(rt.lr_mul, lo) if rt.lr_mul is not None else None, 0, sp))
+                    rt.repack(lo, None, stream=sp)
+                    self.eo_done = True
+                early.label = f'early optimizer step [{lo}, {rt.n_train}) on the side stream'
+                self.bwd.append(early)
 
             def ckpt(st, lo=lo):
                 sync = getattr(m, '_sync_grads', None)
                 if sync is not None and hasattr(sync, 'ready_above'):
+                    if self._last_red_ev is not None:            # (gradients are final behind their slab sums on the third stream)
+                        self.side.wait_event(self._last_red_ev)
                     sync.ready_above(rt.gflat, lo, self.side)
             self.bwd.append(ckpt)
 
@@ -1454,9 +1523,14 @@ class Plan:
         if self.side is not None:
             evj = torch.cuda.Event()
 
-            def join(st, evj=evj):          # the optimizer (main stream) must see every weight gradient
+            evj2 = torch.cuda.Event()
+
+            def join(st, evj=evj, evj2=evj2):          # the optimizer (main stream) must see every weight gradient
                 evj.record(self.side)
                 torch.cuda.current_stream().wait_event(evj)
+                if self.rstream is not None:
+                    evj2.record(self.rstream)
+                    torch.cuda.current_stream().wait_event(evj2)
             self.bwd.append(join)
 
     # -- execution

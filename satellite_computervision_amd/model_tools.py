@@ -1275,14 +1275,24 @@ class Model:
         plan.step_count += 1                     # fresh dropout masks every step
         plan.run_forward(st)
         self._loss_launch(plan, st)
+        opt = self.optimizer
+        # (single replica: the bulk of the optimizer step may run inside the backward pass, engine.Plan `early`)
+        plan.eo_done = False
+        plan.early_opt = dict(beta_1=opt.beta_1, beta_2=opt.beta_2, epsilon=opt.epsilon) if sync_grads is None else None
         plan.run_backward(st)
         if sync_grads is not None:
             sync_grads(rt.gflat)
-        opt = self.optimizer
-        check(lib.satcv_adam_step(rt.pflat.data_ptr(), rt.gflat.data_ptr(), rt.adam_m.data_ptr(), rt.adam_v.data_ptr(), rt.pflat.numel(),
-                                  opt.beta_1, opt.beta_2, opt.epsilon, rt.adam_state.data_ptr(),
-                                  rt.lr_mul.data_ptr() if rt.lr_mul is not None else None, st))
-        rt.repack()
+        if plan.eo_done:
+            lo = plan.eo_lo                  # [lo, n) was updated and repacked on the side stream (joined at the end of the backward pass)
+            check(lib.satcv_adam_step_part(rt.pflat.data_ptr(), rt.gflat.data_ptr(), rt.adam_m.data_ptr(), rt.adam_v.data_ptr(), lo,
+                                           opt.beta_1, opt.beta_2, opt.epsilon, rt.adam_state.data_ptr(),
+                                           rt.lr_mul.data_ptr() if rt.lr_mul is not None else None, 1, st))
+            rt.repack(0, lo)
+        else:
+            check(lib.satcv_adam_step(rt.pflat.data_ptr(), rt.gflat.data_ptr(), rt.adam_m.data_ptr(), rt.adam_v.data_ptr(), rt.pflat.numel(),
+                                      opt.beta_1, opt.beta_2, opt.epsilon, rt.adam_state.data_ptr(),
+                                      rt.lr_mul.data_ptr() if rt.lr_mul is not None else None, st))
+            rt.repack()
         self._weights_version = getattr(self, '_weights_version', 0) + 1
         return plan
 
