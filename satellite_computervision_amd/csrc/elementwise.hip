@@ -772,10 +772,13 @@ extern "C" int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream) {
   int rc = bnbwd_check(d, false); if (rc) return rc;
   const int f = d->dpool ? d->f : 1;
   const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
+  // every workgroup ends with 2 c double atomics into the replica rows: on the deep, small maps (64 x 8 x 8 x 1024: one item per thread on the
+  // full grid) those -- 3 million of them -- were the launch (24 us for 17 MB, 0.09 of its roofline).  At least 8 items per thread.
+  const int grid = ew_grid((items + 7) / 8);
   if (!d->dpool && d->da && (long long)d->n * d->h * d->w_ < 0x7fffffffLL) {
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), (EW_BLOCK + 1) * 16 * sizeof(float), (hipStream_t)stream, *d, 0, d->c));
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, false>), dim3(grid), dim3(EW_BLOCK), (EW_BLOCK + 1) * 16 * sizeof(float), (hipStream_t)stream, *d, 0, d->c));
   } else {
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(ew_grid(items)), dim3(EW_BLOCK), (EW_BLOCK + 1) * 16 * sizeof(float), (hipStream_t)stream, *d));
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(grid), dim3(EW_BLOCK), (EW_BLOCK + 1) * 16 * sizeof(float), (hipStream_t)stream, *d));
   }
   LAUNCH_OK("bn_bwd_reduce");
   return SATCV_OK;
