@@ -52,24 +52,30 @@ extern int g_opt_m16p_prio;            // api.hip
 extern int g_opt_m16p;                 // api.hip: 0 off, 1 on where a workgroup gets at least two tiles
 int g_m16p_launches = 0;               // launches taken here (satcv_get_option("m16p_launches"): tests assert the path)
 
+// BN_: output channels per workgroup -- 128 (two 64-channel wave columns), or 64 for the layers with 64 filters (round 6: 64 -> 64 and
+// 64 + 64 -> 64 at 128 x 128 and their data gradients; wave tile 64 pixels x 32 channels, half the accumulators, the same pixel tile and stream)
+template <int BN_>
 struct M16PGeom {
-  static constexpr int TW = 32, TH = 8, BM = 256, BN = 128, CL = TW + 2, RL = TH + 2;
+  static constexpr int TW = 32, TH = 8, BM = 256, BN = BN_, CL = TW + 2, RL = TH + 2;
   static constexpr int NPIX = ((RL * CL + 7) / 8) * 8;                       // halo pixels, padded to whole octets
   static constexpr int PLANE_E = (((NPIX * 16 + 255) / 256) * 256) / 2;      // elements per 8-channel slot plane (a multiple of 256 bytes)
   static constexpr int A_STAGE_E = 4 * PLANE_E;
   static constexpr int UNIT_E = 3 * 4 * BN * 8;                              // a tap row of one 32-channel chunk: [3 taps][4 slots][128][8]
   static constexpr int A_ITEMS = NPIX * 4;
   static constexpr int NS = 256, AI = (A_ITEMS + NS - 1) / NS;
+  static constexpr int VPR = BN / 8, PPR = NS / VPR;                         // 16-byte groups per image row; pixels per drain round
   static constexpr int ROUNDS = BM * (BN / 8) / NS;                          // drain rounds of 256 x 16 bytes per tile
+  static constexpr int NBW = BN / 32;                                        // 16-channel blocks per matrix wave (wave tile 64 pixels x BN / 2)
+  static constexpr int SWM = BN == 128 ? 15 : 7;                             // image swizzle: 8-byte granule g of pixel p at g ^ 2 (p & SWM)
   static constexpr size_t FIXED_BYTES = (size_t)(2 * A_STAGE_E + 2 * UNIT_E + BM * BN) * 2 + BN * sizeof(float);
 };
 
 // BST: the launch carries the fused BatchNorm-backward sums (a data gradient: no input transform) -- two instantiations so that neither holds the
 // other's per-channel constants in registers
-template <bool BST>
+template <bool BST, int BN_ = 128>
 __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, const int m_total) {
   using T = bf16;
-  using G = M16PGeom;
+  using G = M16PGeom<BN_>;
   constexpr int BN = G::BN, CL = G::CL, TH = G::TH, TW = G::TW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* ldsA = reinterpret_cast<T*>(smem_raw);
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
       }
     };
     // ---- drain: this thread's 16-byte channel group vq of pixels (sid >> 4) + 16 round
-    const int vq = sid & 15, pq0 = sid >> 4;
+    const int vq = sid % G::VPR, pq0 = sid / G::VPR;
     const int cg = nbase + vq * 8;
     float st1[8], st2[8];
 #pragma unroll
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
     // the tile and the round only add wave-uniform terms (round r: tile row r >> 1, column half r & 1)
     const unsigned o_lane = (unsigned)pq0 * (unsigned)a.ldy + (unsigned)cg;
     const unsigned y_lane = BST ? (unsigned)pq0 * yld + ycol : 0u;
-    const unsigned i_lane = (unsigned)(pq0 * BN + ((vq ^ pq0) << 3));       // image: pixel q = pq0 + 16 r -> q & 15 = pq0
+    const unsigned i_lane = (unsigned)(pq0 * BN + ((vq ^ (pq0 & G::SWM)) << 3));       // image: pixel q = pq0 + PPR r -> q & SWM = pq0 & SWM
     auto drain_begin = [&](int v) __attribute__((always_inline)) {
       int n0, y0, x0; tile_origin(v, n0, y0, x0);
       const size_t p0 = (size_t)(n0 * a.h + y0) * a.w_ + x0;
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
       d_tile = v; d_round = 0;
     };
     auto round_off = [&](int r, unsigned ld) __attribute__((always_inline)) -> unsigned {        // wave-uniform element offset of round r
-      return ((unsigned)(r >> 1) * (unsigned)a.w_ + (unsigned)(r & 1) * 16u) * ld;
+      return ((unsigned)((r * G::PPR) >> 5) * (unsigned)a.w_ + (unsigned)((r * G::PPR) & 31)) * ld;
     };
     // One interval's share of the drain, R rounds at a time (R = rpi is 1, 2 or 4 and divides the 16 rounds of a tile: no partial groups, no
     // per-round conditions -- the round-5 form with a run-time count kept its four 16-byte pieces in SCRATCH once nothing else pinned them in
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
       constexpr int R = decltype(RC)::value;
       if (rounds && d_round < G::ROUNDS) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dv[r] = *reinterpret_cast<const u32x4_*>(ldsO + (d_round + r) * 16 * BN + i_lane);
+        for (int r = 0; r < R; ++r) dv[r] = *reinterpret_cast<const u32x4_*>(ldsO + (d_round + r) * G::PPR * BN + i_lane);
       }
     };
     auto drain_step = [&](auto RC, bool rounds, bool prefetch) __attribute__((always_inline)) {
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
       if (sid < BN) {
         const int gq = sid >> 3, e = sid & 7;
         double t1 = 0.0, t2 = 0.0;
-        for (int k = 0; k < NS / 16; ++k) { t1 += (double)r2[e * NS + k * 16 + gq]; t2 += (double)r2[(8 + e) * NS + k * 16 + gq]; }
+        for (int k = 0; k < NS / G::VPR; ++k) { t1 += (double)r2[e * NS + k * G::VPR + gq]; t2 += (double)r2[(8 + e) * NS + k * G::VPR + gq]; }
         if constexpr (BST) t2 = (double)a.bst_rstd[nbase + sid] * (t2 - (double)a.bst_mean[nbase + sid] * t1);
         satcv_stat_t* rowp = a.stats + (size_t)(blockIdx.x % SATCV_STAT_ROWS) * 2 * a.stats_ld;
         atomicAdd(rowp + nbase + sid, (satcv_stat_t)t1);
@@ -414,17 +420,20 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
     const int q = wm * 64 + m * 16 + l16;
     a_off[m] = g4 * G::PLANE_E + ((q >> 5) * CL + (q & 31)) * 8;
   }
-  const int b_lane = (g4 * BN + wn * 64 + l16) * 8;
+  constexpr int NBW = G::NBW;
+  const int b_lane = (g4 * BN + wn * (BN / 2) + l16) * 8;
   const T* wp = reinterpret_cast<const T*>(a.w);
   const unsigned lds_w = lds_addr_of(ldsW);
   // this wave's pieces p = wave + 8 r of unit (chunk x, tap row ky): half (p & 1) of the 2-KB row of (tap-in-row, slot) = ((p >> 1) >> 2,
   // (p >> 1) & 3); contiguous in the packed image [tap][cin / 8][cout_pad][8] and in the LDS slot
   auto dma_unit = [&](int x, int ky, int slot) __attribute__((always_inline)) {
+    constexpr int HALVES = BN / 64, NP = 12 * HALVES;                        // 1-KB pieces of a unit: 64 channels x 8 x 2 bytes each
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int p = wave + 8 * r, run = p >> 1;
+    for (int r = 0; r < (NP + 7) / 8; ++r) {
+      const int p = wave + 8 * r, run = p / HALVES;
+      if (p >= NP) break;                                                    // (wave-uniform: 12 pieces on 8 waves)
       const int tap = ky * 3 + (run >> 2), sl = run & 3;
-      const size_t off = ((size_t)(tap * (cin / 8) + x * 4 + sl) * a.cout_pad + nbase + (p & 1) * 64) * 8;
+      const size_t off = ((size_t)(tap * (cin / 8) + x * 4 + sl) * a.cout_pad + nbase + (p % HALVES) * 64) * 8;
       // (wave-uniform by construction; the read-first-lane pair makes it so for the register allocator too -- an "s" operand)
       const unsigned long long ga = (unsigned long long)(uintptr_t)(wp + off);
       const unsigned long long gu_ = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ga >> 32)) << 32) |
@@ -433,11 +442,11 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
                 (unsigned)__builtin_amdgcn_readfirstlane(lds_w + (unsigned)(slot * G::UNIT_E * 2) + (unsigned)p * 1024u));
     }
   };
-  f32x4 acc[4][4];
+  f32x4 acc[4][NBW];
   auto acc_init = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      int boff = wn * 64 + n * 16 + 4 * g4;
+    for (int n = 0; n < NBW; ++n) {
+      int boff = wn * (BN / 2) + n * 16 + 4 * g4;
       asm volatile("" : "+v"(boff));                                         // (re-read per tile: 16 registers less across the K loop)
       const float4 b4 = *reinterpret_cast<const float4*>(ldsB + boff);
 #pragma unroll
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
   // S += F 1  (row sums): 16 MFMAs and 16 reads per tile and wave (0.7 % of the tile's MFMAs), 8 accumulator registers, fp32 sums over the
   // workgroup's tiles, one pair of double atomics per channel at the end.
   f32x4 g_sq = {0.f, 0.f, 0.f, 0.f}, g_sm = {0.f, 0.f, 0.f, 0.f};
-  const bool mstats = !BST && a.stats != nullptr;
+  const bool mstats = !BST && a.stats != nullptr && wave < BN / 16;
   auto stats_mfma = [&]() __attribute__((always_inline)) {
     const int q = l16 >> 2, pcol = l16 & 3;
     bf16x8 ones;
@@ -462,8 +471,8 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
 #pragma unroll 2
     for (int kp = 0; kp < 8; ++kp) {
       const int p0 = kp * 32 + g4 * 8 + q, p1 = p0 + 4;
-      const bf16x4 lo = m16p_tr_read(ldsO + p0 * BN + ((gidx ^ (2 * (p0 & 15))) << 2));
-      const bf16x4 hi = m16p_tr_read(ldsO + p1 * BN + ((gidx ^ (2 * (p1 & 15))) << 2));
+      const bf16x4 lo = m16p_tr_read(ldsO + p0 * BN + ((gidx ^ (2 * (p0 & G::SWM))) << 2));
+      const bf16x4 hi = m16p_tr_read(ldsO + p1 * BN + ((gidx ^ (2 * (p1 & G::SWM))) << 2));
       const bf16x8 fr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       g_sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr, fr, g_sq, 0, 0, 0);
       g_sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr, ones, g_sm, 0, 0, 0);
@@ -492,14 +501,14 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
           dma_unit(nx, nky, slot ^ 1);
         }
         {
-          FragT<T> af[2][4], bf[2][4];
+          FragT<T> af[2][4], bf[2][NBW];
           const T* Ab = ldsA + (x & 1) * G::A_STAGE_E + ky * CL * 8;
           const T* Wb = ldsW + slot * G::UNIT_E + b_lane;
           auto read_step = [&](int kx, int buf) __attribute__((always_inline)) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) af[buf][m] = lds_frag<T>(Ab + a_off[m] + kx * 8);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) bf[buf][n] = lds_frag<T>(Wb + (kx * 4 * BN + n * 16) * 8);
+            for (int n = 0; n < NBW; ++n) bf[buf][n] = lds_frag<T>(Wb + (kx * 4 * BN + n * 16) * 8);
           };
           if (!PABL(2) || gu == 0) read_step(0, 0);
 #pragma unroll
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-              for (int n = 0; n < 4; ++n) {
+              for (int n = 0; n < NBW; ++n) {
                 if constexpr (!PABL(1)) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[kx & 1][n].v, af[kx & 1][m].v, acc[m][n], 0, 0, 0);
                 else asm volatile("" : "+v"(acc[m][n]) : "v"(bf[kx & 1][n].v), "v"(af[kx & 1][m].v));
               }
@@ -522,8 +531,8 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
           for (int m = 0; m < 4; ++m) {
             const int px = wm * 64 + m * 16 + l16;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-              const int gr = (wn * 16 + n * 4 + g4) ^ (2 * l16);
+            for (int n = 0; n < NBW; ++n) {
+              const int gr = (wn * (BN / 8) + n * 4 + g4) ^ (2 * (l16 & G::SWM));
               bf16x4 o;
 #pragma unroll
               for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[m][n][j];
@@ -566,15 +575,14 @@ __global__ __launch_bounds__(768, 1) void igemm_m16p_kernel(const IgemmArgs a, c
 // bf16 3x3, dilation 1, plain NHWC in and out, whole 8 x 32 tiles, Cin % 64 == 0 (<= the LDS table), Cout % 128 == 0, bias + statistics or
 // fused BatchNorm-backward sums, no ReLU / multiplier / pool / accumulation in the epilogue.  SATCV_ERR_UNSUPPORTED otherwise (the caller
 // continues with the one-tile-per-workgroup kernels).
-int igemm_m16p_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
-  using G = M16PGeom;
-  if (dtype != SATCV_BF16) return SATCV_ERR_UNSUPPORTED;
-  if (!g_opt_m16p) return SATCV_ERR_UNSUPPORTED;
+template <int BN>
+static int m16p_launch_bn(IgemmArgs& a, hipStream_t st, bool dry) {
+  using G = M16PGeom<BN>;
   if (!(a.kh == 3 && a.kw == 3 && a.dil == 1 && a.stride == 1 && a.mode_in == 0 && a.mode_out == 0 && !a.pool_y && !a.out_scale && !a.out_relu && !a.accumulate))
     return SATCV_ERR_UNSUPPORTED;
   const int cin = a.c0 + a.c1;
   if (a.h % G::TH != 0 || a.w_ % G::TW != 0) return SATCV_ERR_UNSUPPORTED;
-  if (cin % 64 != 0 || (a.x1 && a.c0 % 32 != 0) || a.cout % 128 != 0 || a.cout_pad % 64 != 0 || a.cout_pad < a.cout || a.cstat != a.cout) return SATCV_ERR_UNSUPPORTED;
+  if (cin % 64 != 0 || (a.x1 && a.c0 % 32 != 0) || a.cout % BN != 0 || a.cout_pad % 64 != 0 || a.cout_pad < a.cout || a.cstat != a.cout) return SATCV_ERR_UNSUPPORTED;
   if (((uintptr_t)a.w % 16) != 0 || a.ldy % 8 != 0 || ((uintptr_t)a.y % 16) != 0 || ((uintptr_t)a.x0 % 16) != 0 || (a.x1 && ((uintptr_t)a.x1 % 16) != 0)) return SATCV_ERR_UNSUPPORTED;
   if (a.c0 % 8 != 0 || a.c1 % 8 != 0) return SATCV_ERR_UNSUPPORTED;
   if (a.bst_y) {
@@ -596,10 +604,14 @@ int igemm_m16p_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   a.tiles_x = a.w_ / G::TW; a.tiles_y = a.h / G::TH;
   a.rpi = G::TH; a.imgs = 1; a.ngroups = a.n;
   a.seg = G::RL; a.rl = G::RL; a.cl = G::CL; a.pitch = G::CL;
-  a.n_tiles = a.cout / 128;
+  a.n_tiles = a.cout / BN;
   a.cpt = cin / 32; a.nchunks = a.cpt; a.taploop = 0; a.halh_tl = a.halw_tl = 1;
   a.ksplit = 1; a.kslab = nullptr;
   a.dbg = a.bst_y ? g_opt_m16p_prio % 10 : a.in_scale ? (g_opt_m16p_prio / 10) % 10 : (g_opt_m16p_prio / 100) % 10;
+  if (BN == 64) {      // (half the MFMAs per staged byte: the staging waves set the pace of every launch kind -- SATCV_M16P_PRIO64, same digits)
+    static const int p64 = [] { const char* e = getenv("SATCV_M16P_PRIO64"); return e ? atoi(e) : -1; }();
+    if (p64 >= 0) a.dbg = a.bst_y ? p64 % 10 : a.in_scale ? (p64 / 10) % 10 : (p64 / 100) % 10;
+  }
   const long long m_total = (long long)a.n * a.tiles_y * a.tiles_x;
   if (m_total <= 0 || m_total > 0x7fffffffLL || a.n_tiles > ncu) return SATCV_ERR_UNSUPPORTED;
   long long ranges = ncu / a.n_tiles;
@@ -608,11 +620,21 @@ int igemm_m16p_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
   //  option m16p = 2 sends every eligible launch here)
   if (g_opt_m16p < 2 && m_total < 2 * ranges) return SATCV_ERR_UNSUPPORTED;
   if (dry) return SATCV_OK;
-  auto kern = a.bst_y ? igemm_m16p_kernel<true> : igemm_m16p_kernel<false>;
+  auto kern = a.bst_y ? igemm_m16p_kernel<true, BN> : igemm_m16p_kernel<false, BN>;
   { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
   hipLaunchKernelGGL(kern, dim3((unsigned)(ranges * a.n_tiles)), dim3(768), lds, st, a, (int)m_total);
   ++g_m16p_launches;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { satcv_set_error("igemm_m16p launch: %s", hipGetErrorString(e)); return SATCV_ERR_HIP; }
   return SATCV_OK;
+}
+
+// SATCV_M16P_BN64=0: the 64-filter layers stay on the one-tile kernels (A/B switch of the round-6 64-channel block)
+int igemm_m16p_launch(IgemmArgs& a, int dtype, hipStream_t st, bool dry) {
+  if (dtype != SATCV_BF16) return SATCV_ERR_UNSUPPORTED;
+  if (!g_opt_m16p) return SATCV_ERR_UNSUPPORTED;
+  if (a.cout % 128 == 0) return m16p_launch_bn<128>(a, st, dry);
+  static const int bn64 = [] { const char* e = getenv("SATCV_M16P_BN64"); return e ? atoi(e) : 1; }();
+  if (bn64 && a.cout % 64 == 0) return m16p_launch_bn<64>(a, st, dry);
+  return SATCV_ERR_UNSUPPORTED;
 }
