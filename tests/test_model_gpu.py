@@ -990,7 +990,8 @@ def test_round6_scheduling_switches_leave_the_numbers_alone(mt, monkeypatch):
     p1, g1, k1, l1, lab1, plan1 = run(True, False)
     assert any('early optimizer step' in l for l in lab1) and not any('early optimizer step' in l for l in lab0)
     assert plan1.eo_done and 0 < plan1.eo_lo < 0.05 * p1.numel()
-    assert torch.equal(p0, p1) and torch.equal(g0, g1) and torch.equal(k0, k1) and l0 == l1
+    assert torch.equal(p0, p1) and torch.equal(g0, g1) and torch.equal(k0, k1)
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)                  # (the loss scalar is a float atomic sum: last bit)
     p2, g2, k2, l2, _, plan2 = run(False, True)
     assert plan2.rstream is not None
     assert ((g2 - g0).norm() / g0.norm()).item() < 1e-4            # (third step: the sums' orders differ, and two Adam steps lie in between)
