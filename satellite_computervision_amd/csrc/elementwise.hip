@@ -312,7 +312,10 @@ __device__ __forceinline__ void block_channel_reduce(float* lds, const float (&a
   // [16][blockDim + 1]: a value row per partial sum, one column per thread -- the lanes of a wave write consecutive banks, and the
   // readers below (8 lanes per thread column, one per value row) are spread by the odd pitch.  (The [thread][16] form put every
   // fourth lane on the same bank: rocprofv3 counted 88 % of the LDS cycles of the BatchNorm kernels as bank conflicts.)
-  const int pitch = blockDim.x + 1;
+  // (round 6: pitch = block + 8, i.e. 8 modulo 32 banks -- the readers of one 32-lane half are 8 value rows x 4 consecutive thread columns: with
+  //  the odd pitch of round 3 row e and column t met row e + 1 and column t - 1 on one bank, and rocprofv3 still counted half of these kernels' LDS
+  //  cycles as conflicts; every launch site sizes the region (EW_BLOCK + 8) x 16 floats)
+  const int pitch = blockDim.x + 8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) { lds[e * pitch + threadIdx.x] = active ? a[e] : 0.f; lds[(8 + e) * pitch + threadIdx.x] = active ? b[e] : 0.f; }
   __syncthreads();
@@ -412,10 +415,10 @@ extern "C" int satcv_bn_relu_pool(const void* yraw, const float* scale, const fl
   SATCV_CHECK(yraw && scale && shift && n > 0 && h > 0 && w_ > 0 && c > 0 && c % 8 == 0 && c <= 2048 && f >= 1, "bn_relu_pool: bad args");
   const long long items = (long long)n * cdiv(h, f) * cdiv(w_, f) * (c / 8);
   if (f == 2 && h % 2 == 0 && w_ % 2 == 0) {
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_pool_kernel<T, false, 2>), dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 1) * 16 * sizeof(float) : 0,
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_pool_kernel<T, false, 2>), dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 8) * 16 * sizeof(float) : 0,
                                          (hipStream_t)stream, (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld));
   } else {
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_pool_kernel<T>, dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 1) * 16 * sizeof(float) : 0, (hipStream_t)stream,
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_relu_pool_kernel<T>, dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 8) * 16 * sizeof(float) : 0, (hipStream_t)stream,
                                          (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld));
   }
   LAUNCH_OK("bn_relu_pool");
@@ -428,11 +431,11 @@ extern "C" int satcv_bn_relu_pool_amax(const void* yraw, const float* scale, con
               "bn_relu_pool_amax: bad args");
   const long long items = (long long)n * cdiv(h, f) * cdiv(w_, f) * (c / 8);
   if (f == 2 && h % 2 == 0 && w_ % 2 == 0) {
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_pool_kernel<T, true, 2>), dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 1) * 16 * sizeof(float) : 0,
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_pool_kernel<T, true, 2>), dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 8) * 16 * sizeof(float) : 0,
                                          (hipStream_t)stream, (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld,
                                          (unsigned char*)amax));
   } else {
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_pool_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 1) * 16 * sizeof(float) : 0,
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_relu_pool_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), stats ? (EW_BLOCK + 8) * 16 * sizeof(float) : 0,
                                          (hipStream_t)stream, (const T*)yraw, scale, shift, (T*)act, (T*)pooled, stats, stats_ld, n, h, w_, c, f, act_ld,
                                          (unsigned char*)amax));
   }
@@ -776,9 +779,9 @@ extern "C" int satcv_bn_bwd_reduce(const satcv_bnbwd_desc* d, void* stream) {
   // full grid) those -- 3 million of them -- were the launch (24 us for 17 MB, 0.09 of its roofline).  At least 8 items per thread.
   const int grid = ew_grid((items + 7) / 8);
   if (!d->dpool && d->da && (long long)d->n * d->h * d->w_ < 0x7fffffffLL) {
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, false>), dim3(grid), dim3(EW_BLOCK), (EW_BLOCK + 1) * 16 * sizeof(float), (hipStream_t)stream, *d, 0, d->c));
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_dense_kernel<T, false>), dim3(grid), dim3(EW_BLOCK), (EW_BLOCK + 8) * 16 * sizeof(float), (hipStream_t)stream, *d, 0, d->c));
   } else {
-    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(grid), dim3(EW_BLOCK), (EW_BLOCK + 1) * 16 * sizeof(float), (hipStream_t)stream, *d));
+    DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, false>), dim3(grid), dim3(EW_BLOCK), (EW_BLOCK + 8) * 16 * sizeof(float), (hipStream_t)stream, *d));
   }
   LAUNCH_OK("bn_bwd_reduce");
   return SATCV_OK;
@@ -793,14 +796,14 @@ extern "C" int satcv_bn_bwd_apply(const satcv_bnbwd_desc* d, void* stream) {
     satcv_bnbwd_desc e = *d;
     e.c = d->c_split; e.c_split = 0; e.yraw1 = nullptr;
     const long long it1 = (long long)d->n * d->h * d->w_ * (e.c / 8);
-    const size_t lds_1 = d->sk_sums ? (EW_BLOCK + 1) * 16 * sizeof(float) : e.c * sizeof(float);
+    const size_t lds_1 = d->sk_sums ? (EW_BLOCK + 8) * 16 * sizeof(float) : e.c * sizeof(float);
     DISPATCH_T(d->dtype, bn_bwd_apply_dense_launch<T>(e, it1, lds_1, rev, d->c, (hipStream_t)stream));
     LAUNCH_OK("bn_bwd_apply");
     return SATCV_OK;
   }
   const long long items = (long long)d->n * cdiv(d->h, f) * cdiv(d->w_, f) * (d->c / 8);
   if (!d->dpool && d->da && (long long)d->n * d->h * d->w_ < 0x7fffffffLL) {
-    const size_t lds_b = d->sk_sums ? (EW_BLOCK + 1) * 16 * sizeof(float) : d->c * sizeof(float);
+    const size_t lds_b = d->sk_sums ? (EW_BLOCK + 8) * 16 * sizeof(float) : d->c * sizeof(float);
     DISPATCH_T(d->dtype, bn_bwd_apply_dense_launch<T>(*d, items, lds_b, rev, d->c, (hipStream_t)stream));
   } else {
     DISPATCH_T(d->dtype, hipLaunchKernelGGL((bn_bwd_kernel<T, true>), dim3(ew_grid(items)), dim3(EW_BLOCK), d->c * sizeof(float), (hipStream_t)stream, *d));
