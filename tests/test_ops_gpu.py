@@ -1435,3 +1435,65 @@ def test_dilated_conv_double_buffered_taploop(ops, case):
     else:
         y = ops.conv2d(to_dev(x, td), wf, cout, kh=3, kw=3, dil=dil, in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
     close(back(y, cout), y_ref, td, f'double-buffered tap loop {case}')
+
+
+def test_round6_small_entry_points(ops):
+    """round 6 additions to the C ABI: satcv_zero2 (gradient buffer + loss scalar cleared by one launch), satcv_adam_step_part (the update on
+    sub-ranges, the step counter bumped once: two parts == one whole step, bit for bit), satcv_pack_weights_batched with the item counts of
+    satcv_pack_job_items rounded to the block size (every layer's images equal the per-layer satcv_pack_weights, ragged channel counts included)."""
+    import ctypes
+    from satellite_computervision_amd._lib import lib, check, PackJob
+    st = ops.stream_ptr()
+    # ---- zero2
+    a = torch.randn(4 * 1000 + 12, device=dev())
+    b = torch.randn(5, device=dev())
+    check(lib.satcv_zero2(a.data_ptr(), a.numel() * 4, b.data_ptr() + 4, 8, st))
+    torch.cuda.synchronize()
+    assert a.abs().max().item() == 0 and b[1:3].abs().max().item() == 0 and b[0].item() != 0 and b[3].item() != 0
+    assert lib.satcv_zero2(a.data_ptr() + 4, 16, None, 0, st) != 0           # misaligned
+    # ---- Adam in two parts
+    rng = np.random.default_rng(5)
+    n = 4096 + 640
+    p0, g = f32dev(rng.standard_normal(n)), f32dev(rng.standard_normal(n))
+    outs = []
+    for parts in (((0, n, 1),), ((1024, n, 0), (0, 1024, 1))):
+        p, m, v = p0.clone(), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+        state = torch.tensor([1e-2, 0.0, 1.0, 0.0], dtype=torch.float32, device=dev())
+        for _ in range(3):
+            for lo, hi, bump in parts:
+                check(lib.satcv_adam_step_part(p.data_ptr() + 4 * lo, g.data_ptr() + 4 * lo, m.data_ptr() + 4 * lo, v.data_ptr() + 4 * lo, hi - lo, 0.9, 0.999, 1e-7,
+                                               state.data_ptr(), None, bump, st))
+        torch.cuda.synchronize()
+        assert state[1].item() == 3.0
+        outs.append((p, m, v))
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    # ---- batched pack against the per-layer pack
+    shapes = [((3, 3, 4, 32), False), ((3, 3, 13, 32), False), ((3, 3, 64, 64), False), ((1, 1, 32, 2), False), ((2, 2, 32, 64), True), ((3, 3, 24, 16), False)]
+    jobs, keep, refs = [], [], []
+    for shp, tr in shapes:
+        k = f32dev(rng.standard_normal(shp))
+        cin, cout = (shp[3], shp[2]) if tr else (shp[2], shp[3])
+        cp, taps = ops.rup(cin, 16), shp[0] * shp[1]
+        rf, rd = ops.pack_weights(k, cp, ops.BF16, transposed=tr)
+        fw, dg = torch.zeros_like(rf), torch.zeros_like(rd)
+        if not tr:
+            jobs += [PackJob(k.data_ptr(), fw.data_ptr(), 0, taps, cin, cout, cp, ops.rup(cout, 32)), PackJob(k.data_ptr(), dg.data_ptr(), 1, taps, cin, cout, ops.rup(cout, 16), ops.rup(cin, 32))]
+        else:
+            jobs += [PackJob(k.data_ptr(), fw.data_ptr(), 2, taps, cin, cout, cp, ops.rup(taps * cout, 32)), PackJob(k.data_ptr(), dg.data_ptr(), 3, taps, cin, cout, ops.rup(taps * cout, 16), ops.rup(cin, 32))]
+        keep.append(k); refs.append((rf, rd, fw, dg))
+    prefix, tot = [], 0
+    for j in jobs:
+        prefix.append(tot)
+        items = int(lib.satcv_pack_job_items(ctypes.byref(j)))
+        assert items % 256 == 0
+        tot += items
+    arr = (PackJob * len(jobs))(*jobs)
+    jd = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev())
+    pd = torch.tensor(prefix, dtype=torch.int64, device=dev())
+    check(lib.satcv_pack_weights_batched(jd.data_ptr(), pd.data_ptr(), len(jobs), tot, ops.BF16, st))
+    torch.cuda.synchronize()
+    for (rf, rd, fw, dg), (shp, tr) in zip(refs, shapes):
+        assert torch.equal(rf, fw), ('forward image', shp, tr)
+        assert torch.equal(rd, dg), ('data-gradient image', shp, tr)
+    assert lib.satcv_pack_weights_batched(jd.data_ptr(), pd.data_ptr(), len(jobs), tot - 8, ops.BF16, st) != 0      # a prefix table not built from satcv_pack_job_items
