@@ -980,22 +980,30 @@ def test_round6_scheduling_switches_leave_the_numbers_alone(mt, monkeypatch):
         m = mt.get_unet_model(2, 4)
         m.compute_dtype = 'bfloat16'
         m.compile(optimizer=mt.Adam(1e-3), loss=lambda t, p: mt.weighted_categorical_crossentropy(t, p, [1.0, 5.0]))
-        losses = [m.train_on_batch(x, y) for x, y in zip(xs, ys)]
+        losses, gfirst = [], None
+        for x, y in zip(xs, ys):
+            losses.append(m.train_on_batch(x, y))
+            if gfirst is None:
+                gfirst = m.runtime.gflat.clone()          # (the first step's gradient: before any parameter has moved)
         torch.cuda.synchronize()
         plan = m.runtime.plan(2, 64, 64, True)
         labels = [getattr(s_, 'label', '') or '' for s_ in plan.bwd]
         packed = torch.cat([pk['fwd'].float().flatten() for pk in m.runtime.packed.values()])
-        return m.runtime.pflat.clone(), m.runtime.gflat.clone(), packed, losses, labels, plan
-    p0, g0, k0, l0, lab0, _ = run(False, False)
-    p1, g1, k1, l1, lab1, plan1 = run(True, False)
+        return m.runtime.pflat.clone(), m.runtime.gflat.clone(), packed, losses, labels, plan, gfirst
+    p0, g0, k0, l0, lab0, _, f0 = run(False, False)
+    p1, g1, k1, l1, lab1, plan1, _ = run(True, False)
     assert any('early optimizer step' in l for l in lab1) and not any('early optimizer step' in l for l in lab0)
     assert plan1.eo_done and 0 < plan1.eo_lo < 0.05 * p1.numel()
     assert torch.equal(p0, p1) and torch.equal(g0, g1) and torch.equal(k0, k1)
     np.testing.assert_allclose(l1, l0, rtol=1e-6)                  # (the loss scalar is a float atomic sum: last bit)
-    p2, g2, k2, l2, _, plan2 = run(False, True)
+    p2, g2, k2, l2, _, plan2, f2 = run(False, True)
     assert plan2.rstream is not None
-    assert ((g2 - g0).norm() / g0.norm()).item() < 1e-4            # (third step: the sums' orders differ, and two Adam steps lie in between)
-    np.testing.assert_allclose(l2, l0, rtol=1e-4)
+    # the first step's gradients: the same slabs summed in another fixed order (fp32 rounding).  Later steps are not compared element by
+    # element -- Adam's first updates are +-lr whatever the gradient's size, so last-bit differences move weights by 2 lr and the bf16
+    # BatchNorm chain amplifies that -- only the loss curve
+    assert ((f2 - f0).norm() / f0.norm()).item() < 1e-5
+    assert (f2 - f0).abs().max().item() <= 1e-4 * f0.abs().max().item()
+    np.testing.assert_allclose(l2, l0, rtol=2e-2)
 
 
 @pytest.mark.parametrize('channels', [4, 13])
