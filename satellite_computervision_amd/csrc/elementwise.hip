@@ -1571,10 +1571,65 @@ __global__ void loss_kernel(int kind, const float* __restrict__ probs, const flo
   __syncthreads();
   if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < EW_BLOCK / 64; ++i) s += red[i]; atomicAdd(loss_out, s); }
 }
+// Round 6: the same arithmetic, statement for statement, with the class count at compile time (2 or 4: one 8- / 16-byte load and store per
+// tensor and pixel instead of a scalar one per class behind a run-time `k < nc`) for the case every U-Net of the reference trains with --
+// weighted categorical cross-entropy on a softmax head (utils/model_tools.py:25, 414).  42 -> ~25 us per step at batch 64.
+template <int NC>
+__global__ __launch_bounds__(EW_BLOCK) void loss_cce_softmax_kernel(const float* __restrict__ probs, const float* __restrict__ yt, const float* __restrict__ wts,
+                                                                    long long npix, float grad_scale, float* loss_out, float* dlogits) {
+  typedef float fvec __attribute__((ext_vector_type(NC)));
+  __shared__ float red[EW_BLOCK / 64];
+  float lsum = 0.f;
+  const float inv_n = 1.f / (float)npix;
+  float wt[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) wt[k] = wts[k];
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+    const fvec prv = reinterpret_cast<const fvec*>(probs)[p], tv = reinterpret_cast<const fvec*>(yt)[p];
+    float pr[NC], t[NC], gp[NC], G[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { pr[k] = prv[k]; t[k] = tv[k]; }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) s += pr[k];
+    const float lo = 1e-7f, hi = 1.f - 1e-7f;
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const float o = pr[k] / s;
+      const float oc = fminf(fmaxf(o, lo), hi);
+      lsum += -wt[k] * t[k] * logf(oc) * inv_n;
+      const bool inside = (o >= lo) && (o <= hi);
+      G[k] = inside ? -wt[k] * t[k] / oc * inv_n : 0.f;
+      dot += G[k] * o;
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) gp[k] = (G[k] - dot) / s;
+    float dot2 = 0.f;                                   // softmax Jacobian
+#pragma unroll
+    for (int k = 0; k < NC; ++k) dot2 += gp[k] * pr[k];
+    fvec dl;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) dl[k] = grad_scale * pr[k] * (gp[k] - dot2);
+    reinterpret_cast<fvec*>(dlogits)[p] = dl;
+  }
+  lsum = wave_sum(lsum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < EW_BLOCK / 64; ++i) s += red[i]; atomicAdd(loss_out, s); }
+}
 extern "C" int satcv_loss_fwd_bwd(int32_t kind, const float* probs, const float* y_true, const float* weights, int32_t ncls, int32_t activation,
                                   int64_t npix, float grad_scale, float* loss_out, float* dlogits, void* stream) {
   SATCV_CHECK(probs && y_true && weights && loss_out && dlogits, "loss: null pointer");
   SATCV_CHECK((kind == 0 || kind == 1) && ncls >= 1 && ncls <= HEAD_NCMAX && npix > 0, "loss: bad args (kind=%d ncls=%d)", kind, ncls);
+  static const bool fast = !(getenv("SATCV_LOSS_FAST") && atoi(getenv("SATCV_LOSS_FAST")) == 0);
+  const bool al = ((uintptr_t)probs % (4 * ncls) == 0) && ((uintptr_t)y_true % (4 * ncls) == 0) && ((uintptr_t)dlogits % (4 * ncls) == 0);
+  if (fast && kind == 0 && activation == 0 && (ncls == 2 || ncls == 4) && al) {
+    if (ncls == 2) hipLaunchKernelGGL(loss_cce_softmax_kernel<2>, dim3(ew_grid(npix)), dim3(EW_BLOCK), 0, (hipStream_t)stream, probs, y_true, weights, (long long)npix, grad_scale, loss_out, dlogits);
+    else hipLaunchKernelGGL(loss_cce_softmax_kernel<4>, dim3(ew_grid(npix)), dim3(EW_BLOCK), 0, (hipStream_t)stream, probs, y_true, weights, (long long)npix, grad_scale, loss_out, dlogits);
+    LAUNCH_OK("loss");
+    return SATCV_OK;
+  }
   hipLaunchKernelGGL(loss_kernel, dim3(ew_grid(npix, 1024)), dim3(EW_BLOCK), 0, (hipStream_t)stream, kind, probs, y_true, weights, ncls, activation,
                      (long long)npix, grad_scale, loss_out, dlogits);
   LAUNCH_OK("loss");
