@@ -143,6 +143,7 @@ int g_opt_thin_roles = env_int("SATCV_THIN_ROLES", 1);   // conv_thin_roles.hip:
 // conv_igemm_m16p.hip: s_setprio of the staging waves, decimal digits (plain launches)(launches with the fused input BatchNorm)(launches with the
 // fused BatchNorm-backward sums), each 0 ... 3 -- e.g. 30 = priority 3 for the forward launches that transform their input, 0 elsewhere
 int g_opt_m16p_prio = env_int("SATCV_M16P_PRIO", 30);      // (30: profiles/r06_ab_m16p_prio_step.txt)
+int g_opt_wgrad_m16 = env_int("SATCV_WGRAD_M16", 0);   // wgrad_dma_kernel on v_mfma_f32_16x16x32_bf16 (round 6: built as the review asked, measured slower: off)
 int g_opt_splitk = env_int("SATCV_SPLITK", 0);         // split-K of under-filled PLAIN (halo-tile / 1x1) launches: opt-in, see conv_igemm_fast.hip
 static int* opt_slot(const char* key) {
   if (!key) return nullptr;
@@ -156,6 +157,7 @@ static int* opt_slot(const char* key) {
   if (!strcmp(key, "thin_roles_launches")) return &g_tr_launches;
   if (!strcmp(key, "m16p")) return &g_opt_m16p;
   if (!strcmp(key, "m16p_prio")) return &g_opt_m16p_prio;
+  if (!strcmp(key, "wgrad_m16")) return &g_opt_wgrad_m16;
   if (!strcmp(key, "m16p_launches")) return &g_m16p_launches;
   return nullptr;
 }

@@ -731,11 +731,16 @@ __global__ __launch_bounds__(NCI* NCO* NKS * 64, 1) void wgrad_db_kernel(const W
 //     waits for the X registers stay exact).
 // Requires whole tiles (the DMA has no bounds handling), Cin % 64 == 0, Cout % 128 == 0, dilation 1, bf16; everything else stays on
 // wgrad_db_kernel.
-template <int TW>
+// Round 6, M16 = true (SATCV_WGRAD_M16=1): the same block on v_mfma_f32_16x16x32_bf16 -- K = 32 pixels per instruction, a 32 x 32 (ci, co) tile as 2 x 2
+// blocks of 16 x 16 (the same 16 accumulator registers per tap).  A lane group g of 16 lanes holds the k indices 8 g ... 8 g + 7 of a fragment; they are fed
+// the pixels 4 g ... 4 g + 3 and 16 + 4 g ... of the 32-pixel step (the same for X and dY: any k order is a valid contraction), so that the 32 lanes of a
+// transposing read touch 8 CONSECUTIVE pixel rows x 32 bytes: conflict-free with X rows of 160 bytes (XP = 80: start banks 40 r mod 64) and with the dY rows'
+// 32-byte granules XOR-ed by (row & 7) (the 32x32x16 form reads 4 rows x 64 bytes: 192-byte X rows, 64-byte segments XOR-ed by row & 3).
+template <int TW, bool M16 = false>
 __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs a) {
   using T = bf16;
   constexpr int NCI = 2, NCO = 4, NTAPS = 9, NTHREADS = 512, BMPIX = 128, TH = BMPIX / TW;
-  constexpr int CI_T = 32 * NCI, CO_T = 32 * NCO, XP = CI_T + 32, GX = CI_T / 8;
+  constexpr int CI_T = 32 * NCI, CO_T = 32 * NCO, XP = CI_T + (M16 ? 16 : 32), GX = CI_T / 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int x_elems = a.rl * a.cl * XP;
   const int stage_elems = x_elems + BMPIX * CO_T;
@@ -755,11 +760,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs a) {
   const int ci_blk = blk % a.n_ci_blk, co_blk = blk / a.n_ci_blk;
   const int ci0 = ci_blk * CI_T, co0 = co_blk * CO_T;
 
-  f32x16 acc[NTAPS];
+  f32x16 acc[NTAPS];                 // 32x32x16 form: one tile per tap
+  f32x4 acc4[NTAPS][4];              // 16x16x32 form: 2 x 2 blocks per tap (block 2 c + b) -- only one of the two sets is live
 #pragma unroll
-  for (int t = 0; t < NTAPS; ++t)
+  for (int t = 0; t < NTAPS; ++t) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc4[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   for (int q = tid; q < BMPIX; q += NTHREADS) {
     const int t = q / TW, cx = q % TW;
@@ -808,7 +817,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs a) {
     const int t = q / TW, cx = q % TW;
     const int k = (a.imgs == 1) ? 0 : t / a.rpi;
     const int row = t - k * a.rpi;
-    const int chunk = (lane & 15) ^ ((lane >> 4) << 2);
+    // (M16: the 32-byte granule of the chunk XOR-ed with the row's low three bits -- row = 4 p + (lane >> 4), p = 4 wave + j)
+    const int chunk = M16 ? (((((lane & 15) >> 1) ^ (4 * (j & 1) + (lane >> 4))) << 1) | (lane & 1)) : ((lane & 15) ^ ((lane >> 4) << 2));
     d_voff[j] = (unsigned)((((k * a.h + row) * a.w_ + cx) * a.lddy + chunk * 8) * (int)sizeof(T));
   }
   const T* dyp = reinterpret_cast<const T*>(a.dy) + co0;
@@ -877,6 +887,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs a) {
   const int chb = 16 * (gi & 1) + 4 * (i16 & 3);
   const int d_lane = (8 * (gi >> 1) + (i16 >> 2)) * CO_T + ((wco ^ (i16 >> 2)) * 32) + chb;
   const int q_lane = 8 * (gi >> 1) + (i16 >> 2);
+  // M16: this lane's pixel inside a 32-pixel k-step (low half; the high half is + 16) and its 4-channel piece of a 16-channel block
+  const int p16 = 4 * gi + (i16 >> 2), c4 = 4 * (i16 & 3);
+  int d16[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) d16[b] = p16 * CO_T + (((wco * 2 + b) ^ (p16 & 7)) * 16) + c4;
   constexpr int SLOTS = (BMPIX / 16) * NTAPS;          // 72 MFMAs per wave and tile
   for (int i = 0; i < ntl; ++i) {
     T* ldsX = lds0 + (i & 1) * stage_elems;
@@ -936,8 +951,75 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs a) {
         }
       }
     };
-    half_tile(std::integral_constant<int, 0>{});
-    half_tile(std::integral_constant<int, 1>{});
+    // ---- the 16x16x32 form of a half tile: two k-steps of 32 pixels, per step the two dY fragments once and per tap the two X fragments
+    // (4 transposing reads) + 4 MFMAs; the same one-tap-ahead / one-step-ahead reads and the same placement of the staging units
+    auto half_tile16 = [&](auto HALF) {
+      constexpr int H0 = decltype(HALF)::value * 2;
+      // (one pair of X fragment buffers for the whole half: a k-step has 9 taps, so the buffer a step starts on alternates -- index (tap + kq) & 1,
+      //  all compile-time; the first X fragments of the next step are read into the buffer its tap 0 will use, during this step's last tap)
+      // whole 8-element fragments (the two transposing reads of one land in adjacent registers).  dY: ONE buffer, read at the top of its k-step -- a second one
+      // (+8 registers) put the kernel over 256 and its scratch reloads queue behind the prefetched tile on the in-order vmcnt counter
+      bf16x8 nb[1][2], af[2][2];
+      int xl, xh;
+      auto b_reads = [&](int ks, int s_) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          nb[s_][b] = __builtin_shufflevector(tr_read(ldsD + d16[b] + ks * 32 * CO_T), tr_read(ldsD + d16[b] + (ks * 32 + 16) * CO_T), 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      auto a_reads = [&](int buf, int toff) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          af[buf][c] = __builtin_shufflevector(tr_read(ldsX + xl + 16 * c + toff), tr_read(ldsX + xh + 16 * c + toff), 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      auto x_offsets = [&](int ks) {
+        xl = tab[ks * 32 + p16] + wci * 32 + c4;
+        xh = tab[ks * 32 + 16 + p16] + wci * 32 + c4;
+      };
+      x_offsets(H0);
+      a_reads(0, 0);
+#pragma unroll
+      for (int kq = 0; kq < 2; ++kq) {
+        const int cur_ = 0;
+        b_reads(H0 + kq, 0);
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+          const int buf = (tap + kq) & 1;
+          if (tap + 1 < NTAPS) {
+            const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
+            a_reads(buf ^ 1, (ky * (TW + 2) + kx) * XP);
+          } else if (kq + 1 < 2) {
+            x_offsets(H0 + kq + 1);
+            a_reads(buf ^ 1, 0);
+          }
+          const int slot = kq * NTAPS + tap;                 // 0 .. 17 inside the half
+          if constexpr (decltype(HALF)::value == 0) {
+#pragma unroll
+            for (int u = 0; u < XI; ++u)
+              if (slot == 1 + 4 * u) { if (do_store) store_x(u, othX); load_x(u); }
+          } else {
+#pragma unroll
+            for (int u = 0; u < NPIECE; ++u)
+              if (slot == 4 * u) { if (do_store) dma_piece(u, dcur, (i + 1) & 1); }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              acc4[tap][c * 2 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[buf][c], nb[cur_][b], acc4[tap][c * 2 + b], 0, 0, 0);
+            }
+          }
+        }
+      }
+    };
+    static_assert(XI <= 4, "staging units of a half tile: slots 1, 5, 9, 13 of 18");
+    if constexpr (M16) {
+      half_tile16(std::integral_constant<int, 0>{});
+      half_tile16(std::integral_constant<int, 1>{});
+    } else {
+      half_tile(std::integral_constant<int, 0>{});
+      half_tile(std::integral_constant<int, 1>{});
+    }
     dnext = dtmp;
     dma_wait_all();
     __syncthreads();
@@ -946,9 +1028,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs a) {
   for (int tap = 0; tap < NTAPS; ++tap) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int ci = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      const int co = co0 + wco * 32 + r;
-      a.ws[((size_t)(sp * NTAPS + tap) * a.kpad + ci) * a.npad + co] = acc[tap][i];
+      // M16: register 4 (2 c + b) + rr of lane (gi, i16) is row 16 c + 4 gi + rr, column 16 b + i16 of the (ci, co) tile
+      const int ci = M16 ? ci0 + wci * 32 + 16 * (i >> 3) + 4 * gi + (i & 3) : ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      const int co = M16 ? co0 + wco * 32 + 16 * ((i >> 2) & 1) + i16 : co0 + wco * 32 + r;
+      a.ws[((size_t)(sp * NTAPS + tap) * a.kpad + ci) * a.npad + co] = M16 ? acc4[tap][i >> 2][i & 3] : acc[tap][i];
     }
   }
 }
@@ -1077,6 +1160,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce16_kernel(const float* __rest
 // ------------------------------------------------------------------ host side
 struct WgradPlan { int tw, nci, nco, nw, nks, ntaps, nsplit, kpad, npad, n_ci_blk, n_co_blk, pix, db, dma; size_t ws_bytes; };
 extern int g_opt_wgrad_db;        // api.hip: satcv_set_option("wgrad_db", ...)
+extern int g_opt_wgrad_m16;       // api.hip: satcv_set_option("wgrad_m16", ...)
 
 static bool wgrad_pix256() {
   static const bool on = [] { const char* e = getenv("SATCV_WGRAD_PIX256"); return !e || atoi(e) != 0; }();
@@ -1250,9 +1334,9 @@ static int wgrad_db_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStr
   return SATCV_OK;
 }
 
-template <int TW>
+template <int TW, bool M16 = false>
 static int wgrad_dma_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st) {
-  constexpr int PIX = 128, TH = PIX / TW, NTHREADS = 512, XP = 96, GX = 8;
+  constexpr int PIX = 128, TH = PIX / TW, NTHREADS = 512, XP = M16 ? 80 : 96, GX = 8;
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1;
@@ -1278,7 +1362,7 @@ static int wgrad_dma_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipSt
   const size_t stage = (size_t)a.rl * a.cl * XP + (size_t)PIX * 128;
   const size_t lds = 2 * stage * sizeof(bf16) + (size_t)PIX * sizeof(int) + (size_t)GX * 16 * sizeof(float);
   if (lds > 160 * 1024) return SATCV_ERR_UNSUPPORTED;
-  auto kern = wgrad_dma_kernel<TW>;
+  auto kern = wgrad_dma_kernel<TW, M16>;
   { const int rc = satcv_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds); if (rc) return rc; }
   hipLaunchKernelGGL(kern, dim3(p.n_ci_blk * p.n_co_blk * p.nsplit), dim3(NTHREADS), lds, st, a);
   hipError_t e = hipGetLastError();
@@ -1290,7 +1374,10 @@ static int wgrad_dma_launch(const satcv_wgrad_desc* d, const WgradPlan& p, hipSt
 template <typename T, int TW>
 static int wgrad_db_cfg(const satcv_wgrad_desc* d, const WgradPlan& p, hipStream_t st, int sy, int sx) {
   if constexpr (std::is_same<T, bf16>::value) {
-    if (p.dma) return wgrad_dma_launch<TW>(d, p, st);      // (the plan's slab geometry is this kernel's: no other kernel can serve it)
+    if (p.dma) {
+      // option wgrad_m16 (SATCV_WGRAD_M16, default 0): the 16x16x32 form -- correct, and measured 33 % SLOWER per launch (profiles/r06_ab_wgrad_m16.txt)
+      return g_opt_wgrad_m16 ? wgrad_dma_launch<TW, true>(d, p, st) : wgrad_dma_launch<TW, false>(d, p, st);
+    }      // (the plan's slab geometry is this kernel's: no other kernel can serve it)
   }
   if (p.ntaps == 1 && p.nw == 4) return wgrad_db_launch<T, TW, 4, 2, 1, 1, 64, 4>(d, p, st, sy, sx);
   if (p.ntaps == 1 && p.nci == 2) return wgrad_db_launch<T, TW, 2, 4, 1, 1>(d, p, st, sy, sx);

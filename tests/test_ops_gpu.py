@@ -1497,3 +1497,38 @@ def test_round6_small_entry_points(ops):
         assert torch.equal(rf, fw), ('forward image', shp, tr)
         assert torch.equal(rd, dg), ('data-gradient image', shp, tr)
     assert lib.satcv_pack_weights_batched(jd.data_ptr(), pd.data_ptr(), len(jobs), tot - 8, ops.BF16, st) != 0      # a prefix table not built from satcv_pack_job_items
+
+
+@pytest.mark.parametrize('case', [(2, 32, 32, 64, 128, 0), (3, 16, 48, 128, 256, 64), (8, 8, 8, 192, 128, 0), (2, 64, 32, 64, 128, 32)])
+def test_wgrad_dma_kernel_16x16x32_variant(ops, case):
+    """round 6 (review item 2a): wgrad_dma_kernel<TW, M16 = true> -- the deep 3x3 weight gradient on v_mfma_f32_16x16x32_bf16 (option wgrad_m16; 2 x 2 blocks per
+    (ci, co) tile, k order 4 g ... / 16 + 4 g ... per lane group, X rows of 160 bytes, dY granules swizzled by row & 7).  Correct; measured 33 % slower per launch
+    than the 32x32x16 form and therefore off by default (profiles/r06_ab_wgrad_m16.txt).  Tile widths 32 / 16 / 8, one and two sources, the fused input transform;
+    both forms against the float64 oracle and against each other."""
+    import ctypes
+    from satellite_computervision_amd._lib import lib, check
+    n, h, w, cin, cout, split = case
+    td = torch.bfloat16
+    rng = np.random.default_rng(hash(case) % 2**31 + 5)
+    x = rnd(rng, (n, h, w, cin), td)
+    dy = rnd(rng, (n, h, w, cout), td)
+    sc, sh = (rng.random(cin) + 0.5).astype(np.float32), (rng.standard_normal(cin) * 0.3).astype(np.float32)
+    a_ref = np.maximum(x * sc.astype(np.float64) + sh.astype(np.float64), 0)
+    a_ref = torch.tensor(a_ref, dtype=torch.float32).to(td).double().numpy()
+    _, dk_ref, _ = K.conv2d_same_bwd(a_ref, np.zeros((3, 3, cin, cout)), dy, 1)
+    out = {}
+    old = ctypes.c_int32()
+    check(lib.satcv_get_option(b'wgrad_m16', ctypes.byref(old)))
+    try:
+        for m16 in (0, 1):
+            check(lib.satcv_set_option(b'wgrad_m16', m16))
+            if split:
+                dk = ops.conv2d_wgrad(to_dev(x[..., :split], td), to_dev(dy, td), cin, cout, x1=to_dev(x[..., split:], td), in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
+            else:
+                dk = ops.conv2d_wgrad(to_dev(x, td), to_dev(dy, td), cin, cout, in_scale=f32dev(sc), in_shift=f32dev(sh), in_relu=True)
+            out[m16] = back(dk)
+            close(out[m16], dk_ref, td, f'wgrad (m16 = {m16}) {case}', k=0.5)
+    finally:
+        check(lib.satcv_set_option(b'wgrad_m16', old.value))
+    # the same bf16 products in fp32, another summation order
+    assert np.abs(out[0] - out[1]).max() <= 2e-4 * max(np.abs(out[0]).max(), 1e-30)
